@@ -1,0 +1,221 @@
+# coding: utf-8
+"""Headline benchmark: src+tgt tokens/sec of the Transformer-base training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + hand-written backward + (RCCL all-reduce when N>1) + global-norm +
+Adam on ONE synthetic batch per GPU: B=64 sentences x (Ls=64 + Lt=64) tokens = 8192 src+tgt
+tokens per GPU-step (BASELINE.json configs[1]), V=32000, H=512, F=2048, h=8,
+6+6 layers, bf16 MFMA compute / fp32 accumulate / fp32 master weights, dropouts 0.1 and label
+smoothing 0.1 as in the canonical recipe.  Weak scaling: every rank draws its own batch
+(seed 1234+rank).  Rank 0 prints ONE JSON line (contract in the task statement) with two
+extra objects:
+
+  roofline     -- the dominant kernel (the bf16 MFMA GEMM instance with the largest total
+                  time), achieved = algorithmic FLOPs of its launches / their HIP-event time,
+                  measured in an instrumented eager pass right after the timed region;
+  cpu_baseline -- the oracle (oracle/ref_torch.py, unfused torch-CPU fp32 restatement of the
+                  reference path: kind "port") timed on the host cores on a bounded sample of
+                  the same workload.  TF1 itself cannot run here.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from zero_amd.config import transformer_base_params, SyntheticVocab  # noqa: E402
+from zero_amd.utils import parallel  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md chip table (dense bf16)
+B, LS, LT, V = 64, 64, 64, 32000
+
+
+def synthetic_batch(rank):
+    """ids ~ U{3..V-1}, last column eos(2), no padding, seed 1234+rank."""
+    rng = np.random.default_rng(1234 + rank)
+    src = rng.integers(3, V, size=(B, LS), dtype=np.int64)
+    tgt = rng.integers(3, V, size=(B, LT), dtype=np.int64)
+    src[:, -1] = 2
+    tgt[:, -1] = 2
+    return src, tgt
+
+
+def make_params(dropout=0.1):
+    hp = transformer_base_params(dropout=dropout, relu_dropout=dropout, residual_dropout=dropout,
+                                 attention_dropout=dropout, update_cycle=1, token_size=4096)
+    hp.src_vocab = SyntheticVocab(V)
+    hp.tgt_vocab = SyntheticVocab(V)
+    return hp
+
+
+def train_flops_per_step(hp, b=B, ls=LS, lt=LT, v=V):
+    """SURVEY.md 8(d) algorithmic FLOPs: GEMM 2MNK, attention 2*2*B*Lq*Lk*H, bwd = 2x fwd."""
+    H, F = hp.hidden_size, hp.filter_size
+    ts, tt = b * ls, b * lt
+    enc = hp.num_encoder_layer * (2 * ts * H * 3 * H + 4 * b * ls * ls * H + 2 * ts * H * H + 4 * ts * H * F)
+    dec = hp.num_decoder_layer * (
+        2 * tt * H * 3 * H + 4 * b * lt * lt * H + 2 * tt * H * H      # self attention
+        + 2 * tt * H * H + 2 * 2 * ts * H * H + 4 * b * lt * ls * H + 2 * tt * H * H   # cross attention
+        + 4 * tt * H * F)
+    logits = 2 * tt * H * v
+    return 3.0 * (enc + dec + logits)
+
+
+class GemmProfiler(object):
+    """HIP-event timing of every zk_gemm launch of an eager step (same stream as the launch)."""
+
+    def __init__(self, engine):
+        self.eng = engine
+        self.records = []
+        self._orig = engine.gemm
+
+    def __enter__(self):
+        eng = self.eng
+
+        def timed(A, Bm, C, M, N, K, ta, tb, **kw):
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            self._orig(A, Bm, C, M, N, K, ta, tb, **kw)
+            e.record()
+            self.records.append(((ta, tb), 2.0 * M * N * K, s, e))
+        eng.gemm = timed
+        return self
+
+    def __exit__(self, *a):
+        self.eng.gemm = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, fl, s, e in self.records:
+            d = agg.setdefault(key, [0.0, 0.0, 0])
+            d[0] += fl
+            d[1] += s.elapsed_time(e) * 1e-3
+            d[2] += 1
+        return agg
+
+
+def cpu_baseline(hp, budget_s=20.0):
+    """Oracle (torch-CPU fp32, unfused, autograd) train step on a bounded sample."""
+    from oracle import ref_torch as rt
+    import copy
+    hp = copy.copy(hp)
+    bs = 8   # sentences of the same 64/64 shape: 1024 src+tgt tokens per CPU step
+    src, tgt = synthetic_batch(0)
+    src, tgt = src[:bs], tgt[:bs]
+    torch.set_num_threads(os.cpu_count() or 1)
+    P = rt.to_torch(rt.init_params(hp, "transformer", seed=1234))
+    M = {k: torch.zeros_like(v) for k, v in P.items()}
+    Vv = {k: torch.zeros_like(v) for k, v in P.items()}
+    feats = {"source": torch.tensor(src), "target": torch.tensor(tgt)}
+    rt.train_step(P, M, Vv, feats, hp, "transformer", 0, training=True)   # warm-up
+    n, t0 = 0, time.time()
+    while True:
+        rt.train_step(P, M, Vv, feats, hp, "transformer", n + 1, training=True)
+        n += 1
+        if time.time() - t0 > budget_s or n >= 5:
+            break
+    dt = time.time() - t0
+    return {"value": bs * (LS + LT) * n / dt, "unit": "src+tgt tokens/s", "cores": os.cpu_count(),
+            "kind": "port",
+            "sample": "%d timed steps (+1 warm-up) of %d sentences x (64+64) tokens, Transformer-base, "
+                      "fwd+bwd+Adam, torch-CPU fp32 restatement of the TF1 path" % (n, bs)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = parallel.init_distributed()
+    assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+
+    from zero_amd.main import Trainer
+    hp = make_params(args.dropout)
+    hp.random_seed = 1234   # identical initial replicas on every rank
+    tr = Trainer(hp)
+    src, tgt = synthetic_batch(rank)
+    tr.prepare_static({"source": src, "target": tgt})
+    tr.core.eng.set_seed(1234 + rank)
+    use_graph = (world == 1) and not args.no_graph
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 2)):     # >= 2: eager sizing pass + graph capture
+        tr.step_static(use_graph)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.step_static(use_graph)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.cpu()[0])
+    loss_v = float(loss.cpu()[0])
+    gnorm, pnorm, skipped = tr.train_op.stats()
+
+    if rank != 0:
+        return
+    tokens = world * B * (LS + LT) * args.steps
+    ms = dt / args.steps * 1e3
+    flops = train_flops_per_step(hp)
+    out = {
+        "metric": "src+tgt tokens/sec training, Transformer-base d=512 L=6",
+        "value": tokens / dt, "unit": "src+tgt tokens/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "Transformer-base (d=512, L=6+6, F=2048, h=8, V=32000) training step, "
+                               "B=64 x (src 64 + tgt 64) tokens per GPU, dropout %.2f, label_smooth 0.1, "
+                               "fwd+bwd+allreduce+Adam" % args.dropout,
+                   "global_batch_tokens": world * B * (LS + LT), "parallelism": "dp%d" % world,
+                   "hip_graph": bool(use_graph)},
+        "loss": loss_v, "gnorm": gnorm, "update_skipped": skipped,
+        "step_mfma_frac": flops / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12),
+    }
+    # ---- roofline of the dominant kernel: instrumented eager pass (HIP events per launch)
+    with GemmProfiler(tr.core.eng) as prof:
+        for _ in range(3):
+            tr.step_static(False)
+    agg = prof.summary()
+    names = {(0, 0): "k_gemm_mfma<*,*,false,false> (forward x@W)",
+             (0, 1): "k_gemm_mfma<*,*,false,true> (dgrad dY@W^T, logits)",
+             (1, 0): "k_gemm_mfma<*,*,true,false> (wgrad X^T@dY)"}
+    key = max(agg, key=lambda k: agg[k][1])
+    fl, sec, cnt = agg[key]
+    tot_fl = sum(v[0] for v in agg.values())
+    tot_s = sum(v[1] for v in agg.values())
+    out["roofline"] = {
+        "bound": "mfma", "kernel": names.get(key, str(key)), "achieved": fl / sec / 1e12,
+        "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+        "traffic": None, "launches_per_step": cnt // 3, "avg_launch_us": sec / cnt * 1e6,
+        "all_gemm_achieved": tot_fl / tot_s / 1e12, "all_gemm_ms_per_step": tot_s / 3 * 1e3,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(hp)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+/* zero_hip.h -- C-ABI of libzero_hip.so, the MI355X (gfx950) kernels behind the
+ * Transformer training / decode hot path of bzhangGo/zero.
+ *
+ * The reference has NO native layer: every entry point below replaces a group of stock
+ * TF1 ops issued by the cited reference lines (paths relative to the reference root).
+ * A maintainer binds these with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; device pointers unless noted; the caller owns every
+ *     buffer including workspaces (query the size with the *_workspace function);
+ *   - "bf16" = raw uint16 bfloat16 storage; activations and weight matrices are bf16,
+ *     vectors / statistics / gradients of parameters / optimiser state are fp32;
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t); no call
+ *     synchronises, allocates or keeps global state, so the calls are re-entrant and can
+ *     be captured into a hipGraph;
+ *   - return 0 = ok, <0 = argument error, >0 = hipError_t; message in
+ *     zk_last_error_string() (thread local);
+ *   - dropout: `drop_p` in [0,1), `seed` = DEVICE pointer to a uint64 step seed (read at
+ *     kernel run time so a captured graph sees fresh seeds), `sid` = site id; the mask is
+ *     a pure function of (seed, sid, element index) and is regenerated in the backward;
+ *   - `impl`: 0 = auto (MFMA kernel when the shape allows, else the reference HIP kernel),
+ *     1 = reference HIP kernel, 2 = MFMA kernel (error if unsupported).
+ */
+#ifndef ZERO_HIP_H_
+#define ZERO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* zk_stream_t; /* hipStream_t */
+
+int zk_version(void);
+const char* zk_last_error_string(void);
+
+/* ---- func.py:14-65 linear / func.py:327-338 ffn_layer / transformer.py:182-196 logits,
+ *      and the autodiff mirrors TF builds for them (main.py:28).
+ * C[M,N] = alpha * op(A)[M,K] x op(B)[K,N] (+bias[N]) (+residual[M,N]) (act) (dropout)
+ *   ta=0: A is [M,lda] (K contiguous), ta=1: A is [K,lda] (M contiguous)
+ *   tb=0: B is [K,ldb] (N contiguous), tb=1: B is [N,ldb] (K contiguous)
+ *   out_f32: C is fp32 (else bf16).  act: 0 none, 1 ReLU (func.py:332), 2 multiply by
+ *   (aux>0)*aux_scale (ReLU+dropout backward through the saved activation).          */
+size_t zk_gemm_workspace(int M, int N, int K);
+int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+            int ta, int tb, int out_f32, float alpha, const float* bias, const void* residual, int ldr,
+            int act, const void* aux, int ldaux, float aux_scale, float drop_p, const uint64_t* seed,
+            uint32_t sid, int impl, void* workspace, size_t ws_bytes, zk_stream_t stream);
+
+/* ---- func.py:218-256 dot_attention core (+ modules/rpr.py:10-75 relative positions).
+ * q/k/v/out: [B*L, ld] bf16, head h at columns [h*d,(h+1)*d) (split/combine_heads,
+ * func.py:68-104, folded into addressing).  kmask: fp32 [B,Lk] (1 valid / 0 pad) or NULL;
+ * causal: mask keys j > q_pos0+i; masked logits get -mask_inf added (func.py:372-387,
+ * finite 1e8).  lse: fp32 [B,nh,Lq] log-sum-exp saved for the backward (may be NULL).
+ * rpr_k/rpr_v: bf16 [2*max_rel+1, d] tables or NULL.  bsq/bsk/bsv: batch strides in
+ * elements (0 = L*ld); kv_group: k/v/kmask batch index = b / kv_group (decode: beam-tiled
+ * queries attend to un-tiled per-sentence encoder keys, search.py:36-39 never materialised). */
+int zk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int nh, int Lq,
+                int Lk, int d, int ldq, int ldk, int ldv, int ldo, const float* kmask, int causal,
+                int q_pos0, float scale, float mask_inf, const void* rpr_k, const void* rpr_v, int max_rel,
+                float drop_p, const uint64_t* seed, uint32_t sid, long bsq, long bsk, long bsv, int kv_group,
+                int impl, zk_stream_t stream);
+size_t zk_attn_bwd_workspace(int B, int nh, int Lq);
+int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                const float* lse, void* dq, void* dk, void* dv, float* drpr_k, float* drpr_v, int B, int nh,
+                int Lq, int Lk, int d, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk,
+                int lddv, const float* kmask, int causal, int q_pos0, float scale, float mask_inf,
+                const void* rpr_k, const void* rpr_v, int max_rel, float drop_p, const uint64_t* seed,
+                uint32_t sid, int impl, void* workspace, size_t ws_bytes, zk_stream_t stream);
+
+/* ---- transformer.py:16-33 / 88-119 embedding * sqrt(H) + shared bias + timing signal
+ * (func.py:341-369; `timing` = host-precomputed fp32 [Lmax,H] table).  shift=1: decoder
+ * training input (zero first step, transformer.py:108-110).  zero_flag: device int, !=0
+ * zeroes the embedding term (transformer.py:113-115).                                  */
+int zk_embed_fwd(const int* ids, const void* table, const float* bias, const float* timing, void* out, int B,
+                 int L, int H, float scale, int shift, int pos0, const int* zero_flag, float drop_p,
+                 const uint64_t* seed, uint32_t sid, zk_stream_t stream);
+/* dtable (fp32 [V,H]) and dbias (fp32 [H]) are ACCUMULATED into with atomics. */
+int zk_embed_bwd(const int* ids, const void* dout, float* dtable, float* dbias, int B, int L, int H,
+                 float scale, int shift, float drop_p, const uint64_t* seed, uint32_t sid, zk_stream_t stream);
+
+/* ---- func.py:321-324 residual_fn + func.py:289-303 layer_norm (post-LN, eps inside
+ * rsqrt): out = LN(x + dropout(y)).  sum_out/mean/rstd are saved for the backward.    */
+int zk_add_ln_fwd(const void* x, const void* y, const float* gamma, const float* beta, void* out,
+                  void* sum_out, float* mean, float* rstd, int rows, int H, float eps, float drop_p,
+                  const uint64_t* seed, uint32_t sid, zk_stream_t stream);
+size_t zk_add_ln_bwd_workspace(int rows, int H);
+/* dsum = d(x + drop(y)); dy = dsum*dropmask (only written when drop_p>0); dgamma/dbeta and
+ * dbias_prev (= column sum of dy: bias grad of the linear that produced y) are OVERWRITTEN. */
+int zk_add_ln_bwd(const void* dout, const void* sum, const float* mean, const float* rstd, const float* gamma,
+                  void* dsum, void* dy, float* dgamma, float* dbeta, float* dbias_prev, int rows, int H,
+                  float drop_p, const uint64_t* seed, uint32_t sid, void* workspace, size_t ws_bytes,
+                  zk_stream_t stream);
+
+/* column sum of a bf16 [rows,N] matrix -> fp32 [N] (bias gradients, func.py:58-60) */
+size_t zk_colsum_workspace(int rows, int N);
+int zk_colsum(const void* a, int rows, int N, int lda, float* out, void* workspace, size_t ws_bytes,
+              zk_stream_t stream);
+
+/* ---- util.py:88-103 label_smooth + transformer.py:198-207 cross entropy on fp32 logits.
+ * ce_out[r] = -sum soft*log_softmax - normaliser; dlogits (bf16 [rows,ld], NULL to skip)
+ * = w[r]*(softmax - soft).                                                            */
+int zk_ce_fused(const float* logits, const int* ids, const float* w, float* ce_out, void* dlogits, int rows,
+                int V, int ld, float label_smooth, zk_stream_t stream);
+/* transformer.py:208-216: mask=(id!=0); w = loss_scale*mask/(len_b*B); per-sentence loss and mean */
+int zk_target_stats(const int* ids, float* mask, float* w, int B, int L, float loss_scale, zk_stream_t stream);
+int zk_loss_reduce(const float* ce, const int* ids, float* per_sample, float* loss, int B, int L,
+                   zk_stream_t stream);
+int zk_make_mask(const int* ids, float* mask, int n, zk_stream_t stream);
+int zk_all_equal(const int* ids, int n, int value, int* flag, zk_stream_t stream);
+
+/* ---- transformer_aan.py:92-117,165-192 average attention network (train-time scan + gate) */
+int zk_aan_fwd(const void* x, const float* mask, void* cat, int B, int L, int H, int use_mask,
+               zk_stream_t stream);
+int zk_aan_bwd(const void* dcat, const void* dxg, const void* dyg, const void* ds, const float* mask, void* dx,
+               int B, int L, int H, int use_mask, zk_stream_t stream);
+int zk_aan_gate_fwd(const void* z, const void* cat, void* out, int rows, int H, zk_stream_t stream);
+int zk_aan_gate_bwd(const void* dg, const void* z, const void* cat, void* dz, void* dxg, void* dyg, int rows,
+                    int H, zk_stream_t stream);
+
+/* ---- utils/cycle.py:86-101 + tf.train.AdamOptimizer (main.py:178-181) on flat buffers.
+ * hyper (device fp32[8]): lr_t, beta1, beta2, eps, grad_scale, clip_norm(0=off), gnorm(in),
+ * skipped(out).  zk_l2norm: out[0] = scale*||x||_2.                                    */
+size_t zk_norm_workspace(void);
+int zk_l2norm(const float* x, size_t n, float scale, float* out, void* workspace, size_t ws_bytes,
+              zk_stream_t stream);
+int zk_adam(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n, float* hyper,
+            zk_stream_t stream);
+int zk_cast_f32_bf16(const float* x, void* y, size_t n, zk_stream_t stream);
+int zk_cast_bf16_f32(const void* x, float* y, size_t n, zk_stream_t stream);
+int zk_zero(void* p, size_t bytes, zk_stream_t stream);
+int zk_axpby_f32(float* y, const float* x, float a, float b, size_t n, zk_stream_t stream);
+
+/* dropout plumbing */
+int zk_dropout_mask(float* out, size_t n, float drop_p, const uint64_t* seed, uint32_t sid, zk_stream_t stream);
+int zk_seed_advance(uint64_t* seed, uint64_t inc, zk_stream_t stream);
+
+/* ---- search.py:143-176 decode step tail (see zk_decode.hip) */
+int zk_beam_topk(const float* logits, const float* prev_log_probs, float* topk_scores, int* topk_index, int B,
+                 int K, int V, int ld, int k2, float temperature, float length_penalty, int forbid_id,
+                 float forbid_value, zk_stream_t stream);
+/* search.py:198-210 beam reordering: dst row r <- src row index[r] (NULL: r); bytes, multiples of 16 */
+int zk_gather_rows(const void* src, size_t src_stride, const int* index, void* dst, size_t dst_stride, int rows,
+                   size_t row_bytes, zk_stream_t stream);
+/* transformer_aan.py:110-112: cache += x; cat = [x | cache/(t+1)] */
+int zk_aan_decode(const void* x, float* cache, void* cat, int rows, int H, float inv_count, zk_stream_t stream);
+
+/* hipGraph plumbing: capture a sequence of the calls above once, replay per step */
+int zk_graph_begin(zk_stream_t stream);
+int zk_graph_end(zk_stream_t stream, void** exec_out);
+int zk_graph_launch(void* exec, zk_stream_t stream);
+int zk_graph_destroy(void* exec);
+
+/* hardware-layout probes used by the GPU tests */
+int zk_probe_mfma32(const void* A, const void* Bt, float* D, zk_stream_t stream);
+int zk_probe_mfma16(const void* A, const void* Bt, float* D, zk_stream_t stream);
+int zk_probe_tr16(void* out, zk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZERO_HIP_H_ */

@@ -1,0 +1,512 @@
+"""GPU parity of every HIP kernel (through the C-ABI) against plain torch fp32 math on the
+same bf16 inputs.  The reference (TF1) cannot run; the op semantics checked here are the ones
+the oracle (oracle/ref_torch.py) restates from func.py / util.py / search.py."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.util_gpu import eng, bf, rand_bf, mat, rel_err, max_err  # noqa: E402
+from zero_amd import hip  # noqa: E402
+from zero_amd.func import Mat  # noqa: E402
+
+
+# ------------------------------------------------------------------ hardware layout probes
+def test_probe_mfma_layouts():
+    e = eng()
+    A = rand_bf(32, 16, seed=1); Bt = rand_bf(32, 16, seed=2)
+    D = torch.zeros(32, 32, device="cuda")
+    e.lib.call("zk_probe_mfma32", A.data_ptr(), Bt.data_ptr(), D.data_ptr(), e.stream)
+    torch.cuda.synchronize()
+    assert max_err(D, A.float() @ Bt.float().t()) < 1e-4
+    A = rand_bf(16, 32, seed=3); Bt = rand_bf(16, 32, seed=4)
+    D = torch.zeros(16, 16, device="cuda")
+    e.lib.call("zk_probe_mfma16", A.data_ptr(), Bt.data_ptr(), D.data_ptr(), e.stream)
+    torch.cuda.synchronize()
+    assert max_err(D, A.float() @ Bt.float().t()) < 1e-4
+
+
+def test_probe_tr16_dump():
+    e = eng()
+    out = torch.zeros(256, dtype=torch.int16, device="cuda")
+    e.lib.call("zk_probe_tr16", out.data_ptr(), e.stream)
+    torch.cuda.synchronize()
+    print("ds_read_b64_tr_b16 (lds[i]=i, lane l addr=8*l):")
+    print(out.cpu().numpy().reshape(64, 4)[:32].tolist())
+
+
+# ------------------------------------------------------------------ GEMM
+def _gemm_case(impl, M, N, K, ta, tb, out_f32=False, bias=False, residual=False, act=0, drop=0.0, alpha=1.0,
+               seed=0):
+    e = eng()
+    A = rand_bf(*((K, M) if ta else (M, K)), seed=seed + 1)
+    Bm = rand_bf(*((N, K) if tb else (K, N)), seed=seed + 2)
+    C = torch.zeros(M, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device="cuda")
+    bias_t = torch.randn(N, device="cuda") if bias else None
+    res_t = rand_bf(M, N, seed=seed + 3) if residual else None
+    aux_t = rand_bf(M, N, seed=seed + 4) if act == 2 else None
+    e.set_seed(1234)
+    e.gemm(mat(A), mat(Bm), mat(C), M, N, K, ta, tb, alpha=alpha, bias=bias_t,
+           residual=mat(res_t) if residual else None, act=act, aux=mat(aux_t) if act == 2 else None,
+           aux_scale=1.25, drop_p=drop, sid=77, impl=impl)
+    torch.cuda.synchronize()
+    a = A.float().t() if ta else A.float()
+    b = Bm.float().t() if tb else Bm.float()
+    ref = alpha * (a @ b)
+    if bias:
+        ref = ref + bias_t
+    if residual:
+        ref = ref + res_t.float()
+    if act == 1:
+        ref = torch.relu(ref)
+    if act == 2:
+        ref = torch.where(aux_t.float() > 0, ref * 1.25, torch.zeros_like(ref))
+    if drop > 0:
+        msk = torch.zeros(M * N, device="cuda")
+        e.lib.call("zk_dropout_mask", msk.data_ptr(), M * N, drop, e.seed.data_ptr(), 77, e.stream)
+        torch.cuda.synchronize()
+        keep = float((msk > 0).float().mean())
+        assert abs(keep - (1 - drop)) < 0.02, keep
+        ref = ref * msk.view(M, N)
+    return rel_err(C, ref), C, ref
+
+
+@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (256, 192, 160), (72, 40, 24), (200, 264, 136), (64, 512, 1024)])
+def test_gemm_plain(impl, ta, tb, shape):
+    M, N, K = shape
+    err, _, _ = _gemm_case(impl, M, N, K, ta, tb)
+    assert err < 8e-3, err
+
+
+@pytest.mark.parametrize("impl", [1, 2])
+def test_gemm_ragged_rows(impl):
+    # token dimension not a multiple of 8 (M for forward, K for wgrad)
+    assert _gemm_case(impl, 100, 64, 72, 0, 0)[0] < 8e-3
+    assert _gemm_case(impl, 100, 64, 72, 0, 1)[0] < 8e-3
+    assert _gemm_case(impl, 64, 72, 100, 1, 0)[0] < 8e-3
+
+
+@pytest.mark.parametrize("impl", [1, 2])
+def test_gemm_epilogues(impl):
+    assert _gemm_case(impl, 192, 256, 128, 0, 0, bias=True)[0] < 8e-3
+    assert _gemm_case(impl, 192, 256, 128, 0, 0, bias=True, act=1)[0] < 8e-3
+    assert _gemm_case(impl, 192, 256, 128, 0, 1, residual=True)[0] < 8e-3
+    assert _gemm_case(impl, 192, 256, 128, 0, 1, act=2)[0] < 8e-3
+    assert _gemm_case(impl, 192, 256, 128, 0, 0, bias=True, act=1, drop=0.3)[0] < 8e-3
+    assert _gemm_case(impl, 192, 256, 128, 1, 0, out_f32=True)[0] < 2e-3
+    assert _gemm_case(impl, 192, 256, 128, 0, 1, out_f32=True, alpha=0.5)[0] < 2e-3
+
+
+def test_gemm_splitk_wgrad():
+    # 512x512 output, K=4096: the auto configuration splits K
+    err, _, _ = _gemm_case(2, 512, 512, 4096, 1, 0, out_f32=True)
+    assert err < 2e-3, err
+    err, _, _ = _gemm_case(2, 512, 1536, 4096, 1, 0, out_f32=True)
+    assert err < 2e-3, err
+
+
+def test_gemm_base_shapes():
+    for (M, N, K, ta, tb, f32) in [(4096, 1536, 512, 0, 0, False), (4096, 512, 2048, 0, 0, False),
+                                   (4096, 2048, 512, 0, 1, False), (2048, 512, 4096, 1, 0, True),
+                                   (1024, 4000, 512, 0, 1, True)]:
+        err, _, _ = _gemm_case(2, M, N, K, ta, tb, out_f32=f32)
+        assert err < 8e-3, (M, N, K, ta, tb, err)
+
+
+# ------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, B, nh, Lq, Lk, d, kmask, causal, rk=None, rv=None, max_rel=0, drop_mask=None):
+    """func.py:218-256 in torch fp32 on [B*L, nh*d] matrices."""
+    H = nh * d
+    qh = q.float().view(B, Lq, nh, d).permute(0, 2, 1, 3) * d ** -0.5
+    kh = k.float().view(B, Lk, nh, d).permute(0, 2, 1, 3)
+    vh = v.float().view(B, Lk, nh, d).permute(0, 2, 1, 3)
+    lg = qh @ kh.transpose(-1, -2)
+    if rk is not None:
+        idx = (torch.arange(Lq)[:, None] - torch.arange(Lk)[None, :]).clamp(-max_rel, max_rel) + max_rel
+        lg = lg + torch.einsum("bhqd,qkd->bhqk", qh, rk.float()[idx.cuda()])
+    if kmask is not None:
+        lg = lg + ((1 - kmask) * -1e8)[:, None, None, :]
+    if causal:
+        lg = lg + (-1e8 * (1 - torch.tril(torch.ones(Lq, Lk, device="cuda"))))[None, None]
+    w = torch.softmax(lg, -1)
+    lse = torch.logsumexp(lg, -1)
+    wd = w if drop_mask is None else w * drop_mask
+    o = wd @ vh
+    if rv is not None:
+        o = o + torch.einsum("bhqk,qkd->bhqd", wd, rv.float()[idx.cuda()])
+    return o.permute(0, 2, 1, 3).reshape(B * Lq, H), lse, w
+
+
+def _attn_case(impl, B, nh, Lq, Lk, d, use_mask, causal, rpr=False, drop=0.0, seed=0):
+    e = eng()
+    H = nh * d
+    max_rel = 4
+    qkv_q = rand_bf(B * Lq, H, seed=seed + 1).requires_grad_(False)
+    k = rand_bf(B * Lk, H, seed=seed + 2)
+    v = rand_bf(B * Lk, H, seed=seed + 3)
+    kmask = None
+    if use_mask:
+        kmask = torch.ones(B, Lk, device="cuda")
+        for b in range(B):
+            kmask[b, Lk - (b * 3) % max(Lk - 1, 1):] = 0 if b > 0 else 1
+        kmask[:, 0] = 1
+    rk = rand_bf(2 * max_rel + 1, d, scale=0.3, seed=seed + 4) if rpr else None
+    rv = rand_bf(2 * max_rel + 1, d, scale=0.3, seed=seed + 5) if rpr else None
+    out = torch.zeros(B * Lq, H, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B * nh * Lq, device="cuda")
+    e.set_seed(99)
+    e.attn_fwd(mat(qkv_q), mat(k), mat(v), mat(out), lse, B, nh, Lq, Lk, d, kmask=kmask, causal=causal,
+               rpr_k=rk, rpr_v=rv, max_rel=max_rel, drop_p=drop, sid=5, impl=impl)
+    torch.cuda.synchronize()
+    drop_mask = None
+    if drop > 0:
+        n = B * nh * Lq * Lk
+        msk = torch.zeros(n, device="cuda")
+        e.lib.call("zk_dropout_mask", msk.data_ptr(), n, drop, e.seed.data_ptr(), 5, e.stream)
+        drop_mask = msk.view(B, nh, Lq, Lk)
+    # autograd reference
+    qf = qkv_q.float().clone().requires_grad_(True)
+    kf = k.float().clone().requires_grad_(True)
+    vf = v.float().clone().requires_grad_(True)
+    rkf = rk.float().clone().requires_grad_(True) if rpr else None
+    rvf = rv.float().clone().requires_grad_(True) if rpr else None
+    o_ref, lse_ref, _ = _attn_ref(qf, kf, vf, B, nh, Lq, Lk, d, kmask, causal, rkf, rvf, max_rel, drop_mask)
+    errs = {"out": rel_err(out, o_ref), "lse": max_err(lse.view(B, nh, Lq), lse_ref)}
+    # backward
+    dout = rand_bf(B * Lq, H, seed=seed + 9)
+    dq = torch.zeros_like(qkv_q); dk = torch.zeros_like(k); dv = torch.zeros_like(v)
+    drk = torch.zeros(2 * max_rel + 1, d, device="cuda") if rpr else None
+    drv = torch.zeros(2 * max_rel + 1, d, device="cuda") if rpr else None
+    e.attn_bwd(mat(qkv_q), mat(k), mat(v), mat(out), mat(dout), lse, mat(dq), mat(dk), mat(dv), B, nh, Lq, Lk, d,
+               kmask=kmask, causal=causal, rpr_k=rk, rpr_v=rv, drpr_k=drk, drpr_v=drv, max_rel=max_rel,
+               drop_p=drop, sid=5, impl=impl)
+    torch.cuda.synchronize()
+    o_ref.backward(dout.float())
+    errs["dq"] = rel_err(dq, qf.grad); errs["dk"] = rel_err(dk, kf.grad); errs["dv"] = rel_err(dv, vf.grad)
+    if rpr:
+        errs["drk"] = rel_err(drk, rkf.grad); errs["drv"] = rel_err(drv, rvf.grad)
+    return errs
+
+
+ATT_CASES = [(2, 2, 64, 64, False, False), (3, 2, 37, 53, True, False), (2, 3, 50, 50, False, True),
+             (2, 2, 70, 130, True, False), (1, 2, 130, 130, False, True), (2, 8, 64, 64, True, False)]
+
+
+@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("case", ATT_CASES)
+def test_attention_d64(impl, case):
+    B, nh, Lq, Lk, um, causal = case
+    errs = _attn_case(impl, B, nh, Lq, Lk, 64, um, causal)
+    print(impl, case, errs)
+    assert errs["out"] < 1.5e-2 and errs["lse"] < 2e-2
+    assert errs["dq"] < 2.5e-2 and errs["dk"] < 2.5e-2 and errs["dv"] < 2.5e-2, errs
+
+
+@pytest.mark.parametrize("impl", [1, 2])
+def test_attention_dropout(impl):
+    errs = _attn_case(impl, 2, 2, 64, 64, 64, True, False, drop=0.2)
+    print(errs)
+    assert errs["out"] < 1.5e-2 and errs["dq"] < 2.5e-2 and errs["dk"] < 2.5e-2 and errs["dv"] < 2.5e-2, errs
+
+
+def test_attention_small_head_and_rpr():
+    errs = _attn_case(1, 2, 2, 9, 11, 8, True, False)
+    assert max(errs.values()) < 2.5e-2, errs
+    errs = _attn_case(1, 2, 2, 20, 20, 64, False, True, rpr=True)
+    print(errs)
+    assert max(errs.values()) < 2.5e-2, errs
+    errs = _attn_case(1, 2, 2, 13, 17, 16, True, False, rpr=True)
+    assert max(errs.values()) < 2.5e-2, errs
+
+
+def test_attention_fully_masked_row_is_uniform():
+    # func.py:386: the mask is a finite -1e8, so an all-pad key row softmaxes to uniform
+    e = eng()
+    B, nh, L, d = 1, 1, 8, 64
+    q = rand_bf(L, d, seed=1); k = rand_bf(L, d, seed=2); v = rand_bf(L, d, seed=3)
+    kmask = torch.zeros(B, L, device="cuda")
+    for impl in (1, 2):
+        out = torch.zeros(L, d, dtype=torch.bfloat16, device="cuda")
+        e.attn_fwd(mat(q), mat(k), mat(v), mat(out), None, B, nh, L, L, d, kmask=kmask, impl=impl)
+        torch.cuda.synchronize()
+        assert max_err(out, v.float().mean(0, keepdim=True).expand(L, d)) < 2e-2
+
+
+# ------------------------------------------------------------------ embedding / LN / colsum
+def test_embed_fwd_bwd():
+    e = eng()
+    B, L, H, V = 3, 7, 64, 50
+    ids = torch.randint(0, V, (B, L), dtype=torch.int32, device="cuda")
+    table = rand_bf(V, H, seed=1); bias = torch.randn(H, device="cuda")
+    tim = e.timing(L + 5, H)
+    for shift in (False, True):
+        out = torch.zeros(B * L, H, dtype=torch.bfloat16, device="cuda")
+        e.embed_fwd(ids, table, bias, mat(out), B, L, H, shift=shift)
+        torch.cuda.synchronize()
+        emb = table.float()[ids.long()] * H ** 0.5 + bias
+        if shift:
+            emb = torch.cat([torch.zeros(B, 1, H, device="cuda"), emb[:, :-1]], 1)
+        ref = emb + tim[:L][None]
+        assert rel_err(out.view(B, L, H), ref) < 5e-3
+        dout = rand_bf(B * L, H, seed=5)
+        dtab = torch.zeros(V, H, device="cuda"); dbias = torch.zeros(H, device="cuda")
+        e.embed_bwd(ids, mat(dout), dtab, dbias, B, L, H, shift=shift)
+        torch.cuda.synchronize()
+        g = dout.float().view(B, L, H)
+        idl = ids.long()
+        if shift:
+            g = g[:, 1:]; idl = idl[:, :-1]
+        ref_t = torch.zeros(V, H, device="cuda").index_add_(0, idl.reshape(-1), g.reshape(-1, H) * H ** 0.5)
+        assert rel_err(dtab, ref_t) < 1e-4 and rel_err(dbias, g.reshape(-1, H).sum(0)) < 1e-4
+    # decode position + zero flag
+    flag = torch.ones(1, dtype=torch.int32, device="cuda")
+    out = torch.zeros(B, H, dtype=torch.bfloat16, device="cuda")
+    e.embed_fwd(ids[:, 0].contiguous(), table, bias, mat(out), B, 1, H, pos0=4, zero_flag=flag)
+    torch.cuda.synchronize()
+    assert rel_err(out, tim[4][None].expand(B, H)) < 5e-3
+
+
+def test_timing_signal_closed_form():
+    from zero_amd.func import timing_table
+    t = timing_table(5, 8)
+    inv = np.exp(-np.arange(4) * math.log(1e4) / 3.0)
+    assert np.allclose(t[3, :4], np.sin(3 * inv), atol=1e-6) and np.allclose(t[3, 4:], np.cos(3 * inv), atol=1e-6)
+
+
+@pytest.mark.parametrize("H", [64, 512, 1024])
+@pytest.mark.parametrize("drop", [0.0, 0.25])
+def test_add_ln_fwd_bwd(H, drop):
+    e = eng()
+    T = 37
+    x = rand_bf(T, H, seed=1); y = rand_bf(T, H, seed=2)
+    gamma = (1 + 0.1 * torch.randn(H)).cuda(); beta = (0.1 * torch.randn(H)).cuda()
+    out = torch.zeros(T, H, dtype=torch.bfloat16, device="cuda"); s = torch.zeros_like(out)
+    mean = torch.zeros(T, device="cuda"); rstd = torch.zeros(T, device="cuda")
+    e.set_seed(5)
+    e.add_ln_fwd(mat(x), mat(y), gamma, beta, mat(out), mat(s), mean, rstd, drop, 3)
+    msk = torch.ones(T * H, device="cuda")
+    if drop > 0:
+        e.lib.call("zk_dropout_mask", msk.data_ptr(), T * H, drop, e.seed.data_ptr(), 3, e.stream)
+    torch.cuda.synchronize()
+    msk = msk.view(T, H)
+    xf = x.float().clone().requires_grad_(True); yf = y.float().clone().requires_grad_(True)
+    gf = gamma.clone().requires_grad_(True); bfp = beta.clone().requires_grad_(True)
+    sf = xf + yf * msk
+    mu = sf.mean(-1, keepdim=True); var = ((sf - mu) ** 2).mean(-1, keepdim=True)
+    ref = gf * (sf - mu) * torch.rsqrt(var + 1e-8) + bfp
+    assert rel_err(out, ref) < 6e-3 and rel_err(s, sf) < 5e-3
+    dout = rand_bf(T, H, seed=3)
+    ref.backward(dout.float())
+    dsum = torch.zeros_like(out); dy = torch.zeros_like(out)
+    dg = torch.zeros(H, device="cuda"); db = torch.zeros(H, device="cuda"); dbp = torch.zeros(H, device="cuda")
+    e.add_ln_bwd(mat(dout), mat(s), mean, rstd, gamma, mat(dsum), mat(dy) if drop > 0 else None, dg, db, dbp,
+                 drop, 3)
+    torch.cuda.synchronize()
+    assert rel_err(dsum, xf.grad) < 1.5e-2, rel_err(dsum, xf.grad)
+    if drop > 0:
+        assert rel_err(dy, yf.grad) < 1.5e-2
+    assert rel_err(dg, gf.grad) < 1.5e-2 and rel_err(db, bfp.grad) < 1e-3
+    assert rel_err(dbp, yf.grad.sum(0)) < 1.5e-2
+
+
+def test_layer_norm_constant_row_gives_offset():
+    # known answer: LN of a constant row is exactly `offset` (eps=1e-8 keeps rstd finite)
+    e = eng()
+    H = 64
+    x = bf(torch.full((2, H), 3.0)).cuda()
+    gamma = torch.ones(H, device="cuda") * 2; beta = torch.randn(H, device="cuda")
+    out = torch.zeros(2, H, dtype=torch.bfloat16, device="cuda")
+    e.add_ln_fwd(mat(x), None, gamma, beta, mat(out))
+    torch.cuda.synchronize()
+    assert max_err(out, bf(beta)[None].expand(2, H)) < 1e-6
+
+
+def test_colsum():
+    e = eng()
+    for rows, N, ld, off in [(100, 64, 64, 0), (4096, 1536, 1536, 0), (300, 128, 256, 128)]:
+        a = rand_bf(rows, ld, seed=1)
+        out = torch.zeros(N, device="cuda")
+        e.colsum(Mat(a, rows, N, ld, off), out)
+        torch.cuda.synchronize()
+        assert rel_err(out, a.float()[:, off:off + N].sum(0)) < 1e-4
+
+
+# ------------------------------------------------------------------ loss
+@pytest.mark.parametrize("V,ld", [(11, 16), (1000, 1000), (32000, 32000), (517, 520)])
+@pytest.mark.parametrize("ls", [0.0, 0.1])
+def test_ce_fused(V, ld, ls):
+    e = eng()
+    T = 19
+    logits = torch.zeros(T, ld, device="cuda")
+    logits[:, :V] = torch.randn(T, V, device="cuda") * 3
+    logits[:, V:] = 777.0   # pad columns must be ignored
+    ids = torch.randint(0, V, (T,), dtype=torch.int32, device="cuda")
+    w = torch.rand(T, device="cuda"); w[3] = 0
+    ce = torch.zeros(T, device="cuda")
+    dl = torch.full((T, ld), 5.0, dtype=torch.bfloat16, device="cuda")
+    e.ce_fused(Mat(logits, T, ld), ids, w, ce, Mat(dl, T, ld), T, V, ls)
+    torch.cuda.synchronize()
+    z = logits[:, :V].clone().requires_grad_(True)
+    if ls > 0:
+        n = V - 1.0; p = 1 - ls; q = ls / n
+        soft = torch.full((T, V), q, device="cuda"); soft[torch.arange(T), ids.long()] = p
+        norm = -(p * math.log(p) + n * q * math.log(q + 1e-20))
+    else:
+        soft = torch.zeros(T, V, device="cuda"); soft[torch.arange(T), ids.long()] = 1.0
+        norm = 0.0
+    ref = -(soft * torch.log_softmax(z, -1)).sum(-1) - norm
+    assert max_err(ce, ref) < 2e-4 * max(1.0, float(ref.abs().max()))
+    (ref * w).sum().backward()
+    assert rel_err(dl[:, :V], z.grad) < 6e-3
+    assert float(dl[:, V:].float().abs().max()) == 0.0 if ld > V else True
+
+
+def test_uniform_logits_known_answer():
+    # all-equal logits: ce = log V - normaliser exactly (label smoothing on)
+    e = eng()
+    V, T, ls = 64, 4, 0.1
+    logits = torch.zeros(T, V, device="cuda")
+    ids = torch.tensor([0, 1, 2, 63], dtype=torch.int32, device="cuda")
+    ce = torch.zeros(T, device="cuda")
+    e.ce_fused(Mat(logits, T, V), ids, None, ce, None, T, V, ls)
+    torch.cuda.synchronize()
+    n = V - 1.0; p = 1 - ls; q = ls / n
+    norm = -(p * math.log(p) + n * q * math.log(q + 1e-20))
+    assert max_err(ce, torch.full((T,), math.log(V) - norm)) < 1e-5
+
+
+def test_target_stats_and_loss_reduce():
+    e = eng()
+    B, L = 4, 6
+    ids = torch.tensor([[5, 6, 2, 0, 0, 0], [7, 8, 9, 10, 11, 2], [3, 2, 0, 0, 0, 0], [4, 4, 4, 2, 0, 0]],
+                       dtype=torch.int32, device="cuda")
+    mask = torch.zeros(B, L, device="cuda"); w = torch.zeros(B, L, device="cuda")
+    e.target_stats(ids, mask, w, B, L, 2.0)
+    ce = torch.rand(B, L, device="cuda")
+    ps = torch.zeros(B, device="cuda"); loss = torch.zeros(1, device="cuda")
+    e.loss_reduce(ce, ids, ps, loss, B, L)
+    torch.cuda.synchronize()
+    m = (ids != 0).float()
+    assert max_err(mask, m) == 0
+    assert max_err(w, 2.0 * m / (m.sum(1, keepdim=True) * B)) < 1e-7
+    ref = (ce * m).sum(1) / m.sum(1)
+    assert max_err(ps, ref) < 1e-6 and abs(float(loss) - float(ref.mean())) < 1e-6
+
+
+# ------------------------------------------------------------------ AAN
+@pytest.mark.parametrize("use_mask", [True, False])
+def test_aan_scan_and_gate(use_mask):
+    e = eng()
+    B, L, H = 3, 9, 64
+    x = rand_bf(B * L, H, seed=1)
+    mask = torch.ones(B, L, device="cuda"); mask[1, 6:] = 0; mask[2, 3:] = 0
+    cat = torch.zeros(B * L, 2 * H, dtype=torch.bfloat16, device="cuda")
+    e.aan_fwd(mat(x), mask, mat(cat), B, L, H, use_mask)
+    torch.cuda.synchronize()
+    xf = x.float().view(B, L, H).clone().requires_grad_(True)
+    if use_mask:   # func.py:390-398
+        cum = torch.cumsum(torch.eye(L, device="cuda"), 0)[None]
+        mm = mask[:, None, :] * mask[:, :, None] * cum
+        wgt = torch.softmax(mm + (1 - mm) * -1e8, -1) * mm
+        y = wgt @ xf
+    else:          # transformer_aan.py:103-108
+        c = torch.cumsum(mask, 1); c = torch.where(c <= 0, torch.ones_like(c), c)
+        y = torch.cumsum(xf, 1) / c[..., None]
+    assert rel_err(cat[:, :H], x) == 0 and rel_err(cat[:, H:], y.reshape(B * L, H)) < 6e-3
+    # gate + backward chain against autograd
+    z = rand_bf(B * L, 2 * H, seed=2)
+    g = torch.zeros(B * L, H, dtype=torch.bfloat16, device="cuda")
+    e.aan_gate_fwd(mat(z), mat(cat), mat(g), B * L, H)
+    zf = z.float().clone().requires_grad_(True)
+    catf = cat.float().clone().requires_grad_(True)
+    gref = torch.sigmoid(zf[:, :H]) * catf[:, :H] + torch.sigmoid(zf[:, H:]) * catf[:, H:]
+    torch.cuda.synchronize()
+    assert rel_err(g, gref) < 6e-3
+    dg = rand_bf(B * L, H, seed=3)
+    gref.backward(dg.float())
+    dz = torch.zeros_like(z); dxg = torch.zeros_like(g); dyg = torch.zeros_like(g)
+    e.aan_gate_bwd(mat(dg), mat(z), mat(cat), mat(dz), mat(dxg), mat(dyg), B * L, H)
+    torch.cuda.synchronize()
+    assert rel_err(dz, zf.grad) < 1e-2 and rel_err(dxg, catf.grad[:, :H]) < 1e-2
+    assert rel_err(dyg, catf.grad[:, H:]) < 1e-2
+    # scan backward: dx = ds + dxg + dcat_x + revscan(dyg + dcat_y)
+    dcat = rand_bf(B * L, 2 * H, seed=4); ds = rand_bf(B * L, H, seed=5)
+    dx = torch.zeros_like(g)
+    e.aan_bwd(mat(dcat), mat(dxg), mat(dyg), mat(ds), mask, mat(dx), B, L, H, use_mask)
+    torch.cuda.synchronize()
+    y.backward((dyg.float() + dcat.float()[:, H:]).view(B, L, H))
+    ref = ds.float() + dxg.float() + dcat.float()[:, :H] + xf.grad.reshape(B * L, H)
+    assert rel_err(dx, ref) < 1e-2
+
+
+# ------------------------------------------------------------------ optimiser
+def test_l2norm_and_adam_tf1_semantics():
+    e = eng()
+    n = 100003
+    n_pad = (n + 3) // 4 * 4
+    p = torch.randn(n_pad, device="cuda"); g = torch.randn(n_pad, device="cuda") * 0.1
+    m = torch.rand(n_pad, device="cuda") * 0.01; v = torch.rand(n_pad, device="cuda") * 0.001
+    sh = torch.zeros(n_pad, dtype=torch.bfloat16, device="cuda")
+    hyper = torch.zeros(8, device="cuda")
+    ws = torch.empty(e.lib.query("zk_norm_workspace"), dtype=torch.uint8, device="cuda")
+    e.lib.call("zk_l2norm", g.data_ptr(), n, 0.5, hyper.data_ptr() + 24, ws.data_ptr(), ws.numel(), e.stream)
+    torch.cuda.synchronize()
+    gn = 0.5 * float(g[:n].double().norm())
+    assert abs(float(hyper[6]) - gn) / gn < 1e-5
+    lr, b1, b2, eps, clip = 0.01, 0.9, 0.98, 1e-8, gn * 0.5
+    hyper[:6] = torch.tensor([lr, b1, b2, eps, 0.5, clip])
+    p0, m0, v0 = p.clone(), m.clone(), v.clone()
+    e.lib.call("zk_adam", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr(), n,
+               hyper.data_ptr(), e.stream)
+    torch.cuda.synchronize()
+    gg = g * 0.5 * (clip / max(gn, clip))
+    m1 = b1 * m0 + (1 - b1) * gg; v1 = b2 * v0 + (1 - b2) * gg * gg
+    p1 = p0 - lr * m1 / (v1.sqrt() + eps)
+    assert max_err(m[:n], m1[:n]) < 1e-7 and max_err(v[:n], v1[:n]) < 1e-8 and max_err(p[:n], p1[:n]) < 1e-6
+    assert max_err(sh[:n], p1[:n].to(torch.bfloat16)) == 0
+    # non-finite norm -> update skipped, flag raised
+    hyper[6] = float("nan")
+    pb = p.clone()
+    e.lib.call("zk_adam", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr(), n,
+               hyper.data_ptr(), e.stream)
+    torch.cuda.synchronize()
+    assert float(hyper[7]) == 1.0 and max_err(p, pb) == 0
+
+
+# ------------------------------------------------------------------ decode tail
+@pytest.mark.parametrize("B,K,V,ld", [(3, 4, 1000, 1000), (2, 1, 37, 40), (5, 4, 32000, 32000)])
+def test_beam_topk(B, K, V, ld):
+    e = eng()
+    logits = torch.zeros(B * K, ld, device="cuda")
+    logits[:, :V] = torch.randn(B * K, V, device="cuda") * 2
+    logits[0, 5] = logits[0, 9] = 6.5   # an exact tie: lower flat index must win
+    prev = torch.randn(B * K, device="cuda")
+    ts = torch.zeros(B, 2 * K, device="cuda"); ti = torch.zeros(B, 2 * K, dtype=torch.int32, device="cuda")
+    pen = 1.2345
+    for forbid in (2, -1):
+        e.lib.call("zk_beam_topk", logits.data_ptr(), prev.data_ptr(), ts.data_ptr(), ti.data_ptr(), B, K, V, ld,
+                   2 * K, 1.0, pen, forbid, 1e8, e.stream)
+        torch.cuda.synchronize()
+        lp = logits[:, :V] - torch.logsumexp(logits[:, :V], -1, keepdim=True)
+        if forbid >= 0:
+            lp[:, forbid] += -1e8
+        sc = ((prev[:, None] + lp) / pen).view(B, K * V).cpu().numpy()
+        idx = np.argsort(-sc, axis=-1, kind="stable")[:, :2 * K]
+        ref_s = np.take_along_axis(sc, idx, -1)
+        assert np.array_equal(ti.cpu().numpy(), idx), (ti.cpu().numpy(), idx)
+        assert np.abs(ts.cpu().numpy() - ref_s).max() < 1e-4
+
+
+def test_gather_rows():
+    e = eng()
+    src = torch.randn(6, 40, device="cuda")
+    idx = torch.tensor([3, 3, 0, 5], dtype=torch.int32, device="cuda")
+    dst = torch.zeros(4, 64, device="cuda")
+    e.lib.call("zk_gather_rows", src.data_ptr(), 160, idx.data_ptr(), dst.data_ptr(), 256, 4, 32 * 4, e.stream)
+    torch.cuda.synchronize()
+    assert max_err(dst[:, :32], src[idx.long(), :32]) == 0 and float(dst[:, 32:].abs().max()) == 0

@@ -1,0 +1,121 @@
+// zk_common.h -- device helpers shared by every kernel of libzero_hip.so (gfx950 only).
+//
+// Conventions
+//   * activations and matrix weights are bf16 stored as raw uint16 ("bf16_t");
+//   * vectors (bias, LayerNorm scale/offset), statistics, losses, gradients of
+//     parameters and optimizer state are fp32;
+//   * every kernel is launched on the stream handed through the C-ABI; nothing
+//     here allocates, synchronises or keeps global state.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+
+#define ZK_WAVE 64
+
+// ---------------------------------------------------------------- error plumbing
+extern thread_local char zk_err_buf[512];
+int zk_set_error(int code, const char* fmt, ...);
+#define ZK_CHECK_ARG(cond, ...)                                   \
+  do {                                                            \
+    if (!(cond)) return zk_set_error(-1, __VA_ARGS__);            \
+  } while (0)
+#define ZK_LAUNCH_CHECK()                                         \
+  do {                                                            \
+    hipError_t e__ = hipGetLastError();                           \
+    if (e__ != hipSuccess)                                        \
+      return zk_set_error((int)e__, "%s:%d launch failed: %s",    \
+                          __FILE__, __LINE__, hipGetErrorString(e__)); \
+  } while (0)
+
+// ---------------------------------------------------------------- bf16 <-> fp32
+__device__ __forceinline__ float bf2f(bf16_t x) {
+  return __uint_as_float(((uint32_t)x) << 16);
+}
+// round-to-nearest-even; NaN stays NaN
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 v;
+  v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
+  v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+  return v;
+}
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over a block of NW waves; every thread gets the result. sm: >= NW floats.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) sm[w] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) r += sm[i];
+  return r;
+}
+template <int NW>
+__device__ __forceinline__ float block_max(float v, float* sm) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) sm[w] = v;
+  __syncthreads();
+  float r = sm[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) r = fmaxf(r, sm[i]);
+  return r;
+}
+
+// ---------------------------------------------------------------- counter-based dropout RNG
+// keep-decision for element `idx` of dropout site `sid` at step seed `seed`:
+// two rounds of a 32-bit multiply-xorshift mixer over (seed, sid, idx).  Stateless, so the
+// backward kernels regenerate the same mask instead of storing it.
+__device__ __forceinline__ uint32_t zk_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU;
+  x ^= x >> 15; x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t zk_rand_u32(uint64_t seed, uint32_t sid, uint64_t idx) {
+  uint32_t a = zk_mix32((uint32_t)seed ^ (sid * 0x9E3779B1u));
+  uint32_t b = zk_mix32((uint32_t)(seed >> 32) + (uint32_t)(idx >> 32) * 0x85EBCA77u + a);
+  return zk_mix32(((uint32_t)idx) * 0xC2B2AE3Du + b);
+}
+// returns the multiplier to apply: 0 if dropped, 1/(1-p) if kept.  thr = p * 2^32 (clamped).
+__device__ __forceinline__ float zk_drop_scale(uint64_t seed, uint32_t sid, uint64_t idx,
+                                               uint32_t thr, float inv_keep) {
+  return zk_rand_u32(seed, sid, idx) >= thr ? inv_keep : 0.f;
+}
+static inline uint32_t zk_drop_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t < 0) t = 0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (uint32_t)t;
+}

@@ -1,0 +1,157 @@
+// zk_decode.hip -- beam-search decode step tail and cache plumbing (gfx950).
+//
+// search.py:143-176: logits / temperature -> log-softmax -> (step 0: forbid EOS by -1e8)
+// -> + previous beam log-prob -> / length penalty -> top-2K over the K*V candidates of each
+// sentence (ties -> lower flat index, the tf.nn.top_k contract).  One fused kernel: the
+// [B*K, V] log-prob tensor and the [B, K*V] score tensor are never materialised.
+// search.py:198-210: beam reordering of the per-beam caches = row gather.
+// transformer_aan.py:110-112: decode-time cumulative average, cache in HBM (fp32).
+#include "zk_common.h"
+
+#define TOPK_MAX 16
+
+__device__ __forceinline__ bool better(float s1, int i1, float s2, int i2) {
+  return (s1 > s2) || (s1 == s2 && i1 < i2);
+}
+
+__global__ void __launch_bounds__(256) k_beam_topk(const float* __restrict__ logits, const float* __restrict__ prev_lp,
+                                                   float* __restrict__ out_s, int* __restrict__ out_i, int K, int V,
+                                                   int ld, int k2, float inv_temp, float penalty, int forbid_id,
+                                                   float forbid_value) {
+  __shared__ float s_lse[TOPK_MAX];
+  __shared__ float sm[8];
+  __shared__ float ls[256][TOPK_MAX + 1];
+  __shared__ int li[256][TOPK_MAX + 1];
+  __shared__ float ws[4];
+  __shared__ int wi[4];
+  __shared__ int wt[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  // 1. per-row log-sum-exp of logits/temperature
+  for (int k = 0; k < K; ++k) {
+    const float* z = logits + ((size_t)b * K + k) * ld;
+    float m = -INFINITY;
+    for (int c = tid; c < V; c += 256) m = fmaxf(m, z[c] * inv_temp);
+    m = block_max<4>(m, sm);
+    float s = 0.f;
+    for (int c = tid; c < V; c += 256) s += __expf(z[c] * inv_temp - m);
+    s = block_sum<4>(s, sm);
+    if (tid == 0) s_lse[k] = m + __logf(s);
+  }
+  __syncthreads();
+  // 2. thread-local top-k2 over a strided slice of the K*V candidates
+  int cnt = 0;
+  for (int t = 0; t < k2; ++t) { ls[tid][t] = -INFINITY; li[tid][t] = 0x7fffffff; }
+  const long total = (long)K * V;
+  for (long f = tid; f < total; f += 256) {
+    const int k = (int)(f / V), v = (int)(f % V);
+    float lp = logits[((size_t)b * K + k) * ld + v] * inv_temp - s_lse[k];
+    if (v == forbid_id) lp += -forbid_value;
+    const float sc = (prev_lp[b * K + k] + lp) / penalty;
+    if (cnt < k2 || sc > ls[tid][k2 - 1]) {
+      int pos = cnt < k2 ? cnt : k2 - 1;
+      while (pos > 0 && sc > ls[tid][pos - 1]) {   // strict: equal scores keep index order
+        ls[tid][pos] = ls[tid][pos - 1];
+        li[tid][pos] = li[tid][pos - 1];
+        --pos;
+      }
+      ls[tid][pos] = sc;
+      li[tid][pos] = (int)f;
+      if (cnt < k2) ++cnt;
+    }
+  }
+  // 3. k2 rounds of block arg-max over the list heads
+  int head = 0;
+  for (int r = 0; r < k2; ++r) {
+    float s = (head < cnt) ? ls[tid][head] : -INFINITY;
+    int i = (head < cnt) ? li[tid][head] : 0x7fffffff;
+    int t = tid;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float s2 = __shfl_xor(s, o, 64);
+      const int i2 = __shfl_xor(i, o, 64);
+      const int t2 = __shfl_xor(t, o, 64);
+      if (better(s2, i2, s, i)) { s = s2; i = i2; t = t2; }
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { ws[tid >> 6] = s; wi[tid >> 6] = i; wt[tid >> 6] = t; }
+    __syncthreads();
+    float bs = ws[0]; int bi = wi[0], bt = wt[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (better(ws[w], wi[w], bs, bi)) { bs = ws[w]; bi = wi[w]; bt = wt[w]; }
+    if (tid == bt) ++head;
+    if (tid == 0) { out_s[b * k2 + r] = bs; out_i[b * k2 + r] = bi; }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_gather_rows(const uint4* __restrict__ src, size_t src_stride16,
+                                                     const int* __restrict__ index, uint4* __restrict__ dst,
+                                                     size_t dst_stride16, size_t row16) {
+  const int r = blockIdx.x;
+  const size_t s = index ? (size_t)index[r] : (size_t)r;
+  for (size_t c = (size_t)blockIdx.y * 256 + threadIdx.x; c < row16; c += (size_t)gridDim.y * 256)
+    dst[(size_t)r * dst_stride16 + c] = src[s * src_stride16 + c];
+}
+
+// cache += x (fp32 running sum); cat = [x | cache * inv_count]
+__global__ void __launch_bounds__(256) k_aan_decode(const bf16_t* __restrict__ x, float* __restrict__ cache,
+                                                    bf16_t* __restrict__ cat, int rows, int H, float inv_count) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int nc = H / 8;
+  if (idx >= (size_t)rows * nc) return;
+  const size_t r = idx / nc;
+  const int c = (int)(idx % nc) * 8;
+  const uint4 xv = *reinterpret_cast<const uint4*>(x + r * H + c);
+  float v[8], o[8];
+  unpack8(xv, v);
+  float* cp = cache + r * H + c;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const float s = cp[j] + v[j]; cp[j] = s; o[j] = s * inv_count; }
+  *reinterpret_cast<uint4*>(cat + r * 2 * H + c) = xv;
+  *reinterpret_cast<uint4*>(cat + r * 2 * H + H + c) = pack8(o);
+}
+
+extern "C" {
+
+// logits: fp32 [B*K, ld]; prev_log_probs: fp32 [B*K]; outputs fp32/int32 [B, k2]
+// (topk_index = beam*V + symbol).  forbid_id < 0 disables the EOS ban.
+int zk_beam_topk(const float* logits, const float* prev_log_probs, float* topk_scores, int* topk_index, int B,
+                 int K, int V, int ld, int k2, float temperature, float length_penalty, int forbid_id,
+                 float forbid_value, hipStream_t stream) {
+  ZK_CHECK_ARG(k2 >= 1 && k2 <= TOPK_MAX && K >= 1 && K <= TOPK_MAX, "zk_beam_topk: K=%d, k2=%d out of range (<=%d)",
+               K, k2, TOPK_MAX);
+  ZK_CHECK_ARG((long)K * V >= k2, "zk_beam_topk: fewer candidates than k2");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(k_beam_topk, dim3(B), dim3(256), 0, stream, logits, prev_log_probs, topk_scores, topk_index, K,
+                     V, ld, k2, 1.f / temperature, length_penalty, forbid_id, forbid_value);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+// dst row r <- src row index[r] (index NULL: r); strides and row_bytes in bytes, multiples of 16
+int zk_gather_rows(const void* src, size_t src_stride, const int* index, void* dst, size_t dst_stride, int rows,
+                   size_t row_bytes, hipStream_t stream) {
+  ZK_CHECK_ARG(src_stride % 16 == 0 && dst_stride % 16 == 0 && row_bytes % 16 == 0,
+               "zk_gather_rows: strides / row_bytes must be multiples of 16");
+  ZK_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "zk_gather_rows: pointers must be 16-byte aligned");
+  if (rows == 0 || row_bytes == 0) return 0;
+  const size_t row16 = row_bytes / 16;
+  int gy = (int)((row16 + 255) / 256);
+  if (gy > 64) gy = 64;
+  hipLaunchKernelGGL(k_gather_rows, dim3(rows, gy), dim3(256), 0, stream, (const uint4*)src, src_stride / 16, index,
+                     (uint4*)dst, dst_stride / 16, row16);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_aan_decode(const void* x, float* cache, void* cat, int rows, int H, float inv_count, hipStream_t stream) {
+  ZK_CHECK_ARG(H % 8 == 0, "zk_aan_decode: H=%d must be a multiple of 8", H);
+  const size_t n = (size_t)rows * (H / 8);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_aan_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, cache,
+                     (bf16_t*)cat, rows, H, inv_count);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,964 @@
+// zk_elem.hip -- HBM-bound kernels of the Transformer hot path (gfx950).
+//
+// Every kernel here is bandwidth-bound: 16-byte vector accesses, one wave64 per
+// token row with shuffle reductions, fp32 math on bf16 storage.  Reference
+// semantics are cited per kernel (paths relative to bzhangGo/zero).
+#include "zk_common.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+thread_local char zk_err_buf[512] = {0};
+int zk_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(zk_err_buf, sizeof(zk_err_buf), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define MAXC 4  // row kernels keep up to MAXC*64*8 = 2048 channels in registers
+
+// =====================================================================================
+// K1  embedding + sqrt(H) scale + shared bias + timing signal (+ dropout)
+//     transformer.py:16-33 (encoder), 88-119 (decoder: shifted, zero first input,
+//     decode-time zeroing when every fed id is pad), func.py:341-369 (timing table is
+//     precomputed on the host: [Lmax, H], first H/2 sin, last H/2 cos).
+// =====================================================================================
+__global__ void __launch_bounds__(256) k_embed_fwd(
+    const int* __restrict__ ids, const bf16_t* __restrict__ table, const float* __restrict__ bias,
+    const float* __restrict__ timing, bf16_t* __restrict__ out, int rows, int L, int H,
+    float scale, int shift, int pos0, const int* __restrict__ zero_flag, uint32_t thr,
+    float inv_keep, const uint64_t* __restrict__ seedp, uint32_t sid) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint64_t seed = (thr != 0) ? *seedp : 0;
+  const bool zero_all = (zero_flag != nullptr) && (*zero_flag != 0);
+  for (int r = wave; r < rows; r += nwaves) {
+    const int t = r % L;
+    int id = -1;
+    if (!zero_all) {
+      if (shift) { if (t > 0) id = ids[r - 1]; }
+      else id = ids[r];
+    }
+    const float* tim = timing + (size_t)(pos0 + t) * H;
+    for (int c = lane * 8; c < H; c += 64 * 8) {
+      float v[8];
+      if (id >= 0) {
+        uint4 e = *reinterpret_cast<const uint4*>(table + (size_t)id * H + c);
+        unpack8(e, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * scale + bias[c + j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += tim[c + j];
+      if (thr != 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[j] *= zk_drop_scale(seed, sid, (uint64_t)r * H + c + j, thr, inv_keep);
+      }
+      *reinterpret_cast<uint4*>(out + (size_t)r * H + c) = pack8(v);
+    }
+  }
+}
+
+// backward: dtable[id] += scale * dout (*dropmask); dbias += dout (*dropmask) on rows that
+// had an embedding (transformer.py:29-30,104-110).  fp32 hardware atomics.
+__global__ void __launch_bounds__(256) k_embed_bwd(
+    const int* __restrict__ ids, const bf16_t* __restrict__ dout, float* __restrict__ dtable,
+    float* __restrict__ dbias, int rows, int L, int H, float scale, int shift, uint32_t thr,
+    float inv_keep, const uint64_t* __restrict__ seedp, uint32_t sid) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint64_t seed = (thr != 0) ? *seedp : 0;
+  for (int c = lane * 8; c < H; c += 64 * 8) {
+    float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = wave; r < rows; r += nwaves) {
+      const int t = r % L;
+      int id;
+      if (shift) { if (t == 0) continue; id = ids[r - 1]; }
+      else id = ids[r];
+      float v[8];
+      unpack8(*reinterpret_cast<const uint4*>(dout + (size_t)r * H + c), v);
+      if (thr != 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[j] *= zk_drop_scale(seed, sid, (uint64_t)r * H + c + j, thr, inv_keep);
+      }
+      float* dst = dtable + (size_t)id * H + c;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        unsafeAtomicAdd(dst + j, v[j] * scale);
+        bsum[j] += v[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) unsafeAtomicAdd(dbias + c + j, bsum[j]);
+  }
+}
+
+// =====================================================================================
+// K4  residual (+dropout) + LayerNorm, forward:  s = x + drop(y);  out = LN(s)
+//     func.py:321-324 (residual_fn), func.py:289-303 (layer_norm: biased variance,
+//     eps=1e-8 inside rsqrt), post-LN order of transformer.py:57-58.
+//     s is stored (bf16) for the backward; statistics are taken from the stored values.
+// =====================================================================================
+__global__ void __launch_bounds__(256) k_add_ln_fwd(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, const float* __restrict__ gamma,
+    const float* __restrict__ beta, bf16_t* __restrict__ out, bf16_t* __restrict__ sum_out,
+    float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, int H, float eps,
+    uint32_t thr, float inv_keep, const uint64_t* __restrict__ seedp, uint32_t sid) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint64_t seed = (thr != 0) ? *seedp : 0;
+  const float invH = 1.f / (float)H;
+  for (int r = wave; r < rows; r += nwaves) {
+    float v[MAXC][8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < H) {
+        float a[8], b[8];
+        unpack8(*reinterpret_cast<const uint4*>(x + (size_t)r * H + c), a);
+        if (y != nullptr) {
+          unpack8(*reinterpret_cast<const uint4*>(y + (size_t)r * H + c), b);
+          if (thr != 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              b[j] *= zk_drop_scale(seed, sid, (uint64_t)r * H + c + j, thr, inv_keep);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[j] += b[j];
+        }
+        uint4 p = pack8(a);
+        if (sum_out != nullptr) *reinterpret_cast<uint4*>(sum_out + (size_t)r * H + c) = p;
+        unpack8(p, v[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s1 += v[i][j];
+      }
+    }
+    const float mean = wave_sum(s1) * invH;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < H) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; s2 += d * d; }
+      }
+    }
+    const float var = wave_sum(s2) * invH;
+    const float rstd = rsqrtf(var + eps);
+    if (lane == 0 && mean_out != nullptr) { mean_out[r] = mean; rstd_out[r] = rstd; }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < H) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = gamma[c + j] * (v[i][j] - mean) * rstd + beta[c + j];
+        *reinterpret_cast<uint4*>(out + (size_t)r * H + c) = pack8(o);
+      }
+    }
+  }
+}
+
+// backward of the above.  Per row: xhat=(s-mean)*rstd, g=dout*gamma,
+//   ds = rstd*(g - mean(g) - xhat*mean(g*xhat));  dy = ds * dropmask/(1-p).
+// Per column (reduced over rows): dgamma=sum dout*xhat, dbeta=sum dout, dbias_prev=sum dy
+// (the bias of the linear layer that produced y).  Stage 1 writes one partial row per
+// block to `partials` [gridDim.x][3][H]; k_partials_reduce finishes.
+__global__ void __launch_bounds__(256) k_add_ln_bwd(
+    const bf16_t* __restrict__ dout, const bf16_t* __restrict__ s, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, bf16_t* __restrict__ dsum,
+    bf16_t* __restrict__ dy, float* __restrict__ partials, int rows, int H, uint32_t thr,
+    float inv_keep, const uint64_t* __restrict__ seedp, uint32_t sid) {
+  __shared__ float red[4][3][8 * 64];  // per wave, per quantity, one 512-column slab at a time
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + w;
+  const int nwaves = gridDim.x * 4;
+  const uint64_t seed = (thr != 0) ? *seedp : 0;
+  const float invH = 1.f / (float)H;
+  float acc[3][MAXC][8];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[q][i][j] = 0.f;
+
+  for (int r = wave; r < rows; r += nwaves) {
+    const float mu = mean[r], rs = rstd[r];
+    float xh[MAXC][8], g[MAXC][8];
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < H) {
+        float d[8], sv[8];
+        unpack8(*reinterpret_cast<const uint4*>(dout + (size_t)r * H + c), d);
+        unpack8(*reinterpret_cast<const uint4*>(s + (size_t)r * H + c), sv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          xh[i][j] = (sv[j] - mu) * rs;
+          g[i][j] = d[j] * gamma[c + j];
+          sg += g[i][j];
+          sgx += g[i][j] * xh[i][j];
+          acc[0][i][j] += d[j] * xh[i][j];
+          acc[1][i][j] += d[j];
+        }
+      }
+    }
+    const float mg = wave_sum(sg) * invH;
+    const float mgx = wave_sum(sgx) * invH;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < H) {
+        float o[8], oy[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rs * (g[i][j] - mg - xh[i][j] * mgx);
+        uint4 p = pack8(o);
+        *reinterpret_cast<uint4*>(dsum + (size_t)r * H + c) = p;
+        unpack8(p, o);  // dy derives from the stored (rounded) ds
+        if (thr != 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            oy[j] = o[j] * zk_drop_scale(seed, sid, (uint64_t)r * H + c + j, thr, inv_keep);
+          if (dy != nullptr) {
+            uint4 py = pack8(oy);
+            *reinterpret_cast<uint4*>(dy + (size_t)r * H + c) = py;
+            unpack8(py, oy);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) oy[j] = o[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[2][i][j] += oy[j];
+      }
+    }
+  }
+  // cross-wave reduction, one 512-column slab (i) at a time
+  for (int i = 0; i < MAXC; ++i) {
+    if (i * 512 >= H) break;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[w][q][lane * 8 + j] = acc[q][i][j];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 3 * 512; idx += 256) {
+      const int q = idx / 512, cc = idx % 512;
+      const int c = i * 512 + cc;
+      if (c < H) {
+        const float t = red[0][q][cc] + red[1][q][cc] + red[2][q][cc] + red[3][q][cc];
+        partials[((size_t)blockIdx.x * 3 + q) * H + c] = t;
+      }
+    }
+  }
+}
+
+// out_q[c] = sum_b partials[b][q][c]   (q < nq; out pointers may be null)
+__global__ void __launch_bounds__(256) k_partials_reduce(const float* __restrict__ partials, int nblk,
+                                                         int nq, int H, float* o0, float* o1,
+                                                         float* o2) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nq * H) return;
+  const int q = idx / H, c = idx % H;
+  float* o = q == 0 ? o0 : (q == 1 ? o1 : o2);
+  if (o == nullptr) return;
+  float t = 0.f;
+  for (int b = 0; b < nblk; ++b) t += partials[((size_t)b * nq + q) * H + c];
+  o[c] = t;
+}
+
+// =====================================================================================
+// column sum of a bf16 [rows, N] matrix (bias gradients; func.py:58-60 bias_add backward)
+// stage 1: block = 64 columns x row-chunk -> partials[gridDim.y][N]
+// =====================================================================================
+__global__ void __launch_bounds__(256) k_colsum(const bf16_t* __restrict__ a, int rows, int N, int lda,
+                                                float* __restrict__ partials) {
+  __shared__ float red[32][64 + 1];
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * 64 + tx * 8;
+  const int rpb = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rpb;
+  const int r1 = min(rows, r0 + rpb);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c0 < N) {
+    for (int r = r0 + ty; r < r1; r += 32) {
+      float v[8];
+      unpack8(*reinterpret_cast<const uint4*>(a + (size_t)r * lda + c0), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ty][tx * 8 + j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < N) {
+      float t = 0.f;
+      for (int i = 0; i < 32; ++i) t += red[i][threadIdx.x];
+      partials[(size_t)blockIdx.y * N + c] = t;
+    }
+  }
+}
+
+// =====================================================================================
+// K6  label-smoothed cross entropy, fused forward + backward on fp32 logits
+//     util.py:88-103 (soft labels p on gold, q=eps/(V-1) elsewhere, normaliser),
+//     transformer.py:198-207.  Closed form (sum of soft labels is 1):
+//        ce = lse - p*z_gold - q*(sum_z - z_gold) - normaliser
+//        dlogits = w_row * (softmax(z) - soft)        (never materialises soft labels)
+//     One block per token row; pass 1 streams the row from HBM (online max/sum), pass 2
+//     re-reads it from L2 and writes bf16 dlogits.
+// =====================================================================================
+__global__ void __launch_bounds__(256) k_ce_fused(
+    const float* __restrict__ logits, const int* __restrict__ ids, const float* __restrict__ w,
+    float* __restrict__ ce_out, bf16_t* __restrict__ dlogits, int V, int ld, float p, float q,
+    float normalizer) {
+  __shared__ float sm[8];
+  const int r = blockIdx.x;
+  const float* z = logits + (size_t)r * ld;
+  const float wr = (w != nullptr) ? w[r] : 0.f;
+  const bool need_bwd = dlogits != nullptr;
+  const int gold = ids[r];
+  // pass 1
+  float m = -INFINITY, s = 0.f, sz = 0.f;
+  const int V4 = V & ~3;
+  for (int c = threadIdx.x * 4; c < V4; c += 256 * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(z + c);
+    const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    if (mx > m) { s *= __expf(m - mx); m = mx; }
+    s += __expf(v.x - m) + __expf(v.y - m) + __expf(v.z - m) + __expf(v.w - m);
+    sz += (v.x + v.y) + (v.z + v.w);
+  }
+  for (int c = V4 + threadIdx.x; c < V; c += 256) {
+    const float v = z[c];
+    if (v > m) { s *= __expf(m - v); m = v; }
+    s += __expf(v - m);
+    sz += v;
+  }
+  const float gm = block_max<4>(m, sm);
+  s = (m == -INFINITY) ? 0.f : s * __expf(m - gm);
+  const float gs = block_sum<4>(s, sm);
+  const float gsz = block_sum<4>(sz, sm);
+  const float lse = gm + __logf(gs);
+  const float zg = z[gold];
+  if (threadIdx.x == 0 && ce_out != nullptr)
+    ce_out[r] = lse - p * zg - q * (gsz - zg) - normalizer;
+  if (!need_bwd) return;
+  bf16_t* d = dlogits + (size_t)r * ld;
+  if (wr == 0.f) {
+    for (int c = threadIdx.x * 4; c < ld; c += 256 * 4)
+      *reinterpret_cast<uint2*>(d + c) = make_uint2(0u, 0u);
+    return;
+  }
+  for (int c = threadIdx.x * 4; c < ld; c += 256 * 4) {
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cc = c + j;
+      if (cc < V) {
+        const float sl = (cc == gold) ? p : q;
+        o[j] = wr * (__expf(z[cc] - lse) - sl);
+      } else o[j] = 0.f;
+    }
+    *reinterpret_cast<uint2*>(d + c) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+  }
+}
+
+// target statistics: mask=(id!=0), w = loss_scale*mask/(len_b*B) (gradient weight of each
+// token under loss = mean_b( sum_t ce*mask / sum_t mask ), transformer.py:209-211)
+__global__ void __launch_bounds__(256) k_target_stats(const int* __restrict__ ids, float* __restrict__ mask,
+                                                      float* __restrict__ w, int B, int L,
+                                                      float loss_scale) {
+  __shared__ float sm[8];
+  const int b = blockIdx.x;
+  float cnt = 0.f;
+  for (int t = threadIdx.x; t < L; t += 256) cnt += (ids[b * L + t] != 0) ? 1.f : 0.f;
+  const float len = block_sum<4>(cnt, sm);
+  for (int t = threadIdx.x; t < L; t += 256) {
+    const float mk = (ids[b * L + t] != 0) ? 1.f : 0.f;
+    if (mask != nullptr) mask[b * L + t] = mk;
+    if (w != nullptr) w[b * L + t] = loss_scale * mk / (len * (float)B);
+  }
+}
+
+// per_sample[b] = sum_t ce*mask / sum_t mask ; loss = mean_b per_sample (0 if B==0)
+__global__ void __launch_bounds__(256) k_loss_reduce(const float* __restrict__ ce, const int* __restrict__ ids,
+                                                     float* __restrict__ per_sample,
+                                                     float* __restrict__ loss, int B, int L) {
+  __shared__ float sm[8];
+  float tot = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float a = 0.f, c = 0.f;
+    for (int t = threadIdx.x; t < L; t += 256) {
+      const float mk = (ids[b * L + t] != 0) ? 1.f : 0.f;
+      a += ce[b * L + t] * mk;
+      c += mk;
+    }
+    a = block_sum<4>(a, sm);
+    c = block_sum<4>(c, sm);
+    const float ps = a / c;
+    if (threadIdx.x == 0 && per_sample != nullptr) per_sample[b] = ps;
+    tot += ps;
+  }
+  if (threadIdx.x == 0 && loss != nullptr) loss[0] = (B > 0) ? tot / (float)B : 0.f;
+}
+
+__global__ void __launch_bounds__(256) k_make_mask(const int* __restrict__ ids, float* __restrict__ mask, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) mask[i] = (ids[i] != 0) ? 1.f : 0.f;
+}
+
+// flag = 1 iff every id equals `value` (transformer.py:113 reduce_all over the batch)
+__global__ void __launch_bounds__(256) k_all_equal(const int* __restrict__ ids, int n, int value, int* flag) {
+  __shared__ float sm[8];
+  float bad = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) bad += (ids[i] != value) ? 1.f : 0.f;
+  bad = block_sum<4>(bad, sm);
+  if (threadIdx.x == 0) *flag = (bad == 0.f) ? 1 : 0;
+}
+
+// =====================================================================================
+// K5  average attention network: cumulative average over time (transformer_aan.py:92-117)
+//     use_mask=1 (aan_mask=True, func.py:390-398): y_i = m_i * sum_{j<=i} m_j x_j / max(c_i,1)
+//     use_mask=0 (cumsum variant):                  y_i = sum_{j<=i} x_j / (c_i<=0 ? 1 : c_i)
+//     with c_i = sum_{j<=i} m_j.  Writes cat = [x | y]  ([T, 2H]) for the gate GEMM.
+//     O(L*H) scan instead of the reference's [B,L,L]x[B,L,H] matmul.
+// =====================================================================================
+__global__ void __launch_bounds__(256) k_aan_fwd(const bf16_t* __restrict__ x, const float* __restrict__ mask,
+                                                 bf16_t* __restrict__ cat, int B, int L, int H,
+                                                 int use_mask) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int nc = H / 8;
+  if (idx >= B * nc) return;
+  const int b = idx / nc, c = (idx % nc) * 8;
+  float run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float cnt = 0.f;
+  for (int t = 0; t < L; ++t) {
+    const size_t r = (size_t)b * L + t;
+    const float m = mask[r];
+    const uint4 xv = *reinterpret_cast<const uint4*>(x + r * H + c);
+    float v[8], o[8];
+    unpack8(xv, v);
+    cnt += m;
+    const float den = use_mask ? fmaxf(cnt, 1.f) : (cnt <= 0.f ? 1.f : cnt);
+    const float wi = use_mask ? m : 1.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      run[j] += wi * v[j];
+      o[j] = (use_mask ? m : 1.f) * run[j] / den;
+    }
+    *reinterpret_cast<uint4*>(cat + r * 2 * H + c) = xv;
+    *reinterpret_cast<uint4*>(cat + r * 2 * H + H + c) = pack8(o);
+  }
+}
+
+// dx_total = ds + dx_gate + dcat[:, :H] + reverse_scan(dy_gate + dcat[:, H:])
+//   reverse scan: dx_j = w_j * sum_{i>=j} a_i * dy_i   with a_i = (use_mask? m_i : 1)/den_i
+__global__ void __launch_bounds__(256) k_aan_bwd(const bf16_t* __restrict__ dcat, const bf16_t* __restrict__ dxg,
+                                                 const bf16_t* __restrict__ dyg, const bf16_t* __restrict__ ds,
+                                                 const float* __restrict__ mask, bf16_t* __restrict__ dx,
+                                                 int B, int L, int H, int use_mask) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int nc = H / 8;
+  if (idx >= B * nc) return;
+  const int b = idx / nc, c = (idx % nc) * 8;
+  float total = 0.f;
+  for (int t = 0; t < L; ++t) total += mask[(size_t)b * L + t];
+  float run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float cnt = total;
+  for (int t = L - 1; t >= 0; --t) {
+    const size_t r = (size_t)b * L + t;
+    const float m = mask[r];
+    const float den = use_mask ? fmaxf(cnt, 1.f) : (cnt <= 0.f ? 1.f : cnt);
+    const float a = (use_mask ? m : 1.f) / den;
+    float g1[8], g2[8], dc1[8], dc2[8], d0[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(dcat + r * 2 * H + c), dc1);
+    unpack8(*reinterpret_cast<const uint4*>(dcat + r * 2 * H + H + c), dc2);
+    unpack8(*reinterpret_cast<const uint4*>(dxg + r * H + c), g1);
+    unpack8(*reinterpret_cast<const uint4*>(dyg + r * H + c), g2);
+    unpack8(*reinterpret_cast<const uint4*>(ds + r * H + c), d0);
+    const float wj = use_mask ? m : 1.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      run[j] += a * (g2[j] + dc2[j]);
+      o[j] = d0[j] + g1[j] + dc1[j] + wj * run[j];
+    }
+    *reinterpret_cast<uint4*>(dx + r * H + c) = pack8(o);
+    cnt -= m;
+  }
+}
+
+// gate (transformer_aan.py:186-189): i,f = split(z); out = sigmoid(i)*x + sigmoid(f)*y
+// x = cat[:, :H], y = cat[:, H:]
+__global__ void __launch_bounds__(256) k_aan_gate_fwd(const bf16_t* __restrict__ z, const bf16_t* __restrict__ cat,
+                                                      bf16_t* __restrict__ out, int rows, int H) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int nc = H / 8;
+  if (idx >= (size_t)rows * nc) return;
+  const size_t r = idx / nc;
+  const int c = (int)(idx % nc) * 8;
+  float zi[8], zf[8], xv[8], yv[8], o[8];
+  unpack8(*reinterpret_cast<const uint4*>(z + r * 2 * H + c), zi);
+  unpack8(*reinterpret_cast<const uint4*>(z + r * 2 * H + H + c), zf);
+  unpack8(*reinterpret_cast<const uint4*>(cat + r * 2 * H + c), xv);
+  unpack8(*reinterpret_cast<const uint4*>(cat + r * 2 * H + H + c), yv);
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    o[j] = xv[j] / (1.f + __expf(-zi[j])) + yv[j] / (1.f + __expf(-zf[j]));
+  *reinterpret_cast<uint4*>(out + r * H + c) = pack8(o);
+}
+
+__global__ void __launch_bounds__(256) k_aan_gate_bwd(const bf16_t* __restrict__ dg, const bf16_t* __restrict__ z,
+                                                      const bf16_t* __restrict__ cat, bf16_t* __restrict__ dz,
+                                                      bf16_t* __restrict__ dxg, bf16_t* __restrict__ dyg,
+                                                      int rows, int H) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int nc = H / 8;
+  if (idx >= (size_t)rows * nc) return;
+  const size_t r = idx / nc;
+  const int c = (int)(idx % nc) * 8;
+  float g[8], zi[8], zf[8], xv[8], yv[8], dzi[8], dzf[8], dx[8], dy[8];
+  unpack8(*reinterpret_cast<const uint4*>(dg + r * H + c), g);
+  unpack8(*reinterpret_cast<const uint4*>(z + r * 2 * H + c), zi);
+  unpack8(*reinterpret_cast<const uint4*>(z + r * 2 * H + H + c), zf);
+  unpack8(*reinterpret_cast<const uint4*>(cat + r * 2 * H + c), xv);
+  unpack8(*reinterpret_cast<const uint4*>(cat + r * 2 * H + H + c), yv);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float si = 1.f / (1.f + __expf(-zi[j]));
+    const float sf = 1.f / (1.f + __expf(-zf[j]));
+    dzi[j] = g[j] * xv[j] * si * (1.f - si);
+    dzf[j] = g[j] * yv[j] * sf * (1.f - sf);
+    dx[j] = g[j] * si;
+    dy[j] = g[j] * sf;
+  }
+  *reinterpret_cast<uint4*>(dz + r * 2 * H + c) = pack8(dzi);
+  *reinterpret_cast<uint4*>(dz + r * 2 * H + H + c) = pack8(dzf);
+  *reinterpret_cast<uint4*>(dxg + r * H + c) = pack8(dx);
+  *reinterpret_cast<uint4*>(dyg + r * H + c) = pack8(dy);
+}
+
+// =====================================================================================
+// K7  optimiser: global norm, clip, TF1 Adam on flat fp32 buffers (utils/cycle.py:86-101,
+//     tf.train.AdamOptimizer: m,v EMA, theta -= lr_t*m/(sqrt(v)+eps), eps outside sqrt,
+//     lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed on the host and read from `hyper`)
+//     hyper (device floats): [0] lr_t  [1] beta1  [2] beta2  [3] eps  [4] grad_scale
+//                            [5] clip_norm (0 = off)  [6] gnorm (in)  [7] skipped-flag (out)
+//     The bf16 shadow copy used by the GEMMs is refreshed in the same pass
+//     (utils/dtype.py:55-69 fp32 storage / low-precision compute contract).
+// =====================================================================================
+__global__ void __launch_bounds__(256) k_sumsq_partial(const float* __restrict__ x, size_t n,
+                                                       float* __restrict__ partials) {
+  __shared__ float sm[8];
+  float acc = 0.f;
+  const size_t n4 = n / 4;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = x4[i];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    acc += x[i] * x[i];
+  acc = block_sum<4>(acc, sm);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+__global__ void __launch_bounds__(256) k_norm_final(const float* __restrict__ partials, int n, float scale,
+                                                    float* __restrict__ out) {
+  __shared__ float sm[8];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+  acc = block_sum<4>(acc, sm);
+  if (threadIdx.x == 0) out[0] = scale * sqrtf(acc);
+}
+
+__global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g,
+                                              float* __restrict__ m, float* __restrict__ v,
+                                              bf16_t* __restrict__ shadow, size_t n,
+                                              float* __restrict__ hyper) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
+  const float gs = hyper[4], clip = hyper[5], gnorm = hyper[6];
+  if (!(gnorm == gnorm) || fabsf(gnorm) == INFINITY) {  // NaN/Inf guard (main.py:316-319)
+    if (blockIdx.x == 0 && threadIdx.x == 0) hyper[7] = 1.f;
+    return;
+  }
+  float f = gs;
+  if (clip > 0.f) f *= clip / fmaxf(gnorm, clip);  // tf.clip_by_global_norm
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* P = &pp.x; const float* G = &gg.x; float* M = &mm.x; float* Vv = &vv.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gj = G[j] * f;
+      M[j] = b1 * M[j] + (1.f - b1) * gj;
+      Vv[j] = b2 * Vv[j] + (1.f - b2) * gj * gj;
+      P[j] -= lr * M[j] / (sqrtf(Vv[j]) + eps);
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    if (shadow != nullptr)
+      reinterpret_cast<uint2*>(shadow)[i] = make_uint2(pack2bf(P[0], P[1]), pack2bf(P[2], P[3]));
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float gj = g[i] * f;
+    m[i] = b1 * m[i] + (1.f - b1) * gj;
+    v[i] = b2 * v[i] + (1.f - b2) * gj * gj;
+    p[i] -= lr * m[i] / (sqrtf(v[i]) + eps);
+    if (shadow != nullptr) shadow[i] = f2bf(p[i]);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_cast_f32_bf16(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    reinterpret_cast<uint2*>(y)[i] = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w));
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    y[i] = f2bf(x[i]);
+}
+__global__ void __launch_bounds__(256) k_cast_bf16_f32(const bf16_t* __restrict__ x, float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    y[i] = bf2f(x[i]);
+}
+// y += a * x  (gradient accumulation slots of utils/cycle.py:27-36,86-88)
+__global__ void __launch_bounds__(256) k_axpy_f32(float* __restrict__ y, const float* __restrict__ x, float a,
+                                                  float by, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    y[i] = by * y[i] + a * x[i];
+}
+__global__ void __launch_bounds__(256) k_dropout_mask(float* __restrict__ out, size_t n, uint32_t thr,
+                                                      float inv_keep, const uint64_t* __restrict__ seedp,
+                                                      uint32_t sid) {
+  const uint64_t seed = *seedp;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    out[i] = thr ? zk_drop_scale(seed, sid, i, thr, inv_keep) : 1.f;
+}
+__global__ void k_seed_advance(uint64_t* seed, uint64_t inc) { *seed += inc; }
+
+// =====================================================================================
+// C-ABI
+// =====================================================================================
+static inline int row_grid(int rows) {
+  int g = (rows + 3) / 4;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return g;
+}
+static inline int flat_grid(size_t n, int per_thread) {
+  size_t g = (n / per_thread + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" {
+
+const char* zk_last_error_string(void) { return zk_err_buf; }
+int zk_version(void) { return 100; }
+
+int zk_embed_fwd(const int* ids, const void* table, const float* bias, const float* timing, void* out,
+                 int B, int L, int H, float scale, int shift, int pos0, const int* zero_flag,
+                 float drop_p, const uint64_t* seed, uint32_t sid, hipStream_t stream) {
+  ZK_CHECK_ARG(H % 8 == 0, "zk_embed_fwd: H=%d must be a multiple of 8", H);
+  ZK_CHECK_ARG(drop_p == 0.f || seed != nullptr, "zk_embed_fwd: dropout needs a seed pointer");
+  const int rows = B * L;
+  if (rows == 0) return 0;
+  const uint32_t thr = drop_p > 0.f ? zk_drop_threshold(drop_p) : 0;
+  const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  hipLaunchKernelGGL(k_embed_fwd, dim3(row_grid(rows)), dim3(256), 0, stream, ids, (const bf16_t*)table,
+                     bias, timing, (bf16_t*)out, rows, L, H, scale, shift, pos0, zero_flag, thr, ik,
+                     seed, sid);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_embed_bwd(const int* ids, const void* dout, float* dtable, float* dbias, int B, int L, int H,
+                 float scale, int shift, float drop_p, const uint64_t* seed, uint32_t sid,
+                 hipStream_t stream) {
+  ZK_CHECK_ARG(H % 8 == 0, "zk_embed_bwd: H=%d must be a multiple of 8", H);
+  const int rows = B * L;
+  if (rows == 0) return 0;
+  const uint32_t thr = drop_p > 0.f ? zk_drop_threshold(drop_p) : 0;
+  const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  int g = (rows + 3) / 4;
+  if (g > 256) g = 256;
+  hipLaunchKernelGGL(k_embed_bwd, dim3(g), dim3(256), 0, stream, ids, (const bf16_t*)dout, dtable, dbias,
+                     rows, L, H, scale, shift, thr, ik, seed, sid);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_add_ln_fwd(const void* x, const void* y, const float* gamma, const float* beta, void* out,
+                  void* sum_out, float* mean, float* rstd, int rows, int H, float eps, float drop_p,
+                  const uint64_t* seed, uint32_t sid, hipStream_t stream) {
+  ZK_CHECK_ARG(H % 8 == 0 && H <= MAXC * 512, "zk_add_ln_fwd: H=%d must be a multiple of 8 and <= %d", H,
+               MAXC * 512);
+  ZK_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "zk_add_ln_fwd: mean/rstd must both be given");
+  if (rows == 0) return 0;
+  const uint32_t thr = (drop_p > 0.f && y != nullptr) ? zk_drop_threshold(drop_p) : 0;
+  const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  hipLaunchKernelGGL(k_add_ln_fwd, dim3(row_grid(rows)), dim3(256), 0, stream, (const bf16_t*)x,
+                     (const bf16_t*)y, gamma, beta, (bf16_t*)out, (bf16_t*)sum_out, mean, rstd, rows, H,
+                     eps, thr, ik, seed, sid);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t zk_add_ln_bwd_workspace(int rows, int H) {
+  int g = (rows + 15) / 16;
+  if (g > 256) g = 256;
+  if (g < 1) g = 1;
+  return (size_t)g * 3 * H * sizeof(float);
+}
+
+int zk_add_ln_bwd(const void* dout, const void* sum, const float* mean, const float* rstd,
+                  const float* gamma, void* dsum, void* dy, float* dgamma, float* dbeta, float* dbias_prev,
+                  int rows, int H, float drop_p, const uint64_t* seed, uint32_t sid, void* workspace,
+                  size_t ws_bytes, hipStream_t stream) {
+  ZK_CHECK_ARG(H % 8 == 0 && H <= MAXC * 512, "zk_add_ln_bwd: H=%d must be a multiple of 8 and <= %d", H,
+               MAXC * 512);
+  ZK_CHECK_ARG(ws_bytes >= zk_add_ln_bwd_workspace(rows, H), "zk_add_ln_bwd: workspace too small");
+  ZK_CHECK_ARG(drop_p == 0.f || dy != nullptr, "zk_add_ln_bwd: dropout needs a dy output");
+  if (rows == 0) return 0;
+  int g = (rows + 15) / 16;
+  if (g > 256) g = 256;
+  const uint32_t thr = drop_p > 0.f ? zk_drop_threshold(drop_p) : 0;
+  const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  hipLaunchKernelGGL(k_add_ln_bwd, dim3(g), dim3(256), 0, stream, (const bf16_t*)dout, (const bf16_t*)sum,
+                     mean, rstd, gamma, (bf16_t*)dsum, (bf16_t*)dy, (float*)workspace, rows, H, thr, ik,
+                     seed, sid);
+  ZK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_partials_reduce, dim3((3 * H + 255) / 256), dim3(256), 0, stream,
+                     (const float*)workspace, g, 3, H, dgamma, dbeta, dbias_prev);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t zk_colsum_workspace(int rows, int N) {
+  int gy = (rows + 255) / 256;
+  if (gy > 64) gy = 64;
+  if (gy < 1) gy = 1;
+  return (size_t)gy * N * sizeof(float);
+}
+
+int zk_colsum(const void* a, int rows, int N, int lda, float* out, void* workspace, size_t ws_bytes,
+              hipStream_t stream) {
+  ZK_CHECK_ARG(N % 8 == 0 && lda % 8 == 0, "zk_colsum: N=%d, lda=%d must be multiples of 8", N, lda);
+  ZK_CHECK_ARG(ws_bytes >= zk_colsum_workspace(rows, N), "zk_colsum: workspace too small");
+  int gy = (rows + 255) / 256;
+  if (gy > 64) gy = 64;
+  if (gy < 1) gy = 1;
+  hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, gy), dim3(256), 0, stream, (const bf16_t*)a, rows, N, lda,
+                     (float*)workspace);
+  ZK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_partials_reduce, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)workspace,
+                     gy, 1, N, out, (float*)nullptr, (float*)nullptr);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_ce_fused(const float* logits, const int* ids, const float* w, float* ce_out, void* dlogits, int rows,
+                int V, int ld, float label_smooth, hipStream_t stream) {
+  ZK_CHECK_ARG(ld % 4 == 0 && ld >= V, "zk_ce_fused: ld=%d must be a multiple of 4 and >= V=%d", ld, V);
+  if (rows == 0) return 0;
+  float p = 1.f, q = 0.f, normalizer = 0.f;
+  if (label_smooth > 0.f && label_smooth < 1.f) {  // util.py:90-97, fp32 arithmetic
+    const float n = (float)(V - 1);
+    p = 1.f - label_smooth;
+    q = label_smooth / n;
+    normalizer = -(p * logf(p) + n * q * logf(q + 1e-20f));
+  }
+  hipLaunchKernelGGL(k_ce_fused, dim3(rows), dim3(256), 0, stream, logits, ids, w, ce_out, (bf16_t*)dlogits,
+                     V, ld, p, q, normalizer);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_target_stats(const int* ids, float* mask, float* w, int B, int L, float loss_scale,
+                    hipStream_t stream) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(k_target_stats, dim3(B), dim3(256), 0, stream, ids, mask, w, B, L, loss_scale);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_loss_reduce(const float* ce, const int* ids, float* per_sample, float* loss, int B, int L,
+                   hipStream_t stream) {
+  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, stream, ce, ids, per_sample, loss, B, L);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_make_mask(const int* ids, float* mask, int n, hipStream_t stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_make_mask, dim3((n + 255) / 256), dim3(256), 0, stream, ids, mask, n);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_all_equal(const int* ids, int n, int value, int* flag, hipStream_t stream) {
+  hipLaunchKernelGGL(k_all_equal, dim3(1), dim3(256), 0, stream, ids, n, value, flag);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_aan_fwd(const void* x, const float* mask, void* cat, int B, int L, int H, int use_mask,
+               hipStream_t stream) {
+  ZK_CHECK_ARG(H % 8 == 0, "zk_aan_fwd: H=%d must be a multiple of 8", H);
+  const int n = B * (H / 8);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_aan_fwd, dim3((n + 255) / 256), dim3(256), 0, stream, (const bf16_t*)x, mask,
+                     (bf16_t*)cat, B, L, H, use_mask);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_aan_bwd(const void* dcat, const void* dxg, const void* dyg, const void* ds, const float* mask, void* dx,
+               int B, int L, int H, int use_mask, hipStream_t stream) {
+  ZK_CHECK_ARG(H % 8 == 0, "zk_aan_bwd: H=%d must be a multiple of 8", H);
+  const int n = B * (H / 8);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_aan_bwd, dim3((n + 255) / 256), dim3(256), 0, stream, (const bf16_t*)dcat,
+                     (const bf16_t*)dxg, (const bf16_t*)dyg, (const bf16_t*)ds, mask, (bf16_t*)dx, B, L, H,
+                     use_mask);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_aan_gate_fwd(const void* z, const void* cat, void* out, int rows, int H, hipStream_t stream) {
+  ZK_CHECK_ARG(H % 8 == 0, "zk_aan_gate_fwd: H=%d must be a multiple of 8", H);
+  const size_t n = (size_t)rows * (H / 8);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_aan_gate_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)z,
+                     (const bf16_t*)cat, (bf16_t*)out, rows, H);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_aan_gate_bwd(const void* dg, const void* z, const void* cat, void* dz, void* dxg, void* dyg, int rows,
+                    int H, hipStream_t stream) {
+  ZK_CHECK_ARG(H % 8 == 0, "zk_aan_gate_bwd: H=%d must be a multiple of 8", H);
+  const size_t n = (size_t)rows * (H / 8);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_aan_gate_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                     (const bf16_t*)dg, (const bf16_t*)z, (const bf16_t*)cat, (bf16_t*)dz, (bf16_t*)dxg,
+                     (bf16_t*)dyg, rows, H);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+#define ZK_NORM_BLOCKS 1024
+size_t zk_norm_workspace(void) { return ZK_NORM_BLOCKS * sizeof(float); }
+
+// out[0] = scale * ||x||_2   (tf.global_norm over the flat buffer, cycle.py:94-95)
+int zk_l2norm(const float* x, size_t n, float scale, float* out, void* workspace, size_t ws_bytes,
+              hipStream_t stream) {
+  ZK_CHECK_ARG(ws_bytes >= zk_norm_workspace(), "zk_l2norm: workspace too small");
+  ZK_CHECK_ARG(((uintptr_t)x & 15) == 0, "zk_l2norm: x must be 16-byte aligned");
+  hipLaunchKernelGGL(k_sumsq_partial, dim3(ZK_NORM_BLOCKS), dim3(256), 0, stream, x, n, (float*)workspace);
+  ZK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, stream, (const float*)workspace, ZK_NORM_BLOCKS,
+                     scale, out);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_adam(float* p, const float* g, float* m, float* v, void* shadow, size_t n, float* hyper,
+            hipStream_t stream) {
+  ZK_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+               "zk_adam: buffers must be 16-byte aligned");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_adam, dim3(flat_grid(n, 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n,
+                     hyper);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_cast_f32_bf16(const float* x, void* y, size_t n, hipStream_t stream) {
+  if (n == 0) return 0;
+  ZK_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0, "zk_cast_f32_bf16: misaligned");
+  hipLaunchKernelGGL(k_cast_f32_bf16, dim3(flat_grid(n, 4)), dim3(256), 0, stream, x, (bf16_t*)y, n);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+int zk_cast_bf16_f32(const void* x, float* y, size_t n, hipStream_t stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_cast_bf16_f32, dim3(flat_grid(n, 1)), dim3(256), 0, stream, (const bf16_t*)x, y, n);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+int zk_axpby_f32(float* y, const float* x, float a, float b, size_t n, hipStream_t stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_axpy_f32, dim3(flat_grid(n, 1)), dim3(256), 0, stream, y, x, a, b, n);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+int zk_dropout_mask(float* out, size_t n, float drop_p, const uint64_t* seed, uint32_t sid,
+                    hipStream_t stream) {
+  if (n == 0) return 0;
+  const uint32_t thr = drop_p > 0.f ? zk_drop_threshold(drop_p) : 0;
+  const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  hipLaunchKernelGGL(k_dropout_mask, dim3(flat_grid(n, 1)), dim3(256), 0, stream, out, n, thr, ik, seed, sid);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+int zk_seed_advance(uint64_t* seed, uint64_t inc, hipStream_t stream) {
+  hipLaunchKernelGGL(k_seed_advance, dim3(1), dim3(1), 0, stream, seed, inc);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_zero(void* p, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return 0;
+  hipError_t e = hipMemsetAsync(p, 0, bytes, stream);
+  if (e != hipSuccess) return zk_set_error((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+  return 0;
+}
+
+// ---- thin hipGraph wrappers (launch-bound step loop is captured once and replayed)
+int zk_graph_begin(hipStream_t stream) {
+  hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) return zk_set_error((int)e, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+  return 0;
+}
+int zk_graph_end(hipStream_t stream, void** exec_out) {
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(stream, &graph);
+  if (e != hipSuccess) return zk_set_error((int)e, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (e != hipSuccess) return zk_set_error((int)e, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  *exec_out = (void*)exec;
+  return 0;
+}
+int zk_graph_launch(void* exec, hipStream_t stream) {
+  hipError_t e = hipGraphLaunch((hipGraphExec_t)exec, stream);
+  if (e != hipSuccess) return zk_set_error((int)e, "hipGraphLaunch: %s", hipGetErrorString(e));
+  return 0;
+}
+int zk_graph_destroy(void* exec) {
+  if (exec) hipGraphExecDestroy((hipGraphExec_t)exec);
+  return 0;
+}
+
+}  // extern "C"

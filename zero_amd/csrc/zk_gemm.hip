@@ -1,0 +1,343 @@
+// zk_gemm.hip -- bf16 MFMA GEMM with fused epilogues for the dense contractions of the
+// Transformer hot path (func.py:14-65 `linear`, func.py:327-338 FFN, transformer.py:182-196
+// logits, and their dgrad / wgrad mirrors), gfx950 only.
+//
+//   C[M,N] = alpha * op(A)[M,K] x op(B)[K,N]   (+bias[N]) (+residual[M,N]) (act) (dropout)
+//
+//   ta=0: A stored [M,lda], K contiguous      ta=1: A stored [K,lda], M contiguous
+//   tb=0: B stored [K,ldb], N contiguous      tb=1: B stored [N,ldb], K contiguous
+//
+//   forward  x@W      : ta=0 tb=0        dgrad  dY@W^T : ta=0 tb=1
+//   wgrad    X^T@dY   : ta=1 tb=0        logits h@E^T  : ta=0 tb=1
+//
+// Kernel structure (v1): BMxBNx64 block tile, 4 wave64 as 2x2, v_mfma_f32_32x32x16_bf16,
+// single LDS stage + register prefetch of the next K tile.  LDS tiles are [rows][64+8] bf16
+// (K contiguous, 144-byte rows -> conflict-free ds_read_b128 fragments).  Operands whose
+// contraction dim is NOT contiguous in HBM (ta=1 / tb=0) are transposed on the way into
+// LDS: each thread loads 4 k-rows x 8 contiguous rows (4x16 B, coalesced), and writes
+// 8 x ds_write_b64; the tile's rows are stored in a permuted physical order
+// (phys = (r%8)*(R/8) + r/8) so that those writes spread over LDS banks; the permutation is
+// undone in the epilogue's row/column indices.
+#include "zk_common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+#define BK 64
+#define LDS_LD (BK + 8)
+
+struct GemmEpi {
+  void* C; int ldc; int out_f32; float alpha;
+  const float* bias;
+  const bf16_t* res; int ldr;
+  int act;                 // 0 none, 1 relu, 2 multiply by (aux>0)*aux_scale
+  const bf16_t* aux; int ldaux; float aux_scale;
+  uint32_t thr; float inv_keep; const uint64_t* seed; uint32_t sid;  // dropout on the output
+};
+
+__device__ __forceinline__ void epi_store(const GemmEpi& e, float v, int gm, int gn, int N, uint64_t seed) {
+  v *= e.alpha;
+  if (e.bias) v += e.bias[gn];
+  if (e.res) v += bf2f(e.res[(size_t)gm * e.ldr + gn]);
+  if (e.act == 1) v = fmaxf(v, 0.f);
+  else if (e.act == 2) v = (bf2f(e.aux[(size_t)gm * e.ldaux + gn]) > 0.f) ? v * e.aux_scale : 0.f;
+  if (e.thr) v *= zk_drop_scale(seed, e.sid, (uint64_t)gm * N + gn, e.thr, e.inv_keep);
+  if (e.out_f32) reinterpret_cast<float*>(e.C)[(size_t)gm * e.ldc + gn] = v;
+  else reinterpret_cast<bf16_t*>(e.C)[(size_t)gm * e.ldc + gn] = f2bf(v);
+}
+
+// ------------------------------------------------------------------ reference kernel
+// one thread per output element; any shape / alignment.  Used for parity checks of the
+// MFMA kernel and for shapes the MFMA kernel does not accept.
+__global__ void __launch_bounds__(256) k_gemm_naive(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                    int M, int N, int K, int lda, int ldb, int ta, int tb,
+                                                    GemmEpi e) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)M * N) return;
+  const int m = (int)(idx / N), n = (int)(idx % N);
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float a = bf2f(ta ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k]);
+    const float b = bf2f(tb ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n]);
+    acc += a * b;
+  }
+  const uint64_t seed = e.thr ? *e.seed : 0;
+  epi_store(e, acc, m, n, N, seed);
+}
+
+// ------------------------------------------------------------------ MFMA kernel
+template <int R, bool TRANS>
+__device__ __forceinline__ void g2r(uint4 (&reg)[4], const bf16_t* __restrict__ src, int ld, int row0,
+                                    int rows_total, int k0, int kend, int tid) {
+  if (!TRANS) {
+#pragma unroll
+    for (int i = 0; i < (R * 8) / 256; ++i) {
+      const int t = tid + i * 256;
+      const int r = t >> 3, kc = t & 7;
+      const int grow = row0 + r, gk = k0 + kc * 8;
+      if (grow < rows_total && gk < kend)
+        reg[i] = *reinterpret_cast<const uint4*>(src + (size_t)grow * ld + gk);
+      else
+        reg[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+  } else {
+    constexpr int RC = R / 8;
+    if (tid < RC * (BK / 4)) {
+      const int rc = tid % RC, kq = tid / RC;
+      const int grow = row0 + rc * 8;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int gk = k0 + kq * 4 + kk;
+        if (gk < kend && grow < rows_total)
+          reg[kk] = *reinterpret_cast<const uint4*>(src + (size_t)gk * ld + grow);
+        else
+          reg[kk] = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t half_of(const uint4& v, int i) {
+  const uint32_t w = (i >> 1) == 0 ? v.x : ((i >> 1) == 1 ? v.y : ((i >> 1) == 2 ? v.z : v.w));
+  return (i & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+template <int R, bool TRANS>
+__device__ __forceinline__ void r2s(const uint4 (&reg)[4], bf16_t* sT, int tid) {
+  if (!TRANS) {
+#pragma unroll
+    for (int i = 0; i < (R * 8) / 256; ++i) {
+      const int t = tid + i * 256;
+      const int r = t >> 3, kc = t & 7;
+      *reinterpret_cast<uint4*>(sT + r * LDS_LD + kc * 8) = reg[i];
+    }
+  } else {
+    constexpr int RC = R / 8;
+    if (tid < RC * (BK / 4)) {
+      const int rc = tid % RC, kq = tid / RC;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        uint2 o;
+        o.x = half_of(reg[0], i) | (half_of(reg[1], i) << 16);
+        o.y = half_of(reg[2], i) | (half_of(reg[3], i) << 16);
+        const int phys = i * RC + rc;
+        *reinterpret_cast<uint2*>(sT + phys * LDS_LD + kq * 4) = o;
+      }
+    }
+  }
+}
+
+// physical LDS row -> logical tile row
+template <int R, bool TRANS>
+__device__ __forceinline__ int logical_row(int q) {
+  if (!TRANS) return q;
+  constexpr int RC = R / 8;
+  return (q % RC) * 8 + q / RC;
+}
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ void __launch_bounds__(256) k_gemm_mfma(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                   int M, int N, int K, int lda, int ldb, int kchunk,
+                                                   float* __restrict__ slabs, GemmEpi e) {
+  constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
+  __shared__ __attribute__((aligned(16))) bf16_t sA[BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t sB[BN * LDS_LD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * kchunk;
+  const int kend = min(K, kbeg + kchunk);
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 ra[4], rb[4];
+  // A tile rows index M; "transposed staging" when M is the contiguous dim (ta=1).
+  // B tile rows index N; "transposed staging" when N is the contiguous dim (tb=0).
+  g2r<BM, TA>(ra, A, lda, m0, M, kbeg, kend, tid);
+  g2r<BN, !TB>(rb, B, ldb, n0, N, kbeg, kend, tid);
+
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    r2s<BM, TA>(ra, sA, tid);
+    r2s<BN, !TB>(rb, sB, tid);
+    __syncthreads();
+    if (k0 + BK < kend) {
+      g2r<BM, TA>(ra, A, lda, m0, M, k0 + BK, kend, tid);
+      g2r<BN, !TB>(rb, B, ldb, n0, N, k0 + BK, kend, tid);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8_t af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const uint4 v = *reinterpret_cast<const uint4*>(
+            sA + (wm * WTM + i * 32 + (lane & 31)) * LDS_LD + kk * 16 + (lane >> 5) * 8);
+        af[i] = __builtin_bit_cast(bf16x8_t, v);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const uint4 v = *reinterpret_cast<const uint4*>(
+            sB + (wn * WTN + j * 32 + (lane & 31)) * LDS_LD + kk * 16 + (lane >> 5) * 8);
+        bfr[j] = __builtin_bit_cast(bf16x8_t, v);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of v_mfma_f32_32x32x16: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)
+  const uint64_t seed = e.thr ? *e.seed : 0;
+  const bool to_slab = slabs != nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int qn = wn * WTN + j * 32 + (lane & 31);
+      const int gn = n0 + logical_row<BN, !TB>(qn);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qm = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int gm = m0 + logical_row<BM, TA>(qm);
+        if (gm < M && gn < N) {
+          if (to_slab) slabs[((size_t)blockIdx.z * M + gm) * N + gn] = acc[i][j][r];
+          else epi_store(e, acc[i][j][r], gm, gn, N, seed);
+        }
+      }
+    }
+}
+
+// split-K finish: C = epilogue(sum_z slabs[z])
+__global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__ slabs, int splits, int M, int N,
+                                                       GemmEpi e) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)M * N) return;
+  float t = 0.f;
+  for (int z = 0; z < splits; ++z) t += slabs[(size_t)z * M * N + idx];
+  const uint64_t seed = e.thr ? *e.seed : 0;
+  epi_store(e, t, (int)(idx / N), (int)(idx % N), N, seed);
+}
+
+template <int BM, int BN>
+static int launch_mfma(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
+                       int splits, int kchunk, float* slabs, const GemmEpi& e, hipStream_t stream) {
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits);
+  if (!ta && !tb)
+    hipLaunchKernelGGL((k_gemm_mfma<BM, BN, false, false>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, e);
+  else if (!ta && tb)
+    hipLaunchKernelGGL((k_gemm_mfma<BM, BN, false, true>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, e);
+  else if (ta && !tb)
+    hipLaunchKernelGGL((k_gemm_mfma<BM, BN, true, false>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, e);
+  else
+    hipLaunchKernelGGL((k_gemm_mfma<BM, BN, true, true>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, e);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+static bool mfma_ok(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int ta, int tb) {
+  if ((((uintptr_t)A | (uintptr_t)B) & 15) != 0) return false;
+  if (lda % 8 || ldb % 8) return false;
+  if (!ta && K % 8) return false;   // A: K contiguous
+  if (ta && M % 8) return false;    // A: M contiguous
+  if (tb && K % 8) return false;    // B: K contiguous
+  if (!tb && N % 8) return false;   // B: N contiguous
+  return true;
+}
+
+// choose tile + split so that the launch has >= ~256 workgroups when the problem allows it
+static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, int* splits) {
+  const int cands[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+  int best = 3;
+  for (int c = 0; c < 4; ++c) {
+    const long tiles = (long)((M + cands[c][0] - 1) / cands[c][0]) * ((N + cands[c][1] - 1) / cands[c][1]);
+    if (tiles >= 240) { best = c; break; }
+  }
+  *bm = cands[best][0];
+  *bn = cands[best][1];
+  const long tiles = (long)((M + *bm - 1) / *bm) * ((N + *bn - 1) / *bn);
+  int s = 1;
+  if (allow_split && tiles < 192) {
+    s = (int)((256 + tiles - 1) / tiles);
+    const int maxs = K / (4 * BK) > 0 ? K / (4 * BK) : 1;  // keep >= 4 K-tiles per split
+    if (s > maxs) s = maxs;
+    if (s > 16) s = 16;
+    if (s < 1) s = 1;
+  }
+  *splits = s;
+}
+
+extern "C" {
+
+// workspace bytes zk_gemm may need for (M,N,K) (split-K slabs), upper bound
+size_t zk_gemm_workspace(int M, int N, int K) {
+  int bm, bn, s;
+  pick_config(M, N, K, 1, &bm, &bn, &s);
+  return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int ta,
+            int tb, int out_f32, float alpha, const float* bias, const void* residual, int ldr, int act,
+            const void* aux, int ldaux, float aux_scale, float drop_p, const uint64_t* seed, uint32_t sid,
+            int impl, void* workspace, size_t ws_bytes, hipStream_t stream) {
+  ZK_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "zk_gemm: negative dims");
+  ZK_CHECK_ARG(act >= 0 && act <= 2, "zk_gemm: act=%d unknown", act);
+  ZK_CHECK_ARG(act != 2 || aux != nullptr, "zk_gemm: act=2 needs aux");
+  ZK_CHECK_ARG(drop_p == 0.f || seed != nullptr, "zk_gemm: dropout needs a seed pointer");
+  ZK_CHECK_ARG(impl >= 0 && impl <= 2, "zk_gemm: impl=%d unknown", impl);
+  if (M == 0 || N == 0) return 0;
+  GemmEpi e;
+  e.C = C; e.ldc = ldc; e.out_f32 = out_f32; e.alpha = alpha; e.bias = bias;
+  e.res = (const bf16_t*)residual; e.ldr = ldr; e.act = act; e.aux = (const bf16_t*)aux; e.ldaux = ldaux;
+  e.aux_scale = aux_scale;
+  e.thr = drop_p > 0.f ? zk_drop_threshold(drop_p) : 0;
+  e.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  e.seed = seed; e.sid = sid;
+  const bool ok = mfma_ok(A, B, M, N, K, lda, ldb, ta, tb);
+  ZK_CHECK_ARG(impl != 2 || ok, "zk_gemm: shape/alignment not supported by the MFMA kernel "
+               "(M=%d N=%d K=%d lda=%d ldb=%d ta=%d tb=%d)", M, N, K, lda, ldb, ta, tb);
+  if (impl == 1 || (impl == 0 && !ok)) {
+    const size_t n = (size_t)M * N;
+    hipLaunchKernelGGL(k_gemm_naive, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)A,
+                       (const bf16_t*)B, M, N, K, lda, ldb, ta, tb, e);
+    ZK_LAUNCH_CHECK();
+    return 0;
+  }
+  int bm, bn, splits;
+  const bool plain = (bias == nullptr && residual == nullptr && act == 0 && drop_p == 0.f);
+  pick_config(M, N, K, plain ? 1 : 0, &bm, &bn, &splits);
+  if (splits > 1 && ws_bytes < (size_t)splits * M * N * sizeof(float)) splits = 1;
+  int kchunk = K;
+  float* slabs = nullptr;
+  if (splits > 1) {
+    kchunk = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+    splits = (K + kchunk - 1) / kchunk;
+    if (splits > 1) slabs = (float*)workspace;
+    else kchunk = K;
+  }
+  if (kchunk < 1) kchunk = 1;
+  int rc;
+  const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
+  if (bm == 128 && bn == 128) rc = launch_mfma<128, 128>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, stream);
+  else if (bm == 128 && bn == 64) rc = launch_mfma<128, 64>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, stream);
+  else if (bm == 64 && bn == 128) rc = launch_mfma<64, 128>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, stream);
+  else rc = launch_mfma<64, 64>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, stream);
+  if (rc) return rc;
+  if (slabs != nullptr) {
+    const size_t n = (size_t)M * N;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, slabs, splits, M,
+                       N, e);
+    ZK_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,232 @@
+# coding: utf-8
+"""Operator layer: the reference's func.py surface, each op one HIP launch.
+
+Counterpart of the reference's func.py (linear :14-65, dot_attention :164-286,
+layer_norm :289-303, residual_fn :321-324, ffn_layer :327-338,
+add_timing_signal :341-369, attention_bias :372-400) -- but every function here
+enqueues hand-written gfx950 kernels from libzero_hip.so on the current HIP
+stream instead of building TF graph nodes.  Tensors are torch-ROCm storage
+only: a ``Mat`` is (storage, rows, cols, leading dim, element offset) and what
+crosses the C-ABI is its device address.
+
+No op here has a CPU or torch fallback; if the library is missing the import of
+``zero_amd.hip`` raises.
+"""
+
+import ctypes
+import math
+import os
+
+import numpy as np
+import torch
+
+from zero_amd import hip
+from zero_amd.utils import dtype as zdtype
+
+
+class Mat(object):
+    """Row-major matrix view over a torch tensor."""
+    __slots__ = ("t", "rows", "cols", "ld", "off")
+
+    def __init__(self, t, rows, cols, ld=None, off=0):
+        self.t, self.rows, self.cols = t, int(rows), int(cols)
+        self.ld = int(cols if ld is None else ld)
+        self.off = int(off)
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + self.off * self.t.element_size()
+
+    def cols_slice(self, c0, c1):
+        return Mat(self.t, self.rows, c1 - c0, self.ld, self.off + c0)
+
+    def torch(self):
+        """Materialise as a torch tensor (tests / debugging only)."""
+        flat = self.t.reshape(-1)
+        return torch.as_strided(flat, (self.rows, self.cols), (self.ld, 1), self.off)
+
+
+def _impl_from_env(var):
+    v = os.environ.get(var, "auto").lower()
+    return {"auto": 0, "naive": 1, "ref": 1, "mfma": 2}.get(v, 0)
+
+
+def timing_table(length, channels, min_timescale=1.0, max_timescale=1.0e4):
+    """func.py:341-369 as an fp32 [length, channels] table: sin in the first
+    channels/2 columns, cos in the next channels/2 (not interleaved)."""
+    nts = channels // 2
+    inc = math.log(float(max_timescale) / float(min_timescale)) / (float(nts) - 1)
+    inv = min_timescale * np.exp(np.arange(nts, dtype=np.float64) * -inc)
+    st = np.arange(length, dtype=np.float64)[:, None] * inv[None, :]
+    sig = np.zeros((length, channels), dtype=np.float64)
+    sig[:, :nts] = np.sin(st)
+    sig[:, nts:2 * nts] = np.cos(st)
+    return sig.astype(np.float32)
+
+
+class Engine(object):
+    """Owns the per-device plumbing (stream, scratch, seeds) and exposes the ops."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise hip.ZeroHipError("the HIP hot path needs a GPU device (got %s); there is no CPU fallback"
+                                   % self.device)
+        self.lib = hip.lib()
+        self.bufs = {}
+        self._ws = None
+        self.gemm_impl = _impl_from_env("ZERO_HIP_GEMM")
+        self.attn_impl = _impl_from_env("ZERO_HIP_ATTN")
+        self.seed = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._timing = None
+
+    # ---- plumbing -----------------------------------------------------------
+    @property
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def buf(self, name, shape, dt=torch.bfloat16):
+        """Named persistent buffer (static address -> graph-capturable)."""
+        shape = tuple(int(s) for s in shape)
+        b = self.bufs.get(name)
+        if b is None or b.dtype != dt or b.numel() < int(np.prod(shape)):
+            b = torch.empty(int(np.prod(shape)), dtype=dt, device=self.device)
+            self.bufs[name] = b
+        return b[:int(np.prod(shape))].view(*shape)
+
+    def mat(self, name, rows, cols, dt=torch.bfloat16):
+        return Mat(self.buf(name, (rows, cols), dt), rows, cols)
+
+    def workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def timing(self, length, H):
+        if self._timing is None or self._timing.shape[0] < length or self._timing.shape[1] != H:
+            n = max(256, int(length))
+            self._timing = torch.from_numpy(timing_table(n, H)).to(self.device)
+        return self._timing
+
+    def set_seed(self, value):
+        self.seed.fill_(int(value))
+
+    def zero(self, t):
+        self.lib.call("zk_zero", t.data_ptr(), t.numel() * t.element_size(), self.stream)
+
+    # ---- func.py:14-65 linear and its backward mirrors -------------------------
+    def gemm(self, A, B, C, M, N, K, ta, tb, alpha=1.0, bias=None, residual=None, act=0, aux=None,
+             aux_scale=1.0, drop_p=0.0, sid=0, impl=None):
+        out_f32 = 1 if C.t.dtype == torch.float32 else 0
+        ws_bytes = self.lib.query("zk_gemm_workspace", M, N, K)
+        ws = self.workspace(ws_bytes)
+        self.lib.call(
+            "zk_gemm", A.ptr, B.ptr, C.ptr, M, N, K, A.ld, B.ld, C.ld, ta, tb, out_f32, alpha,
+            hip.ptr(bias), residual.ptr if residual is not None else None,
+            residual.ld if residual is not None else 0, act,
+            aux.ptr if aux is not None else None, aux.ld if aux is not None else 0, aux_scale,
+            float(drop_p), self.seed.data_ptr(), sid,
+            self.gemm_impl if impl is None else impl, ws.data_ptr(), ws.numel(), self.stream)
+
+    def colsum(self, A, out):
+        ws_bytes = self.lib.query("zk_colsum_workspace", A.rows, A.cols)
+        ws = self.workspace(ws_bytes)
+        self.lib.call("zk_colsum", A.ptr, A.rows, A.cols, A.ld, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                      self.stream)
+
+    # ---- func.py:164-286 attention core ----------------------------------------
+    def attn_fwd(self, q, k, v, out, lse, B, nh, Lq, Lk, d, kmask=None, causal=False, q_pos0=0,
+                 rpr_k=None, rpr_v=None, max_rel=0, drop_p=0.0, sid=0, bsq=0, bsk=0, bsv=0, kv_group=1,
+                 impl=None):
+        self.lib.call(
+            "zk_attn_fwd", q.ptr, k.ptr, v.ptr, out.ptr, hip.ptr(lse), B, nh, Lq, Lk, d, q.ld, k.ld, v.ld,
+            out.ld, hip.ptr(kmask), 1 if causal else 0, q_pos0, float(d) ** -0.5, zdtype.inf(),
+            hip.ptr(rpr_k), hip.ptr(rpr_v), max_rel, float(drop_p), self.seed.data_ptr(), sid,
+            bsq, bsk, bsv, kv_group, self.attn_impl if impl is None else impl, self.stream)
+
+    def attn_bwd(self, q, k, v, out, dout, lse, dq, dk, dv, B, nh, Lq, Lk, d, kmask=None, causal=False,
+                 rpr_k=None, rpr_v=None, drpr_k=None, drpr_v=None, max_rel=0, drop_p=0.0, sid=0, impl=None):
+        ws_bytes = self.lib.query("zk_attn_bwd_workspace", B, nh, Lq)
+        ws = self.workspace(ws_bytes)
+        self.lib.call(
+            "zk_attn_bwd", q.ptr, k.ptr, v.ptr, out.ptr, dout.ptr, lse.data_ptr(), dq.ptr, dk.ptr, dv.ptr,
+            hip.ptr(drpr_k), hip.ptr(drpr_v), B, nh, Lq, Lk, d, q.ld, k.ld, v.ld, out.ld, dout.ld, dq.ld,
+            dk.ld, dv.ld, hip.ptr(kmask), 1 if causal else 0, 0, float(d) ** -0.5, zdtype.inf(),
+            hip.ptr(rpr_k), hip.ptr(rpr_v), max_rel, float(drop_p), self.seed.data_ptr(), sid,
+            self.attn_impl if impl is None else impl, ws.data_ptr(), ws.numel(), self.stream)
+
+    # ---- embedding + timing (transformer.py:16-33, 88-119; func.py:341-369) -------
+    def embed_fwd(self, ids, table, bias, out, B, L, H, shift=False, pos0=0, zero_flag=None, drop_p=0.0,
+                  sid=0):
+        tim = self.timing(pos0 + L, H)
+        self.lib.call("zk_embed_fwd", ids.data_ptr(), table.data_ptr(), bias.data_ptr(), tim.data_ptr(),
+                      out.ptr, B, L, H, float(H) ** 0.5, 1 if shift else 0, pos0, hip.ptr(zero_flag),
+                      float(drop_p), self.seed.data_ptr(), sid, self.stream)
+
+    def embed_bwd(self, ids, dout, dtable, dbias, B, L, H, shift=False, drop_p=0.0, sid=0):
+        self.lib.call("zk_embed_bwd", ids.data_ptr(), dout.ptr, dtable.data_ptr(), dbias.data_ptr(), B, L, H,
+                      float(H) ** 0.5, 1 if shift else 0, float(drop_p), self.seed.data_ptr(), sid, self.stream)
+
+    # ---- residual + layer norm (func.py:289-303, 321-324) -------------------------
+    def add_ln_fwd(self, x, y, gamma, beta, out, sum_out=None, mean=None, rstd=None, drop_p=0.0, sid=0):
+        self.lib.call("zk_add_ln_fwd", x.ptr, y.ptr if y is not None else None, gamma.data_ptr(),
+                      beta.data_ptr(), out.ptr, sum_out.ptr if sum_out is not None else None, hip.ptr(mean),
+                      hip.ptr(rstd), x.rows, x.cols, zdtype.epsilon(), float(drop_p), self.seed.data_ptr(), sid,
+                      self.stream)
+
+    def add_ln_bwd(self, dout, s, mean, rstd, gamma, dsum, dy, dgamma, dbeta, dbias_prev, drop_p=0.0, sid=0):
+        ws_bytes = self.lib.query("zk_add_ln_bwd_workspace", dout.rows, dout.cols)
+        ws = self.workspace(ws_bytes)
+        self.lib.call("zk_add_ln_bwd", dout.ptr, s.ptr, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                      dsum.ptr, dy.ptr if dy is not None else None, hip.ptr(dgamma), hip.ptr(dbeta),
+                      hip.ptr(dbias_prev), dout.rows, dout.cols, float(drop_p), self.seed.data_ptr(), sid,
+                      ws.data_ptr(), ws.numel(), self.stream)
+
+    # ---- loss (util.py:88-103; transformer.py:198-216) ------------------------------
+    def ce_fused(self, logits, ids, w, ce, dlogits, rows, V, label_smooth):
+        self.lib.call("zk_ce_fused", logits.ptr, ids.data_ptr(), hip.ptr(w), hip.ptr(ce),
+                      dlogits.ptr if dlogits is not None else None, rows, V, logits.ld, float(label_smooth),
+                      self.stream)
+
+    def target_stats(self, ids, mask, w, B, L, loss_scale=1.0):
+        self.lib.call("zk_target_stats", ids.data_ptr(), hip.ptr(mask), hip.ptr(w), B, L, float(loss_scale),
+                      self.stream)
+
+    def loss_reduce(self, ce, ids, per_sample, loss, B, L):
+        self.lib.call("zk_loss_reduce", ce.data_ptr(), ids.data_ptr(), hip.ptr(per_sample), hip.ptr(loss), B, L,
+                      self.stream)
+
+    def make_mask(self, ids, mask, n):
+        self.lib.call("zk_make_mask", ids.data_ptr(), mask.data_ptr(), n, self.stream)
+
+    # ---- average attention network (transformer_aan.py:92-117,186-189) ------------------
+    def aan_fwd(self, x, mask, cat, B, L, H, use_mask):
+        self.lib.call("zk_aan_fwd", x.ptr, mask.data_ptr(), cat.ptr, B, L, H, 1 if use_mask else 0, self.stream)
+
+    def aan_bwd(self, dcat, dxg, dyg, ds, mask, dx, B, L, H, use_mask):
+        self.lib.call("zk_aan_bwd", dcat.ptr, dxg.ptr, dyg.ptr, ds.ptr, mask.data_ptr(), dx.ptr, B, L, H,
+                      1 if use_mask else 0, self.stream)
+
+    def aan_gate_fwd(self, z, cat, out, rows, H):
+        self.lib.call("zk_aan_gate_fwd", z.ptr, cat.ptr, out.ptr, rows, H, self.stream)
+
+    def aan_gate_bwd(self, dg, z, cat, dz, dxg, dyg, rows, H):
+        self.lib.call("zk_aan_gate_bwd", dg.ptr, z.ptr, cat.ptr, dz.ptr, dxg.ptr, dyg.ptr, rows, H, self.stream)
+
+    # ---- hipGraph capture of a launch sequence ----------------------------------------
+    def graph_capture(self, fn):
+        """Run ``fn()`` under stream capture, return a replayable handle."""
+        s = torch.cuda.Stream(self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            self.lib.call("zk_graph_begin", s.cuda_stream)
+            try:
+                fn()
+            finally:
+                exec_ = ctypes.c_void_p()
+                self.lib.call("zk_graph_end", s.cuda_stream, ctypes.byref(exec_))
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        return exec_
+
+    def graph_launch(self, exec_):
+        self.lib.call("zk_graph_launch", exec_, self.stream)

@@ -1,0 +1,443 @@
+# coding: utf-8
+"""Hand-scheduled forward + backward of the Transformer family on HIP kernels.
+
+One class drives the three registered models (``transformer``,
+``transformer_aan``, ``transformer_rpr``): the same layer schedule as the
+reference's ``encoder`` / ``decoder`` (models/transformer.py:15-218,
+models/transformer_aan.py:92-260, models/transformer_rpr.py) but issued eagerly
+as HIP launches on one stream -- there is no graph builder and no autodiff, the
+backward below is written by hand against the same saved activations.
+
+Saved for the backward, per sub-layer: the bf16 input of every GEMM, the
+pre-LayerNorm sum with its fp32 mean / rstd, the attention log-sum-exp.
+Everything lives in named persistent buffers (static addresses), so a whole
+step can be captured into a hipGraph and replayed.
+"""
+
+import numpy as np
+import torch
+
+from zero_amd import hip
+from zero_amd.func import Engine, Mat
+from zero_amd.variables import get_store
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def trim_columns(ids):
+    """utils/util.py:274-287 remove_invalid_seq on the host: drop columns where
+    every row is pad (id 0), always keep column 0."""
+    ids = np.asarray(ids)
+    keep = (ids != 0).any(axis=0)
+    if keep.size:
+        keep[0] = True
+    return np.ascontiguousarray(ids[:, keep])
+
+
+class TransformerCore(object):
+    def __init__(self, params, model_name, store=None, device=None):
+        self.hp = params
+        self.model = model_name
+        if device is None:
+            device = "cuda:%d" % torch.cuda.current_device() if torch.cuda.is_available() else "cpu"
+        self.eng = Engine(device)
+        self.store = store if store is not None else get_store(params, model_name, device)
+        self.H = params.hidden_size
+        self.F = params.filter_size
+        self.nh = params.num_heads
+        self.d = self.H // self.nh
+        self.rpr = model_name == "transformer_rpr"
+        self.aan = model_name == "transformer_aan"
+        if self.aan and params.use_ffn:
+            raise NotImplementedError("transformer_aan with use_ffn=True is not on the HIP path yet")
+        if self.aan and [s.lower() for s in params.strategies] != ["aan"]:
+            raise NotImplementedError("Not supported: {}".format(params.strategies))
+        shared = params.shared_source_target_embedding
+        self.src_emb = "embedding" if shared else "src_embedding"
+        self.tgt_emb = "embedding" if shared else "tgt_embedding"
+        if shared:
+            self.soft_emb = "embedding"
+        else:
+            self.soft_emb = "tgt_embedding" if params.shared_target_softmax_embedding else "softmax_embedding"
+        self.V = params.tgt_vocab.size()
+        self.Vpad = self.store.pshape[self.soft_emb][0]
+
+    # ------------------------------------------------------------------ helpers
+    def W(self, name):
+        t = self.store.s(name)
+        return Mat(t, t.shape[0], t.shape[1])
+
+    def b(self, name):
+        return self.store.w(name)
+
+    def gW(self, name):
+        t = self.store.g(name)
+        return Mat(t, t.shape[0], t.shape[1])
+
+    def gb(self, name):
+        return self.store.g(name)
+
+    def _linear(self, x, scope, out, act=0, drop_p=0.0, sid=0):
+        """y = x @ W + b  (func.py:14-65)."""
+        Wm = self.W(scope + "/W_0_0")
+        self.eng.gemm(x, Wm, out, x.rows, Wm.cols, Wm.rows, 0, 0, bias=self.b(scope + "/b_0"), act=act,
+                      drop_p=drop_p, sid=sid)
+
+    def _linear_bwd(self, x, dy, scope, dx=None, residual=None, bias_grad=True, act=0, aux=None, aux_scale=1.0):
+        """dW = x^T dy (fp32, overwrite), db = colsum(dy), dx = dy @ W^T (+residual)."""
+        Wm = self.W(scope + "/W_0_0")
+        self.eng.gemm(x, dy, self.gW(scope + "/W_0_0"), Wm.rows, Wm.cols, x.rows, 1, 0)
+        if bias_grad:
+            self.eng.colsum(dy, self.gb(scope + "/b_0"))
+        if dx is not None:
+            self.eng.gemm(dy, Wm, dx, dy.rows, Wm.rows, Wm.cols, 0, 1, residual=residual, act=act, aux=aux,
+                          aux_scale=aux_scale)
+
+    # ------------------------------------------------------------------ sub-layers (forward)
+    def _ln_fwd(self, x, y, scope, tag, save, drop_p, sid):
+        T, H = x.rows, self.H
+        e = self.eng
+        out = e.mat(tag + ".o", T, H)
+        if save:
+            s = e.mat(tag + ".s", T, H)
+            mean = e.buf(tag + ".mean", (T,), F32)
+            rstd = e.buf(tag + ".rstd", (T,), F32)
+        else:
+            s, mean, rstd = None, None, None
+        e.add_ln_fwd(x, y, self.b(scope + "/layer_norm/scale"), self.b(scope + "/layer_norm/offset"), out,
+                     s, mean, rstd, drop_p, sid)
+        return out
+
+    def _self_attn_fwd(self, x, B, L, scope, tag, kmask, causal, save, sid0, train):
+        e, H = self.eng, self.H
+        hp = self.hp
+        T = x.rows
+        p = scope + "/dot_attention/"
+        qkv = e.mat(tag + ".qkv", T, 3 * H)
+        self._linear(x, p + "qkv_map", qkv)
+        att = e.mat(tag + ".att", T, H)
+        lse = e.buf(tag + ".lse", (B * self.nh * L,), F32) if save else None
+        rk = self.store.s(p + "rpr_keys/embeddings") if self.rpr else None
+        rv = self.store.s(p + "rpr_values/embeddings") if self.rpr else None
+        e.attn_fwd(qkv.cols_slice(0, H), qkv.cols_slice(H, 2 * H), qkv.cols_slice(2 * H, 3 * H), att, lse, B,
+                   self.nh, L, L, self.d, kmask=kmask, causal=causal, rpr_k=rk, rpr_v=rv,
+                   max_rel=hp.max_relative_position, drop_p=hp.attention_dropout if train else 0.0, sid=sid0)
+        y = e.mat("tmp.y%d" % T, T, H)
+        self._linear(att, p + "o_map", y)
+        return self._ln_fwd(x, y, scope, tag, save, hp.residual_dropout if train else 0.0, sid0 + 1)
+
+    def _cross_attn_fwd(self, x, mem, B, Lq, Lk, scope, tag, kmask, save, sid0, train):
+        e, H = self.eng, self.H
+        hp = self.hp
+        p = scope + "/dot_attention/"
+        q = e.mat(tag + ".q", x.rows, H)
+        self._linear(x, p + "q_map", q)
+        kv = e.mat(tag + ".kv", mem.rows, 2 * H)
+        self._linear(mem, p + "k_map", kv.cols_slice(0, H))
+        self._linear(mem, p + "v_map", kv.cols_slice(H, 2 * H))
+        att = e.mat(tag + ".att", x.rows, H)
+        lse = e.buf(tag + ".lse", (B * self.nh * Lq,), F32) if save else None
+        rk = self.store.s(p + "rpr_keys/embeddings") if self.rpr else None
+        rv = self.store.s(p + "rpr_values/embeddings") if self.rpr else None
+        e.attn_fwd(q, kv.cols_slice(0, H), kv.cols_slice(H, 2 * H), att, lse, B, self.nh, Lq, Lk, self.d,
+                   kmask=kmask, causal=False, rpr_k=rk, rpr_v=rv, max_rel=hp.max_relative_position,
+                   drop_p=hp.attention_dropout if train else 0.0, sid=sid0)
+        y = e.mat("tmp.y%d" % x.rows, x.rows, H)
+        self._linear(att, p + "o_map", y)
+        return self._ln_fwd(x, y, scope, tag, save, hp.residual_dropout if train else 0.0, sid0 + 1)
+
+    def _ffn_fwd(self, x, scope, tag, save, sid0, train):
+        e, H, F = self.eng, self.H, self.F
+        hp = self.hp
+        p = scope + "/ffn_layer/"
+        h = e.mat(tag + ".h", x.rows, F)
+        self._linear(x, p + "enlarge", h, act=1, drop_p=hp.relu_dropout if train else 0.0, sid=sid0)
+        y = e.mat("tmp.y%d" % x.rows, x.rows, H)
+        self._linear(h, p + "output", y)
+        return self._ln_fwd(x, y, scope, tag, save, hp.residual_dropout if train else 0.0, sid0 + 1)
+
+    def _aan_fwd(self, x, B, L, scope, tag, tmask, save, sid0, train):
+        e, H = self.eng, self.H
+        hp = self.hp
+        T = x.rows
+        cat = e.mat(tag + ".cat", T, 2 * H)
+        e.aan_fwd(x, tmask, cat, B, L, H, hp.aan_mask)
+        z = e.mat(tag + ".z", T, 2 * H)
+        self._linear(cat, scope + "/z_project", z)
+        g = e.mat("tmp.y%d" % T, T, H)
+        e.aan_gate_fwd(z, cat, g, T, H)
+        return self._ln_fwd(x, g, scope, tag, save, hp.residual_dropout if train else 0.0, sid0 + 1)
+
+    # ------------------------------------------------------------------ sub-layers (backward)
+    def _ln_bwd(self, dx, scope, tag, prev_bias, drop_p, sid, side):
+        """returns (ds, dy): grads of the residual input and of the sub-layer output."""
+        e, H = self.eng, self.H
+        T = dx.rows
+        ds = e.mat("g%s.ds" % side, T, H)
+        dy = e.mat("g%s.dy" % side, T, H) if drop_p > 0.0 else None
+        e.add_ln_bwd(dx, e.mat(tag + ".s", T, H), e.buf(tag + ".mean", (T,), F32), e.buf(tag + ".rstd", (T,), F32),
+                     self.b(scope + "/layer_norm/scale"), ds, dy, self.gb(scope + "/layer_norm/scale"),
+                     self.gb(scope + "/layer_norm/offset"),
+                     self.gb(prev_bias) if prev_bias is not None else None, drop_p, sid)
+        return ds, (dy if dy is not None else ds)
+
+    def _ffn_bwd(self, dx, x_in, scope, tag, sid0, side, dx_out):
+        e, hp = self.eng, self.hp
+        p = scope + "/ffn_layer/"
+        T = dx.rows
+        ds, dy = self._ln_bwd(dx, scope, tag, p + "output/b_0", hp.residual_dropout, sid0 + 1, side)
+        h = e.mat(tag + ".h", T, self.F)
+        dh = e.mat("g%s.dh" % side, T, self.F)
+        rp = hp.relu_dropout
+        self._linear_bwd(h, dy, p + "output", dx=dh, bias_grad=False, act=2, aux=h,
+                         aux_scale=1.0 / (1.0 - rp) if rp > 0 else 1.0)
+        self._linear_bwd(x_in, dh, p + "enlarge", dx=dx_out, residual=ds)
+        return dx_out
+
+    def _self_attn_bwd(self, dx, x_in, B, L, scope, tag, kmask, causal, sid0, side, dx_out):
+        e, hp, H = self.eng, self.hp, self.H
+        p = scope + "/dot_attention/"
+        T = dx.rows
+        ds, dy = self._ln_bwd(dx, scope, tag, p + "o_map/b_0", hp.residual_dropout, sid0 + 1, side)
+        att = e.mat(tag + ".att", T, H)
+        datt = e.mat("g%s.datt" % side, T, H)
+        self._linear_bwd(att, dy, p + "o_map", dx=datt, bias_grad=False)
+        qkv = e.mat(tag + ".qkv", T, 3 * H)
+        dqkv = e.mat("g%s.dqkv" % side, T, 3 * H)
+        rk = self.store.s(p + "rpr_keys/embeddings") if self.rpr else None
+        rv = self.store.s(p + "rpr_values/embeddings") if self.rpr else None
+        e.attn_bwd(qkv.cols_slice(0, H), qkv.cols_slice(H, 2 * H), qkv.cols_slice(2 * H, 3 * H), att, datt,
+                   e.buf(tag + ".lse", (B * self.nh * L,), F32), dqkv.cols_slice(0, H), dqkv.cols_slice(H, 2 * H),
+                   dqkv.cols_slice(2 * H, 3 * H), B, self.nh, L, L, self.d, kmask=kmask, causal=causal,
+                   rpr_k=rk, rpr_v=rv,
+                   drpr_k=self.gb(p + "rpr_keys/embeddings") if self.rpr else None,
+                   drpr_v=self.gb(p + "rpr_values/embeddings") if self.rpr else None,
+                   max_rel=hp.max_relative_position, drop_p=hp.attention_dropout, sid=sid0)
+        self._linear_bwd(x_in, dqkv, p + "qkv_map", dx=dx_out, residual=ds)
+        return dx_out
+
+    def _cross_attn_bwd(self, dx, x_in, mem, d_mem, B, Lq, Lk, scope, tag, kmask, sid0, side, dx_out):
+        e, hp, H = self.eng, self.hp, self.H
+        p = scope + "/dot_attention/"
+        T = dx.rows
+        ds, dy = self._ln_bwd(dx, scope, tag, p + "o_map/b_0", hp.residual_dropout, sid0 + 1, side)
+        att = e.mat(tag + ".att", T, H)
+        datt = e.mat("g%s.datt" % side, T, H)
+        self._linear_bwd(att, dy, p + "o_map", dx=datt, bias_grad=False)
+        q = e.mat(tag + ".q", T, H)
+        kv = e.mat(tag + ".kv", mem.rows, 2 * H)
+        dq = e.mat("g%s.dq" % side, T, H)
+        dkv = e.mat("g%s.dkv" % side, mem.rows, 2 * H)
+        rk = self.store.s(p + "rpr_keys/embeddings") if self.rpr else None
+        rv = self.store.s(p + "rpr_values/embeddings") if self.rpr else None
+        e.attn_bwd(q, kv.cols_slice(0, H), kv.cols_slice(H, 2 * H), att, datt,
+                   e.buf(tag + ".lse", (B * self.nh * Lq,), F32), dq, dkv.cols_slice(0, H),
+                   dkv.cols_slice(H, 2 * H), B, self.nh, Lq, Lk, self.d, kmask=kmask, causal=False,
+                   rpr_k=rk, rpr_v=rv,
+                   drpr_k=self.gb(p + "rpr_keys/embeddings") if self.rpr else None,
+                   drpr_v=self.gb(p + "rpr_values/embeddings") if self.rpr else None,
+                   max_rel=hp.max_relative_position, drop_p=hp.attention_dropout, sid=sid0)
+        self._linear_bwd(x_in, dq, p + "q_map", dx=dx_out, residual=ds)
+        # memory side: gradients of all decoder layers accumulate in d_mem (in place)
+        self._linear_bwd(mem, dkv.cols_slice(0, H), p + "k_map", dx=d_mem, residual=d_mem)
+        self._linear_bwd(mem, dkv.cols_slice(H, 2 * H), p + "v_map", dx=d_mem, residual=d_mem)
+        return dx_out
+
+    def _aan_bwd(self, dx, B, L, scope, tag, tmask, sid0, side, dx_out):
+        e, hp, H = self.eng, self.hp, self.H
+        T = dx.rows
+        ds, dg = self._ln_bwd(dx, scope, tag, None, hp.residual_dropout, sid0 + 1, side)
+        cat = e.mat(tag + ".cat", T, 2 * H)
+        z = e.mat(tag + ".z", T, 2 * H)
+        dz = e.mat("g%s.dz" % side, T, 2 * H)
+        dxg = e.mat("g%s.dxg" % side, T, H)
+        dyg = e.mat("g%s.dyg" % side, T, H)
+        e.aan_gate_bwd(dg, z, cat, dz, dxg, dyg, T, H)
+        dcat = e.mat("g%s.dcat" % side, T, 2 * H)
+        self._linear_bwd(cat, dz, scope + "/z_project", dx=dcat)
+        e.aan_bwd(dcat, dxg, dyg, ds, tmask, dx_out, B, L, H, hp.aan_mask)
+        return dx_out
+
+    # ------------------------------------------------------------------ whole model
+    def upload(self, source, target=None, trim=True):
+        """Host ids -> device int32 (after remove_invalid_seq).  Returns dict of
+        static device buffers + dims."""
+        e = self.eng
+        src = np.asarray(source.cpu() if torch.is_tensor(source) else source)
+        if trim:
+            src = trim_columns(src)
+        B, Ls = src.shape
+        ids_s = e.buf("ids.src", (B, Ls), torch.int32)
+        ids_s.copy_(torch.from_numpy(src.astype(np.int32)), non_blocking=False)
+        out = {"B": B, "Ls": Ls, "src": ids_s}
+        if target is not None:
+            tgt = np.asarray(target.cpu() if torch.is_tensor(target) else target)
+            if trim:
+                tgt = trim_columns(tgt)
+            Lt = tgt.shape[1]
+            ids_t = e.buf("ids.tgt", (B, Lt), torch.int32)
+            ids_t.copy_(torch.from_numpy(tgt.astype(np.int32)), non_blocking=False)
+            out.update({"Lt": Lt, "tgt": ids_t})
+        return out
+
+    def encode(self, batch, train, save):
+        """transformer.py:15-84."""
+        e, hp, H = self.eng, self.hp, self.H
+        B, Ls = batch["B"], batch["Ls"]
+        Ts = B * Ls
+        smask = e.buf("smask", (B, Ls), F32)
+        e.make_mask(batch["src"], smask, Ts)
+        x = e.mat("enc.x0", Ts, H)
+        e.embed_fwd(batch["src"], self.store.s(self.src_emb), self.b("bias"), x, B, Ls, H,
+                    drop_p=hp.dropout if train else 0.0, sid=9001)
+        for l in range(hp.num_encoder_layer):
+            pre = "encoder/layer_%d" % l
+            x = self._self_attn_fwd(x, B, Ls, pre + "/self_attention", "e%d.sa" % l, smask, False, save,
+                                    100 * l + 1, train)
+            x = self._ffn_fwd(x, pre + "/feed_forward", "e%d.ff" % l, save, 100 * l + 11, train)
+        return x, smask
+
+    def decode_train(self, batch, enc, smask, train, save):
+        """transformer.py:87-181 (training path: shifted inputs, causal self-attention)."""
+        e, hp, H = self.eng, self.hp, self.H
+        B, Ls, Lt = batch["B"], batch["Ls"], batch["Lt"]
+        Tt = B * Lt
+        tmask = e.buf("tmask", (B, Lt), F32)
+        w = e.buf("tw", (B, Lt), F32)
+        e.target_stats(batch["tgt"], tmask, w, B, Lt, hp.loss_scale if train else 1.0)
+        x = e.mat("dec.x0", Tt, H)
+        e.embed_fwd(batch["tgt"], self.store.s(self.tgt_emb), self.b("bias"), x, B, Lt, H, shift=True,
+                    drop_p=hp.dropout if train else 0.0, sid=9002)
+        NE = hp.num_encoder_layer
+        for l in range(hp.num_decoder_layer):
+            pre = "decoder/layer_%d" % l
+            sid = 100 * (NE + l)
+            if self.aan:
+                x = self._aan_fwd(x, B, Lt, pre + "/average_attention", "d%d.aa" % l, tmask, save, sid + 1, train)
+            else:
+                x = self._self_attn_fwd(x, B, Lt, pre + "/self_attention", "d%d.sa" % l, None, True, save,
+                                        sid + 1, train)
+            x = self._cross_attn_fwd(x, enc, B, Lt, Ls, pre + "/cross_attention", "d%d.ca" % l, smask, save,
+                                     sid + 11, train)
+            x = self._ffn_fwd(x, pre + "/feed_forward", "d%d.ff" % l, save, sid + 21, train)
+        return x, tmask, w
+
+    def loss_head(self, batch, feat, w, label_smooth, need_grad):
+        """transformer.py:182-216."""
+        e = self.eng
+        B, Lt = batch["B"], batch["Lt"]
+        Tt = B * Lt
+        E = self.W(self.soft_emb)
+        logits = e.mat("logits", Tt, self.Vpad, F32)
+        e.gemm(feat, E, logits, Tt, self.V, self.H, 0, 1)
+        ce = e.buf("ce", (Tt,), F32)
+        dlogits = e.mat("dlogits", Tt, self.Vpad) if need_grad else None
+        e.ce_fused(logits, batch["tgt"], w if need_grad else None, ce, dlogits, Tt, self.V, label_smooth)
+        per_sample = e.buf("per_sample", (B,), F32)
+        loss = e.buf("loss", (1,), F32)
+        e.loss_reduce(ce, batch["tgt"], per_sample, loss, B, Lt)
+        return loss, per_sample, logits, dlogits
+
+    def forward(self, batch, train=False, save=False, label_smooth=None):
+        ls = self.hp.label_smooth if label_smooth is None else label_smooth
+        enc, smask = self.encode(batch, train, save)
+        feat, tmask, w = self.decode_train(batch, enc, smask, train, save)
+        loss, per_sample, logits, dlogits = self.loss_head(batch, feat, w, ls, save)
+        self._ctx = (batch, enc, smask, feat, tmask, dlogits)
+        return loss, per_sample, logits
+
+    def backward(self, on_ready=None):
+        """Hand-written mirror of forward(train=True, save=True): fills store.grad.
+        ``on_ready(key)`` is called as soon as every gradient under ``key`` (a variable
+        name or ``encoder/layer_i`` / ``decoder/layer_i``) is final, so that the
+        all-reduce of that bucket can overlap the rest of the backward."""
+        e, hp, H = self.eng, self.hp, self.H
+        if on_ready is None:
+            on_ready = lambda key: None
+        batch, enc, smask, feat, tmask, dlogits = self._ctx
+        B, Ls, Lt = batch["B"], batch["Ls"], batch["Lt"]
+        Ts, Tt = B * Ls, B * Lt
+        st = self.store
+        # gradients that are accumulated with atomics start from zero
+        e.zero(st.g("bias"))
+        e.zero(st.g(self.src_emb))
+        if self.tgt_emb != self.soft_emb and self.tgt_emb != self.src_emb:
+            e.zero(st.g(self.tgt_emb))
+        if self.rpr:
+            for name in st.names():
+                if name.endswith("/embeddings"):
+                    e.zero(st.g(name))
+        # logits / softmax embedding
+        E = self.W(self.soft_emb)
+        P = [e.mat("gd.p0", Tt, H), e.mat("gd.p1", Tt, H)]
+        cur = 0
+        e.gemm(dlogits, E, P[cur], Tt, H, self.Vpad, 0, 0)
+        gE = self.gW(self.soft_emb)
+        if self.soft_emb == self.src_emb:
+            # shared table already zeroed above; wgrad must accumulate -> go through a temp
+            tmp = e.mat("g.embtmp", self.Vpad, H, F32)
+            e.gemm(dlogits, feat, tmp, self.Vpad, H, Tt, 1, 0)
+            e.lib.call("zk_axpby_f32", gE.ptr, tmp.ptr, 1.0, 1.0, self.Vpad * H, e.stream)
+        else:
+            e.gemm(dlogits, feat, gE, self.Vpad, H, Tt, 1, 0)
+        d_enc = e.mat("g.denc", Ts, H)
+        e.zero(d_enc.t)
+        NE = hp.num_encoder_layer
+
+        def layer_input(side, l, kind):
+            # output of the sub-layer preceding `kind` in layer l == its residual input
+            if side == "d":
+                order = (["aa"] if self.aan else ["sa"]) + ["ca", "ff"]
+            else:
+                order = ["sa", "ff"]
+            i = order.index(kind)
+            if i > 0:
+                return e.mat("%s%d.%s.o" % (side, l, order[i - 1]), Tt if side == "d" else Ts, H)
+            if l > 0:
+                return e.mat("%s%d.ff.o" % (side, l - 1), Tt if side == "d" else Ts, H)
+            return e.mat("dec.x0" if side == "d" else "enc.x0", Tt if side == "d" else Ts, H)
+
+        for l in reversed(range(hp.num_decoder_layer)):
+            pre = "decoder/layer_%d" % l
+            sid = 100 * (NE + l)
+            self._ffn_bwd(P[cur], layer_input("d", l, "ff"), pre + "/feed_forward", "d%d.ff" % l, sid + 21, "d",
+                          P[cur ^ 1])
+            cur ^= 1
+            self._cross_attn_bwd(P[cur], layer_input("d", l, "ca"), enc, d_enc, B, Lt, Ls,
+                                 pre + "/cross_attention", "d%d.ca" % l, smask, sid + 11, "d", P[cur ^ 1])
+            cur ^= 1
+            if self.aan:
+                self._aan_bwd(P[cur], B, Lt, pre + "/average_attention", "d%d.aa" % l, tmask, sid + 1, "d",
+                              P[cur ^ 1])
+            else:
+                self._self_attn_bwd(P[cur], layer_input("d", l, "sa"), B, Lt, pre + "/self_attention",
+                                    "d%d.sa" % l, None, True, sid + 1, "d", P[cur ^ 1])
+            cur ^= 1
+            on_ready(pre)
+        e.embed_bwd(batch["tgt"], P[cur], st.g(self.tgt_emb), st.g("bias"), B, Lt, H, shift=True,
+                    drop_p=hp.dropout, sid=9002)
+        if self.soft_emb != self.src_emb:
+            on_ready(self.soft_emb)
+        if self.tgt_emb != self.soft_emb and self.tgt_emb != self.src_emb:
+            on_ready(self.tgt_emb)
+        # encoder
+        Q = [d_enc, e.mat("ge.p1", Ts, H)]
+        cur = 0
+        for l in reversed(range(NE)):
+            pre = "encoder/layer_%d" % l
+            other = Q[cur ^ 1] if (Q[cur ^ 1] is not d_enc) else e.mat("ge.p0", Ts, H)
+            self._ffn_bwd(Q[cur], layer_input("e", l, "ff"), pre + "/feed_forward", "e%d.ff" % l, 100 * l + 11,
+                          "e", other)
+            Q[cur ^ 1] = other
+            cur ^= 1
+            other = Q[cur ^ 1] if (Q[cur ^ 1] is not d_enc) else e.mat("ge.p0", Ts, H)
+            self._self_attn_bwd(Q[cur], layer_input("e", l, "sa"), B, Ls, pre + "/self_attention", "e%d.sa" % l,
+                                smask, False, 100 * l + 1, "e", other)
+            Q[cur ^ 1] = other
+            cur ^= 1
+            on_ready(pre)
+        e.embed_bwd(batch["src"], Q[cur], st.g(self.src_emb), st.g("bias"), B, Ls, H, shift=False,
+                    drop_p=hp.dropout, sid=9001)
+        on_ready("bias")
+        on_ready(self.src_emb)

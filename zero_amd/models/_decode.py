@@ -1,0 +1,177 @@
+# coding: utf-8
+"""Incremental (cached) and full-recompute decoding steps on HIP kernels.
+
+``infer_fn`` of the reference (models/transformer.py:252-285, transformer_aan.py:294-327)
+returns two closures; so does :func:`make_infer_fns`:
+
+  encoding_fn(source)                -> state
+  decoding_fn(target, state, time)   -> (logits fp32 [B*K, ld>=V], state)
+
+MI355X layout of ``state`` (instead of the reference's beam-tiled nest, search.py:36-39):
+  * beam-invariant tensors -- encoder output, source mask and the cross-attention keys /
+    values ``mk`` / ``mv`` of every layer (func.py:206-216) -- are stored ONCE per sentence
+    and never tiled or reordered; the attention kernel maps query row b*K+k to sentence b
+    (``kv_group=K``);
+  * per-beam caches -- self-attention ``k`` / ``v`` (func.py:199-205) as preallocated
+    [B*K, Tmax, H] bf16 buffers written in place at position ``time`` (no concat), the AAN
+    running sum (transformer_aan.py:110-112) as fp32 [B*K, H] -- are double-buffered and
+    reordered by a row gather (search.py:206-209).
+``cache_init``'s dummy step (search.py:56-77) is unnecessary: mk/mv are computed by
+``encoding_fn``; the values are the same.
+
+search_mode="dev" (transformer.py:277-281) recomputes the encoder and the whole prefix
+through the training-path decoder each step.
+"""
+
+import numpy as np
+import torch
+
+from zero_amd.func import Mat
+from zero_amd.models._factory import get_core
+
+F32 = torch.float32
+
+
+class DecodeState(dict):
+    """Nested-dict state with the cache plumbing the search needs."""
+
+    def reorder(self, index_dev):
+        """Gather every per-beam cache by flat beam index [B*K] (device int32)."""
+        core = self["_core"]
+        e = core.eng
+        BK, H, t = self["BK"], core.H, self["time_filled"]
+        for l in range(core.hp.num_decoder_layer):
+            lay = self["decoder"]["state"]["layer_%d" % l]
+            if "aan" in lay:
+                src = lay["aan"]
+                dst = e.buf("dc%d.aan.%d" % (l, 1 - lay["_pp"]), (BK, H), F32)
+                e.lib.call("zk_gather_rows", src.data_ptr(), H * 4, index_dev.data_ptr(), dst.data_ptr(), H * 4,
+                           BK, H * 4, e.stream)
+                lay["aan"] = dst
+                lay["_pp"] = 1 - lay["_pp"]
+            if "k" in lay:
+                Tmax = self["Tmax"]
+                for nm in ("k", "v"):
+                    src = lay[nm]
+                    dst = e.buf("dc%d.%s.%d" % (l, nm, 1 - lay["_pp"]), (BK, Tmax, H))
+                    e.lib.call("zk_gather_rows", src.data_ptr(), Tmax * H * 2, index_dev.data_ptr(),
+                               dst.data_ptr(), Tmax * H * 2, BK, t * H * 2, e.stream)
+                    lay[nm] = dst
+                lay["_pp"] = 1 - lay["_pp"]
+
+
+def make_infer_fns(params, model_name):
+    hp = params
+
+    def encoding_fn(source, beam_size=None, max_steps=None):
+        core = get_core(hp, model_name)
+        e, H = core.eng, core.H
+        K = hp.beam_size if beam_size is None else beam_size
+        batch = core.upload(source)
+        B, Ls = batch["B"], batch["Ls"]
+        enc, smask = core.encode(batch, False, False)
+        enc_keep = e.mat("dc.enc", B * Ls, H)
+        enc_keep.t.copy_(enc.t)
+        mask_keep = e.buf("dc.smask", (B, Ls), F32)
+        mask_keep.copy_(smask)
+        if max_steps is None:
+            src_len = (np.asarray(source.cpu() if torch.is_tensor(source) else source) != 0).sum(1)
+            max_steps = int(src_len.max()) + hp.decode_length + 2
+        BK = B * K
+        state = DecodeState()
+        state.update({"_core": core, "B": B, "K": K, "BK": BK, "Ls": Ls, "Tmax": max_steps,
+                      "encodes": enc_keep, "mask": mask_keep, "time_filled": 0,
+                      "decoder": {"state": {}}})
+        for l in range(hp.num_decoder_layer):
+            p = "decoder/layer_%d/cross_attention/dot_attention/" % l
+            kv = e.mat("dc%d.kv" % l, B * Ls, 2 * H)
+            core._linear(enc_keep, p + "k_map", kv.cols_slice(0, H))
+            core._linear(enc_keep, p + "v_map", kv.cols_slice(H, 2 * H))
+            lay = {"mk": kv.cols_slice(0, H), "mv": kv.cols_slice(H, 2 * H), "_pp": 0}
+            if core.aan:
+                a = e.buf("dc%d.aan.0" % l, (BK, H), F32)
+                e.zero(a)
+                lay["aan"] = a
+            else:
+                lay["k"] = e.buf("dc%d.k.0" % l, (BK, max_steps, H))
+                lay["v"] = e.buf("dc%d.v.0" % l, (BK, max_steps, H))
+            state["decoder"]["state"]["layer_%d" % l] = lay
+        state["zero_flag"] = e.buf("dc.zflag", (1,), torch.int32)
+        return state
+
+    def _step_cache(target, state, time):
+        core = state["_core"]
+        e, H, nh, d = core.eng, core.H, core.nh, core.d
+        BK, K, B, Ls, Tmax = state["BK"], state["K"], state["B"], state["Ls"], state["Tmax"]
+        if time >= Tmax:
+            raise RuntimeError("decode step %d exceeds the allocated cache length %d" % (time, Tmax))
+        zf = state["zero_flag"]
+        e.lib.call("zk_all_equal", target.data_ptr(), BK, hp.tgt_vocab.pad(), zf.data_ptr(), e.stream)
+        x = e.mat("dc.x", BK, H)
+        e.embed_fwd(target, core.store.s(core.tgt_emb), core.b("bias"), x, BK, 1, H, pos0=time, zero_flag=zf)
+        for l in range(hp.num_decoder_layer):
+            pre = "decoder/layer_%d" % l
+            lay = state["decoder"]["state"]["layer_%d" % l]
+            if core.aan:
+                a = pre + "/average_attention"
+                cat = e.mat("dc.cat", BK, 2 * H)
+                e.lib.call("zk_aan_decode", x.ptr, lay["aan"].data_ptr(), cat.ptr, BK, H, 1.0 / float(time + 1),
+                           e.stream)
+                z = e.mat("dc.z", BK, 2 * H)
+                core._linear(cat, a + "/z_project", z)
+                g = e.mat("dc.y", BK, H)
+                e.aan_gate_fwd(z, cat, g, BK, H)
+                x = core._ln_fwd(x, g, a, "dc%d.aa" % l, False, 0.0, 0)
+            else:
+                p = pre + "/self_attention/dot_attention/"
+                qkv = e.mat("dc.qkv", BK, 3 * H)
+                core._linear(x, p + "qkv_map", qkv)
+                for nm, c0 in (("k", H), ("v", 2 * H)):
+                    e.lib.call("zk_gather_rows", qkv.ptr + c0 * 2, 3 * H * 2, None,
+                               lay[nm].data_ptr() + time * H * 2, Tmax * H * 2, BK, H * 2, e.stream)
+                att = e.mat("dc.att", BK, H)
+                rk = core.store.s(p + "rpr_keys/embeddings") if core.rpr else None
+                rv = core.store.s(p + "rpr_values/embeddings") if core.rpr else None
+                e.attn_fwd(qkv.cols_slice(0, H), Mat(lay["k"], BK * Tmax, H), Mat(lay["v"], BK * Tmax, H), att,
+                           None, BK, nh, 1, time + 1, d, kmask=None, causal=False, q_pos0=time, rpr_k=rk,
+                           rpr_v=rv, max_rel=hp.max_relative_position, bsq=3 * H, bsk=Tmax * H, bsv=Tmax * H)
+                y = e.mat("dc.y", BK, H)
+                core._linear(att, p + "o_map", y)
+                x = core._ln_fwd(x, y, pre + "/self_attention", "dc%d.sa" % l, False, 0.0, 0)
+            p = pre + "/cross_attention/dot_attention/"
+            q = e.mat("dc.q", BK, H)
+            core._linear(x, p + "q_map", q)
+            att = e.mat("dc.att", BK, H)
+            rk = core.store.s(p + "rpr_keys/embeddings") if core.rpr else None
+            rv = core.store.s(p + "rpr_values/embeddings") if core.rpr else None
+            e.attn_fwd(q, lay["mk"], lay["mv"], att, None, BK, nh, 1, Ls, d, kmask=state["mask"], causal=False,
+                       q_pos0=time, rpr_k=rk, rpr_v=rv, max_rel=hp.max_relative_position, bsq=H,
+                       bsk=Ls * 2 * H, bsv=Ls * 2 * H, kv_group=K)
+            y = e.mat("dc.y", BK, H)
+            core._linear(att, p + "o_map", y)
+            x = core._ln_fwd(x, y, pre + "/cross_attention", "dc%d.ca" % l, False, 0.0, 0)
+            x = core._ffn_fwd(x, pre + "/feed_forward", "dc%d.ff" % l, False, 0, False)
+        logits = e.mat("dc.logits", BK, core.Vpad, F32)
+        e.gemm(x, core.W(core.soft_emb), logits, BK, core.V, H, 0, 1)
+        state["time_filled"] = time + 1
+        return logits, state
+
+    def _step_dev(target, source, time):
+        """transformer.py:277-281: encoder + training-path decoder on the whole prefix."""
+        core = get_core(hp, model_name)
+        e = core.eng
+        batch = core.upload(source, target)
+        enc, smask = core.encode(batch, False, False)
+        feat, _, _ = core.decode_train(batch, enc, smask, False, False)
+        BK, Lt = batch["B"], batch["Lt"]
+        last = Mat(feat.t, BK, core.H, Lt * core.H, (Lt - 1) * core.H)
+        logits = e.mat("dc.logits", BK, core.Vpad, F32)
+        e.gemm(last, core.W(core.soft_emb), logits, BK, core.V, core.H, 0, 1)
+        return logits, source
+
+    def decoding_fn(target, state, time):
+        if hp.search_mode == "cache":
+            return _step_cache(target, state, time)
+        return _step_dev(target, state, time)
+
+    return encoding_fn, decoding_fn

@@ -1,0 +1,141 @@
+# coding: utf-8
+"""Beam search over the HIP decode step.
+
+Same algorithm and the same public function as the reference's search.py:19-275
+(``beam_search(features, encoding_fn, decoding_fn, params)`` -> {'seq', 'score'}):
+alive / finished beam sets, initial log-probs [0, f32.min, ...] so that step 0 expands only
+beam 0 (search.py:46), EOS forbidden at step 0 (search.py:152-155), GNMT length penalty
+((5+t+1)/6)^alpha (search.py:168-170), 2K candidates per sentence, alive top-K of the
+unfinished ones and finished top-K of (previous K + current 2K) (search.py:198-228), stop
+when every sentence's worst finished score beats the best possible alive score or the
+length cap is hit (search.py:85-113).  "Greedy" decoding = ``beam_size=1``.
+
+Division of labour per step: the model step, log-softmax, penalty and the top-2K over
+K*V candidates run on the GPU (one fused kernel, zk_beam_topk); the O(B*K) alive/finished
+bookkeeping on the 2K survivors runs on the host in fp32 numpy exactly as search.py writes
+it (it needs the termination test on the host anyway); caches are reordered on the GPU.
+"""
+
+import numpy as np
+import torch
+
+from zero_amd.utils import dtype as zdtype
+
+F32_MIN = np.finfo(np.float32).min
+
+
+def _top_k(x, k):
+    """tf.nn.top_k: descending, ties -> lower index."""
+    idx = np.argsort(-x, axis=-1, kind="stable")[..., :k]
+    return np.take_along_axis(x, idx, axis=-1), idx
+
+
+def beam_search(features, encoding_fn, decoding_fn, params):
+    f32 = np.float32
+    K = params.beam_size
+    alpha = params.decode_alpha
+    eos_id = params.tgt_vocab.eos()
+    pad_id = params.tgt_vocab.pad()
+    V = params.tgt_vocab.size()
+    source = features["source"]
+    src_np = np.asarray(source.cpu() if torch.is_tensor(source) else source)
+    B = src_np.shape[0]
+    src_len = (src_np != 0).sum(-1).astype(f32)
+    max_target_length = src_len + f32(params.decode_length)
+    cache_mode = params.search_mode == "cache"
+    if cache_mode:
+        state = encoding_fn(source, beam_size=K,
+                            max_steps=int(max_target_length.max()) + 2)
+        core = state["_core"]
+    else:
+        from zero_amd.models._factory import get_core
+        core = get_core(params, params.model_name)
+        state = np.repeat(src_np, K, axis=0)      # expand_tile_dims of the raw source
+    e = core.eng
+    dev = e.device
+
+    log_probs = np.tile(np.array([[0.] + [F32_MIN] * (K - 1)], dtype=f32), (B, 1))
+    scores = np.zeros_like(log_probs)
+    seq = np.full((B, K, 1), pad_id, dtype=np.int64)
+    fin_seq = np.zeros_like(seq)
+    fin_scores = np.full((B, K), F32_MIN, dtype=f32)
+    fin_flags = np.zeros((B, K), dtype=bool)
+
+    d_prev = e.buf("bs.prev", (B * K,), torch.float32)
+    d_ts = e.buf("bs.ts", (B, 2 * K), torch.float32)
+    d_ti = e.buf("bs.ti", (B, 2 * K), torch.int32)
+    d_tok = e.buf("bs.tok", (B * K,), torch.int32)
+    d_idx = e.buf("bs.idx", (B * K,), torch.int32)
+    mtl_i = max_target_length.astype(np.int32)
+    time = 0
+    while True:
+        # ---- search.py:85-113
+        max_lp = np.power((f32(5.) + max_target_length) / f32(6.), f32(alpha)).astype(f32)
+        best_alive = log_probs[:, 0] / max_lp
+        worst_fin = (fin_scores * fin_flags.astype(f32)).min(axis=1)
+        worst_fin = worst_fin + (f32(1.) - fin_flags.any(axis=1).astype(f32)) * F32_MIN
+        bound_is_met = bool((worst_fin > best_alive).all())
+        length_is_met = bool((time < mtl_i).any())
+        if bound_is_met or not length_is_met:
+            break
+        # ---- model step (search.py:118-142)
+        if cache_mode:
+            d_tok.copy_(torch.from_numpy(seq[:, :, -1].reshape(-1).astype(np.int32)))
+            logits, state = decoding_fn(d_tok, state, time)
+        else:
+            flat = seq.reshape(B * K, -1)
+            decode_target = np.concatenate([flat[:, 1:], np.ones((B * K, 1), dtype=flat.dtype)], axis=1)
+            logits, state = decoding_fn(decode_target, state, time)
+        # ---- fused log-softmax + penalty + top-2K (search.py:143-176)
+        penalty = f32(np.power(f32((f32(5.) + f32(time + 1)) / f32(6.)), f32(alpha)))
+        d_prev.copy_(torch.from_numpy(log_probs.reshape(-1)))
+        e.lib.call("zk_beam_topk", logits.ptr, d_prev.data_ptr(), d_ts.data_ptr(), d_ti.data_ptr(), B, K, V,
+                   logits.ld, 2 * K, float(params.beam_search_temperature), float(penalty),
+                   eos_id if time < 1 else -1, float(zdtype.inf()), e.stream)
+        topk_scores = d_ts.cpu().numpy().astype(f32)
+        topk_idx = d_ti.cpu().numpy().astype(np.int64)
+        beam_idx = topk_idx // V
+        sym_idx = topk_idx % V
+        bpos = np.arange(B)[:, None]
+        curr_seq = np.concatenate([seq[bpos, beam_idx], sym_idx[:, :, None]], axis=2)
+        # ---- alive (search.py:192-210)
+        curr_fin = (sym_idx == eos_id) | (time >= mtl_i)[:, None]
+        alive_scores, alive_idx = _top_k(topk_scores + curr_fin.astype(f32) * F32_MIN, K)
+        alive_seq = curr_seq[bpos, alive_idx]
+        alive_beam = beam_idx[bpos, alive_idx]
+        with np.errstate(over="ignore"):
+            alive_lp = (alive_scores * penalty).astype(f32)
+        # ---- finished (search.py:212-228)
+        cfs = topk_scores + (f32(1.) - curr_fin.astype(f32)) * F32_MIN
+        all_flags = np.concatenate([fin_flags, curr_fin], axis=1)
+        all_scores = np.concatenate([fin_scores, cfs], axis=1)
+        fin_scores, fin_idx = _top_k(all_scores, K)
+        fin_flags = all_flags[bpos, fin_idx]
+        pad_col = np.full((B, K, 1), pad_id, dtype=seq.dtype)
+        all_seq = np.concatenate([np.concatenate([fin_seq, pad_col], axis=2), curr_seq], axis=1)
+        fin_seq = all_seq[bpos, fin_idx]
+        seq, log_probs, scores = alive_seq, alive_lp, alive_scores
+        if cache_mode:
+            flat_idx = (np.arange(B)[:, None] * K + alive_beam).reshape(-1).astype(np.int32)
+            d_idx.copy_(torch.from_numpy(flat_idx))
+            state.reorder(d_idx)
+        time += 1
+
+    any_fin = fin_flags.any(axis=1)
+    final_seqs = np.where(any_fin[:, None, None], fin_seq, seq)
+    final_scores = np.where(any_fin[:, None], fin_scores, scores)
+    return {"seq": final_seqs[:, :, 1:], "score": final_scores, "steps": time}
+
+
+def decode_hypothesis(seqs, params):
+    """evalu.py:14-46: take beam 0, cut at the first eos or pad."""
+    out = []
+    for b in range(seqs.shape[0]):
+        ids = []
+        for t in seqs[b, 0]:
+            t = int(t)
+            if t == params.tgt_vocab.eos() or t == params.tgt_vocab.pad():
+                break
+            ids.append(t)
+        out.append(ids)
+    return out

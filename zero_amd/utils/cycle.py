@@ -1,0 +1,94 @@
+# coding: utf-8
+"""Gradient accumulation, global-norm clipping and the Adam update on flat HBM buffers.
+
+Counterpart of the reference's utils/cycle.py:47-135 (``create_train_op``) plus the
+``tf.train.AdamOptimizer`` it wraps (main.py:178-181):
+
+  * ``zero_op``    -> :meth:`TrainOp.zero`     (cycle.py:58-71 zero the slots)
+  * ``collect_op`` -> :meth:`TrainOp.collect`  (cycle.py:73-85 slot += grad, count += 1)
+  * ``train_op``   -> :meth:`TrainOp.apply`    g = (g + slot)/(count+1) (cycle.py:86-88);
+    gnorm = ||g||, pnorm = ||theta|| (cycle.py:94-95); clip iff ``clip_grad_norm`` is a
+    non-zero float (cycle.py:98-101); TF1 Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
+    theta -= lr_t * m / (sqrt(v) + eps).
+
+Everything is one pass per quantity over the scope's flat buffers (zero_amd/variables.py);
+the 1/N of the tower average (utils/parallel.py:184-196) and 1/loss_scale (main.py:28-30)
+are folded into the same pass as ``grad_scale``.  EMA (cycle.py:113-127) is out of scope.
+"""
+
+import math
+
+import torch
+
+from zero_amd import hip
+
+
+class TrainOp(object):
+    def __init__(self, store, params, engine):
+        self.store, self.hp, self.eng = store, params, engine
+        dev = store.device
+        self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.hyper_host = torch.zeros(6, dtype=torch.float32).pin_memory() if dev.type == "cuda" \
+            else torch.zeros(6, dtype=torch.float32)
+        self.pnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.count = 0
+        self._ws = torch.empty(hip.lib().query("zk_norm_workspace") * 2, dtype=torch.uint8, device=dev)
+
+    # cycle.py:58-71
+    def zero(self):
+        if self.hp.update_cycle > 1:
+            if self.store.accum is None:
+                self.store.accum = torch.zeros_like(self.store.grad)
+            else:
+                self.eng.zero(self.store.accum)
+        self.count = 0
+
+    # cycle.py:73-85
+    def collect(self):
+        st = self.store
+        if st.accum is None:
+            st.accum = torch.zeros_like(st.grad)
+        self.eng.lib.call("zk_axpby_f32", st.accum.data_ptr(), st.grad.data_ptr(), 1.0, 1.0, st.numel,
+                          self.eng.stream)
+        self.count += 1
+
+    def set_hyper(self, lr, world=1):
+        """Host-side scalars of this update (lr is fed per step: main.py:157,292)."""
+        hp = self.hp
+        t = self.store.step + 1
+        lr_t = lr * math.sqrt(1.0 - hp.beta2 ** t) / (1.0 - hp.beta1 ** t)
+        clip = hp.clip_grad_norm or None
+        clip = float(clip) if isinstance(clip, float) else 0.0
+        scale = 1.0 / (float(world) * float(hp.loss_scale) * float(self.count + 1))
+        h = self.hyper_host
+        h[0], h[1], h[2], h[3], h[4], h[5] = lr_t, hp.beta1, hp.beta2, hp.epsilon, scale, clip
+        self.hyper[:6].copy_(h, non_blocking=True)
+        return scale
+
+    def launch_update(self, scale):
+        """Device side of train_op; graph-capturable (reads scalars from self.hyper)."""
+        st, lib, s = self.store, self.eng.lib, self.eng.stream
+        nb = self._ws.numel() // 2
+        lib.call("zk_l2norm", st.grad.data_ptr(), st.numel, scale, self.hyper.data_ptr() + 6 * 4,
+                 self._ws.data_ptr(), nb, s)
+        lib.call("zk_l2norm", st.master.data_ptr(), st.numel, 1.0, self.pnorm.data_ptr(),
+                 self._ws.data_ptr() + nb, nb, s)
+        lib.call("zk_adam", st.master.data_ptr(), st.grad.data_ptr(), st.m.data_ptr(), st.v.data_ptr(),
+                 st.shadow.data_ptr(), st.numel, self.hyper.data_ptr(), s)
+
+    def apply(self, lr, world=1, launch=True):
+        st = self.store
+        if self.count > 0:   # cycle.py:86-88: g <- g + slot, scaled by 1/(count+1) below
+            self.eng.lib.call("zk_axpby_f32", st.grad.data_ptr(), st.accum.data_ptr(), 1.0, 1.0, st.numel,
+                              self.eng.stream)
+        scale = self.set_hyper(lr, world)
+        if launch:
+            self.launch_update(scale)
+        st.step += 1
+        self.count = 0
+        return scale
+
+    def stats(self):
+        """(gradient_norm, parameter_norm, skipped) -- forces a sync; call at display time."""
+        h = self.hyper.cpu()
+        return float(h[6]), float(self.pnorm.cpu()[0]), bool(h[7] != 0)

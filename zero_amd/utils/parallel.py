@@ -1,0 +1,116 @@
+# coding: utf-8
+"""Multi-GPU gradient aggregation: one process per GPU, RCCL all-reduce over xGMI.
+
+Counterpart of the reference's utils/parallel.py:79-208.  The reference replicates
+"towers" inside one TF graph, shards the variables parameter-server style across the GPUs
+(parallel.py:105-110) and averages per-variable gradients with concat + reduce_mean
+(parallel.py:184-196).  Here every rank holds a full replica (zero_amd/variables.py) and
+the only exchange is a sum all-reduce of the flat fp32 gradient buffer, issued bucket by
+bucket while the backward is still running (torch.distributed's ``nccl`` backend *is* RCCL
+on ROCm; collectives run on RCCL's own stream and are ordered after the compute stream's
+position at call time, so they overlap with the rest of the backward).  The 1/N of
+``average_gradients`` is folded into the optimizer pass (utils/cycle.py).
+
+Equality with the reference's tower average: mean over ranks of per-rank gradients
+(parallel.py:196) -- identical to the big-batch gradient only when every rank holds the
+same number of sentences (loss is a mean of per-sentence means, transformer.py:210-211).
+"""
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns
+    (rank, world, local_rank).  Single process when WORLD_SIZE is unset or 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def layer_buckets(store):
+    """Contiguous [lo, hi) element ranges of the flat gradient buffer in the order the
+    backward finishes them: softmax/target embedding, decoder layers (last first), encoder
+    layers (last first), source embedding + shared bias."""
+    names = store.names()
+    ends = {}
+    order = []
+    for i, n in enumerate(names):
+        lo = store.offsets[n]
+        hi = store.offsets[names[i + 1]] if i + 1 < len(names) else store.numel
+        parts = n.split("/")
+        key = "/".join(parts[:2]) if parts[0] in ("encoder", "decoder") else n
+        if key not in ends:
+            ends[key] = [lo, hi]
+            order.append(key)
+        else:
+            ends[key][1] = hi
+    return {k: tuple(v) for k, v in ends.items()}, order
+
+
+class GradientAllReduce(object):
+    """Bucketed, overlapped sum all-reduce of ``store.grad``."""
+
+    def __init__(self, store, bucket_elems=8 * 1024 * 1024):
+        self.store = store
+        self.bucket_elems = bucket_elems
+        self.ranges, _ = layer_buckets(store)
+        self.pending = []
+        self._open = None   # (lo, hi) of the bucket being filled (adjacent ranges only)
+
+    def ready(self, key):
+        """Called by the backward when every gradient under ``key`` is final."""
+        if world_size() == 1:
+            return
+        lo, hi = self.ranges[key]
+        if self._open is not None and (self._open[0] == hi or self._open[1] == lo):
+            self._open = (min(lo, self._open[0]), max(hi, self._open[1]))
+        else:
+            self.flush()
+            self._open = (lo, hi)
+        if self._open[1] - self._open[0] >= self.bucket_elems:
+            self.flush()
+
+    def flush(self):
+        if self._open is None or world_size() == 1:
+            self._open = None
+            return
+        lo, hi = self._open
+        self._open = None
+        self.pending.append(dist.all_reduce(self.store.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def wait(self):
+        """Flush the tail and make the current stream wait for every bucket."""
+        self.flush()
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+    def all_reduce_everything(self):
+        """Unbucketed path (used after gradient accumulation: one exchange per update,
+        cycle.py:86-88 semantics)."""
+        if world_size() > 1:
+            dist.all_reduce(self.store.grad, op=dist.ReduceOp.SUM)
+
+
+def average_scalar(t):
+    """Tower-mean of a scalar (main.py:42 loss mean) -- logging only."""
+    if world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t /= world_size()
+    return t
