@@ -110,10 +110,15 @@ def cpu_baseline(hp, budget_s=20.0):
     from oracle import ref_torch as rt
     import copy
     hp = copy.copy(hp)
-    bs = 8   # sentences of the same 64/64 shape: 1024 src+tgt tokens per CPU step
+    bs = 4   # sentences of the same 64/64 shape: 512 src+tgt tokens per CPU step
     src, tgt = synthetic_batch(0)
     src, tgt = src[:bs], tgt[:bs]
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(32, avail))     # more threads only add contention on these small ops
+    torch.set_num_threads(cores)
     P = rt.to_torch(rt.init_params(hp, "transformer", seed=1234))
     M = {k: torch.zeros_like(v) for k, v in P.items()}
     Vv = {k: torch.zeros_like(v) for k, v in P.items()}
@@ -123,10 +128,10 @@ def cpu_baseline(hp, budget_s=20.0):
     while True:
         rt.train_step(P, M, Vv, feats, hp, "transformer", n + 1, training=True)
         n += 1
-        if time.time() - t0 > budget_s or n >= 5:
+        if time.time() - t0 > budget_s or n >= 8:
             break
     dt = time.time() - t0
-    return {"value": bs * (LS + LT) * n / dt, "unit": "src+tgt tokens/s", "cores": os.cpu_count(),
+    return {"value": bs * (LS + LT) * n / dt, "unit": "src+tgt tokens/s", "cores": cores,
             "kind": "port",
             "sample": "%d timed steps (+1 warm-up) of %d sentences x (64+64) tokens, Transformer-base, "
                       "fwd+bwd+Adam, torch-CPU fp32 restatement of the TF1 path" % (n, bs)}

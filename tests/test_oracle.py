@@ -1,0 +1,192 @@
+"""Pins the CPU oracle (the reference cannot run: no TensorFlow, no upstream tests):
+two independent restatements agree, the reference's own dual code paths agree, analytic
+known answers hold, autograd matches finite differences, golden fixtures reproduce."""
+import copy
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_torch as rt, ref_numpy as rn
+from tests.common import make_hp, make_batch, perturb
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+MODELS = ["transformer", "transformer_aan", "transformer_rpr"]
+
+
+def _tiny(model, seed=0, **kw):
+    rng = np.random.default_rng(seed)
+    hp = make_hp(model, H=16, F=32, heads=2, layers=2, Vs=13, Vt=11, max_relative_position=3, **kw)
+    Pn = perturb(rt.init_params(hp, model, seed=seed + 1, dtype=np.float64), rng)
+    src, tgt = make_batch(rng, 4, 7, 6, 13, 11)
+    return hp, Pn, src, tgt
+
+
+@pytest.fixture(autouse=True)
+def _fp64():
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_two_restatements_agree(model):
+    hp, Pn, src, tgt = _tiny(model)
+    P = rt.to_torch(Pn, torch.float64)
+    o = rt.train_fn({"source": torch.tensor(src), "target": torch.tensor(tgt)}, hp, P, model, training=False)
+    n = rn.loss_fn(src, tgt, hp, Pn, model)
+    assert abs(float(o["loss"]) - n["loss"]) < 1e-12
+    assert np.abs(o["logits"].numpy() - n["logits"]).max() < 1e-10
+    assert np.abs(o["per_sample_loss"].numpy() - n["per_sample_loss"]).max() < 1e-12
+
+
+def test_aan_mask_and_cumsum_variants_agree_on_valid_positions():
+    # transformer_aan.py:99-108: both variants average the valid prefix when pads are trailing;
+    # with label weights on valid tokens only the losses are equal
+    hp, Pn, src, tgt = _tiny("transformer_aan")
+    P = rt.to_torch(Pn, torch.float64)
+    f = {"source": torch.tensor(src), "target": torch.tensor(tgt)}
+    a = rt.train_fn(f, hp, P, "transformer_aan", training=False)
+    hp2 = copy.copy(hp); hp2.aan_mask = False
+    b = rt.train_fn(f, hp2, P, "transformer_aan", training=False)
+    assert abs(float(a["loss"]) - float(b["loss"])) < 1e-10
+
+
+@pytest.mark.parametrize("model", MODELS)
+@pytest.mark.parametrize("K", [1, 3])
+def test_cache_dev_and_numpy_beams_agree(model, K):
+    # search.py:27-30,129-142: incremental (cache) and full-recompute (dev) decoding
+    hp, Pn, src, _ = _tiny(model, beam_size=K, decode_length=5)
+    P = rt.to_torch(Pn, torch.float64)
+    outs = {}
+    for mode in ("cache", "dev"):
+        hp.search_mode = mode
+        enc, dec = rt.infer_fn(hp, P, model)
+        outs[mode] = rt.beam_search({"source": torch.tensor(src)}, enc, dec, hp)
+    with np.errstate(over="ignore"):
+        nb = rn.beam_search(src, hp, Pn, model)
+    assert np.array_equal(outs["cache"]["seq"], outs["dev"]["seq"])
+    assert np.array_equal(outs["cache"]["seq"], nb["seq"])
+    assert np.abs(outs["cache"]["score"] - nb["score"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_train_logits_equal_cached_decode_logits(model):
+    # func.py:199-216: position t of the training graph == step t of cached decoding on the gold prefix
+    hp, Pn, src, tgt = _tiny(model)
+    src, tgt = src[:1], tgt[:1]          # one unpadded sentence (row 0 is full length)
+    P = rt.to_torch(Pn, torch.float64)
+    full = rt.train_fn({"source": torch.tensor(src), "target": torch.tensor(tgt)}, hp, P, model,
+                       training=False)["logits"]
+    enc, dec = rt.infer_fn(hp, P, model)
+    state = enc(torch.tensor(src))
+    prev = torch.zeros(1, 1, dtype=torch.long)
+    for t in range(tgt.shape[1]):
+        lg, state = dec(prev, state, t)
+        assert (lg[0] - full[t]).abs().max() < 1e-9, t
+        prev = torch.tensor(tgt[:, t:t + 1])
+
+
+def test_score_fn_is_loss_without_smoothing():
+    hp, Pn, src, tgt = _tiny("transformer")
+    P = rt.to_torch(Pn, torch.float64)
+    f = {"source": torch.tensor(src), "target": torch.tensor(tgt)}
+    s = rt.score_fn(f, hp, P, "transformer")["score"]
+    hp0 = copy.copy(hp); hp0.label_smooth = 0.0
+    l = rt.train_fn(f, hp0, P, "transformer", training=False)
+    assert (s - l["per_sample_loss"]).abs().max() < 1e-12 and abs(float(s.mean()) - float(l["loss"])) < 1e-12
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_autograd_matches_finite_differences(model):
+    hp, Pn, src, tgt = _tiny(model)
+    P = rt.to_torch(Pn, torch.float64, requires_grad=True)
+    f = {"source": torch.tensor(src), "target": torch.tensor(tgt)}
+    rt.train_fn(f, hp, P, model, training=False)["loss"].backward()
+    rng = np.random.default_rng(0)
+    names = list(P.keys())
+    for name in [names[i] for i in rng.choice(len(names), 12, replace=False)]:
+        p = P[name]
+        flat = p.detach().view(-1)
+        idx = int(rng.integers(flat.numel()))
+        h = 1e-6
+        with torch.no_grad():
+            old = float(flat[idx])
+            flat[idx] = old + h
+            lp = float(rt.train_fn(f, hp, P, model, training=False)["loss"])
+            flat[idx] = old - h
+            lm = float(rt.train_fn(f, hp, P, model, training=False)["loss"])
+            flat[idx] = old
+        fd = (lp - lm) / (2 * h)
+        an = float(p.grad.view(-1)[idx])
+        assert abs(fd - an) < 1e-6 + 1e-4 * abs(an), (name, fd, an)
+
+
+def test_known_answers():
+    # timing signal closed form (func.py:355-367): concat[sin, cos], denominator H/2-1
+    sig = rt.timing_signal(4, 8, torch.float64)[0].numpy()
+    inv = np.exp(-np.arange(4) * math.log(1e4) / 3.0)
+    assert np.allclose(sig[2, :4], np.sin(2 * inv)) and np.allclose(sig[2, 4:], np.cos(2 * inv))
+    # label smoothing normaliser (util.py:97) and uniform-logits loss = log V - normaliser
+    V, ls = 11, 0.1
+    soft, norm = rt.label_smooth(torch.tensor([3]), V, ls, torch.float64)
+    assert abs(float(soft.sum()) - 1.0) < 1e-12
+    ce = -(soft * torch.log_softmax(torch.zeros(1, V), -1)).sum() - norm
+    assert abs(float(ce) - (math.log(V) - norm)) < 1e-12
+    # layer norm of a constant row is the offset (eps=1e-8)
+    P = {"s/layer_norm/scale": torch.full((8,), 2.0), "s/layer_norm/offset": torch.arange(8.0)}
+    assert torch.allclose(rt.layer_norm(torch.full((1, 8), 5.0), P, "s"), torch.arange(8.0)[None])
+    # a fully masked attention row is uniform (finite -1e8, func.py:386), not NaN
+    # (an fp32 effect: x - 1e8 rounds to -1e8 for |x| < 4; the reference computes in fp32)
+    w = torch.softmax(torch.randn(1, 5, dtype=torch.float32) + torch.tensor(-1e8, dtype=torch.float32), -1)
+    assert torch.allclose(w, torch.full((1, 5), 0.2, dtype=torch.float32), atol=1e-6)
+    # beam init: only beam 0 is expandable at step 0 (search.py:46)
+    assert rt.F32_MIN == np.finfo(np.float32).min
+
+
+def test_remove_invalid_seq_keeps_column_zero():
+    seq = torch.tensor([[0, 0, 0], [0, 0, 0]])
+    s, m = rt.remove_invalid_seq(seq, (seq != 0).double())
+    assert s.shape == (2, 1)
+    seq = torch.tensor([[4, 2, 0, 0], [5, 6, 2, 0]])
+    s, m = rt.remove_invalid_seq(seq, (seq != 0).double())
+    assert s.shape == (2, 3)
+
+
+def test_adam_and_noam_match_tf1_formulas():
+    with open(os.path.join(GOLD, "reference_scalars.json")) as f:
+        gold = json.load(f)
+    hp = make_hp("transformer", H=512, lrate=1.0, warmup_steps=4000)
+    for step, v in gold["noam_lr_init1_warm4000_h512"].items():
+        assert abs(rt.noam_lr(int(step), hp) - v) < 1e-18 + 1e-12 * v
+    hp2 = make_hp("transformer", H=1024, lrate=2.0, warmup_steps=400, min_lrate=1e-5, max_lrate=1e-3)
+    for step, v in gold["noam_lr_init2_clamped_warm400_h1024"].items():
+        assert abs(rt.noam_lr(int(step), hp2) - v) < 1e-12 * v
+    # one TF1 Adam step by hand: eps outside sqrt, bias correction folded into lr
+    hp.beta1, hp.beta2, hp.epsilon, hp.clip_grad_norm = 0.9, 0.98, 1e-8, 0.0
+    P = {"w": torch.tensor([1.0, -2.0])}
+    G = {"w": torch.tensor([0.5, -0.25])}
+    M = {"w": torch.zeros(2)}; V = {"w": torch.zeros(2)}
+    rt.adam_step(P, G, M, V, 1, 0.1, hp)
+    lr_t = 0.1 * math.sqrt(1 - 0.98) / (1 - 0.9)
+    m = 0.1 * np.array([0.5, -0.25]); v = 0.02 * np.array([0.25, 0.0625])
+    assert np.allclose(P["w"].numpy(), np.array([1.0, -2.0]) - lr_t * m / (np.sqrt(v) + 1e-8))
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_golden_fixtures_reproduce(model):
+    fx = np.load(os.path.join(GOLD, "tiny_%s.npz" % model))
+    hp = make_hp(model, H=16, F=32, heads=2, layers=2, Vs=13, Vt=11, max_relative_position=3, decode_length=6)
+    Pn = {k[6:]: fx[k].astype(np.float64) for k in fx.files if k.startswith("param:")}
+    n = rn.loss_fn(fx["source"], fx["target"], hp, Pn, model)
+    assert abs(n["loss"] - float(fx["loss"])) < 1e-10
+    assert np.abs(n["per_sample_loss"] - fx["per_sample_loss"]).max() < 1e-10
+    P = rt.to_torch(Pn, torch.float64)
+    for K in (1, 4):
+        hp.beam_size = K
+        enc, dec = rt.infer_fn(hp, P, model)
+        b = rt.beam_search({"source": torch.tensor(fx["source"])}, enc, dec, hp)
+        assert np.array_equal(b["seq"], fx["beam%d_seq" % K])

@@ -1,0 +1,118 @@
+# coding: utf-8
+"""CLI contract of the reference's run.py on the HIP hot path.
+
+Same flags (run.py:241-246: --config, --parameters, --name, --mode, --ensemble_dirs), same
+parameter priority -- command line > saved ``param.json`` > ``--config`` dict file >
+defaults (run.py:367-376) -- same ``param.json`` one-line JSON (run.py:250-272).  Only the
+step itself is implemented here (train / score / test on in-memory id batches); the
+reference's data feeding, evaluation cadence and checkpoint rotation are host control plane
+outside the hot path, so ``--mode train`` runs on the synthetic bitext generator unless the
+caller drives :class:`zero_amd.main.Trainer` with its own batches.
+"""
+
+import argparse
+import ast
+import json
+import os
+import random
+
+import numpy as np
+
+from zero_amd.config import default_params, SyntheticVocab
+from zero_amd.utils import dtype
+from zero_amd.vocab import Vocab
+
+
+def save_parameters(params, output_dir):
+    os.makedirs(output_dir, exist_ok=True)
+    with open(os.path.join(output_dir, "param.json"), "w") as writer:
+        writer.write(params.to_json())
+
+
+def load_parameters(params, output_dir):
+    name = os.path.abspath(os.path.join(output_dir, "param.json"))
+    if os.path.exists(name):
+        with open(name, "r") as reader:
+            params.parse_json(reader.readline())
+    return params
+
+
+def build_params(parameters="", config=""):
+    """run.py:367-376."""
+    params = default_params()
+    params.parse(parameters)
+    cfg = None
+    if config and os.path.exists(config):
+        text = open(config).read()
+        try:
+            cfg = ast.literal_eval(text.strip())
+        except (ValueError, SyntaxError):
+            # the reference eval()s a ``dict(k=v, ...)`` expression (run.py:371); evaluate it with
+            # no builtins except dict
+            cfg = eval(text, {"__builtins__": {}, "dict": dict})  # noqa: S307
+        params.override_from_dict(cfg)
+    if params.output_dir:
+        params = load_parameters(params, params.output_dir)
+    if cfg is not None:
+        params.override_from_dict(cfg)
+    params.parse(parameters)
+    return params
+
+
+def setup(params, synthetic_vocab=32000):
+    random.seed(params.random_seed)
+    np.random.seed(params.random_seed)
+    params.src_vocab = Vocab(params.src_vocab_file) if params.src_vocab_file else SyntheticVocab(synthetic_vocab)
+    params.tgt_vocab = Vocab(params.tgt_vocab_file) if params.tgt_vocab_file else SyntheticVocab(synthetic_vocab)
+    dtype.set_floatx(params.default_dtype)
+    dtype.set_epsilon(params.dtype_epsilon)
+    dtype.set_inf(params.dtype_inf)
+    return params
+
+
+def synthetic_batches(params, n_batches, sentences=64, length=64):
+    rng = np.random.default_rng(params.random_seed)
+    for _ in range(n_batches):
+        src = rng.integers(3, params.src_vocab.size(), size=(sentences, length))
+        tgt = rng.integers(3, params.tgt_vocab.size(), size=(sentences, length))
+        src[:, -1] = params.src_vocab.eos()
+        tgt[:, -1] = params.tgt_vocab.eos()
+        yield {"source": src, "target": tgt}
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="")
+    ap.add_argument("--parameters", default="")
+    ap.add_argument("--ensemble_dirs", default="")
+    ap.add_argument("--name", default="model")
+    ap.add_argument("--mode", default="train")
+    args = ap.parse_args(argv)
+    params = setup(build_params(args.parameters, args.config))
+    from zero_amd.main import Trainer, tower_infer_graph, tower_score_graph
+    from zero_amd.models import model, load_all
+    load_all()
+    if args.mode == "train":
+        if params.output_dir:
+            save_parameters(params, params.output_dir)
+        tr = Trainer(params)
+        for i, feats in enumerate(synthetic_batches(params, params.max_training_steps * params.update_cycle)):
+            loss = tr.micro_step(feats)
+            if (i + 1) % max(params.disp_freq, 1) == 0:
+                g, p, bad = tr.train_op.stats()
+                print(json.dumps({"step": tr.global_step, "loss": float(loss.cpu()), "gnorm": g, "pnorm": p}))
+                if bad:
+                    raise FloatingPointError("Encounter NAN or INF ERROR")
+    elif args.mode == "score":
+        for feats in synthetic_batches(params, 1):
+            print(tower_score_graph(feats, model.get_model(params.model_name), params).cpu().numpy())
+    elif args.mode == "test":
+        for feats in synthetic_batches(params, 1, sentences=params.eval_batch_size, length=24):
+            seqs, scores = tower_infer_graph(feats, model.get_model(params.model_name), params)
+            print(seqs[:, 0], scores[:, 0])
+    else:
+        raise ValueError("Invalid mode: {}".format(args.mode))
+
+
+if __name__ == "__main__":
+    main()
