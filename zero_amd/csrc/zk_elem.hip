@@ -267,17 +267,22 @@ __global__ void __launch_bounds__(256) k_add_ln_bwd(
 }
 
 // out_q[c] = sum_b partials[b][q][c]   (q < nq; out pointers may be null)
+// block = 64 columns of one quantity; 4 row-groups of 64 lanes split the partial rows.
 __global__ void __launch_bounds__(256) k_partials_reduce(const float* __restrict__ partials, int nblk,
                                                          int nq, int H, float* o0, float* o1,
                                                          float* o2) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nq * H) return;
-  const int q = idx / H, c = idx % H;
+  __shared__ float red[4][64];
+  const int q = blockIdx.y;
   float* o = q == 0 ? o0 : (q == 1 ? o1 : o2);
   if (o == nullptr) return;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
   float t = 0.f;
-  for (int b = 0; b < nblk; ++b) t += partials[((size_t)b * nq + q) * H + c];
-  o[c] = t;
+  if (c < H)
+    for (int b = g; b < nblk; b += 4) t += partials[((size_t)b * nq + q) * H + c];
+  red[g][threadIdx.x & 63] = t;
+  __syncthreads();
+  if (g == 0 && c < H) o[c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // =====================================================================================
@@ -747,7 +752,7 @@ int zk_add_ln_bwd(const void* dout, const void* sum, const float* mean, const fl
                      mean, rstd, gamma, (bf16_t*)dsum, (bf16_t*)dy, (float*)workspace, rows, H, thr, ik,
                      seed, sid);
   ZK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_partials_reduce, dim3((3 * H + 255) / 256), dim3(256), 0, stream,
+  hipLaunchKernelGGL(k_partials_reduce, dim3((H + 63) / 64, 3), dim3(256), 0, stream,
                      (const float*)workspace, g, 3, H, dgamma, dbeta, dbias_prev);
   ZK_LAUNCH_CHECK();
   return 0;
@@ -770,7 +775,7 @@ int zk_colsum(const void* a, int rows, int N, int lda, float* out, void* workspa
   hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, gy), dim3(256), 0, stream, (const bf16_t*)a, rows, N, lda,
                      (float*)workspace);
   ZK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_partials_reduce, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)workspace,
+  hipLaunchKernelGGL(k_partials_reduce, dim3((N + 63) / 64, 1), dim3(256), 0, stream, (const float*)workspace,
                      gy, 1, N, out, (float*)nullptr, (float*)nullptr);
   ZK_LAUNCH_CHECK();
   return 0;

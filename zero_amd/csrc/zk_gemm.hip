@@ -135,18 +135,39 @@ __device__ __forceinline__ int logical_row(int q) {
   return (q % RC) * 8 + q / RC;
 }
 
+// Tile schedule.  The launch is a 1-D grid of tiles_m*tiles_n*splits workgroups.  Workgroup b is
+// observed to run on XCD b%8 (each XCD has a private 4 MiB L2), so the linear id is first
+// remapped so that every XCD owns a CONTIGUOUS range of the tile order (bijective for any grid
+// size); the tile order itself is split-major, then panel-major over the operand whose panels
+// should stay L2-resident (n_major=0: consecutive tiles share the A row panel; n_major=1: they
+// share the B panel).  Pure speed choice -- any placement gives the same result.
+struct TileSched { int tiles_m, tiles_n, n_major, xcd_remap; };
+
+__device__ __forceinline__ void tile_of_block(const TileSched& ts, int& tm, int& tn, int& z) {
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
+  const int t = ts.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc : bid;
+  const int per = ts.tiles_m * ts.tiles_n;
+  z = t / per;
+  const int rem = t - z * per;
+  if (ts.n_major) { tn = rem / ts.tiles_m; tm = rem - tn * ts.tiles_m; }
+  else { tm = rem / ts.tiles_n; tn = rem - tm * ts.tiles_n; }
+}
+
 template <int BM, int BN, bool TA, bool TB>
 __global__ void __launch_bounds__(256) k_gemm_mfma(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                    int M, int N, int K, int lda, int ldb, int kchunk,
-                                                   float* __restrict__ slabs, GemmEpi e) {
+                                                   float* __restrict__ slabs, TileSched ts, GemmEpi e) {
   constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
   __shared__ __attribute__((aligned(16))) bf16_t sA[BM * LDS_LD];
   __shared__ __attribute__((aligned(16))) bf16_t sB[BN * LDS_LD];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * kchunk;
+  int tm_, tn_, z_;
+  tile_of_block(ts, tm_, tn_, z_);
+  const int m0 = tm_ * BM, n0 = tn_ * BN;
+  const int kbeg = z_ * kchunk;
   const int kend = min(K, kbeg + kchunk);
 
   f32x16_t acc[TM][TN];
@@ -209,7 +230,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const bf16_t* __restrict__ A,
         const int qm = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int gm = m0 + logical_row<BM, TA>(qm);
         if (gm < M && gn < N) {
-          if (to_slab) slabs[((size_t)blockIdx.z * M + gm) * N + gn] = acc[i][j][r];
+          if (to_slab) slabs[((size_t)z_ * M + gm) * N + gn] = acc[i][j][r];
           else epi_store(e, acc[i][j][r], gm, gn, N, seed);
         }
       }
@@ -229,16 +250,23 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 
 template <int BM, int BN>
 static int launch_mfma(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
-                       int splits, int kchunk, float* slabs, const GemmEpi& e, hipStream_t stream) {
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits);
+                       int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags,
+                       hipStream_t stream) {
+  TileSched ts;
+  ts.tiles_m = (M + BM - 1) / BM;
+  ts.tiles_n = (N + BN - 1) / BN;
+  ts.n_major = ((long)N > (long)M) ? 1 : 0;   // keep the panels of the larger operand L2-resident
+  if (sched_flags & 2) ts.n_major ^= 1;
+  ts.xcd_remap = (sched_flags & 1) ? 0 : 1;
+  dim3 grid((unsigned)((long)ts.tiles_m * ts.tiles_n * splits));
   if (!ta && !tb)
-    hipLaunchKernelGGL((k_gemm_mfma<BM, BN, false, false>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, e);
+    hipLaunchKernelGGL((k_gemm_mfma<BM, BN, false, false>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e);
   else if (!ta && tb)
-    hipLaunchKernelGGL((k_gemm_mfma<BM, BN, false, true>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, e);
+    hipLaunchKernelGGL((k_gemm_mfma<BM, BN, false, true>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e);
   else if (ta && !tb)
-    hipLaunchKernelGGL((k_gemm_mfma<BM, BN, true, false>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, e);
+    hipLaunchKernelGGL((k_gemm_mfma<BM, BN, true, false>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e);
   else
-    hipLaunchKernelGGL((k_gemm_mfma<BM, BN, true, true>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, e);
+    hipLaunchKernelGGL((k_gemm_mfma<BM, BN, true, true>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e);
   ZK_LAUNCH_CHECK();
   return 0;
 }
@@ -292,6 +320,11 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
   ZK_CHECK_ARG(act >= 0 && act <= 2, "zk_gemm: act=%d unknown", act);
   ZK_CHECK_ARG(act != 2 || aux != nullptr, "zk_gemm: act=2 needs aux");
   ZK_CHECK_ARG(drop_p == 0.f || seed != nullptr, "zk_gemm: dropout needs a seed pointer");
+  // impl bits: [1:0] 0 auto / 1 reference / 2 mfma; [11:8] tile override (1:128x128 2:128x64
+  // 3:64x128 4:64x64); [23:16] split-K override (tuning / tests)
+  const int tile_ovr = (impl >> 8) & 15, split_ovr = (impl >> 16) & 255;
+  const int sched_flags = (impl >> 12) & 3;   // bit0: no XCD remap, bit1: flip panel order
+  impl &= 3;
   ZK_CHECK_ARG(impl >= 0 && impl <= 2, "zk_gemm: impl=%d unknown", impl);
   if (M == 0 || N == 0) return 0;
   GemmEpi e;
@@ -314,6 +347,8 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
   int bm, bn, splits;
   const bool plain = (bias == nullptr && residual == nullptr && act == 0 && drop_p == 0.f);
   pick_config(M, N, K, plain ? 1 : 0, &bm, &bn, &splits);
+  if (tile_ovr) { const int tb_[5][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}}; bm = tb_[tile_ovr][0]; bn = tb_[tile_ovr][1]; }
+  if (split_ovr && plain) splits = split_ovr;
   if (splits > 1 && ws_bytes < (size_t)splits * M * N * sizeof(float)) splits = 1;
   int kchunk = K;
   float* slabs = nullptr;
@@ -326,10 +361,10 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
   if (kchunk < 1) kchunk = 1;
   int rc;
   const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
-  if (bm == 128 && bn == 128) rc = launch_mfma<128, 128>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, stream);
-  else if (bm == 128 && bn == 64) rc = launch_mfma<128, 64>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, stream);
-  else if (bm == 64 && bn == 128) rc = launch_mfma<64, 128>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, stream);
-  else rc = launch_mfma<64, 64>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, stream);
+  if (bm == 128 && bn == 128) rc = launch_mfma<128, 128>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+  else if (bm == 128 && bn == 64) rc = launch_mfma<128, 64>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+  else if (bm == 64 && bn == 128) rc = launch_mfma<64, 128>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+  else rc = launch_mfma<64, 64>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
   if (rc) return rc;
   if (slabs != nullptr) {
     const size_t n = (size_t)M * N;
