@@ -44,6 +44,7 @@ const char* zk_last_error_string(void);
  *   out_f32: C is fp32 (else bf16).  act: 0 none, 1 ReLU (func.py:332), 2 multiply by
  *   (aux>0)*aux_scale (ReLU+dropout backward through the saved activation).          */
 size_t zk_gemm_workspace(int M, int N, int K);
+size_t zk_gemm_workspace_split(int M, int N, int splits);
 int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
             int ta, int tb, int out_f32, float alpha, const float* bias, const void* residual, int ldr,
             int act, const void* aux, int ldaux, float aux_scale, float drop_p, const uint64_t* seed,
@@ -81,6 +82,13 @@ int zk_embed_fwd(const int* ids, const void* table, const float* bias, const flo
 int zk_embed_bwd(const int* ids, const void* dout, float* dtable, float* dbias, int B, int L, int H,
                  float scale, int shift, float drop_p, const uint64_t* seed, uint32_t sid, zk_stream_t stream);
 
+/* Same gradient without atomics: the host (which owns the ids) sorts token rows by id; one wave
+ * per distinct id sums its rows.  rows_sorted [n_used], seg [n_uniq+1], uid [n_uniq] int32 device
+ * arrays, n_uniq_dev device int (<= max_uniq).  accumulate=0 overwrites the touched rows.      */
+int zk_embed_bwd_sorted(const int* rows_sorted, const int* seg, const int* uid, const int* n_uniq_dev,
+                        int max_uniq, const void* dout, float* dtable, int H, float scale, int accumulate,
+                        float drop_p, const uint64_t* seed, uint32_t sid, zk_stream_t stream);
+
 /* ---- func.py:321-324 residual_fn + func.py:289-303 layer_norm (post-LN, eps inside
  * rsqrt): out = LN(x + dropout(y)).  sum_out/mean/rstd are saved for the backward.    */
 int zk_add_ln_fwd(const void* x, const void* y, const float* gamma, const float* beta, void* out,
@@ -98,6 +106,10 @@ int zk_add_ln_bwd(const void* dout, const void* sum, const float* mean, const fl
 size_t zk_colsum_workspace(int rows, int N);
 int zk_colsum(const void* a, int rows, int N, int lda, float* out, void* workspace, size_t ws_bytes,
               zk_stream_t stream);
+/* skip_L>0: skip rows r with r%skip_L==0 (shifted decoder input); accumulate: out += ;
+ * dropout mask index = r*N + c (the shared embedding bias gradient, transformer.py:27,102) */
+int zk_colsum_ex(const void* a, int rows, int N, int lda, float* out, int skip_L, int accumulate, float drop_p,
+                 const uint64_t* seed, uint32_t sid, void* workspace, size_t ws_bytes, zk_stream_t stream);
 
 /* ---- util.py:88-103 label_smooth + transformer.py:198-207 cross entropy on fp32 logits.
  * ce_out[r] = -sum soft*log_softmax - normaliser; dlogits (bf16 [rows,ld], NULL to skip)

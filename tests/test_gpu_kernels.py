@@ -271,6 +271,36 @@ def test_embed_fwd_bwd():
     assert rel_err(out, tim[4][None].expand(B, H)) < 5e-3
 
 
+def test_embed_bwd_sorted_and_bias_colsum():
+    # atomics-free table gradient (host-sorted rows) + shared-bias gradient with skipped rows
+    import types
+    from zero_amd.models._core import TransformerCore
+    e = eng()
+    B, L, H, V = 4, 9, 64, 23
+    rng = np.random.default_rng(3)
+    ids_np = rng.integers(0, V, (B, L))
+    ids = torch.tensor(ids_np, dtype=torch.int32, device="cuda")
+    dout = rand_bf(B * L, H, seed=5)
+    fake = types.SimpleNamespace(eng=e)
+    for shift in (False, True):
+        srt = TransformerCore._sort_arrays(fake, "t%d" % shift, ids_np, shift)
+        for acc in (False, True):
+            dtab = torch.full((V, H), 0.5 if acc else 0.0, device="cuda")
+            e.embed_bwd_sorted(srt, mat(dout), dtab, H, accumulate=acc)
+            dbias = torch.full((H,), 3.0, device="cuda")
+            e.colsum(mat(dout), dbias, skip_L=L if shift else 0, accumulate=acc)
+            torch.cuda.synchronize()
+            g = dout.float().view(B, L, H)
+            idl = ids.long()
+            if shift:
+                g = g[:, 1:]; idl = idl[:, :-1]
+            ref_t = torch.full((V, H), 0.5 if acc else 0.0, device="cuda")
+            ref_t.index_add_(0, idl.reshape(-1), g.reshape(-1, H) * H ** 0.5)
+            assert rel_err(dtab, ref_t) < 1e-5
+            ref_b = g.reshape(-1, H).sum(0) + (3.0 if acc else 0.0)
+            assert rel_err(dbias, ref_b) < 1e-5
+
+
 def test_timing_signal_closed_form():
     from zero_amd.func import timing_table
     t = timing_table(5, 8)

@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) k_add_ln_bwd(
 // block = 64 columns of one quantity; 4 row-groups of 64 lanes split the partial rows.
 __global__ void __launch_bounds__(256) k_partials_reduce(const float* __restrict__ partials, int nblk,
                                                          int nq, int H, float* o0, float* o1,
-                                                         float* o2) {
+                                                         float* o2, int accumulate) {
   __shared__ float red[4][64];
   const int q = blockIdx.y;
   float* o = q == 0 ? o0 : (q == 1 ? o1 : o2);
@@ -282,7 +282,10 @@ __global__ void __launch_bounds__(256) k_partials_reduce(const float* __restrict
     for (int b = g; b < nblk; b += 4) t += partials[((size_t)b * nq + q) * H + c];
   red[g][threadIdx.x & 63] = t;
   __syncthreads();
-  if (g == 0 && c < H) o[c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (g == 0 && c < H) {
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    o[c] = accumulate ? o[c] + v : v;
+  }
 }
 
 // =====================================================================================
@@ -290,18 +293,25 @@ __global__ void __launch_bounds__(256) k_partials_reduce(const float* __restrict
 // stage 1: block = 64 columns x row-chunk -> partials[gridDim.y][N]
 // =====================================================================================
 __global__ void __launch_bounds__(256) k_colsum(const bf16_t* __restrict__ a, int rows, int N, int lda,
-                                                float* __restrict__ partials) {
+                                                float* __restrict__ partials, int skip_L, uint32_t thr,
+                                                float inv_keep, const uint64_t* __restrict__ seedp, uint32_t sid) {
   __shared__ float red[32][64 + 1];
   const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
   const int c0 = blockIdx.x * 64 + tx * 8;
   const int rpb = (rows + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rpb;
   const int r1 = min(rows, r0 + rpb);
+  const uint64_t seed = thr ? *seedp : 0;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c0 < N) {
     for (int r = r0 + ty; r < r1; r += 32) {
+      if (skip_L > 0 && (r % skip_L) == 0) continue;   // rows without an embedding (shifted input)
       float v[8];
       unpack8(*reinterpret_cast<const uint4*>(a + (size_t)r * lda + c0), v);
+      if (thr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= zk_drop_scale(seed, sid, (uint64_t)r * N + c0 + j, thr, inv_keep);
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] += v[j];
     }
@@ -315,6 +325,48 @@ __global__ void __launch_bounds__(256) k_colsum(const bf16_t* __restrict__ a, in
       float t = 0.f;
       for (int i = 0; i < 32; ++i) t += red[i][threadIdx.x];
       partials[(size_t)blockIdx.y * N + c] = t;
+    }
+  }
+}
+
+// Embedding-table gradient without atomics: the host sorts the token rows by id (it owns the
+// ids anyway); one wave per DISTINCT id sums its rows in fp32 and does a single read-modify-write
+// of the table row.  `rows_sorted` [n_used] = token-row indices grouped by id, `seg` [n_uniq+1]
+// = group boundaries, `uid` [n_uniq] = the id of each group, `n_uniq_dev` = device int.
+__global__ void __launch_bounds__(256) k_embed_bwd_sorted(
+    const int* __restrict__ rows_sorted, const int* __restrict__ seg, const int* __restrict__ uid,
+    const int* __restrict__ n_uniq_dev, const bf16_t* __restrict__ dout, float* __restrict__ dtable, int H,
+    float scale, int accumulate, uint32_t thr, float inv_keep, const uint64_t* __restrict__ seedp, uint32_t sid) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int nu = *n_uniq_dev;
+  const uint64_t seed = thr ? *seedp : 0;
+  for (int u = wave; u < nu; u += nwaves) {
+    const int s0 = seg[u], s1 = seg[u + 1];
+    float* dst = dtable + (size_t)uid[u] * H;
+    for (int c = lane * 8; c < H; c += 64 * 8) {
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k = s0; k < s1; ++k) {
+        const int r = rows_sorted[k];
+        float v[8];
+        unpack8(*reinterpret_cast<const uint4*>(dout + (size_t)r * H + c), v);
+        if (thr) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] *= zk_drop_scale(seed, sid, (uint64_t)r * H + c + j, thr, inv_keep);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v[j];
+      }
+      float4* d4 = reinterpret_cast<float4*>(dst + c);
+      float4 lo = make_float4(acc[0] * scale, acc[1] * scale, acc[2] * scale, acc[3] * scale);
+      float4 hi = make_float4(acc[4] * scale, acc[5] * scale, acc[6] * scale, acc[7] * scale);
+      if (accumulate) {
+        const float4 a = d4[0], b = d4[1];
+        lo.x += a.x; lo.y += a.y; lo.z += a.z; lo.w += a.w;
+        hi.x += b.x; hi.y += b.y; hi.z += b.z; hi.w += b.w;
+      }
+      d4[0] = lo; d4[1] = hi;
     }
   }
 }
@@ -753,7 +805,7 @@ int zk_add_ln_bwd(const void* dout, const void* sum, const float* mean, const fl
                      seed, sid);
   ZK_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_partials_reduce, dim3((H + 63) / 64, 3), dim3(256), 0, stream,
-                     (const float*)workspace, g, 3, H, dgamma, dbeta, dbias_prev);
+                     (const float*)workspace, g, 3, H, dgamma, dbeta, dbias_prev, 0);
   ZK_LAUNCH_CHECK();
   return 0;
 }
@@ -765,18 +817,42 @@ size_t zk_colsum_workspace(int rows, int N) {
   return (size_t)gy * N * sizeof(float);
 }
 
-int zk_colsum(const void* a, int rows, int N, int lda, float* out, void* workspace, size_t ws_bytes,
-              hipStream_t stream) {
+int zk_colsum_ex(const void* a, int rows, int N, int lda, float* out, int skip_L, int accumulate, float drop_p,
+                 const uint64_t* seed, uint32_t sid, void* workspace, size_t ws_bytes, hipStream_t stream) {
   ZK_CHECK_ARG(N % 8 == 0 && lda % 8 == 0, "zk_colsum: N=%d, lda=%d must be multiples of 8", N, lda);
   ZK_CHECK_ARG(ws_bytes >= zk_colsum_workspace(rows, N), "zk_colsum: workspace too small");
+  ZK_CHECK_ARG(drop_p == 0.f || seed != nullptr, "zk_colsum: dropout needs a seed pointer");
   int gy = (rows + 255) / 256;
   if (gy > 64) gy = 64;
   if (gy < 1) gy = 1;
+  const uint32_t thr = drop_p > 0.f ? zk_drop_threshold(drop_p) : 0;
+  const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, gy), dim3(256), 0, stream, (const bf16_t*)a, rows, N, lda,
-                     (float*)workspace);
+                     (float*)workspace, skip_L, thr, ik, seed, sid);
   ZK_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_partials_reduce, dim3((N + 63) / 64, 1), dim3(256), 0, stream, (const float*)workspace,
-                     gy, 1, N, out, (float*)nullptr, (float*)nullptr);
+                     gy, 1, N, out, (float*)nullptr, (float*)nullptr, accumulate);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_colsum(const void* a, int rows, int N, int lda, float* out, void* workspace, size_t ws_bytes,
+              hipStream_t stream) {
+  return zk_colsum_ex(a, rows, N, lda, out, 0, 0, 0.f, nullptr, 0, workspace, ws_bytes, stream);
+}
+
+int zk_embed_bwd_sorted(const int* rows_sorted, const int* seg, const int* uid, const int* n_uniq_dev,
+                        int max_uniq, const void* dout, float* dtable, int H, float scale, int accumulate,
+                        float drop_p, const uint64_t* seed, uint32_t sid, hipStream_t stream) {
+  ZK_CHECK_ARG(H % 8 == 0, "zk_embed_bwd_sorted: H=%d must be a multiple of 8", H);
+  ZK_CHECK_ARG(drop_p == 0.f || seed != nullptr, "zk_embed_bwd_sorted: dropout needs a seed pointer");
+  if (max_uniq == 0) return 0;
+  const uint32_t thr = drop_p > 0.f ? zk_drop_threshold(drop_p) : 0;
+  const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  int g = (max_uniq + 3) / 4;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_embed_bwd_sorted, dim3(g), dim3(256), 0, stream, rows_sorted, seg, uid, n_uniq_dev,
+                     (const bf16_t*)dout, dtable, H, scale, accumulate, thr, ik, seed, sid);
   ZK_LAUNCH_CHECK();
   return 0;
 }

@@ -281,23 +281,23 @@ static bool mfma_ok(const void* A, const void* B, int M, int N, int K, int lda, 
   return true;
 }
 
-// choose tile + split so that the launch has >= ~256 workgroups when the problem allows it
+// Tile / split heuristic (measured on MI355X, scripts/gemm_bench.py).  These GEMMs are small
+// for a 256-CU chip: with <= 1 workgroup per CU the K loop is exposed-latency bound, so the
+// goal is >= ~3 co-resident workgroups per CU (thread-level parallelism hides the L2 latency)
+// before tile area (arithmetic intensity) is considered.  Large outputs use 128x128; mid-size
+// ones 64x128 / 128x64; small ones 64x64 plus split-K when the epilogue allows it.
 static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, int* splits) {
-  const int cands[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-  int best = 3;
-  for (int c = 0; c < 4; ++c) {
-    const long tiles = (long)((M + cands[c][0] - 1) / cands[c][0]) * ((N + cands[c][1] - 1) / cands[c][1]);
-    if (tiles >= 240) { best = c; break; }
-  }
-  *bm = cands[best][0];
-  *bn = cands[best][1];
+  const long out = (long)M * N;
+  if (out >= 128L * 128 * 1024) { *bm = 128; *bn = 128; }
+  else if (out >= 64L * 128 * 640) { if (N >= M) { *bm = 64; *bn = 128; } else { *bm = 128; *bn = 64; } }
+  else { *bm = 64; *bn = 64; }
   const long tiles = (long)((M + *bm - 1) / *bm) * ((N + *bn - 1) / *bn);
   int s = 1;
-  if (allow_split && tiles < 192) {
-    s = (int)((256 + tiles - 1) / tiles);
-    const int maxs = K / (4 * BK) > 0 ? K / (4 * BK) : 1;  // keep >= 4 K-tiles per split
+  if (allow_split && tiles < 1024 && K >= 1024) {
+    s = (int)((1024 + tiles - 1) / tiles);
+    const int maxs = K / (4 * BK);            // keep >= 4 K-tiles per split
     if (s > maxs) s = maxs;
-    if (s > 16) s = 16;
+    if (s > 32) s = 32;
     if (s < 1) s = 1;
   }
   *splits = s;
@@ -311,6 +311,8 @@ size_t zk_gemm_workspace(int M, int N, int K) {
   pick_config(M, N, K, 1, &bm, &bn, &s);
   return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
+// workspace for an explicit split-K override (tuning)
+size_t zk_gemm_workspace_split(int M, int N, int splits) { return (size_t)splits * M * N * sizeof(float); }
 
 int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int ta,
             int tb, int out_f32, float alpha, const float* bias, const void* residual, int ldr, int act,

@@ -74,7 +74,7 @@ class Engine(object):
                                    % self.device)
         self.lib = hip.lib()
         self.bufs = {}
-        self._ws = None
+        self._ws = {}
         self.gemm_impl = _impl_from_env("ZERO_HIP_GEMM")
         self.attn_impl = _impl_from_env("ZERO_HIP_ATTN")
         self.seed = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -98,9 +98,13 @@ class Engine(object):
         return Mat(self.buf(name, (rows, cols), dt), rows, cols)
 
     def workspace(self, nbytes):
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=self.device)
-        return self._ws
+        """Scratch of the CURRENT stream (kernels on different streams may run concurrently)."""
+        key = self.stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
 
     def timing(self, length, H):
         if self._timing is None or self._timing.shape[0] < length or self._timing.shape[1] != H:
@@ -128,11 +132,12 @@ class Engine(object):
             float(drop_p), self.seed.data_ptr(), sid,
             self.gemm_impl if impl is None else impl, ws.data_ptr(), ws.numel(), self.stream)
 
-    def colsum(self, A, out):
+    def colsum(self, A, out, skip_L=0, accumulate=False, drop_p=0.0, sid=0):
         ws_bytes = self.lib.query("zk_colsum_workspace", A.rows, A.cols)
         ws = self.workspace(ws_bytes)
-        self.lib.call("zk_colsum", A.ptr, A.rows, A.cols, A.ld, out.data_ptr(), ws.data_ptr(), ws.numel(),
-                      self.stream)
+        self.lib.call("zk_colsum_ex", A.ptr, A.rows, A.cols, A.ld, out.data_ptr(), skip_L,
+                      1 if accumulate else 0, float(drop_p), self.seed.data_ptr(), sid, ws.data_ptr(),
+                      ws.numel(), self.stream)
 
     # ---- func.py:164-286 attention core ----------------------------------------
     def attn_fwd(self, q, k, v, out, lse, B, nh, Lq, Lk, d, kmask=None, causal=False, q_pos0=0,
@@ -166,6 +171,13 @@ class Engine(object):
     def embed_bwd(self, ids, dout, dtable, dbias, B, L, H, shift=False, drop_p=0.0, sid=0):
         self.lib.call("zk_embed_bwd", ids.data_ptr(), dout.ptr, dtable.data_ptr(), dbias.data_ptr(), B, L, H,
                       float(H) ** 0.5, 1 if shift else 0, float(drop_p), self.seed.data_ptr(), sid, self.stream)
+
+    def embed_bwd_sorted(self, sort, dout, dtable, H, accumulate, drop_p=0.0, sid=0):
+        """sort = dict(rows, seg, uid, n (device int), max_uniq) prepared by the host at upload time."""
+        self.lib.call("zk_embed_bwd_sorted", sort["rows"].data_ptr(), sort["seg"].data_ptr(),
+                      sort["uid"].data_ptr(), sort["n"].data_ptr(), sort["max_uniq"], dout.ptr,
+                      dtable.data_ptr(), H, float(H) ** 0.5, 1 if accumulate else 0, float(drop_p),
+                      self.seed.data_ptr(), sid, self.stream)
 
     # ---- residual + layer norm (func.py:289-303, 321-324) -------------------------
     def add_ln_fwd(self, x, y, gamma, beta, out, sum_out=None, mean=None, rstd=None, drop_p=0.0, sid=0):
@@ -214,18 +226,23 @@ class Engine(object):
         self.lib.call("zk_aan_gate_bwd", dg.ptr, z.ptr, cat.ptr, dz.ptr, dxg.ptr, dyg.ptr, rows, H, self.stream)
 
     # ---- hipGraph capture of a launch sequence ----------------------------------------
+    @property
+    def work_stream(self):
+        """Persistent stream for captured steps (per-stream scratch is keyed by stream, so the eager
+        sizing pass and the capture must run on the same one)."""
+        if getattr(self, "_work_stream", None) is None:
+            self._work_stream = torch.cuda.Stream(self.device)
+        return self._work_stream
+
     def graph_capture(self, fn):
-        """Run ``fn()`` under stream capture, return a replayable handle."""
-        s = torch.cuda.Stream(self.device)
-        s.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(s):
-            self.lib.call("zk_graph_begin", s.cuda_stream)
-            try:
-                fn()
-            finally:
-                exec_ = ctypes.c_void_p()
-                self.lib.call("zk_graph_end", s.cuda_stream, ctypes.byref(exec_))
-        torch.cuda.current_stream(self.device).wait_stream(s)
+        """Capture ``fn()``'s launches on the CURRENT stream, return a replayable handle."""
+        s = torch.cuda.current_stream(self.device)
+        self.lib.call("zk_graph_begin", s.cuda_stream)
+        try:
+            fn()
+        finally:
+            exec_ = ctypes.c_void_p()
+            self.lib.call("zk_graph_end", s.cuda_stream, ctypes.byref(exec_))
         return exec_
 
     def graph_launch(self, exec_):

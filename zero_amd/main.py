@@ -99,6 +99,16 @@ class Trainer(object):
     def step_static(self, use_graph=True):
         """One full update on the static batch: fwd + bwd (+ all-reduce) + Adam.
         With a single rank the whole step is one hipGraph replay."""
+        eng = self.core.eng
+        cur = torch.cuda.current_stream(eng.device)
+        ws = eng.work_stream
+        ws.wait_stream(cur)
+        with torch.cuda.stream(ws):
+            loss = self._step_static(use_graph)
+        cur.wait_stream(ws)
+        return loss
+
+    def _step_static(self, use_graph):
         hp = self.params
         assert hp.update_cycle == 1, "captured step supports update_cycle == 1"
         world = parallel.world_size()
@@ -113,7 +123,7 @@ class Trainer(object):
                 # first use of a shape runs eagerly once (sizes every scratch buffer), then
                 # the same launch sequence is captured
                 self._graphs[key] = "warm"
-                return self.step_static(use_graph=False)
+                return self._step_static(False)
             if g == "warm":
                 def body():
                     self.graph.train_fn(self.batch, hp)

@@ -14,6 +14,8 @@ Everything lives in named persistent buffers (static addresses), so a whole
 step can be captured into a hipGraph and replayed.
 """
 
+import os
+
 import numpy as np
 import torch
 
@@ -62,6 +64,28 @@ class TransformerCore(object):
             self.soft_emb = "tgt_embedding" if params.shared_target_softmax_embedding else "softmax_embedding"
         self.V = params.tgt_vocab.size()
         self.Vpad = self.store.pshape[self.soft_emb][0]
+        # weight-gradient GEMMs and bias column sums leave the critical path: they run on a second
+        # HIP stream, concurrently with the dgrad chain (both are latency-bound at this size)
+        self.use_side = os.environ.get("ZERO_HIP_SIDE_STREAM", "1") != "0"
+        self.side = torch.cuda.Stream(self.eng.device) if self.eng.device.type == "cuda" else None
+
+    # ------------------------------------------------------------------ stream plumbing
+    def _side(self, fn):
+        """Run fn() on the side stream, ordered after everything enqueued so far on the current one."""
+        if not self.use_side:
+            fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            fn()
+
+    def _join_side(self):
+        if self.use_side:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            torch.cuda.current_stream(self.eng.device).wait_event(ev)
 
     # ------------------------------------------------------------------ helpers
     def W(self, name):
@@ -87,9 +111,12 @@ class TransformerCore(object):
     def _linear_bwd(self, x, dy, scope, dx=None, residual=None, bias_grad=True, act=0, aux=None, aux_scale=1.0):
         """dW = x^T dy (fp32, overwrite), db = colsum(dy), dx = dy @ W^T (+residual)."""
         Wm = self.W(scope + "/W_0_0")
-        self.eng.gemm(x, dy, self.gW(scope + "/W_0_0"), Wm.rows, Wm.cols, x.rows, 1, 0)
-        if bias_grad:
-            self.eng.colsum(dy, self.gb(scope + "/b_0"))
+
+        def wgrad():
+            self.eng.gemm(x, dy, self.gW(scope + "/W_0_0"), Wm.rows, Wm.cols, x.rows, 1, 0)
+            if bias_grad:
+                self.eng.colsum(dy, self.gb(scope + "/b_0"))
+        self._side(wgrad)
         if dx is not None:
             self.eng.gemm(dy, Wm, dx, dy.rows, Wm.rows, Wm.cols, 0, 1, residual=residual, act=act, aux=aux,
                           aux_scale=aux_scale)
@@ -174,8 +201,8 @@ class TransformerCore(object):
         """returns (ds, dy): grads of the residual input and of the sub-layer output."""
         e, H = self.eng, self.H
         T = dx.rows
-        ds = e.mat("g%s.ds" % side, T, H)
-        dy = e.mat("g%s.dy" % side, T, H) if drop_p > 0.0 else None
+        ds = e.mat("g.%s.ds" % tag, T, H)
+        dy = e.mat("g.%s.dy" % tag, T, H) if drop_p > 0.0 else None
         e.add_ln_bwd(dx, e.mat(tag + ".s", T, H), e.buf(tag + ".mean", (T,), F32), e.buf(tag + ".rstd", (T,), F32),
                      self.b(scope + "/layer_norm/scale"), ds, dy, self.gb(scope + "/layer_norm/scale"),
                      self.gb(scope + "/layer_norm/offset"),
@@ -188,7 +215,7 @@ class TransformerCore(object):
         T = dx.rows
         ds, dy = self._ln_bwd(dx, scope, tag, p + "output/b_0", hp.residual_dropout, sid0 + 1, side)
         h = e.mat(tag + ".h", T, self.F)
-        dh = e.mat("g%s.dh" % side, T, self.F)
+        dh = e.mat("g.%s.dh" % tag, T, self.F)
         rp = hp.relu_dropout
         self._linear_bwd(h, dy, p + "output", dx=dh, bias_grad=False, act=2, aux=h,
                          aux_scale=1.0 / (1.0 - rp) if rp > 0 else 1.0)
@@ -201,10 +228,10 @@ class TransformerCore(object):
         T = dx.rows
         ds, dy = self._ln_bwd(dx, scope, tag, p + "o_map/b_0", hp.residual_dropout, sid0 + 1, side)
         att = e.mat(tag + ".att", T, H)
-        datt = e.mat("g%s.datt" % side, T, H)
+        datt = e.mat("g.%s.datt" % tag, T, H)
         self._linear_bwd(att, dy, p + "o_map", dx=datt, bias_grad=False)
         qkv = e.mat(tag + ".qkv", T, 3 * H)
-        dqkv = e.mat("g%s.dqkv" % side, T, 3 * H)
+        dqkv = e.mat("g.%s.dqkv" % tag, T, 3 * H)
         rk = self.store.s(p + "rpr_keys/embeddings") if self.rpr else None
         rv = self.store.s(p + "rpr_values/embeddings") if self.rpr else None
         e.attn_bwd(qkv.cols_slice(0, H), qkv.cols_slice(H, 2 * H), qkv.cols_slice(2 * H, 3 * H), att, datt,
@@ -223,12 +250,12 @@ class TransformerCore(object):
         T = dx.rows
         ds, dy = self._ln_bwd(dx, scope, tag, p + "o_map/b_0", hp.residual_dropout, sid0 + 1, side)
         att = e.mat(tag + ".att", T, H)
-        datt = e.mat("g%s.datt" % side, T, H)
+        datt = e.mat("g.%s.datt" % tag, T, H)
         self._linear_bwd(att, dy, p + "o_map", dx=datt, bias_grad=False)
         q = e.mat(tag + ".q", T, H)
         kv = e.mat(tag + ".kv", mem.rows, 2 * H)
-        dq = e.mat("g%s.dq" % side, T, H)
-        dkv = e.mat("g%s.dkv" % side, mem.rows, 2 * H)
+        dq = e.mat("g.%s.dq" % tag, T, H)
+        dkv = e.mat("g.%s.dkv" % tag, mem.rows, 2 * H)
         rk = self.store.s(p + "rpr_keys/embeddings") if self.rpr else None
         rv = self.store.s(p + "rpr_values/embeddings") if self.rpr else None
         e.attn_bwd(q, kv.cols_slice(0, H), kv.cols_slice(H, 2 * H), att, datt,
@@ -250,11 +277,11 @@ class TransformerCore(object):
         ds, dg = self._ln_bwd(dx, scope, tag, None, hp.residual_dropout, sid0 + 1, side)
         cat = e.mat(tag + ".cat", T, 2 * H)
         z = e.mat(tag + ".z", T, 2 * H)
-        dz = e.mat("g%s.dz" % side, T, 2 * H)
-        dxg = e.mat("g%s.dxg" % side, T, H)
-        dyg = e.mat("g%s.dyg" % side, T, H)
+        dz = e.mat("g.%s.dz" % tag, T, 2 * H)
+        dxg = e.mat("g.%s.dxg" % tag, T, H)
+        dyg = e.mat("g.%s.dyg" % tag, T, H)
         e.aan_gate_bwd(dg, z, cat, dz, dxg, dyg, T, H)
-        dcat = e.mat("g%s.dcat" % side, T, 2 * H)
+        dcat = e.mat("g.%s.dcat" % tag, T, 2 * H)
         self._linear_bwd(cat, dz, scope + "/z_project", dx=dcat)
         e.aan_bwd(dcat, dxg, dyg, ds, tmask, dx_out, B, L, H, hp.aan_mask)
         return dx_out
@@ -272,14 +299,43 @@ class TransformerCore(object):
         ids_s.copy_(torch.from_numpy(src.astype(np.int32)), non_blocking=False)
         out = {"B": B, "Ls": Ls, "src": ids_s}
         if target is not None:
+            out["src_sort"] = self._sort_arrays("src", src, False)
+        if target is not None:
             tgt = np.asarray(target.cpu() if torch.is_tensor(target) else target)
             if trim:
                 tgt = trim_columns(tgt)
             Lt = tgt.shape[1]
             ids_t = e.buf("ids.tgt", (B, Lt), torch.int32)
             ids_t.copy_(torch.from_numpy(tgt.astype(np.int32)), non_blocking=False)
-            out.update({"Lt": Lt, "tgt": ids_t})
+            out.update({"Lt": Lt, "tgt": ids_t, "tgt_sort": self._sort_arrays("tgt", tgt, True)})
         return out
+
+    def _sort_arrays(self, name, ids, shift):
+        """Group the token rows by embedding id on the host (it owns the ids), for the atomics-free
+        embedding-gradient kernel.  shift: row (b,t) uses id[b,t-1]; rows with t==0 have no embedding."""
+        e = self.eng
+        B, L = ids.shape
+        T = B * L
+        flat = ids.reshape(-1)
+        rows = np.arange(T, dtype=np.int64)
+        if shift:
+            rows = rows[rows % L != 0]
+            tok = flat[rows - 1]
+        else:
+            tok = flat
+        order = np.argsort(tok, kind="stable")
+        rows_sorted, tok_sorted = rows[order], tok[order]
+        uid, first = np.unique(tok_sorted, return_index=True)
+        seg = np.concatenate([first, [len(tok_sorted)]])
+        d = {"rows": e.buf("sort.%s.rows" % name, (T,), torch.int32),
+             "seg": e.buf("sort.%s.seg" % name, (T + 1,), torch.int32),
+             "uid": e.buf("sort.%s.uid" % name, (T,), torch.int32),
+             "n": e.buf("sort.%s.n" % name, (1,), torch.int32), "max_uniq": T}
+        d["rows"][:len(rows_sorted)].copy_(torch.from_numpy(rows_sorted.astype(np.int32)))
+        d["seg"][:len(seg)].copy_(torch.from_numpy(seg.astype(np.int32)))
+        d["uid"][:len(uid)].copy_(torch.from_numpy(uid.astype(np.int32)))
+        d["n"].copy_(torch.tensor([len(uid)], dtype=torch.int32))
+        return d
 
     def encode(self, batch, train, save):
         """transformer.py:15-84."""
@@ -359,9 +415,10 @@ class TransformerCore(object):
         B, Ls, Lt = batch["B"], batch["Ls"], batch["Lt"]
         Ts, Tt = B * Ls, B * Lt
         st = self.store
-        # gradients that are accumulated with atomics start from zero
-        e.zero(st.g("bias"))
-        e.zero(st.g(self.src_emb))
+        # embedding tables receive dense gradients (zero rows for unseen ids): untouched rows must
+        # read as zero.  The softmax table is fully overwritten by its wgrad GEMM instead.
+        if self.src_emb != self.soft_emb:
+            e.zero(st.g(self.src_emb))
         if self.tgt_emb != self.soft_emb and self.tgt_emb != self.src_emb:
             e.zero(st.g(self.tgt_emb))
         if self.rpr:
@@ -374,13 +431,7 @@ class TransformerCore(object):
         cur = 0
         e.gemm(dlogits, E, P[cur], Tt, H, self.Vpad, 0, 0)
         gE = self.gW(self.soft_emb)
-        if self.soft_emb == self.src_emb:
-            # shared table already zeroed above; wgrad must accumulate -> go through a temp
-            tmp = e.mat("g.embtmp", self.Vpad, H, F32)
-            e.gemm(dlogits, feat, tmp, self.Vpad, H, Tt, 1, 0)
-            e.lib.call("zk_axpby_f32", gE.ptr, tmp.ptr, 1.0, 1.0, self.Vpad * H, e.stream)
-        else:
-            e.gemm(dlogits, feat, gE, self.Vpad, H, Tt, 1, 0)
+        self._side(lambda: e.gemm(dlogits, feat, gE, self.Vpad, H, Tt, 1, 0))
         d_enc = e.mat("g.denc", Ts, H)
         e.zero(d_enc.t)
         NE = hp.num_encoder_layer
@@ -414,13 +465,19 @@ class TransformerCore(object):
                 self._self_attn_bwd(P[cur], layer_input("d", l, "sa"), B, Lt, pre + "/self_attention",
                                     "d%d.sa" % l, None, True, sid + 1, "d", P[cur ^ 1])
             cur ^= 1
-            on_ready(pre)
-        e.embed_bwd(batch["tgt"], P[cur], st.g(self.tgt_emb), st.g("bias"), B, Lt, H, shift=True,
-                    drop_p=hp.dropout, sid=9002)
+            self._side(lambda pre=pre: on_ready(pre))
+        dxt = P[cur]
+
+        def tgt_embed_grads():
+            # side stream is in order: the softmax wgrad that overwrote the shared table is done
+            e.embed_bwd_sorted(batch["tgt_sort"], dxt, st.g(self.tgt_emb), H,
+                               accumulate=(self.tgt_emb == self.soft_emb), drop_p=hp.dropout, sid=9002)
+            e.colsum(dxt, st.g("bias"), skip_L=Lt, accumulate=False, drop_p=hp.dropout, sid=9002)
+        self._side(tgt_embed_grads)
         if self.soft_emb != self.src_emb:
-            on_ready(self.soft_emb)
+            self._side(lambda: on_ready(self.soft_emb))
         if self.tgt_emb != self.soft_emb and self.tgt_emb != self.src_emb:
-            on_ready(self.tgt_emb)
+            self._side(lambda: on_ready(self.tgt_emb))
         # encoder
         Q = [d_enc, e.mat("ge.p1", Ts, H)]
         cur = 0
@@ -436,8 +493,14 @@ class TransformerCore(object):
                                 smask, False, 100 * l + 1, "e", other)
             Q[cur ^ 1] = other
             cur ^= 1
-            on_ready(pre)
-        e.embed_bwd(batch["src"], Q[cur], st.g(self.src_emb), st.g("bias"), B, Ls, H, shift=False,
-                    drop_p=hp.dropout, sid=9001)
-        on_ready("bias")
-        on_ready(self.src_emb)
+            self._side(lambda pre=pre: on_ready(pre))
+        dxs = Q[cur]
+
+        def src_embed_grads():
+            e.embed_bwd_sorted(batch["src_sort"], dxs, st.g(self.src_emb), H,
+                               accumulate=(self.src_emb == self.tgt_emb), drop_p=hp.dropout, sid=9001)
+            e.colsum(dxs, st.g("bias"), skip_L=0, accumulate=True, drop_p=hp.dropout, sid=9001)
+            on_ready("bias")
+            on_ready(self.src_emb)
+        self._side(src_embed_grads)
+        self._join_side()
