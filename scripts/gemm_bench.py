@@ -34,14 +34,14 @@ def run(M, N, K, ta, tb, f32, impl, reps=20):
     return s.elapsed_time(t) / reps * 1e3   # us
 
 
-variants = [(0, 0, 0), (0, 1, 0)] + [(t, 0, 0) for t in (1, 2, 3, 4)]
+variants = [(0, 0, 0), (0, 64, 0)] + [(t, 0, 0) for t in (1, 2, 3, 4)]   # f=64: generation 1 kernel
 extra_split = [(0, 0, s) for s in (1, 2, 4, 8)]
-print("%-11s %-22s | " % ("shape", "M,N,K") + " | ".join("%12s" % ("%s%s" % (TILES[t], "/noxcd" if f & 1 else "")) for t, f, _ in variants))
+print("%-11s %-22s | " % ("shape", "M,N,K") + " | ".join("%12s" % ("%s%s" % (TILES[t], "/gen1" if f & 64 else "")) for t, f, _ in variants))
 tot = {i: 0.0 for i in range(len(variants))}
 for name, M, N, K, ta, tb, f32, cnt in SHAPES:
     row = []
     for i, (t, f, sp) in enumerate(variants):
-        us = run(M, N, K, ta, tb, f32, 2 | (t << 8) | (f << 12) | (sp << 16))
+        us = run(M, N, K, ta, tb, f32, (3 if f & 64 else 2) | (t << 8) | ((f & 3) << 12) | (sp << 16))
         tot[i] += us * cnt
         row.append("%6.1f %5.0f" % (us, 2.0 * M * N * K / us / 1e6))
     line = "%-11s %-22s | " % (name, "%d,%d,%d" % (M, N, K)) + " | ".join(row)

@@ -74,7 +74,8 @@ def _gemm_case(impl, M, N, K, ta, tb, out_f32=False, bias=False, residual=False,
     return rel_err(C, ref), C, ref
 
 
-@pytest.mark.parametrize("impl", [1, 2])
+# impl: 1 = reference HIP kernel, 2 = MFMA LDS-DMA ring kernel (default), 3 = MFMA register-staged kernel
+@pytest.mark.parametrize("impl", [1, 2, 3])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (256, 192, 160), (72, 40, 24), (200, 264, 136), (64, 512, 1024)])
 def test_gemm_plain(impl, ta, tb, shape):
@@ -83,7 +84,7 @@ def test_gemm_plain(impl, ta, tb, shape):
     assert err < 8e-3, err
 
 
-@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("impl", [1, 2, 3])
 def test_gemm_ragged_rows(impl):
     # token dimension not a multiple of 8 (M for forward, K for wgrad)
     assert _gemm_case(impl, 100, 64, 72, 0, 0)[0] < 8e-3
@@ -91,7 +92,7 @@ def test_gemm_ragged_rows(impl):
     assert _gemm_case(impl, 64, 72, 100, 1, 0)[0] < 8e-3
 
 
-@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("impl", [1, 2, 3])
 def test_gemm_epilogues(impl):
     assert _gemm_case(impl, 192, 256, 128, 0, 0, bias=True)[0] < 8e-3
     assert _gemm_case(impl, 192, 256, 128, 0, 0, bias=True, act=1)[0] < 8e-3
@@ -102,20 +103,33 @@ def test_gemm_epilogues(impl):
     assert _gemm_case(impl, 192, 256, 128, 0, 1, out_f32=True, alpha=0.5)[0] < 2e-3
 
 
-def test_gemm_splitk_wgrad():
+@pytest.mark.parametrize("impl", [2, 3])
+def test_gemm_splitk_wgrad(impl):
     # 512x512 output, K=4096: the auto configuration splits K
-    err, _, _ = _gemm_case(2, 512, 512, 4096, 1, 0, out_f32=True)
+    err, _, _ = _gemm_case(impl, 512, 512, 4096, 1, 0, out_f32=True)
     assert err < 2e-3, err
-    err, _, _ = _gemm_case(2, 512, 1536, 4096, 1, 0, out_f32=True)
+    err, _, _ = _gemm_case(impl, 512, 1536, 4096, 1, 0, out_f32=True)
     assert err < 2e-3, err
+    err, _, _ = _gemm_case(impl, 4096, 512, 8192, 0, 0)      # split with bf16 output
+    assert err < 8e-3, err
 
 
-def test_gemm_base_shapes():
+@pytest.mark.parametrize("impl", [2, 3])
+def test_gemm_base_shapes(impl):
     for (M, N, K, ta, tb, f32) in [(4096, 1536, 512, 0, 0, False), (4096, 512, 2048, 0, 0, False),
                                    (4096, 2048, 512, 0, 1, False), (2048, 512, 4096, 1, 0, True),
-                                   (1024, 4000, 512, 0, 1, True)]:
-        err, _, _ = _gemm_case(2, M, N, K, ta, tb, out_f32=f32)
+                                   (1024, 4000, 512, 0, 1, True), (4000, 520, 1000, 1, 1, False)]:
+        err, _, _ = _gemm_case(impl, M, N, K, ta, tb, out_f32=f32)
         assert err < 8e-3, (M, N, K, ta, tb, err)
+
+
+@pytest.mark.parametrize("impl", [2, 3])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_every_tile_shape(impl, tile, ta, tb):
+    # force each block-tile variant (impl bits [11:8]) on a ragged shape with a K tail
+    err, _, _ = _gemm_case(impl | (tile << 8), 328, 200, 456, ta, tb, bias=True, residual=True)
+    assert err < 8e-3, (impl, tile, ta, tb, err)
 
 
 # ------------------------------------------------------------------ attention

@@ -1,0 +1,52 @@
+// zk_gemm.h -- pieces shared by the GEMM kernel generations (zk_gemm.hip, zk_gemm2.hip)
+#pragma once
+#include "zk_common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+#define BK 64
+#define LDS_LD (BK + 8)
+
+struct GemmEpi {
+  void* C; int ldc; int out_f32; float alpha;
+  const float* bias;
+  const bf16_t* res; int ldr;
+  int act;                 // 0 none, 1 relu, 2 multiply by (aux>0)*aux_scale
+  const bf16_t* aux; int ldaux; float aux_scale;
+  uint32_t thr; float inv_keep; const uint64_t* seed; uint32_t sid;  // dropout on the output
+};
+
+__device__ __forceinline__ void epi_store(const GemmEpi& e, float v, int gm, int gn, int N, uint64_t seed) {
+  v *= e.alpha;
+  if (e.bias) v += e.bias[gn];
+  if (e.res) v += bf2f(e.res[(size_t)gm * e.ldr + gn]);
+  if (e.act == 1) v = fmaxf(v, 0.f);
+  else if (e.act == 2) v = (bf2f(e.aux[(size_t)gm * e.ldaux + gn]) > 0.f) ? v * e.aux_scale : 0.f;
+  if (e.thr) v *= zk_drop_scale(seed, e.sid, (uint64_t)gm * N + gn, e.thr, e.inv_keep);
+  if (e.out_f32) reinterpret_cast<float*>(e.C)[(size_t)gm * e.ldc + gn] = v;
+  else reinterpret_cast<bf16_t*>(e.C)[(size_t)gm * e.ldc + gn] = f2bf(v);
+}
+
+
+// Tile schedule.  The launch is a 1-D grid of tiles_m*tiles_n*splits workgroups.  Workgroup b is
+// observed to run on XCD b%8 (each XCD has a private 4 MiB L2), so the linear id is first
+// remapped so that every XCD owns a CONTIGUOUS range of the tile order (bijective for any grid
+// size); the tile order itself is split-major, then panel-major over the operand whose panels
+// should stay L2-resident (n_major=0: consecutive tiles share the A row panel; n_major=1: they
+// share the B panel).  Pure speed choice -- any placement gives the same result.
+struct TileSched { int tiles_m, tiles_n, n_major, xcd_remap; };
+
+__device__ __forceinline__ void tile_of_block(const TileSched& ts, int& tm, int& tn, int& z) {
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
+  const int t = ts.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc : bid;
+  const int per = ts.tiles_m * ts.tiles_n;
+  z = t / per;
+  const int rem = t - z * per;
+  const int d = ts.n_major ? ts.tiles_m : ts.tiles_n;
+  const int hi = rem / d, lo = rem - hi * d;
+  tm = ts.n_major ? lo : hi;
+  tn = ts.n_major ? hi : lo;
+}
+

@@ -20,31 +20,7 @@
 // undone in the epilogue's row/column indices.
 #include "zk_common.h"
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
-
-#define BK 64
-#define LDS_LD (BK + 8)
-
-struct GemmEpi {
-  void* C; int ldc; int out_f32; float alpha;
-  const float* bias;
-  const bf16_t* res; int ldr;
-  int act;                 // 0 none, 1 relu, 2 multiply by (aux>0)*aux_scale
-  const bf16_t* aux; int ldaux; float aux_scale;
-  uint32_t thr; float inv_keep; const uint64_t* seed; uint32_t sid;  // dropout on the output
-};
-
-__device__ __forceinline__ void epi_store(const GemmEpi& e, float v, int gm, int gn, int N, uint64_t seed) {
-  v *= e.alpha;
-  if (e.bias) v += e.bias[gn];
-  if (e.res) v += bf2f(e.res[(size_t)gm * e.ldr + gn]);
-  if (e.act == 1) v = fmaxf(v, 0.f);
-  else if (e.act == 2) v = (bf2f(e.aux[(size_t)gm * e.ldaux + gn]) > 0.f) ? v * e.aux_scale : 0.f;
-  if (e.thr) v *= zk_drop_scale(seed, e.sid, (uint64_t)gm * N + gn, e.thr, e.inv_keep);
-  if (e.out_f32) reinterpret_cast<float*>(e.C)[(size_t)gm * e.ldc + gn] = v;
-  else reinterpret_cast<bf16_t*>(e.C)[(size_t)gm * e.ldc + gn] = f2bf(v);
-}
+#include "zk_gemm.h"
 
 // ------------------------------------------------------------------ reference kernel
 // one thread per output element; any shape / alignment.  Used for parity checks of the
@@ -133,25 +109,6 @@ __device__ __forceinline__ int logical_row(int q) {
   if (!TRANS) return q;
   constexpr int RC = R / 8;
   return (q % RC) * 8 + q / RC;
-}
-
-// Tile schedule.  The launch is a 1-D grid of tiles_m*tiles_n*splits workgroups.  Workgroup b is
-// observed to run on XCD b%8 (each XCD has a private 4 MiB L2), so the linear id is first
-// remapped so that every XCD owns a CONTIGUOUS range of the tile order (bijective for any grid
-// size); the tile order itself is split-major, then panel-major over the operand whose panels
-// should stay L2-resident (n_major=0: consecutive tiles share the A row panel; n_major=1: they
-// share the B panel).  Pure speed choice -- any placement gives the same result.
-struct TileSched { int tiles_m, tiles_n, n_major, xcd_remap; };
-
-__device__ __forceinline__ void tile_of_block(const TileSched& ts, int& tm, int& tn, int& z) {
-  const int nb = gridDim.x, bid = blockIdx.x;
-  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
-  const int t = ts.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc : bid;
-  const int per = ts.tiles_m * ts.tiles_n;
-  z = t / per;
-  const int rem = t - z * per;
-  if (ts.n_major) { tn = rem / ts.tiles_m; tm = rem - tn * ts.tiles_m; }
-  else { tm = rem / ts.tiles_n; tn = rem - tm * ts.tiles_n; }
 }
 
 template <int BM, int BN, bool TA, bool TB>
@@ -303,7 +260,19 @@ static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, 
   *splits = s;
 }
 
+int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
+                          int bm, int bn, int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags,
+                          hipStream_t stream);
+static int g_default_gen = 2;   // generation used by impl=0 (auto) / impl=2: 1 = k_gemm_mfma, 2 = k_gemm_dlds
+
 extern "C" {
+
+// which MFMA kernel generation `auto` uses (tuning / A-B tests); returns the previous value
+int zk_gemm_set_generation(int gen) {
+  const int old = g_default_gen;
+  if (gen == 1 || gen == 2) g_default_gen = gen;
+  return old;
+}
 
 // workspace bytes zk_gemm may need for (M,N,K) (split-K slabs), upper bound
 size_t zk_gemm_workspace(int M, int N, int K) {
@@ -322,12 +291,14 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
   ZK_CHECK_ARG(act >= 0 && act <= 2, "zk_gemm: act=%d unknown", act);
   ZK_CHECK_ARG(act != 2 || aux != nullptr, "zk_gemm: act=2 needs aux");
   ZK_CHECK_ARG(drop_p == 0.f || seed != nullptr, "zk_gemm: dropout needs a seed pointer");
-  // impl bits: [1:0] 0 auto / 1 reference / 2 mfma; [11:8] tile override (1:128x128 2:128x64
+  // impl bits: [1:0] 0 auto / 1 reference / 2 mfma (default generation) / 3 mfma generation 1;
+  // [11:8] tile override (1:128x128 2:128x64
   // 3:64x128 4:64x64); [23:16] split-K override (tuning / tests)
   const int tile_ovr = (impl >> 8) & 15, split_ovr = (impl >> 16) & 255;
   const int sched_flags = (impl >> 12) & 3;   // bit0: no XCD remap, bit1: flip panel order
   impl &= 3;
-  ZK_CHECK_ARG(impl >= 0 && impl <= 2, "zk_gemm: impl=%d unknown", impl);
+  int gen = g_default_gen;
+  if (impl == 3) { gen = 1; impl = 2; }
   if (M == 0 || N == 0) return 0;
   GemmEpi e;
   e.C = C; e.ldc = ldc; e.out_f32 = out_f32; e.alpha = alpha; e.bias = bias;
@@ -363,7 +334,8 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
   if (kchunk < 1) kchunk = 1;
   int rc;
   const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
-  if (bm == 128 && bn == 128) rc = launch_mfma<128, 128>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+  if (gen == 2) rc = zk_gemm_dlds_dispatch(a, b, M, N, K, lda, ldb, ta, tb, bm, bn, splits, kchunk, slabs, e, sched_flags, stream);
+  else if (bm == 128 && bn == 128) rc = launch_mfma<128, 128>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
   else if (bm == 128 && bn == 64) rc = launch_mfma<128, 64>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
   else if (bm == 64 && bn == 128) rc = launch_mfma<64, 128>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
   else rc = launch_mfma<64, 64>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);

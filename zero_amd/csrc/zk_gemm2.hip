@@ -1,0 +1,283 @@
+// zk_gemm2.hip -- second-generation bf16 MFMA GEMM: LDS-DMA ring + hardware-transpose reads.
+//
+// Same contract as k_gemm_mfma (zk_gemm.hip).  What changed, and why (rocprof of round 1: the
+// step's GEMMs are small -- 4096x512x512 is 0.9 us of MFMA work per CU -- so the K loop was
+// bound by exposed L2/fabric latency, one tile ahead was not enough):
+//   * operands go HBM/L2 -> LDS by `global_load_lds_dwordx4` (16 B per lane, no VGPR staging)
+//     into an NS-stage ring; NS-1 K tiles are in flight per workgroup, tracked with a counted
+//     `s_waitcnt vmcnt(N)` and ONE raw s_barrier per K step;
+//   * LDS-DMA writes lane-linear 1 KiB pieces, so the bank-conflict swizzle is applied to the
+//     per-lane SOURCE address and undone in the fragment read (same XOR both sides);
+//   * operands whose contraction dim is not contiguous in HBM (W[K,N] forward, both wgrad
+//     operands) are stored UN-transposed ([k][rows]) and read with ds_read_b64_tr_b16, the
+//     hardware 4x16 transpose read (semantics probed on the device: zk_probe_tr16) -- no
+//     register transposes, no row permutation;
+//   * the epilogue goes through LDS: every thread finishes 8 contiguous outputs with 16-byte
+//     loads/stores (bias, residual, ReLU, ReLU-backward mask, dropout fused as before).
+#include "zk_gemm.h"
+
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+
+__device__ __attribute__((aligned(16))) uint4 zk_zero_page[4];   // source of out-of-range pieces
+
+// LDS-DMA issued from inline asm: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every
+// ds_read that may alias an LDS-DMA it knows about, which would drain the ring each K step.  The
+// asm form is invisible to that pass; completion is tracked by the counted vmcnt waits below.
+// LDS destination = M0 (wave-uniform byte address) + lane*16; M0 is saved/restored around it.
+__device__ __forceinline__ void glds16(const bf16_t* gsrc, uint32_t lds_byte_addr) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_byte_addr)
+               : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) unsigned char*)p);
+}
+
+// chunk-position swizzles (16-byte chunks)
+__device__ __forceinline__ int swz_direct(int row) { return (row >> 1) & 7; }            // 128-B rows
+template <int R>
+__device__ __forceinline__ int swz_trans(int k) { return R == 128 ? ((k & 3) << 2) : (((k >> 1) & 1) << 2); }
+
+// issue the LDS-DMA of one operand tile (R rows x 64 k) into `stage` (R*64 bf16, linear chunks)
+template <int R, bool TRANS>
+__device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ src, int ld, int row0, int rows_total, int k0,
+                                         int kend, bf16_t* stage, int wave, int lane) {
+  constexpr int PER_WAVE = R * 8 / 4;      // chunks per wave
+  constexpr int NINSTR = PER_WAVE / 64;
+#pragma unroll
+  for (int j = 0; j < NINSTR; ++j) {
+    const int P = wave * PER_WAVE + j * 64 + lane;
+    const bf16_t* g = reinterpret_cast<const bf16_t*>(zk_zero_page);
+    if (!TRANS) {
+      const int row = P >> 3, pos = P & 7;
+      const int c = pos ^ swz_direct(row);
+      const int grow = row0 + row, gk = k0 + c * 8;
+      if (grow < rows_total && gk < kend) g = src + (size_t)grow * ld + gk;
+    } else {
+      constexpr int CPR = R / 8;             // chunks per k row
+      const int k = P / CPR, pos = P % CPR;
+      const int c = pos ^ swz_trans<R>(k);
+      const int gk = k0 + k, grow = row0 + c * 8;
+      if (gk < kend && grow < rows_total) g = src + (size_t)gk * ld + grow;
+    }
+    glds16(g, lds_addr(stage) + (uint32_t)(wave * PER_WAVE + j * 64) * 16u);
+  }
+}
+
+// MFMA 32x32x16 operand fragment of rows r0 + (lane&31), k = kk*16 + (lane>>5)*8 .. +7
+template <int R, bool TRANS>
+__device__ __forceinline__ bf16x8_t load_frag(const bf16_t* stage, int r0, int kk, int lane) {
+  if (!TRANS) {
+    const int row = r0 + (lane & 31);
+    const int c = kk * 2 + (lane >> 5);
+    const uint4 v = *reinterpret_cast<const uint4*>(stage + row * 64 + ((c ^ swz_direct(row)) << 3));
+    return __builtin_bit_cast(bf16x8_t, v);
+  } else {
+    // ds_read_b64_tr_b16: in each 16-lane group, lane p supplies 4 contiguous elements of k-row p/4
+    // at column (p%4)*4 and receives column p of the 4(k) x 16 block
+    const int p = lane & 15;
+    const int rr = r0 + ((lane >> 4) & 1) * 16 + (p & 3) * 4;
+    const int kb = kk * 16 + (lane >> 5) * 8 + (p >> 2);
+    const int chunk = rr >> 3, within = rr & 7;
+    v4s_t lo, hi;
+    {
+      const int k = kb;
+      const bf16_t* a = stage + k * R + ((chunk ^ swz_trans<R>(k)) << 3) + within;
+      lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)a);
+    }
+    {
+      const int k = kb + 4;
+      const bf16_t* a = stage + k * R + ((chunk ^ swz_trans<R>(k)) << 3) + within;
+      hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)a);
+    }
+    typedef short v8s_t __attribute__((ext_vector_type(8)));
+    const v8s_t both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, both);
+  }
+}
+
+struct EpiVec {
+  int vec_ok;   // 16-byte vector epilogue allowed (alignment checked on the host)
+};
+
+template <int BM, int BN, int NS, bool TA, bool TB>
+__global__ void __launch_bounds__(256) k_gemm_dlds(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M,
+                                                   int N, int K, int lda, int ldb, int kchunk,
+                                                   float* __restrict__ slabs, TileSched ts, GemmEpi e, EpiVec ev) {
+  constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
+  constexpr int STAGE = (BM + BN) * 64;                     // bf16 elements per ring stage
+  constexpr int PER_STAGE = (BM * 8 / 4 + BN * 8 / 4) / 64;  // DMA instructions per wave per stage
+  constexpr int CLD = BN + 4;                               // fp32 epilogue tile row stride
+  constexpr int RING_BYTES = NS * STAGE * 2, EPI_BYTES = BM * CLD * 4;
+  constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];   // the ONLY LDS object
+  bf16_t* ring = reinterpret_cast<bf16_t*>(smem);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int tm_, tn_, z_;
+  tile_of_block(ts, tm_, tn_, z_);
+  const int m0 = tm_ * BM, n0 = tn_ * BN;
+  const int kbeg = z_ * kchunk;
+  const int kend = min(K, kbeg + kchunk);
+  const int nk = (kend - kbeg + 63) >> 6;
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // prologue: tiles 0 .. NS-2 (tiles past the end are all-zero pieces: keeps the DMA count uniform)
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) {
+    bf16_t* st = ring + s * STAGE;
+    dma_tile<BM, TA>(A, lda, m0, M, kbeg + s * 64, kend, st, wave, lane);
+    dma_tile<BN, !TB>(B, ldb, n0, N, kbeg + s * 64, kend, st + BM * 64, wave, lane);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed once at most NS-2 later tiles of this wave are still in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PER_STAGE) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int t = kt + NS - 1;                 // refill the stage everybody finished reading
+      bf16_t* st = ring + (t % NS) * STAGE;
+      dma_tile<BM, TA>(A, lda, m0, M, kbeg + t * 64, kend, st, wave, lane);
+      dma_tile<BN, !TB>(B, ldb, n0, N, kbeg + t * 64, kend, st + BM * 64, wave, lane);
+    }
+    const bf16_t* sA = ring + (kt % NS) * STAGE;
+    const bf16_t* sB = sA + BM * 64;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8_t af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = load_frag<BM, TA>(sA, wm * WTM + i * 32, kk, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[j] = load_frag<BN, !TB>(sB, wn * WTN + j * 32, kk, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // ---- epilogue through LDS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (all-zero) pieces have landed
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = wn * WTN + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        sC[row * CLD + col] = acc[i][j][r];
+      }
+    }
+  __syncthreads();
+  const uint64_t seed = e.thr ? *e.seed : 0;
+  constexpr int CPRW = BN / 8;
+  for (int c = tid; c < BM * CPRW; c += 256) {
+    const int row = c / CPRW, cc = (c % CPRW) * 8;
+    const int gm = m0 + row, gn = n0 + cc;
+    if (gm >= M || gn >= N) continue;
+    float v[8];
+    {
+      const float4 a = *reinterpret_cast<const float4*>(sC + row * CLD + cc);
+      const float4 b = *reinterpret_cast<const float4*>(sC + row * CLD + cc + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    if (slabs != nullptr) {
+      float* d = slabs + ((size_t)z_ * M + gm) * N + gn;
+      if (gn + 8 <= N && (N & 3) == 0) {
+        reinterpret_cast<float4*>(d)[0] = make_float4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<float4*>(d)[1] = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        for (int j = 0; j < 8 && gn + j < N; ++j) d[j] = v[j];
+      }
+      continue;
+    }
+    if (ev.vec_ok && gn + 8 <= N) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= e.alpha;
+      if (e.bias) {
+        const float4 a = *reinterpret_cast<const float4*>(e.bias + gn);
+        const float4 b = *reinterpret_cast<const float4*>(e.bias + gn + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+      }
+      if (e.res) {
+        float rv[8];
+        unpack8(*reinterpret_cast<const uint4*>(e.res + (size_t)gm * e.ldr + gn), rv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += rv[j];
+      }
+      if (e.act == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      } else if (e.act == 2) {
+        float av[8];
+        unpack8(*reinterpret_cast<const uint4*>(e.aux + (size_t)gm * e.ldaux + gn), av);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = av[j] > 0.f ? v[j] * e.aux_scale : 0.f;
+      }
+      if (e.thr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= zk_drop_scale(seed, e.sid, (uint64_t)gm * N + gn + j, e.thr, e.inv_keep);
+      }
+      if (e.out_f32) {
+        float* d = reinterpret_cast<float*>(e.C) + (size_t)gm * e.ldc + gn;
+        reinterpret_cast<float4*>(d)[0] = make_float4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<float4*>(d)[1] = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)gm * e.ldc + gn) = pack8(v);
+      }
+    } else {
+      for (int j = 0; j < 8 && gn + j < N; ++j) epi_store(e, v[j], gm, gn + j, N, seed);
+    }
+  }
+}
+
+template <int BM, int BN, int NS>
+static int launch_dlds(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
+                       int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags, hipStream_t stream) {
+  TileSched ts;
+  ts.tiles_m = (M + BM - 1) / BM;
+  ts.tiles_n = (N + BN - 1) / BN;
+  ts.n_major = ((long)N > (long)M) ? 1 : 0;
+  if (sched_flags & 2) ts.n_major ^= 1;
+  ts.xcd_remap = (sched_flags & 1) ? 0 : 1;
+  EpiVec ev;
+  const uintptr_t al = (uintptr_t)e.C | (uintptr_t)e.bias | (uintptr_t)e.res | (uintptr_t)e.aux;
+  ev.vec_ok = ((al & 15) == 0) && (e.ldc % 8 == 0) && (e.res == nullptr || e.ldr % 8 == 0) &&
+              (e.aux == nullptr || e.ldaux % 8 == 0);
+  dim3 grid((unsigned)((long)ts.tiles_m * ts.tiles_n * splits));
+  if (!ta && !tb)
+    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, false, false>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
+  else if (!ta && tb)
+    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, false, true>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
+  else if (ta && !tb)
+    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, true, false>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
+  else
+    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, true, true>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+// entry used by zk_gemm (zk_gemm.hip)
+int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
+                          int bm, int bn, int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags,
+                          hipStream_t stream) {
+  if (bm == 128 && bn == 128) return launch_dlds<128, 128, 3>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+  if (bm == 128 && bn == 64) return launch_dlds<128, 64, 3>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+  if (bm == 64 && bn == 128) return launch_dlds<64, 128, 3>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+  return launch_dlds<64, 64, 4>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+}
