@@ -267,23 +267,25 @@ __global__ void __launch_bounds__(256) k_add_ln_bwd(
 }
 
 // out_q[c] = sum_b partials[b][q][c]   (q < nq; out pointers may be null)
-// block = 64 columns of one quantity; 4 row-groups of 64 lanes split the partial rows.
+// block = 16 columns of one quantity x 16 row groups (short dependent chains, 64-B segments).
 __global__ void __launch_bounds__(256) k_partials_reduce(const float* __restrict__ partials, int nblk,
                                                          int nq, int H, float* o0, float* o1,
                                                          float* o2, int accumulate) {
-  __shared__ float red[4][64];
+  __shared__ float red[16][17];
   const int q = blockIdx.y;
   float* o = q == 0 ? o0 : (q == 1 ? o1 : o2);
   if (o == nullptr) return;
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int g = threadIdx.x >> 6;
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float t = 0.f;
   if (c < H)
-    for (int b = g; b < nblk; b += 4) t += partials[((size_t)b * nq + q) * H + c];
-  red[g][threadIdx.x & 63] = t;
+    for (int b = g; b < nblk; b += 16) t += partials[((size_t)b * nq + q) * H + c];
+  red[g][cl] = t;
   __syncthreads();
   if (g == 0 && c < H) {
-    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v += red[i][cl];
     o[c] = accumulate ? o[c] + v : v;
   }
 }
@@ -435,6 +437,86 @@ __global__ void __launch_bounds__(256) k_ce_fused(
   }
 }
 
+// Same computation with the whole row held in registers (V <= NV*4096): one HBM read of the
+// logits row, no second pass -- 1024 threads (16 waves) per row.
+template <int NV>
+__global__ void __launch_bounds__(1024) k_ce_fused_reg(
+    const float* __restrict__ logits, const int* __restrict__ ids, const float* __restrict__ w,
+    float* __restrict__ ce_out, bf16_t* __restrict__ dlogits, int V, int ld, float p, float q,
+    float normalizer) {
+  __shared__ float sm[16];
+  __shared__ float bc;
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* z = logits + (size_t)r * ld;
+  const float wr = (w != nullptr) ? w[r] : 0.f;
+  const int gold = ids[r];
+  float4 v[NV];
+  float m = -INFINITY, sz = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 1024 + tid) * 4;
+    if (c + 3 < V) {
+      v[i] = *reinterpret_cast<const float4*>(z + c);
+    } else {
+      v[i].x = c < V ? z[c] : -INFINITY;
+      v[i].y = c + 1 < V ? z[c + 1] : -INFINITY;
+      v[i].z = c + 2 < V ? z[c + 2] : -INFINITY;
+      v[i].w = -INFINITY;
+    }
+    m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+    sz += (v[i].x > -INFINITY ? v[i].x : 0.f) + (v[i].y > -INFINITY ? v[i].y : 0.f) +
+          (v[i].z > -INFINITY ? v[i].z : 0.f) + (v[i].w > -INFINITY ? v[i].w : 0.f);
+  }
+  // block reductions over 16 waves
+  m = wave_max(m);
+  if (lane == 0) sm[wv] = m;
+  __syncthreads();
+  if (tid == 0) { float t = sm[0]; for (int i = 1; i < 16; ++i) t = fmaxf(t, sm[i]); bc = t; }
+  __syncthreads();
+  const float gm = bc;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i].x = __expf(v[i].x - gm); v[i].y = __expf(v[i].y - gm);
+    v[i].z = __expf(v[i].z - gm); v[i].w = __expf(v[i].w - gm);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  s = wave_sum(s);
+  sz = wave_sum(sz);
+  __syncthreads();
+  if (lane == 0) sm[wv] = s;
+  __syncthreads();
+  if (tid == 0) { float t = 0.f; for (int i = 0; i < 16; ++i) t += sm[i]; bc = t; }
+  __syncthreads();
+  const float gs = bc;
+  __syncthreads();
+  if (lane == 0) sm[wv] = sz;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 16; ++i) t += sm[i];
+    const float lse = gm + __logf(gs);
+    const float zg = z[gold];
+    if (ce_out != nullptr) ce_out[r] = lse - p * zg - q * (t - zg) - normalizer;
+  }
+  if (dlogits == nullptr) return;
+  bf16_t* d = dlogits + (size_t)r * ld;
+  const float inv = wr / gs;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 1024 + tid) * 4;
+    if (c >= ld) continue;
+    float o[4] = {v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv};   // exp(-inf)=0 past V
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cc = c + j;
+      if (cc < V) o[j] -= wr * ((cc == gold) ? p : q);
+      else o[j] = 0.f;
+    }
+    *reinterpret_cast<uint2*>(d + c) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+  }
+}
+
 // target statistics: mask=(id!=0), w = loss_scale*mask/(len_b*B) (gradient weight of each
 // token under loss = mean_b( sum_t ce*mask / sum_t mask ), transformer.py:209-211)
 __global__ void __launch_bounds__(256) k_target_stats(const int* __restrict__ ids, float* __restrict__ mask,
@@ -452,26 +534,27 @@ __global__ void __launch_bounds__(256) k_target_stats(const int* __restrict__ id
   }
 }
 
-// per_sample[b] = sum_t ce*mask / sum_t mask ; loss = mean_b per_sample (0 if B==0)
-__global__ void __launch_bounds__(256) k_loss_reduce(const float* __restrict__ ce, const int* __restrict__ ids,
-                                                     float* __restrict__ per_sample,
-                                                     float* __restrict__ loss, int B, int L) {
+// per_sample[b] = sum_t ce*mask / sum_t mask (one block per sentence); loss = mean_b (0 if B==0)
+__global__ void __launch_bounds__(256) k_per_sample(const float* __restrict__ ce, const int* __restrict__ ids,
+                                                    float* __restrict__ per_sample, int L) {
   __shared__ float sm[8];
-  float tot = 0.f;
-  for (int b = 0; b < B; ++b) {
-    float a = 0.f, c = 0.f;
-    for (int t = threadIdx.x; t < L; t += 256) {
-      const float mk = (ids[b * L + t] != 0) ? 1.f : 0.f;
-      a += ce[b * L + t] * mk;
-      c += mk;
-    }
-    a = block_sum<4>(a, sm);
-    c = block_sum<4>(c, sm);
-    const float ps = a / c;
-    if (threadIdx.x == 0 && per_sample != nullptr) per_sample[b] = ps;
-    tot += ps;
+  const int b = blockIdx.x;
+  float a = 0.f, c = 0.f;
+  for (int t = threadIdx.x; t < L; t += 256) {
+    const float mk = (ids[b * L + t] != 0) ? 1.f : 0.f;
+    a += ce[b * L + t] * mk;
+    c += mk;
   }
-  if (threadIdx.x == 0 && loss != nullptr) loss[0] = (B > 0) ? tot / (float)B : 0.f;
+  a = block_sum<4>(a, sm);
+  c = block_sum<4>(c, sm);
+  if (threadIdx.x == 0) per_sample[b] = a / c;
+}
+__global__ void __launch_bounds__(256) k_mean(const float* __restrict__ x, float* __restrict__ out, int n) {
+  __shared__ float sm[8];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += x[i];
+  a = block_sum<4>(a, sm);
+  if (threadIdx.x == 0) out[0] = (n > 0) ? a / (float)n : 0.f;
 }
 
 __global__ void __launch_bounds__(256) k_make_mask(const int* __restrict__ ids, float* __restrict__ mask, int n) {
@@ -804,7 +887,7 @@ int zk_add_ln_bwd(const void* dout, const void* sum, const float* mean, const fl
                      mean, rstd, gamma, (bf16_t*)dsum, (bf16_t*)dy, (float*)workspace, rows, H, thr, ik,
                      seed, sid);
   ZK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_partials_reduce, dim3((H + 63) / 64, 3), dim3(256), 0, stream,
+  hipLaunchKernelGGL(k_partials_reduce, dim3((H + 15) / 16, 3), dim3(256), 0, stream,
                      (const float*)workspace, g, 3, H, dgamma, dbeta, dbias_prev, 0);
   ZK_LAUNCH_CHECK();
   return 0;
@@ -830,7 +913,7 @@ int zk_colsum_ex(const void* a, int rows, int N, int lda, float* out, int skip_L
   hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, gy), dim3(256), 0, stream, (const bf16_t*)a, rows, N, lda,
                      (float*)workspace, skip_L, thr, ik, seed, sid);
   ZK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_partials_reduce, dim3((N + 63) / 64, 1), dim3(256), 0, stream, (const float*)workspace,
+  hipLaunchKernelGGL(k_partials_reduce, dim3((N + 15) / 16, 1), dim3(256), 0, stream, (const float*)workspace,
                      gy, 1, N, out, (float*)nullptr, (float*)nullptr, accumulate);
   ZK_LAUNCH_CHECK();
   return 0;
@@ -868,8 +951,15 @@ int zk_ce_fused(const float* logits, const int* ids, const float* w, float* ce_o
     q = label_smooth / n;
     normalizer = -(p * logf(p) + n * q * logf(q + 1e-20f));
   }
-  hipLaunchKernelGGL(k_ce_fused, dim3(rows), dim3(256), 0, stream, logits, ids, w, ce_out, (bf16_t*)dlogits,
-                     V, ld, p, q, normalizer);
+  if (ld <= 8 * 4096 && ld > 4 * 4096)
+    hipLaunchKernelGGL(k_ce_fused_reg<8>, dim3(rows), dim3(1024), 0, stream, logits, ids, w, ce_out,
+                       (bf16_t*)dlogits, V, ld, p, q, normalizer);
+  else if (ld <= 4 * 4096 && ld > 4096)
+    hipLaunchKernelGGL(k_ce_fused_reg<4>, dim3(rows), dim3(1024), 0, stream, logits, ids, w, ce_out,
+                       (bf16_t*)dlogits, V, ld, p, q, normalizer);
+  else
+    hipLaunchKernelGGL(k_ce_fused, dim3(rows), dim3(256), 0, stream, logits, ids, w, ce_out, (bf16_t*)dlogits,
+                       V, ld, p, q, normalizer);
   ZK_LAUNCH_CHECK();
   return 0;
 }
@@ -884,8 +974,15 @@ int zk_target_stats(const int* ids, float* mask, float* w, int B, int L, float l
 
 int zk_loss_reduce(const float* ce, const int* ids, float* per_sample, float* loss, int B, int L,
                    hipStream_t stream) {
-  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, stream, ce, ids, per_sample, loss, B, L);
-  ZK_LAUNCH_CHECK();
+  ZK_CHECK_ARG(per_sample != nullptr, "zk_loss_reduce: per_sample buffer required");
+  if (B > 0) {
+    hipLaunchKernelGGL(k_per_sample, dim3(B), dim3(256), 0, stream, ce, ids, per_sample, L);
+    ZK_LAUNCH_CHECK();
+  }
+  if (loss != nullptr) {
+    hipLaunchKernelGGL(k_mean, dim3(1), dim3(256), 0, stream, (const float*)per_sample, loss, B);
+    ZK_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -40,29 +40,50 @@ __device__ __forceinline__ int swz_direct(int row) { return (row >> 1) & 7; }   
 template <int R>
 __device__ __forceinline__ int swz_trans(int k) { return R == 128 ? ((k & 3) << 2) : (((k >> 1) & 1) << 2); }
 
-// issue the LDS-DMA of one operand tile (R rows x 64 k) into `stage` (R*64 bf16, linear chunks)
+// Per-lane LDS-DMA plan of one operand: for each of the wave's NINSTR pieces the source pointer of
+// K tile 0 (null when the tile row / column chunk is out of range) and the k index inside the
+// tile that decides the K-tail predicate.  Built once per workgroup; per K tile only an add,
+// a compare and a select remain in front of each DMA.
+template <int R>
+struct DmaPlan {
+  static constexpr int PER_WAVE = R * 8 / 4;      // 16-byte chunks per wave
+  static constexpr int NINSTR = PER_WAVE / 64;
+  const bf16_t* g0[NINSTR];
+  int kofs[NINSTR];
+};
+
 template <int R, bool TRANS>
-__device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ src, int ld, int row0, int rows_total, int k0,
-                                         int kend, bf16_t* stage, int wave, int lane) {
-  constexpr int PER_WAVE = R * 8 / 4;      // chunks per wave
-  constexpr int NINSTR = PER_WAVE / 64;
+__device__ __forceinline__ void dma_plan(DmaPlan<R>& pl, const bf16_t* __restrict__ src, int ld, int row0,
+                                         int rows_total, int kbeg, int wave, int lane) {
 #pragma unroll
-  for (int j = 0; j < NINSTR; ++j) {
-    const int P = wave * PER_WAVE + j * 64 + lane;
-    const bf16_t* g = reinterpret_cast<const bf16_t*>(zk_zero_page);
+  for (int j = 0; j < DmaPlan<R>::NINSTR; ++j) {
+    const int P = wave * DmaPlan<R>::PER_WAVE + j * 64 + lane;
     if (!TRANS) {
       const int row = P >> 3, pos = P & 7;
       const int c = pos ^ swz_direct(row);
-      const int grow = row0 + row, gk = k0 + c * 8;
-      if (grow < rows_total && gk < kend) g = src + (size_t)grow * ld + gk;
+      const int grow = row0 + row;
+      pl.kofs[j] = c * 8;
+      pl.g0[j] = grow < rows_total ? src + (size_t)grow * ld + kbeg + c * 8 : nullptr;
     } else {
       constexpr int CPR = R / 8;             // chunks per k row
       const int k = P / CPR, pos = P % CPR;
       const int c = pos ^ swz_trans<R>(k);
-      const int gk = k0 + k, grow = row0 + c * 8;
-      if (gk < kend && grow < rows_total) g = src + (size_t)gk * ld + grow;
+      const int grow = row0 + c * 8;
+      pl.kofs[j] = k;
+      pl.g0[j] = grow < rows_total ? src + (size_t)(kbeg + k) * ld + grow : nullptr;
     }
-    glds16(g, lds_addr(stage) + (uint32_t)(wave * PER_WAVE + j * 64) * 16u);
+  }
+}
+
+// issue the LDS-DMA of K tile `t` (k range [kbeg + 64 t, ...)) of one operand into `stage`
+template <int R, bool TRANS>
+__device__ __forceinline__ void dma_tile(const DmaPlan<R>& pl, int ld, int t, int klen, bf16_t* stage, int wave) {
+  const size_t step = TRANS ? (size_t)64 * ld : (size_t)64;
+#pragma unroll
+  for (int j = 0; j < DmaPlan<R>::NINSTR; ++j) {
+    const bool ok = (pl.g0[j] != nullptr) && (t * 64 + pl.kofs[j] < klen);
+    const bf16_t* g = ok ? pl.g0[j] + (size_t)t * step : reinterpret_cast<const bf16_t*>(zk_zero_page);
+    glds16(g, lds_addr(stage) + (uint32_t)(wave * DmaPlan<R>::PER_WAVE + j * 64) * 16u);
   }
 }
 
@@ -133,12 +154,17 @@ __global__ void __launch_bounds__(256) k_gemm_dlds(const bf16_t* __restrict__ A,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  DmaPlan<BM> planA;
+  DmaPlan<BN> planB;
+  dma_plan<BM, TA>(planA, A, lda, m0, M, kbeg, wave, lane);
+  dma_plan<BN, !TB>(planB, B, ldb, n0, N, kbeg, wave, lane);
+  const int klen = kend - kbeg;
   // prologue: tiles 0 .. NS-2 (tiles past the end are all-zero pieces: keeps the DMA count uniform)
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s) {
     bf16_t* st = ring + s * STAGE;
-    dma_tile<BM, TA>(A, lda, m0, M, kbeg + s * 64, kend, st, wave, lane);
-    dma_tile<BN, !TB>(B, ldb, n0, N, kbeg + s * 64, kend, st + BM * 64, wave, lane);
+    dma_tile<BM, TA>(planA, lda, s, klen, st, wave);
+    dma_tile<BN, !TB>(planB, ldb, s, klen, st + BM * 64, wave);
   }
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed once at most NS-2 later tiles of this wave are still in flight
@@ -148,23 +174,30 @@ __global__ void __launch_bounds__(256) k_gemm_dlds(const bf16_t* __restrict__ A,
     {
       const int t = kt + NS - 1;                 // refill the stage everybody finished reading
       bf16_t* st = ring + (t % NS) * STAGE;
-      dma_tile<BM, TA>(A, lda, m0, M, kbeg + t * 64, kend, st, wave, lane);
-      dma_tile<BN, !TB>(B, ldb, n0, N, kbeg + t * 64, kend, st + BM * 64, wave, lane);
+      dma_tile<BM, TA>(planA, lda, t, klen, st, wave);
+      dma_tile<BN, !TB>(planB, ldb, t, klen, st + BM * 64, wave);
     }
     const bf16_t* sA = ring + (kt % NS) * STAGE;
     const bf16_t* sB = sA + BM * 64;
+    // fragments of k-slice kk+1 are read while the MFMAs of slice kk run (two register sets)
+    bf16x8_t af[2][TM], bfr[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = load_frag<BM, TA>(sA, wm * WTM + i * 32, 0, lane);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bfr[0][j] = load_frag<BN, !TB>(sB, wn * WTN + j * 32, 0, lane);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      bf16x8_t af[TM], bfr[TN];
+      if (kk < 3) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = load_frag<BM, TA>(sA, wm * WTM + i * 32, kk, lane);
+        for (int i = 0; i < TM; ++i) af[(kk + 1) & 1][i] = load_frag<BM, TA>(sA, wm * WTM + i * 32, kk + 1, lane);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bfr[j] = load_frag<BN, !TB>(sB, wn * WTN + j * 32, kk, lane);
+        for (int j = 0; j < TN; ++j) bfr[(kk + 1) & 1][j] = load_frag<BN, !TB>(sB, wn * WTN + j * 32, kk + 1, lane);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
     }
   }
   // ---- epilogue through LDS
