@@ -51,6 +51,15 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
             int act, const void* aux, int ldaux, float aux_scale, float drop_p, const uint64_t* seed,
             uint32_t sid, int impl, void* workspace, size_t ws_bytes, zk_stream_t stream);
 
+/* Grouped launch of independent GEMMs with the same ta/tb in one grid (the deferred weight
+ * gradients of several layers; the cross-attention k_map / v_map projections of every decoder
+ * layer, func.py:206-216).  descs: DEVICE array of nprob records
+ *   { const void* A, B; void* C; const float* bias; int M, N, K, lda, ldb, ldc, out_f32,
+ *     tile_start, tiles_n, pad; }            (72 bytes)
+ * tile_start = running sum of ceil(M/T)*ceil(N/T) with T = 128 (tile=1) or 64 (tile=4). */
+int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int tb, int tile,
+                    zk_stream_t stream);
+
 /* ---- func.py:218-256 dot_attention core (+ modules/rpr.py:10-75 relative positions).
  * q/k/v/out: [B*L, ld] bf16, head h at columns [h*d,(h+1)*d) (split/combine_heads,
  * func.py:68-104, folded into addressing).  kmask: fp32 [B,Lk] (1 valid / 0 pad) or NULL;

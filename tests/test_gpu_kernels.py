@@ -132,6 +132,30 @@ def test_gemm_every_tile_shape(impl, tile, ta, tb):
     assert err < 8e-3, (impl, tile, ta, tb, err)
 
 
+@pytest.mark.parametrize("ta,tb", [(1, 0), (0, 0), (0, 1)])
+def test_gemm_grouped(ta, tb):
+    e = eng()
+    shapes = [(512, 384, 1000), (136, 520, 264), (128, 128, 64), (264, 72, 4096)]
+    probs, refs = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        A = rand_bf(*((K, M) if ta else (M, K)), seed=10 + i)
+        Bm = rand_bf(*((N, K) if tb else (K, N)), seed=20 + i)
+        f32 = (i % 2 == 0)
+        C = torch.zeros(M, N, dtype=torch.float32 if f32 else torch.bfloat16, device="cuda")
+        bias = torch.randn(N, device="cuda") if i == 1 else None
+        probs.append((mat(A), mat(Bm), mat(C), M, N, K, bias))
+        a = A.float().t() if ta else A.float()
+        b = Bm.float().t() if tb else Bm.float()
+        refs.append(a @ b + (bias if bias is not None else 0))
+    for tile in (128, 64):
+        for p in probs:
+            p[2].t.zero_()
+        e.gemm_grouped(probs, ta, tb, tile=tile)
+        torch.cuda.synchronize()
+        for p, r in zip(probs, refs):
+            assert rel_err(p[2].t, r) < 8e-3, (tile, p[3:6], rel_err(p[2].t, r))
+
+
 # ------------------------------------------------------------------ attention
 def _attn_ref(q, k, v, B, nh, Lq, Lk, d, kmask, causal, rk=None, rv=None, max_rel=0, drop_mask=None):
     """func.py:218-256 in torch fp32 on [B*L, nh*d] matrices."""

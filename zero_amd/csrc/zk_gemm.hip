@@ -245,7 +245,7 @@ static bool mfma_ok(const void* A, const void* B, int M, int N, int K, int lda, 
 // ones 64x128 / 128x64; small ones 64x64 plus split-K when the epilogue allows it.
 static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, int* splits) {
   const long out = (long)M * N;
-  if (out >= 128L * 128 * 1024) { *bm = 128; *bn = 128; }
+  if (out >= 8L * 1024 * 1024 || (K >= 1024 && M >= 128 && N >= 128)) { *bm = 128; *bn = 128; }
   else if (out >= 64L * 128 * 640) { if (N >= M) { *bm = 64; *bn = 128; } else { *bm = 128; *bn = 64; } }
   else { *bm = 64; *bn = 64; }
   const long tiles = (long)((M + *bm - 1) / *bm) * ((N + *bn - 1) / *bn);
@@ -254,7 +254,7 @@ static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, 
     s = (int)((1024 + tiles - 1) / tiles);
     const int maxs = K / (4 * BK);            // keep >= 4 K-tiles per split
     if (s > maxs) s = maxs;
-    if (s > 32) s = 32;
+    if (s > 8) s = 8;
     if (s < 1) s = 1;
   }
   *splits = s;
@@ -299,6 +299,10 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
   impl &= 3;
   int gen = g_default_gen;
   if (impl == 3) { gen = 1; impl = 2; }
+  // measured (scripts/gemm_bench.py): a huge fp32 output with a short K loop (the logits GEMM) is
+  // epilogue-bound; the register-staged kernel keeps 2 workgroups per CU and overlaps one's
+  // epilogue with the other's K loop
+  else if (impl == 0 && gen == 2 && out_f32 && K <= 512 && (long)M * N >= 64L * 1024 * 1024) gen = 1;
   if (M == 0 || N == 0) return 0;
   GemmEpi e;
   e.C = C; e.ldc = ldc; e.out_f32 = out_f32; e.alpha = alpha; e.bias = bias;

@@ -123,27 +123,29 @@ struct EpiVec {
   int vec_ok;   // 16-byte vector epilogue allowed (alignment checked on the host)
 };
 
+template <int BM, int BN, int NS>
+struct DldsCfg {
+  static constexpr int STAGE = (BM + BN) * 64;                     // bf16 elements per ring stage
+  static constexpr int CLD = BN + 4;                               // fp32 epilogue tile row stride
+  static constexpr int RING_BYTES = NS * STAGE * 2, EPI_BYTES = BM * CLD * 4;
+  static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
+};
+
+// one BMxBN output tile over k in [kbeg, kend); slab != null: write the fp32 partial tile there
 template <int BM, int BN, int NS, bool TA, bool TB>
-__global__ void __launch_bounds__(256) k_gemm_dlds(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M,
-                                                   int N, int K, int lda, int ldb, int kchunk,
-                                                   float* __restrict__ slabs, TileSched ts, GemmEpi e, EpiVec ev) {
+__device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __restrict__ A,
+                                          const bf16_t* __restrict__ B, int M, int N, int lda, int ldb, int kbeg,
+                                          int kend, int m0, int n0, float* __restrict__ slab, const GemmEpi& e,
+                                          int vec_ok) {
   constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
-  constexpr int STAGE = (BM + BN) * 64;                     // bf16 elements per ring stage
+  constexpr int STAGE = DldsCfg<BM, BN, NS>::STAGE;
   constexpr int PER_STAGE = (BM * 8 / 4 + BN * 8 / 4) / 64;  // DMA instructions per wave per stage
-  constexpr int CLD = BN + 4;                               // fp32 epilogue tile row stride
-  constexpr int RING_BYTES = NS * STAGE * 2, EPI_BYTES = BM * CLD * 4;
-  constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];   // the ONLY LDS object
+  constexpr int CLD = DldsCfg<BM, BN, NS>::CLD;
   bf16_t* ring = reinterpret_cast<bf16_t*>(smem);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  int tm_, tn_, z_;
-  tile_of_block(ts, tm_, tn_, z_);
-  const int m0 = tm_ * BM, n0 = tn_ * BN;
-  const int kbeg = z_ * kchunk;
-  const int kend = min(K, kbeg + kchunk);
   const int nk = (kend - kbeg + 63) >> 6;
 
   f32x16_t acc[TM][TN];
@@ -229,8 +231,8 @@ __global__ void __launch_bounds__(256) k_gemm_dlds(const bf16_t* __restrict__ A,
       const float4 b = *reinterpret_cast<const float4*>(sC + row * CLD + cc + 4);
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     }
-    if (slabs != nullptr) {
-      float* d = slabs + ((size_t)z_ * M + gm) * N + gn;
+    if (slab != nullptr) {
+      float* d = slab + (size_t)gm * N + gn;
       if (gn + 8 <= N && (N & 3) == 0) {
         reinterpret_cast<float4*>(d)[0] = make_float4(v[0], v[1], v[2], v[3]);
         reinterpret_cast<float4*>(d)[1] = make_float4(v[4], v[5], v[6], v[7]);
@@ -239,7 +241,7 @@ __global__ void __launch_bounds__(256) k_gemm_dlds(const bf16_t* __restrict__ A,
       }
       continue;
     }
-    if (ev.vec_ok && gn + 8 <= N) {
+    if (vec_ok && gn + 8 <= N) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] *= e.alpha;
       if (e.bias) {
@@ -279,6 +281,49 @@ __global__ void __launch_bounds__(256) k_gemm_dlds(const bf16_t* __restrict__ A,
   }
 }
 
+template <int BM, int BN, int NS, bool TA, bool TB>
+__global__ void __launch_bounds__(256) k_gemm_dlds(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M,
+                                                   int N, int K, int lda, int ldb, int kchunk,
+                                                   float* __restrict__ slabs, TileSched ts, GemmEpi e, EpiVec ev) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DldsCfg<BM, BN, NS>::LDS_BYTES];   // the ONLY LDS object
+  int tm_, tn_, z_;
+  tile_of_block(ts, tm_, tn_, z_);
+  const int kbeg = z_ * kchunk;
+  const int kend = min(K, kbeg + kchunk);
+  gemm_tile<BM, BN, NS, TA, TB>(smem, A, B, M, N, lda, ldb, kbeg, kend, tm_ * BM, tn_ * BN,
+                                slabs ? slabs + (size_t)z_ * M * N : nullptr, e, ev.vec_ok);
+}
+
+// Grouped launch: many independent GEMMs (same transposition flags) in ONE grid -- the deferred
+// weight-gradient GEMMs of several layers, or the cross-attention K/V projections of all decoder
+// layers.  Each problem is far too small to fill 256 CUs; together they do, with 128x128 tiles, the
+// full K per tile and no split-K slabs.  Descriptors live in device memory.
+struct GroupDesc {
+  const bf16_t* A; const bf16_t* B; void* C; const float* bias;
+  int M, N, K, lda, ldb, ldc, out_f32, tile_start, tiles_n, pad_;
+};
+
+template <int BM, int BN, int NS, bool TA, bool TB>
+__global__ void __launch_bounds__(256) k_gemm_grouped(const GroupDesc* __restrict__ descs, int nprob) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DldsCfg<BM, BN, NS>::LDS_BYTES];
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  int p = 0;
+  while (p + 1 < nprob && descs[p + 1].tile_start <= t) ++p;
+  const GroupDesc d = descs[p];
+  const int local = t - d.tile_start;
+  const int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
+  GemmEpi e;
+  e.C = d.C; e.ldc = d.ldc; e.out_f32 = d.out_f32; e.alpha = 1.f; e.bias = d.bias;
+  e.res = nullptr; e.ldr = 0; e.act = 0; e.aux = nullptr; e.ldaux = 0; e.aux_scale = 1.f;
+  e.thr = 0; e.inv_keep = 1.f; e.seed = nullptr; e.sid = 0;
+  const uintptr_t al = (uintptr_t)d.C | (uintptr_t)d.bias;
+  const int vec_ok = ((al & 15) == 0) && (d.ldc % 8 == 0);
+  gemm_tile<BM, BN, NS, TA, TB>(smem, d.A, d.B, d.M, d.N, d.lda, d.ldb, 0, d.K, tm * BM, tn * BN, nullptr, e,
+                                vec_ok);
+}
+
 template <int BM, int BN, int NS>
 static int launch_dlds(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
                        int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags, hipStream_t stream) {
@@ -304,6 +349,29 @@ static int launch_dlds(const bf16_t* A, const bf16_t* B, int M, int N, int K, in
   ZK_LAUNCH_CHECK();
   return 0;
 }
+
+extern "C" {
+// descs: device array of `nprob` GroupDesc (72 bytes each, see zk_gemm2.hip) whose tile_start
+// fields are the running sum of ceil(M/bm)*ceil(N/bn); total_tiles = that sum.
+int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int tb, int tile, hipStream_t stream) {
+  ZK_CHECK_ARG(nprob >= 1 && total_tiles >= 1, "zk_gemm_grouped: empty group");
+  ZK_CHECK_ARG(tile == 1 || tile == 4, "zk_gemm_grouped: tile must be 1 (128x128) or 4 (64x64)");
+  const GroupDesc* d = (const GroupDesc*)descs;
+  dim3 grid((unsigned)total_tiles);
+#define ZK_GROUP_LAUNCH(BM_, BN_, NS_)                                                                          \
+  do {                                                                                                         \
+    if (!ta && !tb) hipLaunchKernelGGL((k_gemm_grouped<BM_, BN_, NS_, false, false>), grid, dim3(256), 0, stream, d, nprob); \
+    else if (!ta && tb) hipLaunchKernelGGL((k_gemm_grouped<BM_, BN_, NS_, false, true>), grid, dim3(256), 0, stream, d, nprob); \
+    else if (ta && !tb) hipLaunchKernelGGL((k_gemm_grouped<BM_, BN_, NS_, true, false>), grid, dim3(256), 0, stream, d, nprob); \
+    else hipLaunchKernelGGL((k_gemm_grouped<BM_, BN_, NS_, true, true>), grid, dim3(256), 0, stream, d, nprob);     \
+  } while (0)
+  if (tile == 1) ZK_GROUP_LAUNCH(128, 128, 3);
+  else ZK_GROUP_LAUNCH(64, 64, 4);
+#undef ZK_GROUP_LAUNCH
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+}  // extern "C"
 
 // entry used by zk_gemm (zk_gemm.hip)
 int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,

@@ -24,6 +24,14 @@ from zero_amd import hip
 from zero_amd.utils import dtype as zdtype
 
 
+class _GroupDesc(ctypes.Structure):
+    """Mirror of ``struct GroupDesc`` (zero_amd/csrc/zk_gemm2.hip, include/zero_hip.h)."""
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p),
+                ("bias", ctypes.c_void_p)] + [(n, ctypes.c_int) for n in
+                                              ("M", "N", "K", "lda", "ldb", "ldc", "out_f32", "tile_start",
+                                               "tiles_n", "pad")]
+
+
 class Mat(object):
     """Row-major matrix view over a torch tensor."""
     __slots__ = ("t", "rows", "cols", "ld", "off")
@@ -131,6 +139,31 @@ class Engine(object):
             aux.ptr if aux is not None else None, aux.ld if aux is not None else 0, aux_scale,
             float(drop_p), self.seed.data_ptr(), sid,
             self.gemm_impl if impl is None else impl, ws.data_ptr(), ws.numel(), self.stream)
+
+    def gemm_grouped(self, problems, ta, tb, tile=128):
+        """One launch for many independent GEMMs with the same ta/tb.
+        problems: list of (A, B, C, M, N, K, bias-or-None) with Mat operands.  The device descriptor
+        table is cached per problem list (buffers are static, so it is built once)."""
+        key = (ta, tb, tile) + tuple((a.ptr, b.ptr, c.ptr, M, N, K, hip.ptr(bias) or 0)
+                                     for a, b, c, M, N, K, bias in problems)
+        cache = self.__dict__.setdefault("_group_cache", {})
+        ent = cache.get(key)
+        if ent is None:
+            arr = (_GroupDesc * len(problems))()
+            start = 0
+            for i, (a, b, c, M, N, K, bias) in enumerate(problems):
+                tn = (N + tile - 1) // tile
+                d = arr[i]
+                d.A, d.B, d.C, d.bias = a.ptr, b.ptr, c.ptr, hip.ptr(bias) or 0
+                d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, a.ld, b.ld, c.ld
+                d.out_f32 = 1 if c.t.dtype == torch.float32 else 0
+                d.tile_start, d.tiles_n, d.pad = start, tn, 0
+                start += ((M + tile - 1) // tile) * tn
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            ent = (host.to(self.device), len(problems), start)
+            cache[key] = ent
+        dev, n, total = ent
+        self.lib.call("zk_gemm_grouped", dev.data_ptr(), n, total, ta, tb, 1 if tile == 128 else 4, self.stream)
 
     def colsum(self, A, out, skip_L=0, accumulate=False, drop_p=0.0, sid=0):
         ws_bytes = self.lib.query("zk_colsum_workspace", A.rows, A.cols)

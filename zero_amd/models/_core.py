@@ -67,6 +67,11 @@ class TransformerCore(object):
         # weight-gradient GEMMs and bias column sums leave the critical path: they run on a second
         # HIP stream, concurrently with the dgrad chain (both are latency-bound at this size)
         self.use_side = os.environ.get("ZERO_HIP_SIDE_STREAM", "1") != "0"
+        # weight-gradient GEMMs are deferred and launched as ONE grouped grid per `group_layers`
+        # layers (each is far too small to fill 256 CUs on its own)
+        self.group_wgrad = os.environ.get("ZERO_HIP_GROUP_WGRAD", "1") != "0"
+        self.group_layers = int(os.environ.get("ZERO_HIP_GROUP_LAYERS", "3"))
+        self._pending_wgrads = []
         self.side = torch.cuda.Stream(self.eng.device) if self.eng.device.type == "cuda" else None
 
     # ------------------------------------------------------------------ stream plumbing
@@ -80,6 +85,13 @@ class TransformerCore(object):
         self.side.wait_event(ev)
         with torch.cuda.stream(self.side):
             fn()
+
+    def _flush_wgrads(self):
+        """Launch every deferred weight-gradient GEMM as one grouped grid on the side stream."""
+        if self._pending_wgrads:
+            probs = self._pending_wgrads
+            self._pending_wgrads = []
+            self._side(lambda: self.eng.gemm_grouped(probs, 1, 0))
 
     def _join_side(self):
         if self.use_side:
@@ -112,11 +124,16 @@ class TransformerCore(object):
         """dW = x^T dy (fp32, overwrite), db = colsum(dy), dx = dy @ W^T (+residual)."""
         Wm = self.W(scope + "/W_0_0")
 
-        def wgrad():
-            self.eng.gemm(x, dy, self.gW(scope + "/W_0_0"), Wm.rows, Wm.cols, x.rows, 1, 0)
+        if self.group_wgrad and self.eng.gemm_impl == 0:
+            self._pending_wgrads.append((x, dy, self.gW(scope + "/W_0_0"), Wm.rows, Wm.cols, x.rows, None))
             if bias_grad:
-                self.eng.colsum(dy, self.gb(scope + "/b_0"))
-        self._side(wgrad)
+                self._side(lambda: self.eng.colsum(dy, self.gb(scope + "/b_0")))
+        else:
+            def wgrad():
+                self.eng.gemm(x, dy, self.gW(scope + "/W_0_0"), Wm.rows, Wm.cols, x.rows, 1, 0)
+                if bias_grad:
+                    self.eng.colsum(dy, self.gb(scope + "/b_0"))
+            self._side(wgrad)
         if dx is not None:
             self.eng.gemm(dy, Wm, dx, dy.rows, Wm.rows, Wm.cols, 0, 1, residual=residual, act=act, aux=aux,
                           aux_scale=aux_scale)
@@ -431,7 +448,10 @@ class TransformerCore(object):
         cur = 0
         e.gemm(dlogits, E, P[cur], Tt, H, self.Vpad, 0, 0)
         gE = self.gW(self.soft_emb)
-        self._side(lambda: e.gemm(dlogits, feat, gE, self.Vpad, H, Tt, 1, 0))
+        if self.group_wgrad and e.gemm_impl == 0:
+            self._pending_wgrads.append((dlogits, feat, gE, self.Vpad, H, Tt, None))
+        else:
+            self._side(lambda: e.gemm(dlogits, feat, gE, self.Vpad, H, Tt, 1, 0))
         d_enc = e.mat("g.denc", Ts, H)
         e.zero(d_enc.t)
         NE = hp.num_encoder_layer
@@ -449,6 +469,7 @@ class TransformerCore(object):
                 return e.mat("%s%d.ff.o" % (side, l - 1), Tt if side == "d" else Ts, H)
             return e.mat("dec.x0" if side == "d" else "enc.x0", Tt if side == "d" else Ts, H)
 
+        ready_d = []
         for l in reversed(range(hp.num_decoder_layer)):
             pre = "decoder/layer_%d" % l
             sid = 100 * (NE + l)
@@ -465,7 +486,12 @@ class TransformerCore(object):
                 self._self_attn_bwd(P[cur], layer_input("d", l, "sa"), B, Lt, pre + "/self_attention",
                                     "d%d.sa" % l, None, True, sid + 1, "d", P[cur ^ 1])
             cur ^= 1
-            self._side(lambda pre=pre: on_ready(pre))
+            ready_d.append(pre)
+            if len(ready_d) >= self.group_layers or l == 0:
+                self._flush_wgrads()
+                for key in ready_d:
+                    self._side(lambda key=key: on_ready(key))
+                ready_d = []
         dxt = P[cur]
 
         def tgt_embed_grads():
@@ -481,6 +507,7 @@ class TransformerCore(object):
         # encoder
         Q = [d_enc, e.mat("ge.p1", Ts, H)]
         cur = 0
+        ready_e = []
         for l in reversed(range(NE)):
             pre = "encoder/layer_%d" % l
             other = Q[cur ^ 1] if (Q[cur ^ 1] is not d_enc) else e.mat("ge.p0", Ts, H)
@@ -493,7 +520,12 @@ class TransformerCore(object):
                                 smask, False, 100 * l + 1, "e", other)
             Q[cur ^ 1] = other
             cur ^= 1
-            self._side(lambda pre=pre: on_ready(pre))
+            ready_e.append(pre)
+            if len(ready_e) >= self.group_layers or l == 0:
+                self._flush_wgrads()
+                for key in ready_e:
+                    self._side(lambda key=key: on_ready(key))
+                ready_e = []
         dxs = Q[cur]
 
         def src_embed_grads():
