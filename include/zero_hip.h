@@ -144,12 +144,12 @@ int zk_aan_gate_bwd(const void* dg, const void* z, const void* cat, void* dz, vo
 
 /* ---- utils/cycle.py:86-101 + tf.train.AdamOptimizer (main.py:178-181) on flat buffers.
  * hyper (device fp32[8]): lr_t, beta1, beta2, eps, grad_scale, clip_norm(0=off), gnorm(in),
- * skipped(out).  zk_l2norm: out[0] = scale*||x||_2.                                    */
+ * skipped(out).  zk_l2norm: out[0] = scale*||x||_2; zk_adam's pnorm_out = ||p|| before the update.                                   */
 size_t zk_norm_workspace(void);
 int zk_l2norm(const float* x, size_t n, float scale, float* out, void* workspace, size_t ws_bytes,
               zk_stream_t stream);
 int zk_adam(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n, float* hyper,
-            zk_stream_t stream);
+            float* pnorm_out, void* workspace, size_t ws_bytes, zk_stream_t stream);
 int zk_cast_f32_bf16(const float* x, void* y, size_t n, zk_stream_t stream);
 int zk_cast_bf16_f32(const void* x, float* y, size_t n, zk_stream_t stream);
 int zk_zero(void* p, size_t bytes, zk_stream_t stream);

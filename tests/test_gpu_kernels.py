@@ -529,9 +529,11 @@ def test_l2norm_and_adam_tf1_semantics():
     lr, b1, b2, eps, clip = 0.01, 0.9, 0.98, 1e-8, gn * 0.5
     hyper[:6] = torch.tensor([lr, b1, b2, eps, 0.5, clip])
     p0, m0, v0 = p.clone(), m.clone(), v.clone()
+    pn = torch.zeros(1, device="cuda")
     e.lib.call("zk_adam", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr(), n,
-               hyper.data_ptr(), e.stream)
+               hyper.data_ptr(), pn.data_ptr(), ws.data_ptr(), ws.numel(), e.stream)
     torch.cuda.synchronize()
+    assert abs(float(pn) - float(p0[:n].double().norm())) / float(p0[:n].double().norm()) < 1e-5
     gg = g * 0.5 * (clip / max(gn, clip))
     m1 = b1 * m0 + (1 - b1) * gg; v1 = b2 * v0 + (1 - b2) * gg * gg
     p1 = p0 - lr * m1 / (v1.sqrt() + eps)
@@ -541,7 +543,7 @@ def test_l2norm_and_adam_tf1_semantics():
     hyper[6] = float("nan")
     pb = p.clone()
     e.lib.call("zk_adam", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr(), n,
-               hyper.data_ptr(), e.stream)
+               hyper.data_ptr(), None, None, 0, e.stream)
     torch.cuda.synchronize()
     assert float(hyper[7]) == 1.0 and max_err(p, pb) == 0
 

@@ -16,7 +16,7 @@ int zk_set_error(int code, const char* fmt, ...) {
   return code;
 }
 
-#define MAXC 4  // row kernels keep up to MAXC*64*8 = 2048 channels in registers
+#define MAXC_LIMIT 4  // row kernels keep up to 4*64*8 = 2048 channels in registers (templated on the slab count)
 
 // =====================================================================================
 // K1  embedding + sqrt(H) scale + shared bias + timing signal (+ dropout)
@@ -107,6 +107,7 @@ __global__ void __launch_bounds__(256) k_embed_bwd(
 //     eps=1e-8 inside rsqrt), post-LN order of transformer.py:57-58.
 //     s is stored (bf16) for the backward; statistics are taken from the stored values.
 // =====================================================================================
+template <int MAXC>
 __global__ void __launch_bounds__(256) k_add_ln_fwd(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, const float* __restrict__ gamma,
     const float* __restrict__ beta, bf16_t* __restrict__ out, bf16_t* __restrict__ sum_out,
@@ -174,6 +175,7 @@ __global__ void __launch_bounds__(256) k_add_ln_fwd(
 // Per column (reduced over rows): dgamma=sum dout*xhat, dbeta=sum dout, dbias_prev=sum dy
 // (the bias of the linear layer that produced y).  Stage 1 writes one partial row per
 // block to `partials` [gridDim.x][3][H]; k_partials_reduce finishes.
+template <int MAXC>
 __global__ void __launch_bounds__(256) k_add_ln_bwd(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ s, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, bf16_t* __restrict__ dsum,
@@ -728,7 +730,9 @@ __global__ void __launch_bounds__(256) k_norm_final(const float* __restrict__ pa
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g,
                                               float* __restrict__ m, float* __restrict__ v,
                                               bf16_t* __restrict__ shadow, size_t n,
-                                              float* __restrict__ hyper) {
+                                              float* __restrict__ hyper, float* __restrict__ psq) {
+  __shared__ float sm_[8];
+  float pacc = 0.f;   // sum of squares of the parameters BEFORE this update (tf.global_norm(variables))
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
   const float gs = hyper[4], clip = hyper[5], gnorm = hyper[6];
   if (!(gnorm == gnorm) || fabsf(gnorm) == INFINITY) {  // NaN/Inf guard (main.py:316-319)
@@ -740,6 +744,7 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
   const size_t n4 = n / 4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
+    pacc += pp.x * pp.x + pp.y * pp.y + pp.z * pp.z + pp.w * pp.w;
     const float4 gg = reinterpret_cast<const float4*>(g)[i];
     float4 mm = reinterpret_cast<float4*>(m)[i];
     float4 vv = reinterpret_cast<float4*>(v)[i];
@@ -759,10 +764,15 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
   }
   for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float gj = g[i] * f;
+    pacc += p[i] * p[i];
     m[i] = b1 * m[i] + (1.f - b1) * gj;
     v[i] = b2 * v[i] + (1.f - b2) * gj * gj;
     p[i] -= lr * m[i] / (sqrtf(v[i]) + eps);
     if (shadow != nullptr) shadow[i] = f2bf(p[i]);
+  }
+  if (psq != nullptr) {
+    pacc = block_sum<4>(pacc, sm_);
+    if (threadIdx.x == 0) psq[blockIdx.x] = pacc;
   }
 }
 
@@ -850,15 +860,20 @@ int zk_embed_bwd(const int* ids, const void* dout, float* dtable, float* dbias, 
 int zk_add_ln_fwd(const void* x, const void* y, const float* gamma, const float* beta, void* out,
                   void* sum_out, float* mean, float* rstd, int rows, int H, float eps, float drop_p,
                   const uint64_t* seed, uint32_t sid, hipStream_t stream) {
-  ZK_CHECK_ARG(H % 8 == 0 && H <= MAXC * 512, "zk_add_ln_fwd: H=%d must be a multiple of 8 and <= %d", H,
-               MAXC * 512);
+  ZK_CHECK_ARG(H % 8 == 0 && H <= MAXC_LIMIT * 512, "zk_add_ln_fwd: H=%d must be a multiple of 8 and <= %d", H,
+               MAXC_LIMIT * 512);
   ZK_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "zk_add_ln_fwd: mean/rstd must both be given");
   if (rows == 0) return 0;
   const uint32_t thr = (drop_p > 0.f && y != nullptr) ? zk_drop_threshold(drop_p) : 0;
   const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  hipLaunchKernelGGL(k_add_ln_fwd, dim3(row_grid(rows)), dim3(256), 0, stream, (const bf16_t*)x,
-                     (const bf16_t*)y, gamma, beta, (bf16_t*)out, (bf16_t*)sum_out, mean, rstd, rows, H,
-                     eps, thr, ik, seed, sid);
+#define ZK_LN_FWD(NC)                                                                                   \
+  hipLaunchKernelGGL(k_add_ln_fwd<NC>, dim3(row_grid(rows)), dim3(256), 0, stream, (const bf16_t*)x,    \
+                     (const bf16_t*)y, gamma, beta, (bf16_t*)out, (bf16_t*)sum_out, mean, rstd, rows, H, \
+                     eps, thr, ik, seed, sid)
+  if (H <= 512) ZK_LN_FWD(1);
+  else if (H <= 1024) ZK_LN_FWD(2);
+  else ZK_LN_FWD(4);
+#undef ZK_LN_FWD
   ZK_LAUNCH_CHECK();
   return 0;
 }
@@ -874,8 +889,8 @@ int zk_add_ln_bwd(const void* dout, const void* sum, const float* mean, const fl
                   const float* gamma, void* dsum, void* dy, float* dgamma, float* dbeta, float* dbias_prev,
                   int rows, int H, float drop_p, const uint64_t* seed, uint32_t sid, void* workspace,
                   size_t ws_bytes, hipStream_t stream) {
-  ZK_CHECK_ARG(H % 8 == 0 && H <= MAXC * 512, "zk_add_ln_bwd: H=%d must be a multiple of 8 and <= %d", H,
-               MAXC * 512);
+  ZK_CHECK_ARG(H % 8 == 0 && H <= MAXC_LIMIT * 512, "zk_add_ln_bwd: H=%d must be a multiple of 8 and <= %d", H,
+               MAXC_LIMIT * 512);
   ZK_CHECK_ARG(ws_bytes >= zk_add_ln_bwd_workspace(rows, H), "zk_add_ln_bwd: workspace too small");
   ZK_CHECK_ARG(drop_p == 0.f || dy != nullptr, "zk_add_ln_bwd: dropout needs a dy output");
   if (rows == 0) return 0;
@@ -883,9 +898,14 @@ int zk_add_ln_bwd(const void* dout, const void* sum, const float* mean, const fl
   if (g > 256) g = 256;
   const uint32_t thr = drop_p > 0.f ? zk_drop_threshold(drop_p) : 0;
   const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  hipLaunchKernelGGL(k_add_ln_bwd, dim3(g), dim3(256), 0, stream, (const bf16_t*)dout, (const bf16_t*)sum,
-                     mean, rstd, gamma, (bf16_t*)dsum, (bf16_t*)dy, (float*)workspace, rows, H, thr, ik,
-                     seed, sid);
+#define ZK_LN_BWD(NC)                                                                                     \
+  hipLaunchKernelGGL(k_add_ln_bwd<NC>, dim3(g), dim3(256), 0, stream, (const bf16_t*)dout, (const bf16_t*)sum, \
+                     mean, rstd, gamma, (bf16_t*)dsum, (bf16_t*)dy, (float*)workspace, rows, H, thr, ik,     \
+                     seed, sid)
+  if (H <= 512) ZK_LN_BWD(1);
+  else if (H <= 1024) ZK_LN_BWD(2);
+  else ZK_LN_BWD(4);
+#undef ZK_LN_BWD
   ZK_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_partials_reduce, dim3((H + 15) / 16, 3), dim3(256), 0, stream,
                      (const float*)workspace, g, 3, H, dgamma, dbeta, dbias_prev, 0);
@@ -1045,7 +1065,7 @@ int zk_aan_gate_bwd(const void* dg, const void* z, const void* cat, void* dz, vo
 }
 
 #define ZK_NORM_BLOCKS 1024
-size_t zk_norm_workspace(void) { return ZK_NORM_BLOCKS * sizeof(float); }
+size_t zk_norm_workspace(void) { return 2048 * sizeof(float); }
 
 // out[0] = scale * ||x||_2   (tf.global_norm over the flat buffer, cycle.py:94-95)
 int zk_l2norm(const float* x, size_t n, float scale, float* out, void* workspace, size_t ws_bytes,
@@ -1060,14 +1080,22 @@ int zk_l2norm(const float* x, size_t n, float scale, float* out, void* workspace
   return 0;
 }
 
+// pnorm_out (device float, may be NULL): ||p||_2 of the parameters BEFORE the update
+// (cycle.py:95), accumulated in the same pass; workspace >= zk_norm_workspace() bytes then.
 int zk_adam(float* p, const float* g, float* m, float* v, void* shadow, size_t n, float* hyper,
-            hipStream_t stream) {
+            float* pnorm_out, void* workspace, size_t ws_bytes, hipStream_t stream) {
   ZK_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                "zk_adam: buffers must be 16-byte aligned");
+  ZK_CHECK_ARG(pnorm_out == nullptr || ws_bytes >= 2048 * sizeof(float), "zk_adam: workspace too small");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_adam, dim3(flat_grid(n, 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n,
-                     hyper);
+  const int grid = flat_grid(n, 4);
+  float* psq = pnorm_out ? (float*)workspace : nullptr;
+  hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n, hyper, psq);
   ZK_LAUNCH_CHECK();
+  if (pnorm_out) {
+    hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, stream, (const float*)psq, grid, 1.f, pnorm_out);
+    ZK_LAUNCH_CHECK();
+  }
   return 0;
 }
 

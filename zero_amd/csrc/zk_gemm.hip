@@ -278,6 +278,7 @@ int zk_gemm_set_generation(int gen) {
 size_t zk_gemm_workspace(int M, int N, int K) {
   int bm, bn, s;
   pick_config(M, N, K, 1, &bm, &bn, &s);
+  if (s < 2 && K >= 1024) s = 2;
   return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 // workspace for an explicit split-K override (tuning)
@@ -324,6 +325,12 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
   int bm, bn, splits;
   const bool plain = (bias == nullptr && residual == nullptr && act == 0 && drop_p == 0.f);
   pick_config(M, N, K, plain ? 1 : 0, &bm, &bn, &splits);
+  if (!plain && bm == 128 && bn == 128 && K >= 1024) {
+    // <= 128 tiles of 128x128 leave half of the 256 CUs idle: split K in two, the reduce kernel
+    // applies the fused epilogue (measured faster than smaller tiles at these shapes)
+    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (tiles <= 128) splits = 2;
+  }
   if (tile_ovr) { const int tb_[5][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}}; bm = tb_[tile_ovr][0]; bn = tb_[tile_ovr][1]; }
   if (split_ovr && plain) splits = split_ovr;
   if (splits > 1 && ws_bytes < (size_t)splits * M * N * sizeof(float)) splits = 1;

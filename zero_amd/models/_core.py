@@ -171,15 +171,29 @@ class TransformerCore(object):
         self._linear(att, p + "o_map", y)
         return self._ln_fwd(x, y, scope, tag, save, hp.residual_dropout if train else 0.0, sid0 + 1)
 
-    def _cross_attn_fwd(self, x, mem, B, Lq, Lk, scope, tag, kmask, save, sid0, train):
+    def _cross_kv_grouped(self, mem, n_layers):
+        """k_map / v_map of EVERY decoder layer read only the encoder output (func.py:206-216): one
+        grouped GEMM on the side stream, overlapped with the first decoder sub-layer."""
+        e, H = self.eng, self.H
+        probs = []
+        for l in range(n_layers):
+            p = "decoder/layer_%d/cross_attention/dot_attention/" % l
+            kv = e.mat("d%d.ca.kv" % l, mem.rows, 2 * H)
+            for nm, c0 in (("k_map", 0), ("v_map", H)):
+                Wm = self.W(p + nm + "/W_0_0")
+                probs.append((mem, Wm, kv.cols_slice(c0, c0 + H), mem.rows, H, H, self.b(p + nm + "/b_0")))
+        self._side(lambda: e.gemm_grouped(probs, 0, 0))
+
+    def _cross_attn_fwd(self, x, mem, B, Lq, Lk, scope, tag, kmask, save, sid0, train, kv_ready=False):
         e, H = self.eng, self.H
         hp = self.hp
         p = scope + "/dot_attention/"
         q = e.mat(tag + ".q", x.rows, H)
         self._linear(x, p + "q_map", q)
         kv = e.mat(tag + ".kv", mem.rows, 2 * H)
-        self._linear(mem, p + "k_map", kv.cols_slice(0, H))
-        self._linear(mem, p + "v_map", kv.cols_slice(H, 2 * H))
+        if not kv_ready:
+            self._linear(mem, p + "k_map", kv.cols_slice(0, H))
+            self._linear(mem, p + "v_map", kv.cols_slice(H, 2 * H))
         att = e.mat(tag + ".att", x.rows, H)
         lse = e.buf(tag + ".lse", (B * self.nh * Lq,), F32) if save else None
         rk = self.store.s(p + "rpr_keys/embeddings") if self.rpr else None
@@ -383,6 +397,9 @@ class TransformerCore(object):
         e.embed_fwd(batch["tgt"], self.store.s(self.tgt_emb), self.b("bias"), x, B, Lt, H, shift=True,
                     drop_p=hp.dropout if train else 0.0, sid=9002)
         NE = hp.num_encoder_layer
+        group_kv = self.group_wgrad and e.gemm_impl == 0 and self.use_side
+        if group_kv:
+            self._cross_kv_grouped(enc, hp.num_decoder_layer)
         for l in range(hp.num_decoder_layer):
             pre = "decoder/layer_%d" % l
             sid = 100 * (NE + l)
@@ -391,8 +408,10 @@ class TransformerCore(object):
             else:
                 x = self._self_attn_fwd(x, B, Lt, pre + "/self_attention", "d%d.sa" % l, None, True, save,
                                         sid + 1, train)
+            if group_kv and l == 0:
+                self._join_side()
             x = self._cross_attn_fwd(x, enc, B, Lt, Ls, pre + "/cross_attention", "d%d.ca" % l, smask, save,
-                                     sid + 11, train)
+                                     sid + 11, train, kv_ready=group_kv)
             x = self._ffn_fwd(x, pre + "/feed_forward", "d%d.ff" % l, save, sid + 21, train)
         return x, tmask, w
 

@@ -71,10 +71,10 @@ class TrainOp(object):
         nb = self._ws.numel() // 2
         lib.call("zk_l2norm", st.grad.data_ptr(), st.numel, scale, self.hyper.data_ptr() + 6 * 4,
                  self._ws.data_ptr(), nb, s)
-        lib.call("zk_l2norm", st.master.data_ptr(), st.numel, 1.0, self.pnorm.data_ptr(),
-                 self._ws.data_ptr() + nb, nb, s)
+        # parameter norm (cycle.py:95) is accumulated inside the Adam pass over the same data
         lib.call("zk_adam", st.master.data_ptr(), st.grad.data_ptr(), st.m.data_ptr(), st.v.data_ptr(),
-                 st.shadow.data_ptr(), st.numel, self.hyper.data_ptr(), s)
+                 st.shadow.data_ptr(), st.numel, self.hyper.data_ptr(), self.pnorm.data_ptr(),
+                 self._ws.data_ptr() + nb, nb, s)
 
     def apply(self, lr, world=1, launch=True):
         st = self.store
