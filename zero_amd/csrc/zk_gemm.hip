@@ -238,14 +238,18 @@ static bool mfma_ok(const void* A, const void* B, int M, int N, int K, int lda, 
   return true;
 }
 
-// Tile / split heuristic (measured on MI355X, scripts/gemm_bench.py).  These GEMMs are small
+// Tile / split heuristic (measured on MI355X, scripts/gemm_bench.py, scripts/gemm_ns_bench.py).
+// Finding of round 1: the K loop of these small GEMMs is bound by the per-wave cost of ISSUING
+// loads (one 1-KiB LDS-DMA per ~100-150 cycles), not by HBM, L2 (82 % hits) or ring depth; what
+// helps is (a) more co-resident workgroups per CU and (b) more MFMAs per load (bigger tiles) --
+// which conflict for outputs as small as 4096x512.  These GEMMs are small
 // for a 256-CU chip: with <= 1 workgroup per CU the K loop is exposed-latency bound, so the
 // goal is >= ~3 co-resident workgroups per CU (thread-level parallelism hides the L2 latency)
 // before tile area (arithmetic intensity) is considered.  Large outputs use 128x128; mid-size
 // ones 64x128 / 128x64; small ones 64x64 plus split-K when the epilogue allows it.
 static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, int* splits) {
   const long out = (long)M * N;
-  if (out >= 8L * 1024 * 1024 || (K >= 1024 && M >= 128 && N >= 128)) { *bm = 128; *bn = 128; }
+  if (out >= 8L * 1024 * 1024 || (K >= 8192 && M >= 128 && N >= 128)) { *bm = 128; *bn = 128; }
   else if (out >= 64L * 128 * 640) { if (N >= M) { *bm = 64; *bn = 128; } else { *bm = 128; *bn = 64; } }
   else { *bm = 64; *bn = 64; }
   const long tiles = (long)((M + *bm - 1) / *bm) * ((N + *bn - 1) / *bn);
@@ -255,6 +259,8 @@ static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, 
     const int maxs = K / (4 * BK);            // keep >= 4 K-tiles per split
     if (s > maxs) s = maxs;
     if (s > 8) s = 8;
+    const long slab_cap = (16L << 20) / ((long)M * N * 4);   // keep the fp32 slab traffic <= 16 MiB
+    if (s > slab_cap) s = (int)slab_cap;
     if (s < 1) s = 1;
   }
   *splits = s;
@@ -296,7 +302,7 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
   // [11:8] tile override (1:128x128 2:128x64
   // 3:64x128 4:64x64); [23:16] split-K override (tuning / tests)
   const int tile_ovr = (impl >> 8) & 15, split_ovr = (impl >> 16) & 255;
-  const int sched_flags = (impl >> 12) & 3;   // bit0: no XCD remap, bit1: flip panel order
+  const int sched_flags = ((impl >> 12) & 3) | (((impl >> 24) & 15) << 4);   // bit0: no XCD remap, bit1: flip panel order, [7:4] ring depth override
   impl &= 3;
   int gen = g_default_gen;
   if (impl == 3) { gen = 1; impl = 2; }
@@ -325,12 +331,7 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
   int bm, bn, splits;
   const bool plain = (bias == nullptr && residual == nullptr && act == 0 && drop_p == 0.f);
   pick_config(M, N, K, plain ? 1 : 0, &bm, &bn, &splits);
-  if (!plain && bm == 128 && bn == 128 && K >= 1024) {
-    // <= 128 tiles of 128x128 leave half of the 256 CUs idle: split K in two, the reduce kernel
-    // applies the fused epilogue (measured faster than smaller tiles at these shapes)
-    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (tiles <= 128) splits = 2;
-  }
+
   if (tile_ovr) { const int tb_[5][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}}; bm = tb_[tile_ovr][0]; bn = tb_[tile_ovr][1]; }
   if (split_ovr && plain) splits = split_ovr;
   if (splits > 1 && ws_bytes < (size_t)splits * M * N * sizeof(float)) splits = 1;

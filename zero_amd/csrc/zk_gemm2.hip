@@ -365,7 +365,7 @@ int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int t
     else if (ta && !tb) hipLaunchKernelGGL((k_gemm_grouped<BM_, BN_, NS_, true, false>), grid, dim3(256), 0, stream, d, nprob); \
     else hipLaunchKernelGGL((k_gemm_grouped<BM_, BN_, NS_, true, true>), grid, dim3(256), 0, stream, d, nprob);     \
   } while (0)
-  if (tile == 1) ZK_GROUP_LAUNCH(128, 128, 3);
+  if (tile == 1) ZK_GROUP_LAUNCH(128, 128, 2);
   else ZK_GROUP_LAUNCH(64, 64, 4);
 #undef ZK_GROUP_LAUNCH
   ZK_LAUNCH_CHECK();
@@ -377,8 +377,18 @@ int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int t
 int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
                           int bm, int bn, int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags,
                           hipStream_t stream) {
-  if (bm == 128 && bn == 128) return launch_dlds<128, 128, 3>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
-  if (bm == 128 && bn == 64) return launch_dlds<128, 64, 3>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
-  if (bm == 64 && bn == 128) return launch_dlds<64, 128, 3>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+  const int ns = (sched_flags >> 4) & 15;   // ring-depth override (tuning)
+  if (ns) {
+#define ZK_NS(BM_, BN_, NS_) return launch_dlds<BM_, BN_, NS_>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream)
+    if (bm == 64 && bn == 64) { if (ns == 2) ZK_NS(64, 64, 2); if (ns == 6) ZK_NS(64, 64, 6); if (ns == 8) ZK_NS(64, 64, 8); }
+    if (bm == 128 && bn == 64) { if (ns == 3) ZK_NS(128, 64, 3); if (ns == 6) ZK_NS(128, 64, 6); }
+    if (bm == 128 && bn == 128) { if (ns == 3) ZK_NS(128, 128, 3); if (ns == 4) ZK_NS(128, 128, 4); }
+#undef ZK_NS
+  }
+  // ring depth 2 for the larger tiles: the measured optimum is MORE workgroups per CU (64 KiB /
+  // 48 KiB of LDS each), not deeper prefetch
+  if (bm == 128 && bn == 128) return launch_dlds<128, 128, 2>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+  if (bm == 128 && bn == 64) return launch_dlds<128, 64, 2>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+  if (bm == 64 && bn == 128) return launch_dlds<64, 128, 2>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
   return launch_dlds<64, 64, 4>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
 }
