@@ -110,7 +110,11 @@ size_t zk_add_ln_bwd_workspace(int rows, int H);
 int zk_add_ln_bwd(const void* dout, const void* sum, const float* mean, const float* rstd, const float* gamma,
                   void* dsum, void* dy, float* dgamma, float* dbeta, float* dbias_prev, int rows, int H,
                   float drop_p, const uint64_t* seed, uint32_t sid, void* workspace, size_t ws_bytes,
-                  zk_stream_t stream);
+                  int defer_reduce, zk_stream_t stream);
+/* defer_reduce=1: only the per-block partial sums are written to `workspace` (which must then be
+ * private to this call); finish them later, possibly on another stream, with: */
+int zk_add_ln_bwd_reduce(const void* workspace, int rows, int H, float* dgamma, float* dbeta, float* dbias_prev,
+                         zk_stream_t stream);
 
 /* column sum of a bf16 [rows,N] matrix -> fp32 [N] (bias gradients, func.py:58-60) */
 size_t zk_colsum_workspace(int rows, int N);

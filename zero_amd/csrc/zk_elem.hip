@@ -268,6 +268,88 @@ __global__ void __launch_bounds__(256) k_add_ln_bwd(
   }
 }
 
+// Wide variant for H <= 512: 1024 threads = 16 waves, every wave owns whole rows (8 channels per
+// lane), so 16 rows are in flight per block and the per-row latency chain (two wave reductions)
+// is overlapped 16 ways; column partials are reduced across the 16 waves through LDS, one
+// quantity at a time.
+__global__ void __launch_bounds__(1024) k_add_ln_bwd_wide(
+    const bf16_t* __restrict__ dout, const bf16_t* __restrict__ s, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, bf16_t* __restrict__ dsum,
+    bf16_t* __restrict__ dy, float* __restrict__ partials, int rows, int H, uint32_t thr,
+    float inv_keep, const uint64_t* __restrict__ seedp, uint32_t sid) {
+  __shared__ float red[16][512 + 8];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = lane * 8;
+  const bool on = c < H;
+  const uint64_t seed = (thr != 0) ? *seedp : 0;
+  const float invH = 1.f / (float)H;
+  float acc[3][8];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[q][j] = 0.f;
+  float gam[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) gam[j] = on ? gamma[c + j] : 0.f;
+  for (int r = blockIdx.x * 16 + w; r < rows; r += gridDim.x * 16) {
+    const float mu = mean[r], rs = rstd[r];
+    float xh[8], g[8], d[8];
+    float sg = 0.f, sgx = 0.f;
+    if (on) {
+      float sv[8];
+      unpack8(*reinterpret_cast<const uint4*>(dout + (size_t)r * H + c), d);
+      unpack8(*reinterpret_cast<const uint4*>(s + (size_t)r * H + c), sv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xh[j] = (sv[j] - mu) * rs;
+        g[j] = d[j] * gam[j];
+        sg += g[j];
+        sgx += g[j] * xh[j];
+        acc[0][j] += d[j] * xh[j];
+        acc[1][j] += d[j];
+      }
+    }
+    const float mg = wave_sum(sg) * invH;
+    const float mgx = wave_sum(sgx) * invH;
+    if (on) {
+      float o[8], oy[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = rs * (g[j] - mg - xh[j] * mgx);
+      uint4 p = pack8(o);
+      *reinterpret_cast<uint4*>(dsum + (size_t)r * H + c) = p;
+      unpack8(p, o);
+      if (thr != 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          oy[j] = o[j] * zk_drop_scale(seed, sid, (uint64_t)r * H + c + j, thr, inv_keep);
+        if (dy != nullptr) {
+          uint4 py = pack8(oy);
+          *reinterpret_cast<uint4*>(dy + (size_t)r * H + c) = py;
+          unpack8(py, oy);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) oy[j] = o[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[2][j] += oy[j];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[w][c + j] = acc[q][j];
+    __syncthreads();
+    if (threadIdx.x < H) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
+      partials[((size_t)blockIdx.x * 3 + q) * H + threadIdx.x] = t;
+    }
+  }
+}
+
 // out_q[c] = sum_b partials[b][q][c]   (q < nq; out pointers may be null)
 // block = 16 columns of one quantity x 16 row groups (short dependent chains, 64-B segments).
 __global__ void __launch_bounds__(256) k_partials_reduce(const float* __restrict__ partials, int nblk,
@@ -885,10 +967,26 @@ size_t zk_add_ln_bwd_workspace(int rows, int H) {
   return (size_t)g * 3 * H * sizeof(float);
 }
 
+static int ln_bwd_blocks(int rows) {
+  int g = (rows + 15) / 16;
+  if (g > 256) g = 256;
+  if (g < 1) g = 1;
+  return g;
+}
+
+// second stage of zk_add_ln_bwd(defer_reduce=1): may run later and on another stream
+int zk_add_ln_bwd_reduce(const void* workspace, int rows, int H, float* dgamma, float* dbeta, float* dbias_prev,
+                         hipStream_t stream) {
+  hipLaunchKernelGGL(k_partials_reduce, dim3((H + 15) / 16, 3), dim3(256), 0, stream, (const float*)workspace,
+                     ln_bwd_blocks(rows), 3, H, dgamma, dbeta, dbias_prev, 0);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
 int zk_add_ln_bwd(const void* dout, const void* sum, const float* mean, const float* rstd,
                   const float* gamma, void* dsum, void* dy, float* dgamma, float* dbeta, float* dbias_prev,
                   int rows, int H, float drop_p, const uint64_t* seed, uint32_t sid, void* workspace,
-                  size_t ws_bytes, hipStream_t stream) {
+                  size_t ws_bytes, int defer_reduce, hipStream_t stream) {
   ZK_CHECK_ARG(H % 8 == 0 && H <= MAXC_LIMIT * 512, "zk_add_ln_bwd: H=%d must be a multiple of 8 and <= %d", H,
                MAXC_LIMIT * 512);
   ZK_CHECK_ARG(ws_bytes >= zk_add_ln_bwd_workspace(rows, H), "zk_add_ln_bwd: workspace too small");
@@ -902,15 +1000,16 @@ int zk_add_ln_bwd(const void* dout, const void* sum, const float* mean, const fl
   hipLaunchKernelGGL(k_add_ln_bwd<NC>, dim3(g), dim3(256), 0, stream, (const bf16_t*)dout, (const bf16_t*)sum, \
                      mean, rstd, gamma, (bf16_t*)dsum, (bf16_t*)dy, (float*)workspace, rows, H, thr, ik,     \
                      seed, sid)
-  if (H <= 512) ZK_LN_BWD(1);
+  if (H <= 512)
+    hipLaunchKernelGGL(k_add_ln_bwd_wide, dim3(g), dim3(1024), 0, stream, (const bf16_t*)dout, (const bf16_t*)sum,
+                       mean, rstd, gamma, (bf16_t*)dsum, (bf16_t*)dy, (float*)workspace, rows, H, thr, ik, seed,
+                       sid);
   else if (H <= 1024) ZK_LN_BWD(2);
   else ZK_LN_BWD(4);
 #undef ZK_LN_BWD
   ZK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_partials_reduce, dim3((H + 15) / 16, 3), dim3(256), 0, stream,
-                     (const float*)workspace, g, 3, H, dgamma, dbeta, dbias_prev, 0);
-  ZK_LAUNCH_CHECK();
-  return 0;
+  if (defer_reduce) return 0;
+  return zk_add_ln_bwd_reduce(workspace, rows, H, dgamma, dbeta, dbias_prev, stream);
 }
 
 size_t zk_colsum_workspace(int rows, int N) {

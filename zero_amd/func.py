@@ -219,13 +219,22 @@ class Engine(object):
                       hip.ptr(rstd), x.rows, x.cols, zdtype.epsilon(), float(drop_p), self.seed.data_ptr(), sid,
                       self.stream)
 
-    def add_ln_bwd(self, dout, s, mean, rstd, gamma, dsum, dy, dgamma, dbeta, dbias_prev, drop_p=0.0, sid=0):
+    def add_ln_bwd(self, dout, s, mean, rstd, gamma, dsum, dy, dgamma, dbeta, dbias_prev, drop_p=0.0, sid=0,
+                   private_ws=None):
+        """private_ws: a buffer owned by this call -> the column reduction is deferred; finish it with
+        :meth:`add_ln_bwd_reduce` (e.g. on the side stream)."""
         ws_bytes = self.lib.query("zk_add_ln_bwd_workspace", dout.rows, dout.cols)
-        ws = self.workspace(ws_bytes)
+        ws = private_ws if private_ws is not None else self.workspace(ws_bytes)
+        assert ws.numel() * ws.element_size() >= ws_bytes
         self.lib.call("zk_add_ln_bwd", dout.ptr, s.ptr, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                       dsum.ptr, dy.ptr if dy is not None else None, hip.ptr(dgamma), hip.ptr(dbeta),
                       hip.ptr(dbias_prev), dout.rows, dout.cols, float(drop_p), self.seed.data_ptr(), sid,
-                      ws.data_ptr(), ws.numel(), self.stream)
+                      ws.data_ptr(), ws.numel() * ws.element_size(), 1 if private_ws is not None else 0,
+                      self.stream)
+
+    def add_ln_bwd_reduce(self, ws, rows, H, dgamma, dbeta, dbias_prev):
+        self.lib.call("zk_add_ln_bwd_reduce", ws.data_ptr(), rows, H, hip.ptr(dgamma), hip.ptr(dbeta),
+                      hip.ptr(dbias_prev), self.stream)
 
     # ---- loss (util.py:88-103; transformer.py:198-216) ------------------------------
     def ce_fused(self, logits, ids, w, ce, dlogits, rows, V, label_smooth):

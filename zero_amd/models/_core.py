@@ -234,10 +234,21 @@ class TransformerCore(object):
         T = dx.rows
         ds = e.mat("g.%s.ds" % tag, T, H)
         dy = e.mat("g.%s.dy" % tag, T, H) if drop_p > 0.0 else None
-        e.add_ln_bwd(dx, e.mat(tag + ".s", T, H), e.buf(tag + ".mean", (T,), F32), e.buf(tag + ".rstd", (T,), F32),
-                     self.b(scope + "/layer_norm/scale"), ds, dy, self.gb(scope + "/layer_norm/scale"),
-                     self.gb(scope + "/layer_norm/offset"),
-                     self.gb(prev_bias) if prev_bias is not None else None, drop_p, sid)
+        dgam, dbet = self.gb(scope + "/layer_norm/scale"), self.gb(scope + "/layer_norm/offset")
+        dbp = self.gb(prev_bias) if prev_bias is not None else None
+        if self.use_side:
+            # per-block partial sums go to a buffer private to this sub-layer; the tiny column
+            # reduction leaves the dgrad critical path (side stream)
+            nbytes = e.lib.query("zk_add_ln_bwd_workspace", T, H)
+            pws = e.buf("g.%s.lnws" % tag, (nbytes // 4,), F32)
+            e.add_ln_bwd(dx, e.mat(tag + ".s", T, H), e.buf(tag + ".mean", (T,), F32),
+                         e.buf(tag + ".rstd", (T,), F32), self.b(scope + "/layer_norm/scale"), ds, dy, dgam, dbet,
+                         dbp, drop_p, sid, private_ws=pws)
+            self._side(lambda: e.add_ln_bwd_reduce(pws, T, H, dgam, dbet, dbp))
+        else:
+            e.add_ln_bwd(dx, e.mat(tag + ".s", T, H), e.buf(tag + ".mean", (T,), F32),
+                         e.buf(tag + ".rstd", (T,), F32), self.b(scope + "/layer_norm/scale"), ds, dy, dgam, dbet,
+                         dbp, drop_p, sid)
         return ds, (dy if dy is not None else ds)
 
     def _ffn_bwd(self, dx, x_in, scope, tag, sid0, side, dx_out):
