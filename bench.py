@@ -153,6 +153,10 @@ def main():
     torch.cuda.set_device(local)
 
     from zero_amd.main import Trainer
+    from zero_amd import hip as _hip
+    for kv in os.environ.get("ZERO_HIP_TUNE", "").split(","):     # e.g. ZERO_HIP_TUNE=0:0 (A/B switches)
+        if ":" in kv:
+            _hip.lib().raw("zk_tune")(int(kv.split(":")[0]), int(kv.split(":")[1]))
     hp = make_params(args.dropout)
     hp.random_seed = 1234   # identical initial replicas on every rank
     tr = Trainer(hp)

@@ -125,6 +125,17 @@ int zk_colsum(const void* a, int rows, int N, int lda, float* out, void* workspa
 int zk_colsum_ex(const void* a, int rows, int N, int lda, float* out, int skip_L, int accumulate, float drop_p,
                  const uint64_t* seed, uint32_t sid, void* workspace, size_t ws_bytes, zk_stream_t stream);
 
+/* Grouped column reductions (all bias / LayerNorm-parameter gradients of a layer group in two
+ * launches).  DEVICE descriptor arrays:
+ *   colsum : { const void* a; float* partials; int rows, N, lda, gy, block_start, pad; }   (40 B)
+ *            gy = zk_colsum_rowchunks(rows); blocks of problem = ceil(N/64)*gy
+ *   reduce : { const float* partials; float* out[3]; int nblk, nq, H, block_start; }       (48 B)
+ *            blocks of problem = nq*ceil(H/16); nblk = gy (colsum) or zk_ln_bwd_blocks(rows) */
+int zk_colsum_grouped(const void* descs, int nprob, int total_blocks, zk_stream_t stream);
+int zk_reduce_grouped(const void* descs, int nprob, int total_blocks, zk_stream_t stream);
+int zk_ln_bwd_blocks(int rows);
+int zk_colsum_rowchunks(int rows);
+
 /* ---- util.py:88-103 label_smooth + transformer.py:198-207 cross entropy on fp32 logits.
  * ce_out[r] = -sum soft*log_softmax - normaliser; dlogits (bf16 [rows,ld], NULL to skip)
  * = w[r]*(softmax - soft).                                                            */
@@ -157,6 +168,7 @@ int zk_adam(float* p, const float* g, float* m, float* v, void* shadow_bf16, siz
 int zk_cast_f32_bf16(const float* x, void* y, size_t n, zk_stream_t stream);
 int zk_cast_bf16_f32(const void* x, float* y, size_t n, zk_stream_t stream);
 int zk_zero(void* p, size_t bytes, zk_stream_t stream);
+int zk_tune(int key, int value);   /* A/B switches for measurements; key 0 = wide LayerNorm-backward kernel */
 int zk_axpby_f32(float* y, const float* x, float a, float b, size_t n, zk_stream_t stream);
 
 /* dropout plumbing */

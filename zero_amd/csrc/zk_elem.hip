@@ -415,6 +415,77 @@ __global__ void __launch_bounds__(256) k_colsum(const bf16_t* __restrict__ a, in
   }
 }
 
+// ---- grouped column reductions: every bias gradient / LayerNorm parameter gradient of a group of
+// layers in TWO launches instead of two per tensor (each is a few microseconds of work).
+// stage 1 (bf16 matrices -> per-row-chunk partial sums), one block = 64 columns x one row chunk
+struct ColsumDesc {
+  const bf16_t* a; float* partials;   // partials: [gy][N] fp32, private to this problem
+  int rows, N, lda, gy, block_start, pad_;
+};
+__global__ void __launch_bounds__(256) k_colsum_grouped(const ColsumDesc* __restrict__ descs, int nprob) {
+  __shared__ float red[32][64 + 1];
+  const int bid = blockIdx.x;
+  int p = 0;
+  while (p + 1 < nprob && descs[p + 1].block_start <= bid) ++p;
+  const ColsumDesc d = descs[p];
+  const int local = bid - d.block_start;
+  const int bx = local / d.gy, by = local - bx * d.gy;
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+  const int c0 = bx * 64 + tx * 8;
+  const int rpb = (d.rows + d.gy - 1) / d.gy;
+  const int r0 = by * rpb, r1 = min(d.rows, r0 + rpb);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c0 < d.N) {
+    for (int r = r0 + ty; r < r1; r += 32) {
+      float v[8];
+      unpack8(*reinterpret_cast<const uint4*>(d.a + (size_t)r * d.lda + c0), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ty][tx * 8 + j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int c = bx * 64 + threadIdx.x;
+    if (c < d.N) {
+      float t = 0.f;
+      for (int i = 0; i < 32; ++i) t += red[i][threadIdx.x];
+      d.partials[(size_t)by * d.N + c] = t;
+    }
+  }
+}
+// stage 2: out[c] = sum_b partials[b][q][c]; one block = 16 columns of one quantity of one problem
+struct ReduceDesc {
+  const float* partials; float* out[3];
+  int nblk, nq, H, block_start;
+};
+__global__ void __launch_bounds__(256) k_reduce_grouped(const ReduceDesc* __restrict__ descs, int nprob) {
+  __shared__ float red[16][17];
+  const int bid = blockIdx.x;
+  int p = 0;
+  while (p + 1 < nprob && descs[p + 1].block_start <= bid) ++p;
+  const ReduceDesc d = descs[p];
+  const int local = bid - d.block_start;
+  const int ncb = (d.H + 15) / 16;
+  const int q = local / ncb, cb = local - q * ncb;
+  float* o = d.out[q];
+  if (o == nullptr) return;
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = cb * 16 + cl;
+  float t = 0.f;
+  if (c < d.H)
+    for (int b = g; b < d.nblk; b += 16) t += d.partials[((size_t)b * d.nq + q) * d.H + c];
+  red[g][cl] = t;
+  __syncthreads();
+  if (g == 0 && c < d.H) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v += red[i][cl];
+    o[c] = v;
+  }
+}
+
 // Embedding-table gradient without atomics: the host sorts the token rows by id (it owns the
 // ids anyway); one wave per DISTINCT id sums its rows in fp32 and does a single read-modify-write
 // of the table row.  `rows_sorted` [n_used] = token-row indices grouped by id, `seg` [n_uniq+1]
@@ -967,11 +1038,20 @@ size_t zk_add_ln_bwd_workspace(int rows, int H) {
   return (size_t)g * 3 * H * sizeof(float);
 }
 
+static int g_tune[8] = {1, 0, 0, 0, 0, 0, 0, 0};   // [0] wide LayerNorm backward kernel
 static int ln_bwd_blocks(int rows) {
   int g = (rows + 15) / 16;
   if (g > 256) g = 256;
   if (g < 1) g = 1;
   return g;
+}
+
+// tuning switches for A/B measurements (key 0: wide LayerNorm-backward kernel); returns the old value
+int zk_tune(int key, int value) {
+  if (key < 0 || key >= 8) return -1;
+  const int old = g_tune[key];
+  g_tune[key] = value;
+  return old;
 }
 
 // second stage of zk_add_ln_bwd(defer_reduce=1): may run later and on another stream
@@ -1000,10 +1080,11 @@ int zk_add_ln_bwd(const void* dout, const void* sum, const float* mean, const fl
   hipLaunchKernelGGL(k_add_ln_bwd<NC>, dim3(g), dim3(256), 0, stream, (const bf16_t*)dout, (const bf16_t*)sum, \
                      mean, rstd, gamma, (bf16_t*)dsum, (bf16_t*)dy, (float*)workspace, rows, H, thr, ik,     \
                      seed, sid)
-  if (H <= 512)
+  if (H <= 512 && g_tune[0])
     hipLaunchKernelGGL(k_add_ln_bwd_wide, dim3(g), dim3(1024), 0, stream, (const bf16_t*)dout, (const bf16_t*)sum,
                        mean, rstd, gamma, (bf16_t*)dsum, (bf16_t*)dy, (float*)workspace, rows, H, thr, ik, seed,
                        sid);
+  else if (H <= 512) ZK_LN_BWD(1);
   else if (H <= 1024) ZK_LN_BWD(2);
   else ZK_LN_BWD(4);
 #undef ZK_LN_BWD
@@ -1041,6 +1122,27 @@ int zk_colsum_ex(const void* a, int rows, int N, int lda, float* out, int skip_L
 int zk_colsum(const void* a, int rows, int N, int lda, float* out, void* workspace, size_t ws_bytes,
               hipStream_t stream) {
   return zk_colsum_ex(a, rows, N, lda, out, 0, 0, 0.f, nullptr, 0, workspace, ws_bytes, stream);
+}
+
+// descs: DEVICE arrays (layouts: struct ColsumDesc / struct ReduceDesc in zk_elem.hip)
+int zk_colsum_grouped(const void* descs, int nprob, int total_blocks, hipStream_t stream) {
+  if (nprob == 0 || total_blocks == 0) return 0;
+  hipLaunchKernelGGL(k_colsum_grouped, dim3(total_blocks), dim3(256), 0, stream, (const ColsumDesc*)descs, nprob);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+int zk_reduce_grouped(const void* descs, int nprob, int total_blocks, hipStream_t stream) {
+  if (nprob == 0 || total_blocks == 0) return 0;
+  hipLaunchKernelGGL(k_reduce_grouped, dim3(total_blocks), dim3(256), 0, stream, (const ReduceDesc*)descs, nprob);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+int zk_ln_bwd_blocks(int rows) { return ln_bwd_blocks(rows); }
+int zk_colsum_rowchunks(int rows) {
+  int gy = (rows + 255) / 256;
+  if (gy > 64) gy = 64;
+  if (gy < 1) gy = 1;
+  return gy;
 }
 
 int zk_embed_bwd_sorted(const int* rows_sorted, const int* seg, const int* uid, const int* n_uniq_dev,

@@ -32,6 +32,16 @@ class _GroupDesc(ctypes.Structure):
                                                "tiles_n", "pad")]
 
 
+class _ColsumDesc(ctypes.Structure):
+    _fields_ = [("a", ctypes.c_void_p), ("partials", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int) for n in ("rows", "N", "lda", "gy", "block_start", "pad")]
+
+
+class _ReduceDesc(ctypes.Structure):
+    _fields_ = [("partials", ctypes.c_void_p), ("out", ctypes.c_void_p * 3)] + \
+               [(n, ctypes.c_int) for n in ("nblk", "nq", "H", "block_start")]
+
+
 class Mat(object):
     """Row-major matrix view over a torch tensor."""
     __slots__ = ("t", "rows", "cols", "ld", "off")
@@ -164,6 +174,48 @@ class Engine(object):
             cache[key] = ent
         dev, n, total = ent
         self.lib.call("zk_gemm_grouped", dev.data_ptr(), n, total, ta, tb, 1 if tile == 128 else 4, self.stream)
+
+    def reductions_grouped(self, colsums, ln_parts):
+        """colsums: [(Mat dY, out fp32 view, private fp32 partial buffer)];
+        ln_parts: [(partials buffer, rows, H, dgamma, dbeta, dbias_prev-or-None)].
+        Two launches: column partial sums of every dY, then every final reduction."""
+        key = tuple((a.ptr, o.data_ptr()) for a, o, _ in colsums) + \
+            tuple((w.data_ptr(), r) for w, r, _, _, _, _ in ln_parts)
+        cache = self.__dict__.setdefault("_red_cache", {})
+        ent = cache.get(key)
+        if ent is None:
+            lib = self.lib
+            cd = (_ColsumDesc * max(len(colsums), 1))()
+            rd = (_ReduceDesc * max(len(colsums) + len(ln_parts), 1))()
+            cstart = rstart = 0
+            k = 0
+            for i, (a, o, pw) in enumerate(colsums):
+                gy = lib.raw("zk_colsum_rowchunks")(a.rows)
+                assert pw.numel() >= gy * a.cols
+                d = cd[i]
+                d.a, d.partials, d.rows, d.N, d.lda, d.gy, d.block_start, d.pad = \
+                    a.ptr, pw.data_ptr(), a.rows, a.cols, a.ld, gy, cstart, 0
+                cstart += ((a.cols + 63) // 64) * gy
+                r = rd[k]
+                r.partials, r.nblk, r.nq, r.H, r.block_start = pw.data_ptr(), gy, 1, a.cols, rstart
+                r.out[0], r.out[1], r.out[2] = o.data_ptr(), None, None
+                rstart += (a.cols + 15) // 16
+                k += 1
+            for (pw, rows, H, dg, db, dbp) in ln_parts:
+                r = rd[k]
+                r.partials, r.nblk, r.nq, r.H, r.block_start = pw.data_ptr(), lib.raw("zk_ln_bwd_blocks")(rows), 3, H, rstart
+                r.out[0], r.out[1], r.out[2] = dg.data_ptr(), db.data_ptr(), hip.ptr(dbp)
+                rstart += 3 * ((H + 15) // 16)
+                k += 1
+            cdev = torch.frombuffer(bytearray(bytes(cd)), dtype=torch.uint8).to(self.device)
+            rdev = torch.frombuffer(bytearray(bytes(rd)), dtype=torch.uint8).to(self.device)
+            ent = (cdev, len(colsums), cstart, rdev, k, rstart)
+            cache[key] = ent
+        cdev, nc, cblocks, rdev, nr, rblocks = ent
+        if nc:
+            self.lib.call("zk_colsum_grouped", cdev.data_ptr(), nc, cblocks, self.stream)
+        if nr:
+            self.lib.call("zk_reduce_grouped", rdev.data_ptr(), nr, rblocks, self.stream)
 
     def colsum(self, A, out, skip_L=0, accumulate=False, drop_p=0.0, sid=0):
         ws_bytes = self.lib.query("zk_colsum_workspace", A.rows, A.cols)

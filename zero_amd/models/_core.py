@@ -66,12 +66,17 @@ class TransformerCore(object):
         self.Vpad = self.store.pshape[self.soft_emb][0]
         # weight-gradient GEMMs and bias column sums leave the critical path: they run on a second
         # HIP stream, concurrently with the dgrad chain (both are latency-bound at this size)
-        self.use_side = os.environ.get("ZERO_HIP_SIDE_STREAM", "1") != "0"
+        # (measured in round 1: with one rank the second stream LOSES ~3 % -- cross-stream graph
+        # edges cost more than the overlap buys once the small GEMMs are grouped -- so it is opt-in)
+        self.use_side = os.environ.get("ZERO_HIP_SIDE_STREAM", "0") != "0"
         # weight-gradient GEMMs are deferred and launched as ONE grouped grid per `group_layers`
         # layers (each is far too small to fill 256 CUs on its own)
         self.group_wgrad = os.environ.get("ZERO_HIP_GROUP_WGRAD", "1") != "0"
         self.group_layers = int(os.environ.get("ZERO_HIP_GROUP_LAYERS", "3"))
         self._pending_wgrads = []
+        self._pending_colsums = []     # (dY Mat, bias-gradient view, private partial buffer)
+        self._pending_lnred = []       # (partials, rows, H, dgamma, dbeta, dbias_prev)
+        self._red_id = 0
         self.side = torch.cuda.Stream(self.eng.device) if self.eng.device.type == "cuda" else None
 
     # ------------------------------------------------------------------ stream plumbing
@@ -92,6 +97,10 @@ class TransformerCore(object):
             probs = self._pending_wgrads
             self._pending_wgrads = []
             self._side(lambda: self.eng.gemm_grouped(probs, 1, 0))
+        if self._pending_colsums or self._pending_lnred:
+            cs, ln = self._pending_colsums, self._pending_lnred
+            self._pending_colsums, self._pending_lnred = [], []
+            self._side(lambda: self.eng.reductions_grouped(cs, ln))
 
     def _join_side(self):
         if self.use_side:
@@ -127,7 +136,9 @@ class TransformerCore(object):
         if self.group_wgrad and self.eng.gemm_impl == 0:
             self._pending_wgrads.append((x, dy, self.gW(scope + "/W_0_0"), Wm.rows, Wm.cols, x.rows, None))
             if bias_grad:
-                self._side(lambda: self.eng.colsum(dy, self.gb(scope + "/b_0")))
+                gy = self.eng.lib.raw("zk_colsum_rowchunks")(dy.rows)
+                pw = self.eng.buf("g.cs%d" % len(self._pending_colsums) + scope, (gy * dy.cols,), F32)
+                self._pending_colsums.append((dy, self.gb(scope + "/b_0"), pw))
         else:
             def wgrad():
                 self.eng.gemm(x, dy, self.gW(scope + "/W_0_0"), Wm.rows, Wm.cols, x.rows, 1, 0)
@@ -236,15 +247,15 @@ class TransformerCore(object):
         dy = e.mat("g.%s.dy" % tag, T, H) if drop_p > 0.0 else None
         dgam, dbet = self.gb(scope + "/layer_norm/scale"), self.gb(scope + "/layer_norm/offset")
         dbp = self.gb(prev_bias) if prev_bias is not None else None
-        if self.use_side:
-            # per-block partial sums go to a buffer private to this sub-layer; the tiny column
-            # reduction leaves the dgrad critical path (side stream)
+        if self.group_wgrad and e.gemm_impl == 0:
+            # per-block partial sums go to a buffer private to this sub-layer; the column reduction
+            # joins the grouped reduction launch of this layer group
             nbytes = e.lib.query("zk_add_ln_bwd_workspace", T, H)
             pws = e.buf("g.%s.lnws" % tag, (nbytes // 4,), F32)
             e.add_ln_bwd(dx, e.mat(tag + ".s", T, H), e.buf(tag + ".mean", (T,), F32),
                          e.buf(tag + ".rstd", (T,), F32), self.b(scope + "/layer_norm/scale"), ds, dy, dgam, dbet,
                          dbp, drop_p, sid, private_ws=pws)
-            self._side(lambda: e.add_ln_bwd_reduce(pws, T, H, dgam, dbet, dbp))
+            self._pending_lnred.append((pws, T, H, dgam, dbet, dbp))
         else:
             e.add_ln_bwd(dx, e.mat(tag + ".s", T, H), e.buf(tag + ".mean", (T,), F32),
                          e.buf(tag + ".rstd", (T,), F32), self.b(scope + "/layer_norm/scale"), ds, dy, dgam, dbet,
@@ -408,7 +419,7 @@ class TransformerCore(object):
         e.embed_fwd(batch["tgt"], self.store.s(self.tgt_emb), self.b("bias"), x, B, Lt, H, shift=True,
                     drop_p=hp.dropout if train else 0.0, sid=9002)
         NE = hp.num_encoder_layer
-        group_kv = self.group_wgrad and e.gemm_impl == 0 and self.use_side
+        group_kv = self.group_wgrad and e.gemm_impl == 0
         if group_kv:
             self._cross_kv_grouped(enc, hp.num_decoder_layer)
         for l in range(hp.num_decoder_layer):
