@@ -72,7 +72,11 @@ class TransformerCore(object):
         # weight-gradient GEMMs are deferred and launched as ONE grouped grid per `group_layers`
         # layers (each is far too small to fill 256 CUs on its own)
         self.group_wgrad = os.environ.get("ZERO_HIP_GROUP_WGRAD", "1") != "0"
-        self.group_layers = int(os.environ.get("ZERO_HIP_GROUP_LAYERS", "3"))
+        # one group per side of the model with a single rank (fewest launches); smaller groups with
+        # data parallelism so that the gradient all-reduce of finished layers starts early
+        import torch.distributed as _dist
+        _multi = _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1
+        self.group_layers = int(os.environ.get("ZERO_HIP_GROUP_LAYERS", "2" if _multi else "6"))
         self._pending_wgrads = []
         self._pending_colsums = []     # (dY Mat, bias-gradient view, private partial buffer)
         self._pending_lnred = []       # (partials, rows, H, dgamma, dbeta, dbias_prev)
