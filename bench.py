@@ -71,28 +71,47 @@ def train_flops_per_step(hp, b=B, ls=LS, lt=LT, v=V):
 
 
 class GemmProfiler(object):
-    """HIP-event timing of every zk_gemm launch of an eager step (same stream as the launch)."""
+    """HIP-event timing of every GEMM launch of an eager step (events on the launch stream),
+    keyed by the kernel instance that runs (same names rocprofv3 --stats reports)."""
 
     def __init__(self, engine):
         self.eng = engine
         self.records = []
-        self._orig = engine.gemm
+        self._gemm, self._grouped = engine.gemm, engine.gemm_grouped
+
+    def _name(self, M, N, K, ta, tb, out_f32, plain):
+        code = self.eng.lib.raw("zk_gemm_plan")(M, N, K, out_f32, plain)
+        gen, bm, bn = code & 255, (code >> 8) & 255, (code >> 16) & 255
+        tf = lambda v: "true" if v else "false"
+        if gen == 2:
+            ns = 4 if (bm, bn) == (64, 64) else 2
+            return "k_gemm_dlds<%d, %d, %d, %s, %s>" % (bm, bn, ns, tf(ta), tf(tb))
+        return "k_gemm_mfma<%d, %d, %s, %s>" % (bm, bn, tf(ta), tf(tb))
 
     def __enter__(self):
-        eng = self.eng
-
         def timed(A, Bm, C, M, N, K, ta, tb, **kw):
-            s = torch.cuda.Event(enable_timing=True)
-            e = torch.cuda.Event(enable_timing=True)
+            plain = not any(kw.get(k) is not None for k in ("bias", "residual")) and not kw.get("act") \
+                and not kw.get("drop_p")
+            name = self._name(M, N, K, ta, tb, 1 if C.t.dtype == torch.float32 else 0, 1 if plain else 0)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            self._orig(A, Bm, C, M, N, K, ta, tb, **kw)
+            self._gemm(A, Bm, C, M, N, K, ta, tb, **kw)
             e.record()
-            self.records.append(((ta, tb), 2.0 * M * N * K, s, e))
-        eng.gemm = timed
+            self.records.append((name, 2.0 * M * N * K, s, e))
+
+        def timed_grouped(problems, ta, tb, tile=128):
+            tf = lambda v: "true" if v else "false"
+            name = "k_gemm_grouped<%d, %d, %d, %s, %s>" % (tile, tile, 2 if tile == 128 else 4, tf(ta), tf(tb))
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            self._grouped(problems, ta, tb, tile=tile)
+            e.record()
+            self.records.append((name, sum(2.0 * p[3] * p[4] * p[5] for p in problems), s, e))
+        self.eng.gemm, self.eng.gemm_grouped = timed, timed_grouped
         return self
 
     def __exit__(self, *a):
-        self.eng.gemm = self._orig
+        self.eng.gemm, self.eng.gemm_grouped = self._gemm, self._grouped
 
     def summary(self):
         torch.cuda.synchronize()
@@ -185,7 +204,17 @@ def main():
     loss_v = float(loss.cpu()[0])
     gnorm, pnorm, skipped = tr.train_op.stats()
 
+    # ---- roofline of the dominant kernel: instrumented eager pass (HIP events per launch).  Every
+    # rank runs it (the step contains collectives); only rank 0 reports.
+    NPROF = 3
+    with GemmProfiler(tr.core.eng) as prof:
+        for _ in range(NPROF):
+            tr.step_static(False)
+    agg = prof.summary()
+    barrier()
     if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
         return
     tokens = world * B * (LS + LT) * args.steps
     ms = dt / args.steps * 1e3
@@ -203,27 +232,24 @@ def main():
         "loss": loss_v, "gnorm": gnorm, "update_skipped": skipped,
         "step_mfma_frac": flops / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12),
     }
-    # ---- roofline of the dominant kernel: instrumented eager pass (HIP events per launch)
-    with GemmProfiler(tr.core.eng) as prof:
-        for _ in range(3):
-            tr.step_static(False)
-    agg = prof.summary()
-    names = {(0, 0): "k_gemm_mfma<*,*,false,false> (forward x@W)",
-             (0, 1): "k_gemm_mfma<*,*,false,true> (dgrad dY@W^T, logits)",
-             (1, 0): "k_gemm_mfma<*,*,true,false> (wgrad X^T@dY)"}
     key = max(agg, key=lambda k: agg[k][1])
     fl, sec, cnt = agg[key]
     tot_fl = sum(v[0] for v in agg.values())
     tot_s = sum(v[1] for v in agg.values())
     out["roofline"] = {
-        "bound": "mfma", "kernel": names.get(key, str(key)), "achieved": fl / sec / 1e12,
+        "bound": "mfma", "kernel": key, "achieved": fl / sec / 1e12,
         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-        "traffic": None, "launches_per_step": cnt // 3, "avg_launch_us": sec / cnt * 1e6,
-        "all_gemm_achieved": tot_fl / tot_s / 1e12, "all_gemm_ms_per_step": tot_s / 3 * 1e3,
+        "traffic": None, "launches_per_step": cnt // NPROF, "avg_launch_us": sec / cnt * 1e6,
+        "flop_per_launch": fl / cnt,
+        "all_gemm_achieved": tot_fl / tot_s / 1e12, "all_gemm_ms_per_step": tot_s / NPROF * 1e3,
+        "by_kernel": {k: {"launches_per_step": v[2] // NPROF, "avg_us": v[1] / v[2] * 1e6,
+                          "tflops": v[0] / v[1] / 1e12} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(hp)
     print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

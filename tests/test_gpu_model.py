@@ -95,6 +95,27 @@ def test_naive_and_mfma_paths_agree(model, monkeypatch):
             assert np.linalg.norm(a - b) / np.linalg.norm(a) < 1e-1, k
 
 
+def test_big_layer_shapes_and_long_sequences():
+    # Transformer-big widths (H=1024, F=4096, 16 heads of 64: BASELINE config 3) and sequences that
+    # need 2-3 attention key tiles; 2 layers keep the CPU oracle fast
+    reset_cores()
+    rng = np.random.default_rng(9)
+    hp = make_hp("transformer", H=1024, F=4096, heads=16, layers=2, Vs=500, Vt=400)
+    Pn = perturb(rt.init_params(hp, "transformer", seed=2), rng)
+    src, tgt = make_batch(rng, 3, 150, 90, 500, 400)
+    ref_loss, ref_ps, ref_G = _oracle(hp, Pn, src, tgt, "transformer")
+    out = registry.get_model("transformer").train_fn({"source": src, "target": tgt}, hp, initializer=Pn)
+    torch.cuda.synchronize()
+    loss = float(out["loss"].cpu())
+    print("big-width loss hip=%.6f oracle=%.6f" % (loss, ref_loss))
+    assert abs(loss - ref_loss) / abs(ref_loss) < 1e-3
+    G = out["store"].export("grad")
+    for k in ("encoder/layer_0/self_attention/dot_attention/qkv_map/W_0_0",
+              "decoder/layer_1/cross_attention/dot_attention/k_map/W_0_0", "tgt_embedding"):
+        err = np.linalg.norm(G[k] - ref_G[k]) / np.linalg.norm(ref_G[k])
+        assert err < 1.2e-1, (k, err)
+
+
 def test_score_fn_matches_oracle():
     hp, Pn, src, tgt = _setup("transformer")
     P = rt.to_torch(Pn)

@@ -287,6 +287,16 @@ size_t zk_gemm_workspace(int M, int N, int K) {
   if (s < 2 && K >= 1024) s = 2;
   return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
+// Which kernel would impl=0 pick?  Returns gen | bm<<8 | bn<<16 | splits<<24 (for labelling
+// measurements with the kernel instance that actually runs).
+int zk_gemm_plan(int M, int N, int K, int out_f32, int plain) {
+  int bm, bn, s;
+  pick_config(M, N, K, plain ? 1 : 0, &bm, &bn, &s);
+  int gen = g_default_gen;
+  if (gen == 2 && out_f32 && K <= 512 && (long)M * N >= 64L * 1024 * 1024) gen = 1;
+  return gen | (bm << 8) | (bn << 16) | (s << 24);
+}
+
 // workspace for an explicit split-K override (tuning)
 size_t zk_gemm_workspace_split(int M, int N, int splits) { return (size_t)splits * M * N * sizeof(float); }
 
