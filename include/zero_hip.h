@@ -85,10 +85,11 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
 /* ---- transformer.py:16-33 / 88-119 embedding * sqrt(H) + shared bias + timing signal
  * (func.py:341-369; `timing` = host-precomputed fp32 [Lmax,H] table).  shift=1: decoder
  * training input (zero first step, transformer.py:108-110).  zero_flag: device int, !=0
- * zeroes the embedding term (transformer.py:113-115).                                  */
+ * zeroes the embedding term (transformer.py:113-115).  pos0_dev (device int, may be NULL)
+ * overrides pos0 at run time, so a captured decode-step graph sees the current time step.  */
 int zk_embed_fwd(const int* ids, const void* table, const float* bias, const float* timing, void* out, int B,
                  int L, int H, float scale, int shift, int pos0, const int* zero_flag, float drop_p,
-                 const uint64_t* seed, uint32_t sid, zk_stream_t stream);
+                 const uint64_t* seed, uint32_t sid, const int* pos0_dev, zk_stream_t stream);
 /* dtable (fp32 [V,H]) and dbias (fp32 [H]) are ACCUMULATED into with atomics. */
 int zk_embed_bwd(const int* ids, const void* dout, float* dtable, float* dbias, int B, int L, int H,
                  float scale, int shift, float drop_p, const uint64_t* seed, uint32_t sid, zk_stream_t stream);
@@ -177,14 +178,16 @@ int zk_dropout_mask(float* out, size_t n, float drop_p, const uint64_t* seed, ui
 int zk_seed_advance(uint64_t* seed, uint64_t inc, zk_stream_t stream);
 
 /* ---- search.py:143-176 decode step tail (see zk_decode.hip) */
+size_t zk_beam_topk_workspace(int B, int K, int k2);
 int zk_beam_topk(const float* logits, const float* prev_log_probs, float* topk_scores, int* topk_index, int B,
                  int K, int V, int ld, int k2, float temperature, float length_penalty, int forbid_id,
-                 float forbid_value, zk_stream_t stream);
+                 float forbid_value, const int* scal_dev, void* workspace, size_t ws_bytes, zk_stream_t stream);
 /* search.py:198-210 beam reordering: dst row r <- src row index[r] (NULL: r); bytes, multiples of 16 */
 int zk_gather_rows(const void* src, size_t src_stride, const int* index, void* dst, size_t dst_stride, int rows,
                    size_t row_bytes, zk_stream_t stream);
 /* transformer_aan.py:110-112: cache += x; cat = [x | cache/(t+1)] */
-int zk_aan_decode(const void* x, float* cache, void* cat, int rows, int H, float inv_count, zk_stream_t stream);
+int zk_aan_decode(const void* x, float* cache, void* cat, int rows, int H, float inv_count, const int* time_dev,
+                  zk_stream_t stream);
 
 /* hipGraph plumbing: capture a sequence of the calls above once, replay per step */
 int zk_graph_begin(zk_stream_t stream);

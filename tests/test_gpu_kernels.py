@@ -549,7 +549,7 @@ def test_l2norm_and_adam_tf1_semantics():
 
 
 # ------------------------------------------------------------------ decode tail
-@pytest.mark.parametrize("B,K,V,ld", [(3, 4, 1000, 1000), (2, 1, 37, 40), (5, 4, 32000, 32000)])
+@pytest.mark.parametrize("B,K,V,ld", [(3, 4, 1000, 1000), (2, 1, 37, 40), (5, 4, 32000, 32000), (2, 8, 517, 520)])
 def test_beam_topk(B, K, V, ld):
     e = eng()
     logits = torch.zeros(B * K, ld, device="cuda")
@@ -559,8 +559,7 @@ def test_beam_topk(B, K, V, ld):
     ts = torch.zeros(B, 2 * K, device="cuda"); ti = torch.zeros(B, 2 * K, dtype=torch.int32, device="cuda")
     pen = 1.2345
     for forbid in (2, -1):
-        e.lib.call("zk_beam_topk", logits.data_ptr(), prev.data_ptr(), ts.data_ptr(), ti.data_ptr(), B, K, V, ld,
-                   2 * K, 1.0, pen, forbid, 1e8, e.stream)
+        e.beam_topk(Mat(logits, B * K, ld), prev, ts, ti, B, K, V, 2 * K, 1.0, pen, forbid, 1e8)
         torch.cuda.synchronize()
         lp = logits[:, :V] - torch.logsumexp(logits[:, :V], -1, keepdim=True)
         if forbid >= 0:
@@ -570,6 +569,25 @@ def test_beam_topk(B, K, V, ld):
         ref_s = np.take_along_axis(sc, idx, -1)
         assert np.array_equal(ti.cpu().numpy(), idx), (ti.cpu().numpy(), idx)
         assert np.abs(ts.cpu().numpy() - ref_s).max() < 1e-4
+
+
+def test_beam_topk_device_scalars():
+    # the per-step scalars (length penalty, EOS ban) can come from device memory (captured graphs)
+    e = eng()
+    B, K, V = 2, 4, 300
+    logits = torch.randn(B * K, V, device="cuda")
+    prev = torch.randn(B * K, device="cuda")
+    outs = []
+    for mode in ("args", "dev"):
+        ts = torch.zeros(B, 2 * K, device="cuda"); ti = torch.zeros(B, 2 * K, dtype=torch.int32, device="cuda")
+        scal = torch.tensor([np.float32(1.7).view(np.int32), 2], dtype=torch.int32, device="cuda")
+        if mode == "args":
+            e.beam_topk(Mat(logits, B * K, V), prev, ts, ti, B, K, V, 2 * K, 1.0, 1.7, 2, 1e8)
+        else:
+            e.beam_topk(Mat(logits, B * K, V), prev, ts, ti, B, K, V, 2 * K, 1.0, 99.0, -1, 1e8, scal_dev=scal)
+        torch.cuda.synchronize()
+        outs.append((ts.cpu().numpy(), ti.cpu().numpy()))
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][0], outs[1][0])
 
 
 def test_gather_rows():

@@ -14,52 +14,11 @@ __device__ __forceinline__ bool better(float s1, int i1, float s2, int i2) {
   return (s1 > s2) || (s1 == s2 && i1 < i2);
 }
 
-__global__ void __launch_bounds__(256) k_beam_topk(const float* __restrict__ logits, const float* __restrict__ prev_lp,
-                                                   float* __restrict__ out_s, int* __restrict__ out_i, int K, int V,
-                                                   int ld, int k2, float inv_temp, float penalty, int forbid_id,
-                                                   float forbid_value) {
-  __shared__ float s_lse[TOPK_MAX];
-  __shared__ float sm[8];
-  __shared__ float ls[256][TOPK_MAX + 1];
-  __shared__ int li[256][TOPK_MAX + 1];
-  __shared__ float ws[4];
-  __shared__ int wi[4];
-  __shared__ int wt[4];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  // 1. per-row log-sum-exp of logits/temperature
-  for (int k = 0; k < K; ++k) {
-    const float* z = logits + ((size_t)b * K + k) * ld;
-    float m = -INFINITY;
-    for (int c = tid; c < V; c += 256) m = fmaxf(m, z[c] * inv_temp);
-    m = block_max<4>(m, sm);
-    float s = 0.f;
-    for (int c = tid; c < V; c += 256) s += __expf(z[c] * inv_temp - m);
-    s = block_sum<4>(s, sm);
-    if (tid == 0) s_lse[k] = m + __logf(s);
-  }
-  __syncthreads();
-  // 2. thread-local top-k2 over a strided slice of the K*V candidates
-  int cnt = 0;
-  for (int t = 0; t < k2; ++t) { ls[tid][t] = -INFINITY; li[tid][t] = 0x7fffffff; }
-  const long total = (long)K * V;
-  for (long f = tid; f < total; f += 256) {
-    const int k = (int)(f / V), v = (int)(f % V);
-    float lp = logits[((size_t)b * K + k) * ld + v] * inv_temp - s_lse[k];
-    if (v == forbid_id) lp += -forbid_value;
-    const float sc = (prev_lp[b * K + k] + lp) / penalty;
-    if (cnt < k2 || sc > ls[tid][k2 - 1]) {
-      int pos = cnt < k2 ? cnt : k2 - 1;
-      while (pos > 0 && sc > ls[tid][pos - 1]) {   // strict: equal scores keep index order
-        ls[tid][pos] = ls[tid][pos - 1];
-        li[tid][pos] = li[tid][pos - 1];
-        --pos;
-      }
-      ls[tid][pos] = sc;
-      li[tid][pos] = (int)f;
-      if (cnt < k2) ++cnt;
-    }
-  }
-  // 3. k2 rounds of block arg-max over the list heads
+// block-wide selection of the k2 best (score, index) pairs out of per-thread sorted lists in LDS
+// (ls/li: [256][TOPK_MAX+1], cnt entries each).  Every round: arg-max over the list heads.
+__device__ __forceinline__ void block_select(float (*ls)[TOPK_MAX + 1], int (*li)[TOPK_MAX + 1], int cnt, int k2,
+                                             float* out_s, int* out_i, float* ws, int* wi, int* wt) {
+  const int tid = threadIdx.x;
   int head = 0;
   for (int r = 0; r < k2; ++r) {
     float s = (head < cnt) ? ls[tid][head] : -INFINITY;
@@ -80,8 +39,76 @@ __global__ void __launch_bounds__(256) k_beam_topk(const float* __restrict__ log
     for (int w = 1; w < 4; ++w)
       if (better(ws[w], wi[w], bs, bi)) { bs = ws[w]; bi = wi[w]; bt = wt[w]; }
     if (tid == bt) ++head;
-    if (tid == 0) { out_s[b * k2 + r] = bs; out_i[b * k2 + r] = bi; }
+    if (tid == 0) { out_s[r] = bs; out_i[r] = bi; }
   }
+}
+
+// stage 1: one block per (sentence, beam) ROW: log-sum-exp of the row, candidate scores
+// (prev + log-prob) / penalty, the row's own top-k2 -> cand_s / cand_i [B*K, k2] (flat index k*V+v).
+// penalty / forbid_id may come from device memory (scal_dev: {penalty as float bits, forbid_id})
+// so that a captured decode-step graph picks up the per-step values.
+__global__ void __launch_bounds__(256) k_beam_topk_rows(const float* __restrict__ logits, const float* __restrict__ prev_lp,
+                                                        float* __restrict__ cand_s, int* __restrict__ cand_i, int K,
+                                                        int V, int ld, int k2, float inv_temp, float penalty,
+                                                        int forbid_id, float forbid_value,
+                                                        const int* __restrict__ scal_dev) {
+  __shared__ float sm[8];
+  __shared__ float ls[256][TOPK_MAX + 1];
+  __shared__ int li[256][TOPK_MAX + 1];
+  __shared__ float ws[4];
+  __shared__ int wi[4];
+  __shared__ int wt[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const int k = row % K;
+  if (scal_dev != nullptr) { penalty = __int_as_float(scal_dev[0]); forbid_id = scal_dev[1]; }
+  const float* z = logits + (size_t)row * ld;
+  float m = -INFINITY;
+  for (int c = tid; c < V; c += 256) m = fmaxf(m, z[c] * inv_temp);
+  m = block_max<4>(m, sm);
+  float s = 0.f;
+  for (int c = tid; c < V; c += 256) s += __expf(z[c] * inv_temp - m);
+  s = block_sum<4>(s, sm);
+  const float lse = m + __logf(s);
+  const float prev = prev_lp[row];
+  int cnt = 0;
+  for (int t = 0; t < k2; ++t) { ls[tid][t] = -INFINITY; li[tid][t] = 0x7fffffff; }
+  for (int v = tid; v < V; v += 256) {
+    float lp = z[v] * inv_temp - lse;
+    if (v == forbid_id) lp += -forbid_value;
+    const float sc = (prev + lp) / penalty;
+    if (cnt < k2 || sc > ls[tid][k2 - 1]) {
+      int pos = cnt < k2 ? cnt : k2 - 1;
+      while (pos > 0 && sc > ls[tid][pos - 1]) {   // strict: equal scores keep index order
+        ls[tid][pos] = ls[tid][pos - 1];
+        li[tid][pos] = li[tid][pos - 1];
+        --pos;
+      }
+      ls[tid][pos] = sc;
+      li[tid][pos] = k * V + v;
+      if (cnt < k2) ++cnt;
+    }
+  }
+  block_select(ls, li, cnt, k2, cand_s + (size_t)row * k2, cand_i + (size_t)row * k2, ws, wi, wt);
+}
+
+// stage 2: one block per sentence merges its K*k2 candidates (ties -> lower flat index)
+__global__ void __launch_bounds__(256) k_beam_topk_merge(const float* __restrict__ cand_s, const int* __restrict__ cand_i,
+                                                         float* __restrict__ out_s, int* __restrict__ out_i, int K,
+                                                         int k2) {
+  __shared__ float ls[256][TOPK_MAX + 1];
+  __shared__ int li[256][TOPK_MAX + 1];
+  __shared__ float ws[4];
+  __shared__ int wi[4];
+  __shared__ int wt[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = K * k2;                    // <= 256
+  int cnt = 0;
+  if (tid < n) {
+    ls[tid][0] = cand_s[(size_t)b * n + tid];
+    li[tid][0] = cand_i[(size_t)b * n + tid];
+    cnt = 1;
+  }
+  block_select(ls, li, cnt, k2, out_s + (size_t)b * k2, out_i + (size_t)b * k2, ws, wi, wt);
 }
 
 __global__ void __launch_bounds__(256) k_gather_rows(const uint4* __restrict__ src, size_t src_stride16,
@@ -95,7 +122,9 @@ __global__ void __launch_bounds__(256) k_gather_rows(const uint4* __restrict__ s
 
 // cache += x (fp32 running sum); cat = [x | cache * inv_count]
 __global__ void __launch_bounds__(256) k_aan_decode(const bf16_t* __restrict__ x, float* __restrict__ cache,
-                                                    bf16_t* __restrict__ cat, int rows, int H, float inv_count) {
+                                                    bf16_t* __restrict__ cat, int rows, int H, float inv_count,
+                                                    const int* __restrict__ time_dev) {
+  if (time_dev != nullptr) inv_count = 1.f / (float)(*time_dev + 1);
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int nc = H / 8;
   if (idx >= (size_t)rows * nc) return;
@@ -114,16 +143,25 @@ __global__ void __launch_bounds__(256) k_aan_decode(const bf16_t* __restrict__ x
 extern "C" {
 
 // logits: fp32 [B*K, ld]; prev_log_probs: fp32 [B*K]; outputs fp32/int32 [B, k2]
-// (topk_index = beam*V + symbol).  forbid_id < 0 disables the EOS ban.
+// (topk_index = beam*V + symbol).  forbid_id < 0 disables the EOS ban.  scal_dev (device int[2] =
+// {float bits of the length penalty, forbid_id}, or NULL) overrides the two per-step scalars at
+// run time.  workspace: B*K*k2*8 bytes.
+size_t zk_beam_topk_workspace(int B, int K, int k2) { return (size_t)B * K * k2 * 8; }
 int zk_beam_topk(const float* logits, const float* prev_log_probs, float* topk_scores, int* topk_index, int B,
                  int K, int V, int ld, int k2, float temperature, float length_penalty, int forbid_id,
-                 float forbid_value, hipStream_t stream) {
+                 float forbid_value, const int* scal_dev, void* workspace, size_t ws_bytes, hipStream_t stream) {
   ZK_CHECK_ARG(k2 >= 1 && k2 <= TOPK_MAX && K >= 1 && K <= TOPK_MAX, "zk_beam_topk: K=%d, k2=%d out of range (<=%d)",
                K, k2, TOPK_MAX);
-  ZK_CHECK_ARG((long)K * V >= k2, "zk_beam_topk: fewer candidates than k2");
+  ZK_CHECK_ARG((long)K * V >= k2 && V >= k2, "zk_beam_topk: fewer candidates than k2");
+  ZK_CHECK_ARG(ws_bytes >= zk_beam_topk_workspace(B, K, k2), "zk_beam_topk: workspace too small");
   if (B == 0) return 0;
-  hipLaunchKernelGGL(k_beam_topk, dim3(B), dim3(256), 0, stream, logits, prev_log_probs, topk_scores, topk_index, K,
-                     V, ld, k2, 1.f / temperature, length_penalty, forbid_id, forbid_value);
+  float* cs = (float*)workspace;
+  int* ci = (int*)(cs + (size_t)B * K * k2);
+  hipLaunchKernelGGL(k_beam_topk_rows, dim3(B * K), dim3(256), 0, stream, logits, prev_log_probs, cs, ci, K, V, ld,
+                     k2, 1.f / temperature, length_penalty, forbid_id, forbid_value, scal_dev);
+  ZK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_beam_topk_merge, dim3(B), dim3(256), 0, stream, (const float*)cs, (const int*)ci, topk_scores,
+                     topk_index, K, k2);
   ZK_LAUNCH_CHECK();
   return 0;
 }
@@ -144,12 +182,13 @@ int zk_gather_rows(const void* src, size_t src_stride, const int* index, void* d
   return 0;
 }
 
-int zk_aan_decode(const void* x, float* cache, void* cat, int rows, int H, float inv_count, hipStream_t stream) {
+int zk_aan_decode(const void* x, float* cache, void* cat, int rows, int H, float inv_count, const int* time_dev,
+                  hipStream_t stream) {
   ZK_CHECK_ARG(H % 8 == 0, "zk_aan_decode: H=%d must be a multiple of 8", H);
   const size_t n = (size_t)rows * (H / 8);
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_aan_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, cache,
-                     (bf16_t*)cat, rows, H, inv_count);
+                     (bf16_t*)cat, rows, H, inv_count, time_dev);
   ZK_LAUNCH_CHECK();
   return 0;
 }

@@ -28,12 +28,13 @@ __global__ void __launch_bounds__(256) k_embed_fwd(
     const int* __restrict__ ids, const bf16_t* __restrict__ table, const float* __restrict__ bias,
     const float* __restrict__ timing, bf16_t* __restrict__ out, int rows, int L, int H,
     float scale, int shift, int pos0, const int* __restrict__ zero_flag, uint32_t thr,
-    float inv_keep, const uint64_t* __restrict__ seedp, uint32_t sid) {
+    float inv_keep, const uint64_t* __restrict__ seedp, uint32_t sid, const int* __restrict__ pos0_dev) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const uint64_t seed = (thr != 0) ? *seedp : 0;
   const bool zero_all = (zero_flag != nullptr) && (*zero_flag != 0);
+  if (pos0_dev != nullptr) pos0 = *pos0_dev;   // decode step read at run time (captured graphs)
   for (int r = wave; r < rows; r += nwaves) {
     const int t = r % L;
     int id = -1;
@@ -980,7 +981,7 @@ int zk_version(void) { return 100; }
 
 int zk_embed_fwd(const int* ids, const void* table, const float* bias, const float* timing, void* out,
                  int B, int L, int H, float scale, int shift, int pos0, const int* zero_flag,
-                 float drop_p, const uint64_t* seed, uint32_t sid, hipStream_t stream) {
+                 float drop_p, const uint64_t* seed, uint32_t sid, const int* pos0_dev, hipStream_t stream) {
   ZK_CHECK_ARG(H % 8 == 0, "zk_embed_fwd: H=%d must be a multiple of 8", H);
   ZK_CHECK_ARG(drop_p == 0.f || seed != nullptr, "zk_embed_fwd: dropout needs a seed pointer");
   const int rows = B * L;
@@ -989,7 +990,7 @@ int zk_embed_fwd(const int* ids, const void* table, const float* bias, const flo
   const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   hipLaunchKernelGGL(k_embed_fwd, dim3(row_grid(rows)), dim3(256), 0, stream, ids, (const bf16_t*)table,
                      bias, timing, (bf16_t*)out, rows, L, H, scale, shift, pos0, zero_flag, thr, ik,
-                     seed, sid);
+                     seed, sid, pos0_dev);
   ZK_LAUNCH_CHECK();
   return 0;
 }

@@ -247,11 +247,19 @@ class Engine(object):
 
     # ---- embedding + timing (transformer.py:16-33, 88-119; func.py:341-369) -------
     def embed_fwd(self, ids, table, bias, out, B, L, H, shift=False, pos0=0, zero_flag=None, drop_p=0.0,
-                  sid=0):
-        tim = self.timing(pos0 + L, H)
+                  sid=0, pos0_dev=None, max_pos=None):
+        tim = self.timing((max_pos if max_pos is not None else pos0) + L, H)
         self.lib.call("zk_embed_fwd", ids.data_ptr(), table.data_ptr(), bias.data_ptr(), tim.data_ptr(),
                       out.ptr, B, L, H, float(H) ** 0.5, 1 if shift else 0, pos0, hip.ptr(zero_flag),
-                      float(drop_p), self.seed.data_ptr(), sid, self.stream)
+                      float(drop_p), self.seed.data_ptr(), sid, hip.ptr(pos0_dev), self.stream)
+
+    def beam_topk(self, logits, prev_lp, out_s, out_i, B, K, V, k2, temperature, penalty, forbid_id, forbid_value,
+                  scal_dev=None):
+        ws_bytes = self.lib.query("zk_beam_topk_workspace", B, K, k2)
+        ws = self.workspace(ws_bytes)
+        self.lib.call("zk_beam_topk", logits.ptr, prev_lp.data_ptr(), out_s.data_ptr(), out_i.data_ptr(), B, K, V,
+                      logits.ld, k2, float(temperature), float(penalty), int(forbid_id), float(forbid_value),
+                      hip.ptr(scal_dev), ws.data_ptr(), ws.numel(), self.stream)
 
     def embed_bwd(self, ids, dout, dtable, dbias, B, L, H, shift=False, drop_p=0.0, sid=0):
         self.lib.call("zk_embed_bwd", ids.data_ptr(), dout.ptr, dtable.data_ptr(), dbias.data_ptr(), B, L, H,

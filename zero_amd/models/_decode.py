@@ -97,26 +97,69 @@ def make_infer_fns(params, model_name):
                 lay["v"] = e.buf("dc%d.v.0" % l, (BK, max_steps, H))
             state["decoder"]["state"]["layer_%d" % l] = lay
         state["zero_flag"] = e.buf("dc.zflag", (1,), torch.int32)
+        # per-step scalars live in device memory ({time, float bits of the length penalty, EOS-ban id}):
+        # a captured decode-step graph reads the current values at replay time
+        state["stepbuf"] = e.buf("dc.stepbuf", (4,), torch.int32)
+        state["stepbuf_host"] = torch.zeros(4, dtype=torch.int32).pin_memory()
+        state["tok"] = e.buf("bs.tok", (BK,), torch.int32)
+        state["prev"] = e.buf("bs.prev", (BK,), torch.float32)
+        state["idx"] = e.buf("bs.idx", (BK,), torch.int32)
+        state["ts"] = e.buf("bs.ts", (B, 2 * K), torch.float32)
+        state["ti"] = e.buf("bs.ti", (B, 2 * K), torch.int32)
+        state["graphs"] = {}
+        state["static_ok"] = core.aan          # every launch argument of an AAN step is static
         return state
 
-    def _step_cache(target, state, time):
+    def step_static(state, temperature, forbid_value):
+        """One whole decode step with every per-step value read from device memory: beam reorder of
+        the caches (indices chosen by the previous step), the AAN decoder step, logits, fused
+        log-softmax + length penalty + top-2K.  The launch sequence is identical every step (per
+        ping-pong parity), so after one eager pass per parity it is captured into a hipGraph."""
+        core = state["_core"]
+        e = core.eng
+        parity = state["decoder"]["state"]["layer_0"]["_pp"]
+        g = state["graphs"].get(parity)
+
+        def body():
+            state.reorder(state["idx"])
+            sb = state["stepbuf"]
+            logits, _ = _step_cache(state["tok"], state, None, time_dev=sb[0:1])
+            e.beam_topk(logits, state["prev"], state["ts"], state["ti"], state["B"], state["K"], core.V,
+                        2 * state["K"], temperature, 1.0, -1, forbid_value, scal_dev=sb[1:3])
+        if g is None:
+            state["graphs"][parity] = "warm"
+            body()
+        elif g == "warm":
+            # capture: python-side ping-pong bookkeeping runs during capture exactly as in an eager call
+            state["graphs"][parity] = e.graph_capture(body)
+            e.graph_launch(state["graphs"][parity])
+        else:
+            for l in range(hp.num_decoder_layer):      # replay: redo the python-side pointer flips
+                lay = state["decoder"]["state"]["layer_%d" % l]
+                lay["aan"] = e.buf("dc%d.aan.%d" % (l, 1 - lay["_pp"]), (state["BK"], core.H), F32)
+                lay["_pp"] = 1 - lay["_pp"]
+            e.graph_launch(g)
+
+    def _step_cache(target, state, time, time_dev=None):
         core = state["_core"]
         e, H, nh, d = core.eng, core.H, core.nh, core.d
         BK, K, B, Ls, Tmax = state["BK"], state["K"], state["B"], state["Ls"], state["Tmax"]
-        if time >= Tmax:
+        if time_dev is None and time >= Tmax:
             raise RuntimeError("decode step %d exceeds the allocated cache length %d" % (time, Tmax))
         zf = state["zero_flag"]
         e.lib.call("zk_all_equal", target.data_ptr(), BK, hp.tgt_vocab.pad(), zf.data_ptr(), e.stream)
         x = e.mat("dc.x", BK, H)
-        e.embed_fwd(target, core.store.s(core.tgt_emb), core.b("bias"), x, BK, 1, H, pos0=time, zero_flag=zf)
+        e.embed_fwd(target, core.store.s(core.tgt_emb), core.b("bias"), x, BK, 1, H,
+                    pos0=0 if time_dev is not None else time, zero_flag=zf, pos0_dev=time_dev, max_pos=Tmax)
         for l in range(hp.num_decoder_layer):
             pre = "decoder/layer_%d" % l
             lay = state["decoder"]["state"]["layer_%d" % l]
             if core.aan:
                 a = pre + "/average_attention"
                 cat = e.mat("dc.cat", BK, 2 * H)
-                e.lib.call("zk_aan_decode", x.ptr, lay["aan"].data_ptr(), cat.ptr, BK, H, 1.0 / float(time + 1),
-                           e.stream)
+                e.lib.call("zk_aan_decode", x.ptr, lay["aan"].data_ptr(), cat.ptr, BK, H,
+                           1.0 if time_dev is not None else 1.0 / float(time + 1),
+                           time_dev.data_ptr() if time_dev is not None else None, e.stream)
                 z = e.mat("dc.z", BK, 2 * H)
                 core._linear(cat, a + "/z_project", z)
                 g = e.mat("dc.y", BK, H)
@@ -153,7 +196,8 @@ def make_infer_fns(params, model_name):
             x = core._ffn_fwd(x, pre + "/feed_forward", "dc%d.ff" % l, False, 0, False)
         logits = e.mat("dc.logits", BK, core.Vpad, F32)
         e.gemm(x, core.W(core.soft_emb), logits, BK, core.V, H, 0, 1)
-        state["time_filled"] = time + 1
+        if time_dev is None:
+            state["time_filled"] = time + 1
         return logits, state
 
     def _step_dev(target, source, time):
@@ -174,4 +218,5 @@ def make_infer_fns(params, model_name):
             return _step_cache(target, state, time)
         return _step_dev(target, state, time)
 
+    decoding_fn.step_static = step_static
     return encoding_fn, decoding_fn

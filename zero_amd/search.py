@@ -16,6 +16,8 @@ bookkeeping on the 2K survivors runs on the host in fp32 numpy exactly as search
 it (it needs the termination test on the host anyway); caches are reordered on the GPU.
 """
 
+import os
+
 import numpy as np
 import torch
 
@@ -31,6 +33,22 @@ def _top_k(x, k):
 
 
 def beam_search(features, encoding_fn, decoding_fn, params):
+    """search.py:19-275.  Runs on the engine's work stream (decode-step graphs cannot be captured on
+    the legacy default stream)."""
+    if params.search_mode == "cache":
+        from zero_amd.models._factory import get_core
+        eng = get_core(params, params.model_name).eng
+        cur = torch.cuda.current_stream(eng.device)
+        ws = eng.work_stream
+        ws.wait_stream(cur)
+        with torch.cuda.stream(ws):
+            out = _beam_search(features, encoding_fn, decoding_fn, params)
+        cur.wait_stream(ws)
+        return out
+    return _beam_search(features, encoding_fn, decoding_fn, params)
+
+
+def _beam_search(features, encoding_fn, decoding_fn, params):
     f32 = np.float32
     K = params.beam_size
     alpha = params.decode_alpha
@@ -68,6 +86,12 @@ def beam_search(features, encoding_fn, decoding_fn, params):
     d_idx = e.buf("bs.idx", (B * K,), torch.int32)
     mtl_i = max_target_length.astype(np.int32)
     time = 0
+    # AAN decoding: the whole step (cache reorder + model + top-2K) has static launch arguments and is
+    # replayed as a hipGraph; per-step scalars travel through a small device buffer
+    static_step = cache_mode and state.get("static_ok", False) and hasattr(decoding_fn, "step_static") \
+        and os.environ.get("ZERO_HIP_DECODE_GRAPH", "1") != "0"
+    if static_step:
+        d_idx.copy_(torch.arange(B * K, dtype=torch.int32))     # step 0: identity reorder
     while True:
         # ---- search.py:85-113
         max_lp = np.power((f32(5.) + max_target_length) / f32(6.), f32(alpha)).astype(f32)
@@ -79,7 +103,18 @@ def beam_search(features, encoding_fn, decoding_fn, params):
         if bound_is_met or not length_is_met:
             break
         # ---- model step (search.py:118-142)
-        if cache_mode:
+        penalty = f32(np.power(f32((f32(5.) + f32(time + 1)) / f32(6.)), f32(alpha)))
+        if static_step:
+            if time >= state["Tmax"]:
+                raise RuntimeError("decode step %d exceeds the allocated cache length %d" % (time, state["Tmax"]))
+            d_tok.copy_(torch.from_numpy(seq[:, :, -1].reshape(-1).astype(np.int32)), non_blocking=True)
+            d_prev.copy_(torch.from_numpy(log_probs.reshape(-1)), non_blocking=True)
+            hb = state["stepbuf_host"]
+            hb[0], hb[1], hb[2] = time, int(np.float32(penalty).view(np.int32)), (eos_id if time < 1 else -1)
+            state["stepbuf"].copy_(hb, non_blocking=True)
+            decoding_fn.step_static(state, params.beam_search_temperature, zdtype.inf())
+            logits = None
+        elif cache_mode:
             d_tok.copy_(torch.from_numpy(seq[:, :, -1].reshape(-1).astype(np.int32)))
             logits, state = decoding_fn(d_tok, state, time)
         else:
@@ -87,11 +122,10 @@ def beam_search(features, encoding_fn, decoding_fn, params):
             decode_target = np.concatenate([flat[:, 1:], np.ones((B * K, 1), dtype=flat.dtype)], axis=1)
             logits, state = decoding_fn(decode_target, state, time)
         # ---- fused log-softmax + penalty + top-2K (search.py:143-176)
-        penalty = f32(np.power(f32((f32(5.) + f32(time + 1)) / f32(6.)), f32(alpha)))
-        d_prev.copy_(torch.from_numpy(log_probs.reshape(-1)))
-        e.lib.call("zk_beam_topk", logits.ptr, d_prev.data_ptr(), d_ts.data_ptr(), d_ti.data_ptr(), B, K, V,
-                   logits.ld, 2 * K, float(params.beam_search_temperature), float(penalty),
-                   eos_id if time < 1 else -1, float(zdtype.inf()), e.stream)
+        if not static_step:
+            d_prev.copy_(torch.from_numpy(log_probs.reshape(-1)))
+            e.beam_topk(logits, d_prev, d_ts, d_ti, B, K, V, 2 * K, params.beam_search_temperature, penalty,
+                        eos_id if time < 1 else -1, zdtype.inf())
         topk_scores = d_ts.cpu().numpy().astype(f32)
         topk_idx = d_ti.cpu().numpy().astype(np.int64)
         beam_idx = topk_idx // V
@@ -117,8 +151,9 @@ def beam_search(features, encoding_fn, decoding_fn, params):
         seq, log_probs, scores = alive_seq, alive_lp, alive_scores
         if cache_mode:
             flat_idx = (np.arange(B)[:, None] * K + alive_beam).reshape(-1).astype(np.int32)
-            d_idx.copy_(torch.from_numpy(flat_idx))
-            state.reorder(d_idx)
+            d_idx.copy_(torch.from_numpy(flat_idx), non_blocking=static_step)
+            if not static_step:
+                state.reorder(d_idx)        # (the static step reorders at its own start)
         time += 1
 
     any_fin = fin_flags.any(axis=1)
