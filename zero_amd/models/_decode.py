@@ -188,7 +188,7 @@ def make_infer_fns(params, model_name):
             rk = core.store.s(p + "rpr_keys/embeddings") if core.rpr else None
             rv = core.store.s(p + "rpr_values/embeddings") if core.rpr else None
             e.attn_fwd(q, lay["mk"], lay["mv"], att, None, BK, nh, 1, Ls, d, kmask=state["mask"], causal=False,
-                       q_pos0=time, rpr_k=rk, rpr_v=rv, max_rel=hp.max_relative_position, bsq=H,
+                       q_pos0=time if time is not None else 0, rpr_k=rk, rpr_v=rv, max_rel=hp.max_relative_position, bsq=H,
                        bsk=Ls * 2 * H, bsv=Ls * 2 * H, kv_group=K)
             y = e.mat("dc.y", BK, H)
             core._linear(att, p + "o_map", y)
