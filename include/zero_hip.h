@@ -170,6 +170,7 @@ int zk_adam(float* p, const float* g, float* m, float* v, void* shadow_bf16, siz
 int zk_cast_f32_bf16(const float* x, void* y, size_t n, zk_stream_t stream);
 int zk_cast_bf16_f32(const void* x, float* y, size_t n, zk_stream_t stream);
 int zk_zero(void* p, size_t bytes, zk_stream_t stream);
+int zk_spin(uint32_t usec, zk_stream_t stream);   /* measurement aid: occupy the stream for usec (<= 200 ms) */
 int zk_tune(int key, int value);   /* A/B switches for measurements; key 0 = wide LayerNorm-backward kernel */
 int zk_axpby_f32(float* y, const float* x, float a, float b, size_t n, zk_stream_t stream);
 

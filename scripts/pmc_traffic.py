@@ -1,0 +1,31 @@
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes per kernel name (JSON to stdout).
+Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters
+are reported in KB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at
+64 bytes, so it is doubled; WRITE_SIZE matched the exact output size of the GEMMs and is taken
+as is (profiles/r01_pmc_gemm.txt)."""
+import csv, glob, json, sys, collections
+
+
+def load(d, counter):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+            a = acc[name]
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+    return acc
+
+
+fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+out = {}
+for name in sorted(set(fetch) | set(write)):
+    fk, fn = fetch.get(name, [0.0, 0])
+    wk, wn = write.get(name, [0.0, 0])
+    out[name] = {"launches": max(fn, wn),
+                 "fetch_bytes_per_launch": 2.0 * 1024.0 * fk / max(fn, 1),
+                 "write_bytes_per_launch": 1024.0 * wk / max(wn, 1)}
+print(json.dumps({"note": "FETCH_SIZE KB x2 (gfx950 correction), WRITE_SIZE KB x1; per-launch averages over "
+                          "bench.py --steps 2 --warmup 2 --no-graph", "kernels": out}, indent=1))

@@ -1335,6 +1335,20 @@ int zk_seed_advance(uint64_t* seed, uint64_t inc, hipStream_t stream) {
   return 0;
 }
 
+// Measurement aid: keeps the stream busy for `usec` so that the launches enqueued behind it are
+// already queued when they start (bench.py's per-launch HIP-event brackets then exclude the host
+// launch latency).  One thread polling the 100 MHz wall clock.
+__global__ void k_spin(uint64_t ticks) {
+  const uint64_t t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+int zk_spin(uint32_t usec, hipStream_t stream) {
+  if (usec > 200000u) return zk_set_error(-1, "zk_spin: at most 200 ms");
+  hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, stream, (uint64_t)usec * 100u);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
 int zk_zero(void* p, size_t bytes, hipStream_t stream) {
   if (bytes == 0) return 0;
   hipError_t e = hipMemsetAsync(p, 0, bytes, stream);

@@ -23,11 +23,11 @@ __device__ __attribute__((aligned(16))) uint4 zk_zero_page[4];   // source of ou
 // LDS-DMA issued from inline asm: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every
 // ds_read that may alias an LDS-DMA it knows about, which would drain the ring each K step.  The
 // asm form is invisible to that pass; completion is tracked by the counted vmcnt waits below.
-// LDS destination = M0 (wave-uniform byte address) + lane*16; M0 is saved/restored around it.
+// LDS destination = M0 (wave-uniform byte address) + lane*16.  Nothing else in these kernels reads
+// M0 (gfx9+ DS instructions do not), so it is written and left.
 __device__ __forceinline__ void glds16(const bf16_t* gsrc, uint32_t lds_byte_addr) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :
                : "v"(gsrc), "s"(lds_byte_addr)
                : "memory");
 }
@@ -40,15 +40,16 @@ __device__ __forceinline__ int swz_direct(int row) { return (row >> 1) & 7; }   
 template <int R>
 __device__ __forceinline__ int swz_trans(int k) { return R == 128 ? ((k & 3) << 2) : (((k >> 1) & 1) << 2); }
 
-// Per-lane LDS-DMA plan of one operand: for each of the wave's NINSTR pieces the source pointer of
-// K tile 0 (null when the tile row / column chunk is out of range) and the k index inside the
-// tile that decides the K-tail predicate.  Built once per workgroup; per K tile only an add,
-// a compare and a select remain in front of each DMA.
+// Per-lane LDS-DMA plan of one operand: for each of the wave's NINSTR pieces the running source
+// pointer (advanced by one K tile after every issue) and the k index inside the tile that decides
+// the K-tail predicate.  Tile rows / column chunks outside the matrix are CLAMPED to a valid
+// row / chunk 0: what they bring in only feeds output rows / columns the epilogue never stores.
+// Only a K tile that crosses kend needs zero fill (both operands), done by the TAIL variant.
 template <int R>
 struct DmaPlan {
   static constexpr int PER_WAVE = R * 8 / 4;      // 16-byte chunks per wave
   static constexpr int NINSTR = PER_WAVE / 64;
-  const bf16_t* g0[NINSTR];
+  const bf16_t* cur[NINSTR];
   int kofs[NINSTR];
 };
 
@@ -61,29 +62,31 @@ __device__ __forceinline__ void dma_plan(DmaPlan<R>& pl, const bf16_t* __restric
     if (!TRANS) {
       const int row = P >> 3, pos = P & 7;
       const int c = pos ^ swz_direct(row);
-      const int grow = row0 + row;
+      const int grow = min(row0 + row, rows_total - 1);
       pl.kofs[j] = c * 8;
-      pl.g0[j] = grow < rows_total ? src + (size_t)grow * ld + kbeg + c * 8 : nullptr;
+      pl.cur[j] = src + (size_t)grow * ld + kbeg + c * 8;
     } else {
       constexpr int CPR = R / 8;             // chunks per k row
       const int k = P / CPR, pos = P % CPR;
       const int c = pos ^ swz_trans<R>(k);
-      const int grow = row0 + c * 8;
+      int grow = row0 + c * 8;
+      grow = grow < rows_total ? grow : 0;
       pl.kofs[j] = k;
-      pl.g0[j] = grow < rows_total ? src + (size_t)(kbeg + k) * ld + grow : nullptr;
+      pl.cur[j] = src + (size_t)(kbeg + k) * ld + grow;
     }
   }
 }
 
-// issue the LDS-DMA of K tile `t` (k range [kbeg + 64 t, ...)) of one operand into `stage`
-template <int R, bool TRANS>
-__device__ __forceinline__ void dma_tile(const DmaPlan<R>& pl, int ld, int t, int klen, bf16_t* stage, int wave) {
-  const size_t step = TRANS ? (size_t)64 * ld : (size_t)64;
+// issue the LDS-DMA of the next K tile `t` (k range [kbeg + 64 t, ...)) of one operand into `stage`
+// and advance the plan.  TAIL: the tile crosses (or lies past) kend.
+template <int R, bool TRANS, bool TAIL>
+__device__ __forceinline__ void dma_tile(DmaPlan<R>& pl, size_t step, int t, int klen, uint32_t stage_addr, int wave) {
 #pragma unroll
   for (int j = 0; j < DmaPlan<R>::NINSTR; ++j) {
-    const bool ok = (pl.g0[j] != nullptr) && (t * 64 + pl.kofs[j] < klen);
-    const bf16_t* g = ok ? pl.g0[j] + (size_t)t * step : reinterpret_cast<const bf16_t*>(zk_zero_page);
-    glds16(g, lds_addr(stage) + (uint32_t)(wave * DmaPlan<R>::PER_WAVE + j * 64) * 16u);
+    const bf16_t* g = pl.cur[j];
+    if (TAIL) g = (t * 64 + pl.kofs[j] < klen) ? g : reinterpret_cast<const bf16_t*>(zk_zero_page);
+    glds16(g, stage_addr + (uint32_t)(wave * DmaPlan<R>::PER_WAVE + j * 64) * 16u);
+    pl.cur[j] += step;
   }
 }
 
@@ -161,24 +164,28 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
   dma_plan<BM, TA>(planA, A, lda, m0, M, kbeg, wave, lane);
   dma_plan<BN, !TB>(planB, B, ldb, n0, N, kbeg, wave, lane);
   const int klen = kend - kbeg;
+  const size_t stepA = TA ? (size_t)64 * lda : (size_t)64;
+  const size_t stepB = !TB ? (size_t)64 * ldb : (size_t)64;
+  const uint32_t ring_addr = lds_addr(ring);
+  auto issue = [&](int t) {
+    const uint32_t st = ring_addr + (uint32_t)((t % NS) * STAGE * 2);
+    if (t * 64 + 64 <= klen) {
+      dma_tile<BM, TA, false>(planA, stepA, t, klen, st, wave);
+      dma_tile<BN, !TB, false>(planB, stepB, t, klen, st + BM * 128, wave);
+    } else {
+      dma_tile<BM, TA, true>(planA, stepA, t, klen, st, wave);
+      dma_tile<BN, !TB, true>(planB, stepB, t, klen, st + BM * 128, wave);
+    }
+  };
   // prologue: tiles 0 .. NS-2 (tiles past the end are all-zero pieces: keeps the DMA count uniform)
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s) {
-    bf16_t* st = ring + s * STAGE;
-    dma_tile<BM, TA>(planA, lda, s, klen, st, wave);
-    dma_tile<BN, !TB>(planB, ldb, s, klen, st + BM * 64, wave);
-  }
+  for (int s = 0; s < NS - 1; ++s) issue(s);
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed once at most NS-2 later tiles of this wave are still in flight
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PER_STAGE) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    {
-      const int t = kt + NS - 1;                 // refill the stage everybody finished reading
-      bf16_t* st = ring + (t % NS) * STAGE;
-      dma_tile<BM, TA>(planA, lda, t, klen, st, wave);
-      dma_tile<BN, !TB>(planB, ldb, t, klen, st + BM * 64, wave);
-    }
+    issue(kt + NS - 1);                         // refill the stage everybody finished reading
     const bf16_t* sA = ring + (kt % NS) * STAGE;
     const bf16_t* sB = sA + BM * 64;
     // fragments of k-slice kk+1 are read while the MFMAs of slice kk run (two register sets)
