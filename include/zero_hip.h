@@ -170,8 +170,14 @@ int zk_adam(float* p, const float* g, float* m, float* v, void* shadow_bf16, siz
 int zk_cast_f32_bf16(const float* x, void* y, size_t n, zk_stream_t stream);
 int zk_cast_bf16_f32(const void* x, float* y, size_t n, zk_stream_t stream);
 int zk_zero(void* p, size_t bytes, zk_stream_t stream);
+/* host-only CRC32C of a byte range (seed crc = 0 for a fresh checksum): TensorFlow-bundle checkpoint
+   tensors, utils/saver.py:75,131-170 */
+uint32_t zk_crc32c(const void* data, size_t n, uint32_t crc);
 int zk_spin(uint32_t usec, zk_stream_t stream);   /* measurement aid: occupy the stream for usec (<= 200 ms) */
 int zk_tune(int key, int value);   /* A/B switches for measurements; key 0 = wide LayerNorm-backward kernel */
+/* utils/cycle.py:113-119 (tf.train.ExponentialMovingAverage): ema -= (1 - hyper[8]) * (ema - p); skipped like
+   the Adam update when hyper[6] (gradient norm) is not finite */
+int zk_ema(float* ema, const float* p, const float* hyper, size_t n, zk_stream_t stream);
 int zk_axpby_f32(float* y, const float* x, float a, float b, size_t n, zk_stream_t stream);
 
 /* dropout plumbing */

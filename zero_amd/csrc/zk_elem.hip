@@ -4,6 +4,7 @@
 // token row with shuffle reductions, fp32 math on bf16 storage.  Reference
 // semantics are cited per kernel (paths relative to bzhangGo/zero).
 #include "zk_common.h"
+#include <cstring>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -949,6 +950,26 @@ __global__ void __launch_bounds__(256) k_axpy_f32(float* __restrict__ y, const f
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
     y[i] = by * y[i] + a * x[i];
 }
+// tf.train.ExponentialMovingAverage update after train_op (utils/cycle.py:113-119):
+// shadow -= (1 - d) * (shadow - p), d = hyper[8] (fed per step: min(decay, (1+t)/(10+t)));
+// skipped together with the Adam update when the gradient norm is not finite.
+__global__ void __launch_bounds__(256) k_ema(float* __restrict__ ema, const float* __restrict__ p,
+                                             const float* __restrict__ hyper, size_t n) {
+  const float gnorm = hyper[6], d = hyper[8];
+  if (!(gnorm == gnorm) || fabsf(gnorm) == INFINITY) return;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 e = reinterpret_cast<float4*>(ema)[i];
+    const float4 w = reinterpret_cast<const float4*>(p)[i];
+    e.x -= (1.f - d) * (e.x - w.x); e.y -= (1.f - d) * (e.y - w.y);
+    e.z -= (1.f - d) * (e.z - w.z); e.w -= (1.f - d) * (e.w - w.w);
+    reinterpret_cast<float4*>(ema)[i] = e;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    ema[i] -= (1.f - d) * (ema[i] - p[i]);
+  }
+}
 __global__ void __launch_bounds__(256) k_dropout_mask(float* __restrict__ out, size_t n, uint32_t thr,
                                                       float inv_keep, const uint64_t* __restrict__ seedp,
                                                       uint32_t sid) {
@@ -1320,6 +1341,14 @@ int zk_axpby_f32(float* y, const float* x, float a, float b, size_t n, hipStream
   ZK_LAUNCH_CHECK();
   return 0;
 }
+int zk_ema(float* ema, const float* p, const float* hyper, size_t n, hipStream_t stream) {
+  if (n == 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(ema) | reinterpret_cast<uintptr_t>(p)) & 15)
+    return zk_set_error(-1, "zk_ema: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(k_ema, dim3(flat_grid(n, 4)), dim3(256), 0, stream, ema, p, hyper, n);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
 int zk_dropout_mask(float* out, size_t n, float drop_p, const uint64_t* seed, uint32_t sid,
                     hipStream_t stream) {
   if (n == 0) return 0;
@@ -1333,6 +1362,39 @@ int zk_seed_advance(uint64_t* seed, uint64_t inc, hipStream_t stream) {
   hipLaunchKernelGGL(k_seed_advance, dim3(1), dim3(1), 0, stream, seed, inc);
   ZK_LAUNCH_CHECK();
   return 0;
+}
+
+// Host-side CRC32C (Castagnoli, reflected 0x82f63b78), slicing-by-8: checksums of checkpoint
+// tensors in the TensorFlow bundle format (zero_amd/utils/bundle.py; utils/saver.py:75,131-170).
+// Pure host function: no device work, callable without a GPU.
+static uint32_t g_crc_tab[8][256];
+static bool g_crc_ready = false;
+static void crc_init() {
+  for (uint32_t i = 0; i < 256; ++i) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82f63b78u : c >> 1;
+    g_crc_tab[0][i] = c;
+  }
+  for (uint32_t i = 0; i < 256; ++i)
+    for (int t = 1; t < 8; ++t) g_crc_tab[t][i] = (g_crc_tab[t - 1][i] >> 8) ^ g_crc_tab[0][g_crc_tab[t - 1][i] & 0xff];
+  g_crc_ready = true;
+}
+uint32_t zk_crc32c(const void* data, size_t n, uint32_t crc) {
+  if (!g_crc_ready) crc_init();
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  crc = ~crc;
+  while (n && (reinterpret_cast<uintptr_t>(p) & 7)) { crc = g_crc_tab[0][(crc ^ *p++) & 0xff] ^ (crc >> 8); --n; }
+  while (n >= 8) {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    w ^= crc;
+    crc = g_crc_tab[7][w & 0xff] ^ g_crc_tab[6][(w >> 8) & 0xff] ^ g_crc_tab[5][(w >> 16) & 0xff] ^
+          g_crc_tab[4][(w >> 24) & 0xff] ^ g_crc_tab[3][(w >> 32) & 0xff] ^ g_crc_tab[2][(w >> 40) & 0xff] ^
+          g_crc_tab[1][(w >> 48) & 0xff] ^ g_crc_tab[0][(w >> 56) & 0xff];
+    p += 8; n -= 8;
+  }
+  while (n--) crc = g_crc_tab[0][(crc ^ *p++) & 0xff] ^ (crc >> 8);
+  return ~crc;
 }
 
 // Measurement aid: keeps the stream busy for `usec` so that the launches enqueued behind it are

@@ -1,0 +1,139 @@
+# coding: utf-8
+"""Evaluation loop around the decode / score hot paths (evalu.py of the reference;
+SURVEY.md §8(f)-4).  The TF session + placeholder plumbing is gone: ``decoding`` and ``scoring``
+take the model wrapper (models/model.py) and call ``tower_infer_graph`` / ``tower_score_graph``
+of zero_amd/main.py on each batch.
+
+  decode_target_token  evalu.py:14-22   cut at the first eos **or pad**, map ids to tokens
+  decode_hypothesis    evalu.py:25-46   beam 0 of every sentence (+ its score)
+  decoding             evalu.py:49-139  batches in length-sorted order; returns
+                                        (translations, scores, indices) in *batch* order
+  scoring              evalu.py:142-243 per-sentence scores restored to file order, and
+                                        ppl = exp(sum_s score_s * len_s / sum_s len_s)
+  eval_metric          evalu.py:246-263 BLEU against ``target_file`` (or ``target_file0..``)
+  dump_tanslation      evalu.py:266-280 one line per hypothesis, optionally re-ordered by index
+"""
+
+import logging
+import os
+import time
+
+import numpy as np
+
+from zero_amd.utils import metric, queuer
+
+log = logging.getLogger("zero_amd")
+
+
+def decode_target_token(id_seq, vocab):
+    keep = []
+    for tok in id_seq:
+        tok = int(tok)
+        if tok == vocab.eos() or tok == vocab.pad():
+            break
+        keep.append(tok)
+    return vocab.to_tokens(keep)
+
+
+def decode_hypothesis(seqs, scores, params, mask=None):
+    """``seqs`` / ``scores``: per tower, [B, K, L] ids and [B, K] scores."""
+    if mask is None:
+        mask = [1.] * len(seqs)
+    hypoes, marks = [], []
+    for tower_seqs, tower_scores, m in zip(seqs, scores, mask):
+        if m < 1.:
+            continue
+        for seq, score in zip(tower_seqs, tower_scores):
+            hypoes.append(decode_target_token(seq[0], params.tgt_vocab))
+            marks.append(score[0])
+    return hypoes, marks
+
+
+def _batches(dataset, params):
+    return queuer.EnQueuer(
+        dataset.batcher(params.eval_batch_size, buffer_size=params.buffer_size, shuffle=False, train=False),
+        lambda x: x,
+        worker_processes_num=params.process_num,
+        input_queue_size=params.input_queue_size,
+        output_queue_size=params.output_queue_size,
+    )
+
+
+def decoding(graph, dataset, params, infer=None):
+    """Translate ``dataset``; ``infer(features, graph, params) -> (seqs [B,K,L], scores [B,K])``
+    defaults to zero_amd.main.tower_infer_graph."""
+    if infer is None:
+        from zero_amd.main import tower_infer_graph as infer
+    translations, scores, indices = [], [], []
+    begin = time.time()
+    for bidx, data in enumerate(_batches(dataset, params)):
+        if bidx == 0:
+            begin = time.time()              # reading time excluded, evalu.py:99-101
+        start = time.time()
+        seqs, sc = infer({"source": data['src']}, graph, params)
+        hyp, marks = decode_hypothesis([np.asarray(seqs)], [np.asarray(sc)], params)
+        translations.extend(hyp)
+        scores.extend(float(m) for m in marks)
+        indices.extend(data['index'])
+        log.info("Decoding Batch %s using %.3f s, translating %d sentences using %.3f s in total",
+                 bidx, time.time() - start, len(translations), time.time() - begin)
+    return translations, scores, indices
+
+
+def scoring(graph, dataset, params, score=None):
+    """Per-sentence length-normalised losses in file order and corpus perplexity."""
+    if score is None:
+        from zero_amd.main import tower_score_graph as score
+    scores, indices = [], []
+    total_entropy = total_tokens = 0.
+    for bidx, data in enumerate(_batches(dataset, params)):
+        s = _to_numpy(score({"source": data['src'], "target": data['tgt']}, graph, params))
+        lens = (data['tgt'] > 0).sum(axis=1)
+        total_entropy += float(sum(si * float(li) for si, li in zip(s.tolist(), lens)))
+        total_tokens += float(lens.sum())
+        scores.extend(s.tolist())
+        indices.extend(data['index'])
+    scores = [d[1] for d in sorted(zip(indices, scores), key=lambda x: x[0])]
+    ppl = np.exp(total_entropy / total_tokens)
+    return scores, ppl
+
+
+def _to_numpy(x):
+    if hasattr(x, "detach"):
+        return x.detach().float().cpu().numpy()
+    return np.asarray(x)
+
+
+def fetch_valid_ref_files(path):
+    """utils/util.py:232-251: ``path`` itself, else ``path.ref0, path.ref1, ...``; None (with a
+    warning) if neither exists."""
+    path = os.path.abspath(path)
+    if os.path.exists(path):
+        return [path]
+    files = []
+    while os.path.exists(path + ".ref%s" % len(files)):
+        files.append(path + ".ref%s" % len(files))
+    if not files:
+        log.warning("Invalid Reference Format %s", path)
+        return None
+    return files
+
+
+def eval_metric(trans, target_file, indices=None):
+    files = fetch_valid_ref_files(target_file)
+    if files is None:
+        return 0.0
+    if indices is not None:
+        trans = [d[1] for d in sorted(zip(indices, trans), key=lambda x: x[0])]
+    references = [[line.strip().split() for line in open(f).readlines()] for f in files]
+    return metric.bleu(trans, list(zip(*references)))
+
+
+def dump_tanslation(tranes, output, indices=None):
+    if indices is not None:
+        tranes = [d[1] for d in sorted(zip(indices, tranes), key=lambda x: x[0])]
+    os.makedirs(os.path.dirname(os.path.abspath(output)), exist_ok=True)
+    with open(output, 'w') as writer:
+        for hypo in tranes:
+            writer.write((' '.join(hypo) if isinstance(hypo, list) else str(hypo)) + "\n")
+    log.info("Saving translations into %s", output)

@@ -46,12 +46,14 @@ def parse_header(path=HEADER_PATH):
     text = open(path).read()
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
     protos = {}
-    for m in re.finditer(r"(const char\*|size_t|int)\s+(zk_\w+)\s*\(([^)]*)\)\s*;", text):
+    for m in re.finditer(r"(const char\*|size_t|uint32_t|int)\s+(zk_\w+)\s*\(([^)]*)\)\s*;", text):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         if ret == "int":
             restype = ctypes.c_int
         elif ret == "size_t":
             restype = ctypes.c_size_t
+        elif ret == "uint32_t":
+            restype = ctypes.c_uint32
         else:
             restype = ctypes.c_char_p
         argtypes, argnames = [], []

@@ -140,3 +140,200 @@ class Trainer(object):
         self.store.step += 1
         self.global_step += 1
         return eng.buf("loss", (1,), torch.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# The callers either side of the step (SURVEY.md §8(f)-1,4): main.py:133-466 (train),
+# main.py:469-535 (evaluate), main.py:538-607 (scorer).  Host control flow only; every number
+# comes from the HIP paths above.
+# ---------------------------------------------------------------------------------------------
+import logging
+import os
+import time
+
+import numpy as np
+
+log = logging.getLogger("zero_amd")
+
+
+def _restore(trainer, saver, path=None):
+    from zero_amd.utils.saver import assign_tensors
+    tensors = saver.restore(path)
+    if tensors is None:
+        return False
+    got, missing, step = assign_tensors(trainer.store, trainer.params.scope_name or "model", tensors)
+    for name in missing:
+        log.warning("%s is missed", name)
+    if step is not None and path is None:
+        trainer.global_step = step
+        trainer.store.step = step
+    log.info("restored %d variables (%d missing)", len(got), len(missing))
+    return True
+
+
+def _evaluate_dev(trainer, dataset, params, target_file, tag):
+    from zero_amd import evalu
+    trainer.train_op.ema_backup()
+    trainer.train_op.ema_assign()
+    t0 = time.time()
+    tranes, scores, indices = evalu.decoding(trainer.graph, dataset, params)
+    bleu = evalu.eval_metric(tranes, target_file, indices=indices)
+    trainer.train_op.ema_restore()
+    log.info("GStep %s, Scores %s, BLEU %s, Duration %.3f s", tag, np.mean(scores) if scores else 0.0, bleu,
+             time.time() - t0)
+    evalu.dump_tanslation(tranes, os.path.join(params.output_dir, "eval-{}.trans.txt".format(tag)), indices=indices)
+    return bleu, scores
+
+
+def train(params):
+    """main.py:133-466: epochs over the bitext, update_cycle micro steps per update, periodic
+    save / dev-set BLEU / early stopping, final evaluation.  Returns the best dev score."""
+    from zero_amd.data import Dataset
+    from zero_amd.utils import queuer
+    from zero_amd.utils.saver import Saver, collect_tensors
+    rec = params.recorder
+    if rec.estop or rec.epoch > params.epoches or rec.step > params.max_training_steps:
+        log.info("Stop condition reached, you have finished training your model.")
+        return 0.
+    train_dataset = Dataset(params.src_train_file, params.tgt_train_file, params.src_vocab, params.tgt_vocab,
+                            params.max_len, batch_or_token=params.batch_or_token,
+                            data_leak_ratio=params.data_leak_ratio)
+    dev_dataset = Dataset(params.src_dev_file, params.src_dev_file, params.src_vocab, params.src_vocab,
+                          params.eval_max_len, batch_or_token='batch', data_leak_ratio=params.data_leak_ratio)
+    trainer = Trainer(params)
+    rank, world = parallel.rank(), parallel.world_size()
+    saver = Saver(checkpoints=params.checkpoints, output_dir=params.output_dir,
+                  best_checkpoints=params.best_checkpoints)
+    if params.pretrained_model:
+        _restore(trainer, saver, params.pretrained_model)
+    _restore(trainer, saver)
+    trainer.lr.lrate = rec.lrate
+    scope = params.scope_name or "model"
+
+    def checkpoint(gstep, score=None):
+        if rank == 0:
+            saver.save(collect_tensors(trainer.store, scope, gstep, params), gstep, score)
+            rec.save_to_json(os.path.join(params.output_dir, "record.json"))
+
+    start_time, cum_tokens = time.time(), 0
+    pending = []
+    for epoch in range(rec.epoch, params.epoches + 1):
+        rec.epoch = epoch
+        log.info("Training the model for epoch %d", epoch)
+        size = params.batch_size if params.batch_or_token == 'batch' else params.token_size
+        feed = queuer.EnQueuer(
+            train_dataset.batcher(size, buffer_size=params.buffer_size, shuffle=params.shuffle_batch, train=True),
+            lambda x: x, worker_processes_num=params.process_num,
+            input_queue_size=params.input_queue_size, output_queue_size=params.output_queue_size)
+        trainer.lr.before_epoch(eidx=epoch)
+        for lidx, data in enumerate(feed):
+            if params.train_continue and lidx <= rec.lidx:
+                continue
+            rec.lidx = lidx
+            pending.append(data)          # one batch per tower (main.py:268-273)
+            if len(pending) < world:
+                continue
+            data = pending[rank]
+            pending = []
+            cum_tokens += int(np.sum(data['tgt'] > 0))
+            last = (trainer.cycle_counter + 1) >= params.update_cycle
+            loss = trainer.micro_step({"source": data['src'], "target": data['tgt']})
+            if not last:
+                continue
+            gstep = trainer.global_step
+            if gstep % params.disp_freq == 0 or params.safe_nan:
+                gnorm, pnorm, skipped = trainer.train_op.stats()
+                loss_v = float(loss.cpu()[0]) if hasattr(loss, "cpu") else float(loss)
+                if skipped or not np.isfinite(loss_v) or not np.isfinite(gnorm):
+                    log.error("Nan or Inf raised! Loss %s GNorm %s.", loss_v, gnorm)
+                    if not params.safe_nan:          # main.py:316-319
+                        rec.estop = True
+                        break
+                if gstep % params.disp_freq == 0:
+                    now = time.time()
+                    log.info("Epoch %d, GStep %d~%d, LStep %d~%d, Loss %.3f, GNorm %.3f, PNorm %.3f, Lr %.5f, "
+                             "Src %s, Tgt %s, Tokens %d, UD %.3f s", epoch, gstep - params.disp_freq + 1, gstep,
+                             lidx - params.disp_freq + 1, lidx, loss_v, gnorm, pnorm, trainer.lr.get_lr(),
+                             data['src'].shape, data['tgt'].shape, cum_tokens, now - start_time)
+                    start_time, cum_tokens = now, 0
+            if gstep > 0 and gstep % params.save_freq == 0:
+                checkpoint(gstep)
+            if gstep > 0 and gstep % params.eval_freq == 0:
+                bleu, scores = _evaluate_dev(trainer, dev_dataset, params, params.tgt_dev_file, gstep)
+                checkpoint(gstep, bleu)
+                valid = [v[1] for v in rec.valid_script_scores]
+                if not valid or bleu > np.max(valid):
+                    rec.bad_counter = 0
+                else:
+                    rec.bad_counter += 1
+                    if rec.bad_counter > params.estop_patience:
+                        rec.estop = True
+                        break
+                rec.history_scores.append((int(gstep), float(np.mean(scores)) if scores else 0.0))
+                rec.valid_script_scores.append((int(gstep), float(bleu)))
+                if rank == 0:
+                    rec.save_to_json(os.path.join(params.output_dir, "record.json"))
+                trainer.lr.after_eval(float(bleu))
+            if gstep >= params.max_training_steps:
+                rec.estop = True
+                break
+            rec.step = int(gstep)
+            rec.lrate = trainer.lr.lrate
+        if rec.estop:
+            log.info("Early Stopped!")
+            break
+        rec.lidx = -1
+        trainer.lr.after_epoch(eidx=epoch)
+    log.info("Start Final Evaluating")
+    _evaluate_dev(trainer, dev_dataset, params, params.tgt_dev_file, int(rec.step + 1))
+    log.info("Your training is finished :)")
+    return saver.best_score
+
+
+def _eval_trainer(params):
+    """Model + restored (and, with ema_decay > 0, averaged) weights for test / score modes."""
+    from zero_amd.utils.saver import Saver
+    trainer = Trainer(params)
+    saver = Saver(checkpoints=params.checkpoints, output_dir=params.output_dir)
+    tensors = saver.restore(params.output_dir)
+    if tensors is not None:
+        from zero_amd.utils.saver import assign_tensors
+        scope = params.scope_name or "model"
+        if params.ema_decay > 0.:
+            # main.py:507-514: evaluate with the ExponentialMovingAverage shadows when present
+            for key in list(tensors):
+                ema_key = key + "/ExponentialMovingAverage"
+                if ema_key in tensors:
+                    tensors[key] = tensors[ema_key]
+        assign_tensors(trainer.store, scope, tensors)
+    return trainer
+
+
+def evaluate(params):
+    """main.py:469-535: translate the test set, BLEU against ``tgt_test_file``, dump to
+    ``test_output``."""
+    from zero_amd import evalu
+    from zero_amd.data import Dataset
+    dataset = Dataset(params.src_test_file, params.src_test_file, params.src_vocab, params.src_vocab,
+                      params.eval_max_len, batch_or_token='batch', data_leak_ratio=params.data_leak_ratio)
+    trainer = _eval_trainer(params)
+    t0 = time.time()
+    tranes, scores, indices = evalu.decoding(trainer.graph, dataset, params)
+    bleu = evalu.eval_metric(tranes, params.tgt_test_file, indices=indices)
+    log.info("Scores %s, BLEU %s, Duration %ss", np.mean(scores) if scores else 0.0, bleu, time.time() - t0)
+    evalu.dump_tanslation(tranes, params.test_output, indices=indices)
+    return bleu
+
+
+def scorer(params):
+    """main.py:538-607: per-sentence scores of (src_test_file, tgt_test_file) + perplexity."""
+    from zero_amd import evalu
+    from zero_amd.data import Dataset
+    dataset = Dataset(params.src_test_file, params.tgt_test_file, params.src_vocab, params.tgt_vocab,
+                      params.eval_max_len, batch_or_token='batch', data_leak_ratio=params.data_leak_ratio)
+    trainer = _eval_trainer(params)
+    t0 = time.time()
+    scores, ppl = evalu.scoring(trainer.graph, dataset, params)
+    log.info("Scores %s, PPL %s, Duration %ss", np.mean(scores), ppl, time.time() - t0)
+    evalu.dump_tanslation(scores, params.test_output)
+    return float(np.mean(scores))

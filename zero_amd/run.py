@@ -3,11 +3,12 @@
 
 Same flags (run.py:241-246: --config, --parameters, --name, --mode, --ensemble_dirs), same
 parameter priority -- command line > saved ``param.json`` > ``--config`` dict file >
-defaults (run.py:367-376) -- same ``param.json`` one-line JSON (run.py:250-272).  Only the
-step itself is implemented here (train / score / test on in-memory id batches); the
-reference's data feeding, evaluation cadence and checkpoint rotation are host control plane
-outside the hot path, so ``--mode train`` runs on the synthetic bitext generator unless the
-caller drives :class:`zero_amd.main.Trainer` with its own batches.
+defaults (run.py:367-376) -- same ``param.json`` one-line JSON (run.py:250-272) and
+``record.json`` (run.py:275-293).  With ``src_train_file`` / ``src_test_file`` set the modes run
+the reference's loops over real bitext (zero_amd/main.py train / evaluate / scorer: data feed,
+save / eval cadence, BLEU, early stopping); without data files they fall back to the synthetic
+id generator so the step can be exercised on a bare GPU box.  Model ensembling
+(``--mode ensemble``) is not part of the hot path and is not provided.
 """
 
 import argparse
@@ -70,6 +71,20 @@ def setup(params, synthetic_vocab=32000):
     return params
 
 
+def setup_recorder(params):
+    """run.py:275-293."""
+    from zero_amd.utils.recorder import new_recorder
+    recorder = new_recorder(params)
+    path = os.path.abspath(os.path.join(params.output_dir or ".", "record.json"))
+    if os.path.exists(path):
+        recorder.load_from_json(path)
+    if hasattr(params, "recorder"):
+        params.recorder = recorder
+    else:
+        params.add_hparam("recorder", recorder)
+    return params
+
+
 def synthetic_batches(params, n_batches, sentences=64, length=64):
     rng = np.random.default_rng(params.random_seed)
     for _ in range(n_batches):
@@ -92,7 +107,20 @@ def main(argv=None):
     from zero_amd.main import Trainer, tower_infer_graph, tower_score_graph
     from zero_amd.models import model, load_all
     load_all()
-    if args.mode == "train":
+    import logging
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s %(message)s")
+    from zero_amd import main as loops
+    from zero_amd.utils import parallel
+    parallel.init_distributed()
+    if args.mode == "train" and params.src_train_file:
+        save_parameters(params, params.output_dir or ".")
+        setup_recorder(params)
+        print(json.dumps({"best_score": loops.train(params)}))
+    elif args.mode == "test" and params.src_test_file:
+        print(json.dumps({"bleu": loops.evaluate(params)}))
+    elif args.mode == "score" and params.src_test_file:
+        print(json.dumps({"score": loops.scorer(params)}))
+    elif args.mode == "train":
         if params.output_dir:
             save_parameters(params, params.output_dir)
         tr = Trainer(params)

@@ -27,9 +27,15 @@ class TrainOp(object):
     def __init__(self, store, params, engine):
         self.store, self.hp, self.eng = store, params, engine
         dev = store.device
-        self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.hyper = torch.zeros(12, dtype=torch.float32, device=dev)   # [0:6] host scalars, 6 gnorm, 7 skipped, 8 ema decay
         self.hyper_host = torch.zeros(6, dtype=torch.float32).pin_memory() if dev.type == "cuda" \
             else torch.zeros(6, dtype=torch.float32)
+        self.ema_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" \
+            else torch.zeros(1, dtype=torch.float32)
+        self.ema = None          # tf.train.ExponentialMovingAverage shadows (cycle.py:113-127), on demand
+        self._backup = None
+        if getattr(params, "ema_decay", -1.) > 0.:
+            self.ema = store.master.clone()      # shadows start at the variables' initial values
         self.pnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.count = 0
         self._ws = torch.empty(hip.lib().query("zk_norm_workspace") * 2, dtype=torch.uint8, device=dev)
@@ -63,6 +69,11 @@ class TrainOp(object):
         h = self.hyper_host
         h[0], h[1], h[2], h[3], h[4], h[5] = lr_t, hp.beta1, hp.beta2, hp.epsilon, scale, clip
         self.hyper[:6].copy_(h, non_blocking=True)
+        if self.ema is not None:
+            # num_updates = global_step after this update (ema.apply runs under train_op's control
+            # dependency, cycle.py:116-118): d = min(decay, (1 + n) / (10 + n))
+            self.ema_host[0] = min(float(hp.ema_decay), (1.0 + t) / (10.0 + t))
+            self.hyper[8:9].copy_(self.ema_host, non_blocking=True)
         return scale
 
     def launch_update(self, scale):
@@ -75,6 +86,24 @@ class TrainOp(object):
         lib.call("zk_adam", st.master.data_ptr(), st.grad.data_ptr(), st.m.data_ptr(), st.v.data_ptr(),
                  st.shadow.data_ptr(), st.numel, self.hyper.data_ptr(), self.pnorm.data_ptr(),
                  self._ws.data_ptr() + nb, nb, s)
+        if self.ema is not None:
+            lib.call("zk_ema", self.ema.data_ptr(), st.master.data_ptr(), self.hyper.data_ptr(), st.numel, s)
+
+    # cycle.py:120-127: evaluate with the averaged weights, then put the raw ones back
+    def ema_backup(self):
+        if self.ema is not None:
+            self._backup = self.store.master.clone()
+
+    def ema_assign(self):
+        if self.ema is not None:
+            self.store.master.copy_(self.ema)
+            self.store.refresh_shadow()
+
+    def ema_restore(self):
+        if self.ema is not None and self._backup is not None:
+            self.store.master.copy_(self._backup)
+            self.store.refresh_shadow()
+            self._backup = None
 
     def apply(self, lr, world=1, launch=True):
         st = self.store

@@ -43,6 +43,10 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
 def layer_buckets(store):
     """Contiguous [lo, hi) element ranges of the flat gradient buffer in the order the
     backward finishes them: softmax/target embedding, decoder layers (last first), encoder
