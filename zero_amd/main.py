@@ -243,7 +243,7 @@ def train(params):
             gstep = trainer.global_step
             if gstep % params.disp_freq == 0 or params.safe_nan:
                 gnorm, pnorm, skipped = trainer.train_op.stats()
-                loss_v = float(loss.cpu()[0]) if hasattr(loss, "cpu") else float(loss)
+                loss_v = float(loss.reshape(-1)[0].cpu()) if hasattr(loss, "cpu") else float(loss)
                 if skipped or not np.isfinite(loss_v) or not np.isfinite(gnorm):
                     log.error("Nan or Inf raised! Loss %s GNorm %s.", loss_v, gnorm)
                     if not params.safe_nan:          # main.py:316-319
