@@ -153,6 +153,10 @@ int zk_all_equal(const int* ids, int n, int value, int* flag, zk_stream_t stream
 /* ---- transformer_aan.py:92-117,165-192 average attention network (train-time scan + gate) */
 int zk_aan_fwd(const void* x, const float* mask, void* cat, int B, int L, int H, int use_mask,
                zk_stream_t stream);
+/* use_mask bit 0: aan_mask (run.py:117); bit 1 (backward only): dcat[:, H:] is already folded into dyg
+   (the use_ffn variant, transformer_aan.py:176-183) */
+int zk_add_bf16(void* out, int ldo, const void* a, int lda, const void* b, int ldb, int rows, int cols,
+                zk_stream_t stream);
 int zk_aan_bwd(const void* dcat, const void* dxg, const void* dyg, const void* ds, const float* mask, void* dx,
                int B, int L, int H, int use_mask, zk_stream_t stream);
 int zk_aan_gate_fwd(const void* z, const void* cat, void* out, int rows, int H, zk_stream_t stream);
@@ -192,6 +196,14 @@ int zk_beam_topk(const float* logits, const float* prev_log_probs, float* topk_s
 /* search.py:198-210 beam reordering: dst row r <- src row index[r] (NULL: r); bytes, multiples of 16 */
 int zk_gather_rows(const void* src, size_t src_stride, const int* index, void* dst, size_t dst_stride, int rows,
                    size_t row_bytes, zk_stream_t stream);
+/* transformer_fuse (func.py:258-275) merged attention: the averaged v_map(query) term summed into the
+   cross-attention heads.  train: out = att + cumavg_mask(vq) and its transpose; decode: cache += vq,
+   att += cache/(t+1) (func.py:262-272) */
+int zk_cumavg_add_fwd(const void* vq, const float* mask, const void* att, void* out, int B, int L, int H,
+                      zk_stream_t stream);
+int zk_cumavg_bwd(const void* dy, const float* mask, void* dvq, int B, int L, int H, zk_stream_t stream);
+int zk_fuse_decode(const void* vq, float* cache, void* att, int rows, int H, float inv_count, const int* time_dev,
+                   zk_stream_t stream);
 /* transformer_aan.py:110-112: cache += x; cat = [x | cache/(t+1)] */
 int zk_aan_decode(const void* x, float* cache, void* cat, int rows, int H, float inv_count, const int* time_dev,
                   zk_stream_t stream);

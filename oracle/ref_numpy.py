@@ -53,7 +53,7 @@ def _keep_cols(ids):
     return ids[:, keep]
 
 
-def _mha(xq, xkv, P, scope, nh, key_bias, causal, rpr, max_rel):
+def _mha(xq, xkv, P, scope, nh, key_bias, causal, rpr, max_rel, fuse_mask=None):
     """func.py:164-286.  xq [B,Lq,H]; xkv None (self) or [B,Lk,H];
     key_bias [B,Lk] additive (0 / -INF) or None."""
     H = xq.shape[-1]
@@ -91,6 +91,12 @@ def _mha(xq, xkv, P, scope, nh, key_bias, causal, rpr, max_rel):
         if rpr:
             oh = oh + np.einsum("bqk,qkc->bqc", w, Rv)
         out[..., h * d:(h + 1) * d] = oh
+    if fuse_mask is not None:
+        # func.py:258-275: averaged v_map(query) over valid positions j <= i (zero on pad rows)
+        m = fuse_mask
+        vq = xq @ P[s + "v_map/W_0_0"] + P[s + "v_map/b_0"]
+        cm = np.cumsum(m, axis=1)
+        out = out + np.cumsum(vq * m[..., None], axis=1) / np.maximum(cm, 1.0)[..., None] * m[..., None]
     return out @ P[s + "o_map/W_0_0"] + P[s + "o_map/b_0"]
 
 
@@ -143,6 +149,12 @@ def decode_full(tgt, enc, smask, hp, P, model):
     rpr = model == "transformer_rpr"
     for l in range(hp.num_decoder_layer):
         s = "decoder/layer_%d" % l
+        if model == "transformer_fuse":
+            # transformer_fuse.py:131-160
+            x = _lnp(x + _mha(x, enc, P, s + "/fuse_attention", hp.num_heads, kb, False, False,
+                              hp.max_relative_position, fuse_mask=m), P, s + "/fuse_attention")
+            x = _lnp(x + _ffn(x, P, s + "/feed_forward"), P, s + "/feed_forward")
+            continue
         if model == "transformer_aan":
             a = s + "/average_attention"
             if hp.aan_mask:

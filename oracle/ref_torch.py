@@ -71,6 +71,7 @@ def variable_specs(hp, model_name):
     d = H // hp.num_heads
     rpr = model_name == "transformer_rpr"
     aan = model_name == "transformer_aan"
+    fuse = model_name == "transformer_fuse"
     nrel = 2 * hp.max_relative_position + 1
     Vs, Vt = hp.src_vocab.size(), hp.tgt_vocab.size()
     specs = []
@@ -89,6 +90,13 @@ def variable_specs(hp, model_name):
         specs.append(("tgt_embedding", (Vt, E), "embed", None))
     for l in range(hp.num_decoder_layer):
         pre = "decoder/layer_%d" % l
+        if fuse:
+            # transformer_fuse.py:131-160: one merged attention sub-layer, then the FFN
+            for n, s, k in _attn_vars(pre + "/fuse_attention", H, False, False, nrel, d):
+                specs.append((n, s, k, l))
+            for n, s, k in _ffn_vars(pre + "/feed_forward", H, Fs):
+                specs.append((n, s, k, l))
+            continue
         if aan:
             a = pre + "/average_attention"
             if hp.use_ffn:
@@ -232,8 +240,11 @@ def relative_attention_inner(x, y, z, transpose):
 
 def dot_attention(query, memory, mem_mask, H, P, scope, num_heads, cache=None,
                   drop=None, use_rpr=False, max_rel=16, decode_step=None,
-                  training=True):
-    """func.py:164-286 (no fuse_mask, out_map=True)."""
+                  training=True, fuse_mask=None):
+    """func.py:164-286 (out_map=True).  fuse_mask (func.py:258-275): the [B,L,L] averaging matrix
+    during training, the time step (number) while decoding."""
+    if fuse_mask is not None:
+        assert memory is not None, 'Fuse mechanism only applied with cross-attention'
     scope = scope + "/dot_attention"
     if memory is None:
         h = linear(query, P, scope + "/qkv_map")
@@ -274,6 +285,15 @@ def dot_attention(query, memory, mem_mask, H, P, scope, num_heads, cache=None,
     else:
         o = torch.matmul(dweights, v)
     o = combine_heads(o)
+    if fuse_mask is not None:
+        v_q = linear(query, P, scope + "/v_map")        # shares v_map with the memory side
+        if cache is not None and 'aan' in cache:
+            aan_o = (v_q + cache['aan']) / float(fuse_mask + 1)
+        else:
+            aan_o = torch.matmul(fuse_mask, v_q)
+        if cache is not None:
+            cache['aan'] = v_q if 'aan' not in cache else v_q + cache['aan']
+        o = o + aan_o
     o = linear(o, P, scope + "/o_map")
     return {'weights': weights, 'output': o, 'cache': cache}
 
@@ -397,7 +417,7 @@ def encoder(source, hp, P, model_name, training=True):
         y = ffn_layer(x, P, pre + "/feed_forward", hp.relu_dropout, training)
         x = layer_norm(residual_fn(x, y, hp.residual_dropout, training), P, pre + "/feed_forward")
     B = x.shape[0]
-    if model_name == "transformer_aan":
+    if model_name in ("transformer_aan", "transformer_fuse"):
         dec_init = {"layer_%d" % l: {"aan": torch.zeros(B, 1, H, dtype=dt)}
                     for l in range(hp.num_decoder_layer)}
     else:
@@ -447,6 +467,18 @@ def decoder(target, state, hp, P, model_name, training=True):
     for l in range(hp.num_decoder_layer):
         pre = "decoder/layer_%d" % l
         lcache = None if is_training else state['decoder']['state']['layer_%d' % l]
+        if model_name == "transformer_fuse":
+            # transformer_fuse.py:131-160
+            r = dot_attention(x, state['encodes'], attention_bias(state['mask'], "masking"), H, P,
+                              pre + "/fuse_attention", hp.num_heads, cache=lcache,
+                              drop=hp.attention_dropout, training=training,
+                              fuse_mask=attention_bias(mask, "aan") if is_training else state['time'])
+            if not is_training:
+                lcache.update(r['cache'])
+            x = layer_norm(residual_fn(x, r['output'], hp.residual_dropout, training), P, pre + "/fuse_attention")
+            y = ffn_layer(x, P, pre + "/feed_forward", hp.relu_dropout, training)
+            x = layer_norm(residual_fn(x, y, hp.residual_dropout, training), P, pre + "/feed_forward")
+            continue
         if aan:
             assert [s.lower() for s in hp.strategies] == ["aan"]
             y = average_attention(x, mask, state, l, hp, is_training)

@@ -5,7 +5,7 @@
    modules from /root/reference (lrs/noamlr.py, vocab.py).  These are the only reference
    code paths that can execute here (no TensorFlow); they pin the host-side scalars.
 2. ``tiny_<model>.npz`` -- inputs and expected outputs of the CPU oracle (fp64 torch
-   restatement, cross-checked against the numpy restatement) for the three registered
+   restatement, cross-checked against the numpy restatement) for the four registered
    models on a tiny config: parameters by reference variable name, ids, loss, per-sentence
    loss, gradient norms, beam-search results (beam 1 and 4, cache mode).
    PARITY UNPINNED: these are restatement outputs, TF1 itself was never executed.
@@ -86,6 +86,6 @@ def tiny_fixture(model):
 if __name__ == "__main__":
     with open(os.path.join(HERE, "reference_scalars.json"), "w") as f:
         json.dump(reference_scalars(), f, indent=1, sort_keys=True)
-    for m in ("transformer", "transformer_aan", "transformer_rpr"):
+    for m in ("transformer", "transformer_aan", "transformer_rpr", "transformer_fuse"):
         np.savez_compressed(os.path.join(HERE, "tiny_%s.npz" % m), **tiny_fixture(m))
     print("golden fixtures written to", HERE)

@@ -20,7 +20,7 @@ from zero_amd.models._factory import get_core, reset_cores  # noqa: E402
 from zero_amd.models import model as registry, load_all  # noqa: E402
 
 load_all()
-MODELS = ["transformer", "transformer_aan", "transformer_rpr"]
+MODELS = ["transformer", "transformer_aan", "transformer_rpr", "transformer_fuse"]
 
 
 def _setup(model, seed=0, **kw):
@@ -244,3 +244,26 @@ def test_beam_search_token_ids(model, K):
               (model, K, mode, same, len(hyp), np.abs(scores[:, 0] - ref["score"][:, 0]).max()))
         assert same == len(hyp), (hyp, hyp_ref)
     assert np.array_equal(outs["cache"][0], outs["dev"][0])
+
+
+def test_aan_use_ffn_variant():
+    """transformer_aan.py:176-183: an FFN between the cumulative average and the gate (use_ffn=True,
+    off by default in run.py:119): loss / gradients of the extra ffn_layer variables, beam ids."""
+    model = "transformer_aan"
+    hp, Pn, src, tgt = _setup(model, seed=2, use_ffn=True, aan_mask=True)
+    assert "decoder/layer_0/average_attention/ffn_layer/enlarge/W_0_0" in Pn
+    ref_loss, ref_ps, ref_G = _oracle(hp, Pn, src, tgt, model)
+    out = registry.get_model(model).train_fn({"source": src, "target": tgt}, hp, initializer=Pn)
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"].cpu()) - ref_loss) / abs(ref_loss) < 1e-3
+    G = out["store"].export("grad")
+    gmax = max(np.linalg.norm(v) for v in ref_G.values())
+    for k, ref in ref_G.items():
+        if np.linalg.norm(ref) < 1e-3 * gmax:
+            continue
+        err = np.linalg.norm(G[k] - ref) / np.linalg.norm(ref)
+        assert err < 1.2e-1, (k, err)
+    Pn["tgt_embedding"] = (Pn["tgt_embedding"] * 6.0).astype(np.float32)
+    ref, outs = _decode_both(model, 4, hp, Pn, src)
+    from zero_amd.search import decode_hypothesis
+    assert decode_hypothesis(outs["cache"][0], hp) == rt.decode_hypothesis(ref["seq"], hp)

@@ -54,7 +54,7 @@ def test_parse_override_json_roundtrip():
 
 def test_registry_contract():
     load_all()
-    for name in ("transformer", "transformer_aan", "transformer_rpr", "TRANSFORMER"):
+    for name in ("transformer", "transformer_aan", "transformer_rpr", "transformer_fuse", "TRANSFORMER"):
         m = registry.get_model(name)
         assert callable(m.train_fn) and callable(m.score_fn) and callable(m.infer_fn)
     with pytest.raises(Exception) as e:
@@ -83,7 +83,7 @@ def test_vocab_and_noam_against_reference_values():
         assert lr.get_lr() == pytest.approx(val, rel=1e-12)
 
 
-@pytest.mark.parametrize("model", ["transformer", "transformer_aan", "transformer_rpr"])
+@pytest.mark.parametrize("model", ["transformer", "transformer_aan", "transformer_rpr", "transformer_fuse"])
 def test_variable_names_match_the_oracles(model):
     from oracle import ref_torch as rt
     hp = make_hp(model, Vs=13, Vt=11)

@@ -140,6 +140,25 @@ __global__ void __launch_bounds__(256) k_aan_decode(const bf16_t* __restrict__ x
   *reinterpret_cast<uint4*>(cat + r * 2 * H + H + c) = pack8(o);
 }
 
+// transformer_fuse decode step (func.py:262-272): cache += vq;  att += cache / (time + 1)
+__global__ void __launch_bounds__(256) k_fuse_decode(const bf16_t* __restrict__ vq, float* __restrict__ cache,
+                                                     bf16_t* __restrict__ att, int rows, int H, float inv_count,
+                                                     const int* __restrict__ time_dev) {
+  if (time_dev != nullptr) inv_count = 1.f / (float)(*time_dev + 1);
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int nc = H / 8;
+  if (idx >= (size_t)rows * nc) return;
+  const size_t r = idx / nc;
+  const int c = (int)(idx % nc) * 8;
+  float v[8], o[8];
+  unpack8(*reinterpret_cast<const uint4*>(vq + r * H + c), v);
+  unpack8(*reinterpret_cast<const uint4*>(att + r * H + c), o);
+  float* cp = cache + r * H + c;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const float s = cp[j] + v[j]; cp[j] = s; o[j] += s * inv_count; }
+  *reinterpret_cast<uint4*>(att + r * H + c) = pack8(o);
+}
+
 extern "C" {
 
 // logits: fp32 [B*K, ld]; prev_log_probs: fp32 [B*K]; outputs fp32/int32 [B, k2]
@@ -189,6 +208,17 @@ int zk_aan_decode(const void* x, float* cache, void* cat, int rows, int H, float
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_aan_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, cache,
                      (bf16_t*)cat, rows, H, inv_count, time_dev);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_fuse_decode(const void* vq, float* cache, void* att, int rows, int H, float inv_count, const int* time_dev,
+                   hipStream_t stream) {
+  ZK_CHECK_ARG(H % 8 == 0, "zk_fuse_decode: H=%d must be a multiple of 8", H);
+  const size_t n = (size_t)rows * (H / 8);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_fuse_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)vq, cache,
+                     (bf16_t*)att, rows, H, inv_count, time_dev);
   ZK_LAUNCH_CHECK();
   return 0;
 }

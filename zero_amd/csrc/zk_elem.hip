@@ -769,6 +769,8 @@ __global__ void __launch_bounds__(256) k_aan_bwd(const bf16_t* __restrict__ dcat
                                                  const bf16_t* __restrict__ dyg, const bf16_t* __restrict__ ds,
                                                  const float* __restrict__ mask, bf16_t* __restrict__ dx,
                                                  int B, int L, int H, int use_mask) {
+  const bool skip_dc2 = (use_mask & 2) != 0;   // dcat[:, H:] already folded into dyg by the caller (use_ffn)
+  use_mask &= 1;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const int nc = H / 8;
   if (idx >= B * nc) return;
@@ -791,12 +793,81 @@ __global__ void __launch_bounds__(256) k_aan_bwd(const bf16_t* __restrict__ dcat
     const float wj = use_mask ? m : 1.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      run[j] += a * (g2[j] + dc2[j]);
+      run[j] += a * (g2[j] + (skip_dc2 ? 0.f : dc2[j]));
       o[j] = d0[j] + g1[j] + dc1[j] + wj * run[j];
     }
     *reinterpret_cast<uint4*>(dx + r * H + c) = pack8(o);
     cnt -= m;
   }
+}
+
+// transformer_fuse (func.py:258-275, training branch): the simplified average-attention term that is
+// summed into the cross-attention heads before o_map.  With fuse_mask = attention_bias(mask, "aan")
+// (func.py:390-398):  att[b,t,:] += m_t * sum_{s<=t} m_s vq[b,s,:] / max(sum_{s<=t} m_s, 1).
+__global__ void __launch_bounds__(256) k_cumavg_add_fwd(const bf16_t* __restrict__ vq, const float* __restrict__ mask,
+                                                        const bf16_t* att, bf16_t* out, int B, int L, int H) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int nc = H / 8;
+  if (idx >= B * nc) return;
+  const int b = idx / nc, c = (idx % nc) * 8;
+  float run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float cnt = 0.f;
+  for (int t = 0; t < L; ++t) {
+    const size_t r = (size_t)b * L + t;
+    const float m = mask[r];
+    float v[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(vq + r * H + c), v);
+    unpack8(*reinterpret_cast<const uint4*>(att + r * H + c), o);
+    cnt += m;
+    const float a = m / fmaxf(cnt, 1.f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      run[j] += m * v[j];
+      o[j] += a * run[j];
+    }
+    *reinterpret_cast<uint4*>(out + r * H + c) = pack8(o);
+  }
+}
+// its transpose: dvq[b,s,:] = m_s * sum_{t>=s} (m_t / max(cnt_t, 1)) * dy[b,t,:]
+__global__ void __launch_bounds__(256) k_cumavg_bwd(const bf16_t* __restrict__ dy, const float* __restrict__ mask,
+                                                    bf16_t* __restrict__ dvq, int B, int L, int H) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int nc = H / 8;
+  if (idx >= B * nc) return;
+  const int b = idx / nc, c = (idx % nc) * 8;
+  float cnt = 0.f;
+  for (int t = 0; t < L; ++t) cnt += mask[(size_t)b * L + t];
+  float run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int t = L - 1; t >= 0; --t) {
+    const size_t r = (size_t)b * L + t;
+    const float m = mask[r];
+    const float a = m / fmaxf(cnt, 1.f);
+    float g[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(dy + r * H + c), g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      run[j] += a * g[j];
+      o[j] = m * run[j];
+    }
+    *reinterpret_cast<uint4*>(dvq + r * H + c) = pack8(o);
+    cnt -= m;
+  }
+}
+
+// out = a + b on bf16 row blocks with independent leading dimensions (cols % 8 == 0)
+__global__ void __launch_bounds__(256) k_add_bf16(bf16_t* __restrict__ out, int ldo, const bf16_t* __restrict__ a,
+                                                  int lda, const bf16_t* __restrict__ b, int ldb, int rows, int cols) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int nc = cols / 8;
+  if (idx >= (size_t)rows * nc) return;
+  const size_t r = idx / nc;
+  const int c = (int)(idx % nc) * 8;
+  float x[8], y[8];
+  unpack8(*reinterpret_cast<const uint4*>(a + r * lda + c), x);
+  unpack8(*reinterpret_cast<const uint4*>(b + r * ldb + c), y);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] += y[j];
+  *reinterpret_cast<uint4*>(out + r * ldo + c) = pack8(x);
 }
 
 // gate (transformer_aan.py:186-189): i,f = split(z); out = sigmoid(i)*x + sigmoid(f)*y
@@ -1261,6 +1332,38 @@ int zk_aan_bwd(const void* dcat, const void* dxg, const void* dyg, const void* d
   hipLaunchKernelGGL(k_aan_bwd, dim3((n + 255) / 256), dim3(256), 0, stream, (const bf16_t*)dcat,
                      (const bf16_t*)dxg, (const bf16_t*)dyg, (const bf16_t*)ds, mask, (bf16_t*)dx, B, L, H,
                      use_mask);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_cumavg_add_fwd(const void* vq, const float* mask, const void* att, void* out, int B, int L, int H,
+                      hipStream_t stream) {
+  ZK_CHECK_ARG(H % 8 == 0, "zk_cumavg_add_fwd: H=%d must be a multiple of 8", H);
+  const int n = B * (H / 8);
+  if (n == 0 || L == 0) return 0;
+  hipLaunchKernelGGL(k_cumavg_add_fwd, dim3((n + 255) / 256), dim3(256), 0, stream, (const bf16_t*)vq, mask,
+                     (const bf16_t*)att, (bf16_t*)out, B, L, H);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+int zk_cumavg_bwd(const void* dy, const float* mask, void* dvq, int B, int L, int H, hipStream_t stream) {
+  ZK_CHECK_ARG(H % 8 == 0, "zk_cumavg_bwd: H=%d must be a multiple of 8", H);
+  const int n = B * (H / 8);
+  if (n == 0 || L == 0) return 0;
+  hipLaunchKernelGGL(k_cumavg_bwd, dim3((n + 255) / 256), dim3(256), 0, stream, (const bf16_t*)dy, mask,
+                     (bf16_t*)dvq, B, L, H);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_add_bf16(void* out, int ldo, const void* a, int lda, const void* b, int ldb, int rows, int cols,
+                hipStream_t stream) {
+  ZK_CHECK_ARG(cols % 8 == 0 && ldo % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0,
+               "zk_add_bf16: cols=%d and leading dimensions must be multiples of 8", cols);
+  const size_t n = (size_t)rows * (cols / 8);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_add_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (bf16_t*)out, ldo,
+                     (const bf16_t*)a, lda, (const bf16_t*)b, ldb, rows, cols);
   ZK_LAUNCH_CHECK();
   return 0;
 }

@@ -321,6 +321,13 @@ class Engine(object):
         self.lib.call("zk_aan_bwd", dcat.ptr, dxg.ptr, dyg.ptr, ds.ptr, mask.data_ptr(), dx.ptr, B, L, H,
                       1 if use_mask else 0, self.stream)
 
+    # ---- merged attention of transformer_fuse (func.py:258-275) ------------------------------
+    def cumavg_add_fwd(self, vq, mask, att, out, B, L, H):
+        self.lib.call("zk_cumavg_add_fwd", vq.ptr, mask.data_ptr(), att.ptr, out.ptr, B, L, H, self.stream)
+
+    def cumavg_bwd(self, dy, mask, dvq, B, L, H):
+        self.lib.call("zk_cumavg_bwd", dy.ptr, mask.data_ptr(), dvq.ptr, B, L, H, self.stream)
+
     def aan_gate_fwd(self, z, cat, out, rows, H):
         self.lib.call("zk_aan_gate_fwd", z.ptr, cat.ptr, out.ptr, rows, H, self.stream)
 

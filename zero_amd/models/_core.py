@@ -51,8 +51,10 @@ class TransformerCore(object):
         self.d = self.H // self.nh
         self.rpr = model_name == "transformer_rpr"
         self.aan = model_name == "transformer_aan"
-        if self.aan and params.use_ffn:
-            raise NotImplementedError("transformer_aan with use_ffn=True is not on the HIP path yet")
+        # transformer_fuse (transformer_fuse.py:131-160): no decoder self-attention; one merged
+        # sub-layer = cross-attention + averaged v_map(query) (func.py:258-275), then the FFN
+        self.fuse = model_name == "transformer_fuse"
+        self.cross = "fuse_attention" if self.fuse else "cross_attention"
         if self.aan and [s.lower() for s in params.strategies] != ["aan"]:
             raise NotImplementedError("Not supported: {}".format(params.strategies))
         shared = params.shared_source_target_embedding
@@ -80,6 +82,7 @@ class TransformerCore(object):
         self._pending_wgrads = []
         self._pending_colsums = []     # (dY Mat, bias-gradient view, private partial buffer)
         self._pending_lnred = []       # (partials, rows, H, dgamma, dbeta, dbias_prev)
+        self._pending_adds = []        # (fp32 gradient view, fp32 temporary): dst += src after the flush
         self._red_id = 0
         self.side = torch.cuda.Stream(self.eng.device) if self.eng.device.type == "cuda" else None
 
@@ -105,6 +108,14 @@ class TransformerCore(object):
             cs, ln = self._pending_colsums, self._pending_lnred
             self._pending_colsums, self._pending_lnred = [], []
             self._side(lambda: self.eng.reductions_grouped(cs, ln))
+        if self._pending_adds:
+            adds = self._pending_adds
+            self._pending_adds = []
+            self._side(lambda: [self._accumulate(dst, src) for dst, src in adds])
+
+    def _accumulate(self, dst, src):
+        """dst += src (fp32 gradient views of equal size)."""
+        self.eng.lib.call("zk_axpby_f32", dst.data_ptr(), src.data_ptr(), 1.0, 1.0, dst.numel(), self.eng.stream)
 
     def _join_side(self):
         if self.use_side:
@@ -133,22 +144,35 @@ class TransformerCore(object):
         self.eng.gemm(x, Wm, out, x.rows, Wm.cols, Wm.rows, 0, 0, bias=self.b(scope + "/b_0"), act=act,
                       drop_p=drop_p, sid=sid)
 
-    def _linear_bwd(self, x, dy, scope, dx=None, residual=None, bias_grad=True, act=0, aux=None, aux_scale=1.0):
-        """dW = x^T dy (fp32, overwrite), db = colsum(dy), dx = dy @ W^T (+residual)."""
+    def _linear_bwd(self, x, dy, scope, dx=None, residual=None, bias_grad=True, act=0, aux=None, aux_scale=1.0,
+                    accumulate=False):
+        """dW = x^T dy (fp32, overwrite), db = colsum(dy), dx = dy @ W^T (+residual).
+        accumulate: the variable is used twice in the graph (v_map of the merged attention); this
+        use's gradients go to temporaries that are added once the overwriting use has run."""
         Wm = self.W(scope + "/W_0_0")
+        gW, gb = self.gW(scope + "/W_0_0"), self.gb(scope + "/b_0")
+        adds = []
+        if accumulate:
+            tW = self.eng.buf("g.acc.W." + scope, tuple(gW.t.shape), F32)
+            tb = self.eng.buf("g.acc.b." + scope, tuple(gb.shape), F32)
+            adds = [(gW.t, tW)] + ([(gb, tb)] if bias_grad else [])
+            gW, gb = Mat(tW, gW.rows, gW.cols), tb
 
         if self.group_wgrad and self.eng.gemm_impl == 0:
-            self._pending_wgrads.append((x, dy, self.gW(scope + "/W_0_0"), Wm.rows, Wm.cols, x.rows, None))
+            self._pending_wgrads.append((x, dy, gW, Wm.rows, Wm.cols, x.rows, None))
             if bias_grad:
                 gy = self.eng.lib.raw("zk_colsum_rowchunks")(dy.rows)
                 pw = self.eng.buf("g.cs%d" % len(self._pending_colsums) + scope, (gy * dy.cols,), F32)
-                self._pending_colsums.append((dy, self.gb(scope + "/b_0"), pw))
+                self._pending_colsums.append((dy, gb, pw))
+            self._pending_adds += adds
         else:
             def wgrad():
-                self.eng.gemm(x, dy, self.gW(scope + "/W_0_0"), Wm.rows, Wm.cols, x.rows, 1, 0)
+                self.eng.gemm(x, dy, gW, Wm.rows, Wm.cols, x.rows, 1, 0)
                 if bias_grad:
-                    self.eng.colsum(dy, self.gb(scope + "/b_0"))
+                    self.eng.colsum(dy, gb)
             self._side(wgrad)
+            # the overwriting use of the variable must already have run: callers issue it first
+            self._pending_adds += adds
         if dx is not None:
             self.eng.gemm(dy, Wm, dx, dy.rows, Wm.rows, Wm.cols, 0, 1, residual=residual, act=act, aux=aux,
                           aux_scale=aux_scale)
@@ -192,14 +216,15 @@ class TransformerCore(object):
         e, H = self.eng, self.H
         probs = []
         for l in range(n_layers):
-            p = "decoder/layer_%d/cross_attention/dot_attention/" % l
+            p = "decoder/layer_%d/%s/dot_attention/" % (l, self.cross)
             kv = e.mat("d%d.ca.kv" % l, mem.rows, 2 * H)
             for nm, c0 in (("k_map", 0), ("v_map", H)):
                 Wm = self.W(p + nm + "/W_0_0")
                 probs.append((mem, Wm, kv.cols_slice(c0, c0 + H), mem.rows, H, H, self.b(p + nm + "/b_0")))
         self._side(lambda: e.gemm_grouped(probs, 0, 0))
 
-    def _cross_attn_fwd(self, x, mem, B, Lq, Lk, scope, tag, kmask, save, sid0, train, kv_ready=False):
+    def _cross_attn_fwd(self, x, mem, B, Lq, Lk, scope, tag, kmask, save, sid0, train, kv_ready=False,
+                        fuse_tmask=None):
         e, H = self.eng, self.H
         hp = self.hp
         p = scope + "/dot_attention/"
@@ -216,6 +241,13 @@ class TransformerCore(object):
         e.attn_fwd(q, kv.cols_slice(0, H), kv.cols_slice(H, 2 * H), att, lse, B, self.nh, Lq, Lk, self.d,
                    kmask=kmask, causal=False, rpr_k=rk, rpr_v=rv, max_rel=hp.max_relative_position,
                    drop_p=hp.attention_dropout if train else 0.0, sid=sid0)
+        if fuse_tmask is not None:
+            # func.py:258-275: o += average over valid positions j <= i of v_map(query)
+            vq = e.mat("tmp.vq%d" % x.rows, x.rows, H)
+            self._linear(x, p + "v_map", vq)
+            atts = e.mat(tag + ".atts", x.rows, H)
+            e.cumavg_add_fwd(vq, fuse_tmask, att, atts, B, Lq, H)
+            att = atts
         y = e.mat("tmp.y%d" % x.rows, x.rows, H)
         self._linear(att, p + "o_map", y)
         return self._ln_fwd(x, y, scope, tag, save, hp.residual_dropout if train else 0.0, sid0 + 1)
@@ -236,6 +268,14 @@ class TransformerCore(object):
         T = x.rows
         cat = e.mat(tag + ".cat", T, 2 * H)
         e.aan_fwd(x, tmask, cat, B, L, H, hp.aan_mask)
+        if hp.use_ffn:
+            # transformer_aan.py:176-183: y = ffn_layer(average) (no residual / LN of its own)
+            ya = e.mat(tag + ".ya", T, H)
+            e.lib.call("zk_gather_rows", cat.ptr + H * 2, 2 * H * 2, None, ya.ptr, H * 2, T, H * 2, e.stream)
+            h = e.mat(tag + ".h", T, self.F)
+            self._linear(ya, scope + "/ffn_layer/enlarge", h, act=1, drop_p=hp.relu_dropout if train else 0.0,
+                         sid=sid0 + 2)
+            self._linear(h, scope + "/ffn_layer/output", cat.cols_slice(H, 2 * H))
         z = e.mat(tag + ".z", T, 2 * H)
         self._linear(cat, scope + "/z_project", z)
         g = e.mat("tmp.y%d" % T, T, H)
@@ -301,14 +341,17 @@ class TransformerCore(object):
         self._linear_bwd(x_in, dqkv, p + "qkv_map", dx=dx_out, residual=ds)
         return dx_out
 
-    def _cross_attn_bwd(self, dx, x_in, mem, d_mem, B, Lq, Lk, scope, tag, kmask, sid0, side, dx_out):
+    def _cross_attn_bwd(self, dx, x_in, mem, d_mem, B, Lq, Lk, scope, tag, kmask, sid0, side, dx_out,
+                        fuse_tmask=None):
         e, hp, H = self.eng, self.hp, self.H
         p = scope + "/dot_attention/"
         T = dx.rows
         ds, dy = self._ln_bwd(dx, scope, tag, p + "o_map/b_0", hp.residual_dropout, sid0 + 1, side)
         att = e.mat(tag + ".att", T, H)
         datt = e.mat("g.%s.datt" % tag, T, H)
-        self._linear_bwd(att, dy, p + "o_map", dx=datt, bias_grad=False)
+        # merged attention: o_map saw att + averaged v_map(query); both terms get the same gradient
+        self._linear_bwd(e.mat(tag + ".atts", T, H) if fuse_tmask is not None else att, dy, p + "o_map",
+                         dx=datt, bias_grad=False)
         q = e.mat(tag + ".q", T, H)
         kv = e.mat(tag + ".kv", mem.rows, 2 * H)
         dq = e.mat("g.%s.dq" % tag, T, H)
@@ -326,6 +369,12 @@ class TransformerCore(object):
         # memory side: gradients of all decoder layers accumulate in d_mem (in place)
         self._linear_bwd(mem, dkv.cols_slice(0, H), p + "k_map", dx=d_mem, residual=d_mem)
         self._linear_bwd(mem, dkv.cols_slice(H, 2 * H), p + "v_map", dx=d_mem, residual=d_mem)
+        if fuse_tmask is not None:
+            # query side of the shared v_map: transpose of the averaging, then dgrad into dx and
+            # wgrad / bias-grad ADDED to what the memory side wrote
+            dvq = e.mat("g.%s.dvq" % tag, T, H)
+            e.cumavg_bwd(datt, fuse_tmask, dvq, B, Lq, H)
+            self._linear_bwd(x_in, dvq, p + "v_map", dx=dx_out, residual=dx_out, accumulate=True)
         return dx_out
 
     def _aan_bwd(self, dx, B, L, scope, tag, tmask, sid0, side, dx_out):
@@ -340,7 +389,21 @@ class TransformerCore(object):
         e.aan_gate_bwd(dg, z, cat, dz, dxg, dyg, T, H)
         dcat = e.mat("g.%s.dcat" % tag, T, 2 * H)
         self._linear_bwd(cat, dz, scope + "/z_project", dx=dcat)
-        e.aan_bwd(dcat, dxg, dyg, ds, tmask, dx_out, B, L, H, hp.aan_mask)
+        flags = 1 if hp.aan_mask else 0
+        if hp.use_ffn:
+            # through the FFN that sits between the average and the gate
+            dyp = e.mat("g.%s.dyp" % tag, T, H)
+            e.lib.call("zk_add_bf16", dyp.ptr, H, dyg.ptr, dyg.ld, dcat.ptr + H * 2, 2 * H, T, H, e.stream)
+            h = e.mat(tag + ".h", T, self.F)
+            dh = e.mat("g.%s.dh" % tag, T, self.F)
+            rp = hp.relu_dropout
+            self._linear_bwd(h, dyp, scope + "/ffn_layer/output", dx=dh, act=2, aux=h,
+                             aux_scale=1.0 / (1.0 - rp) if rp > 0 else 1.0)
+            dya = e.mat("g.%s.dya" % tag, T, H)
+            self._linear_bwd(e.mat(tag + ".ya", T, H), dh, scope + "/ffn_layer/enlarge", dx=dya)
+            dyg, flags = dya, flags | 2
+        e.lib.call("zk_aan_bwd", dcat.ptr, dxg.ptr, dyg.ptr, ds.ptr, tmask.data_ptr(), dx_out.ptr, B, L, H, flags,
+                   e.stream)
         return dx_out
 
     # ------------------------------------------------------------------ whole model
@@ -431,13 +494,13 @@ class TransformerCore(object):
             sid = 100 * (NE + l)
             if self.aan:
                 x = self._aan_fwd(x, B, Lt, pre + "/average_attention", "d%d.aa" % l, tmask, save, sid + 1, train)
-            else:
+            elif not self.fuse:
                 x = self._self_attn_fwd(x, B, Lt, pre + "/self_attention", "d%d.sa" % l, None, True, save,
                                         sid + 1, train)
             if group_kv and l == 0:
                 self._join_side()
-            x = self._cross_attn_fwd(x, enc, B, Lt, Ls, pre + "/cross_attention", "d%d.ca" % l, smask, save,
-                                     sid + 11, train, kv_ready=group_kv)
+            x = self._cross_attn_fwd(x, enc, B, Lt, Ls, pre + "/" + self.cross, "d%d.ca" % l, smask, save,
+                                     sid + 11, train, kv_ready=group_kv, fuse_tmask=tmask if self.fuse else None)
             x = self._ffn_fwd(x, pre + "/feed_forward", "d%d.ff" % l, save, sid + 21, train)
         return x, tmask, w
 
@@ -504,7 +567,7 @@ class TransformerCore(object):
         def layer_input(side, l, kind):
             # output of the sub-layer preceding `kind` in layer l == its residual input
             if side == "d":
-                order = (["aa"] if self.aan else ["sa"]) + ["ca", "ff"]
+                order = ([] if self.fuse else ["aa"] if self.aan else ["sa"]) + ["ca", "ff"]
             else:
                 order = ["sa", "ff"]
             i = order.index(kind)
@@ -522,15 +585,17 @@ class TransformerCore(object):
                           P[cur ^ 1])
             cur ^= 1
             self._cross_attn_bwd(P[cur], layer_input("d", l, "ca"), enc, d_enc, B, Lt, Ls,
-                                 pre + "/cross_attention", "d%d.ca" % l, smask, sid + 11, "d", P[cur ^ 1])
+                                 pre + "/" + self.cross, "d%d.ca" % l, smask, sid + 11, "d", P[cur ^ 1],
+                                 fuse_tmask=tmask if self.fuse else None)
             cur ^= 1
             if self.aan:
                 self._aan_bwd(P[cur], B, Lt, pre + "/average_attention", "d%d.aa" % l, tmask, sid + 1, "d",
                               P[cur ^ 1])
-            else:
+                cur ^= 1
+            elif not self.fuse:
                 self._self_attn_bwd(P[cur], layer_input("d", l, "sa"), B, Lt, pre + "/self_attention",
                                     "d%d.sa" % l, None, True, sid + 1, "d", P[cur ^ 1])
-            cur ^= 1
+                cur ^= 1
             ready_d.append(pre)
             if len(ready_d) >= self.group_layers or l == 0:
                 self._flush_wgrads()

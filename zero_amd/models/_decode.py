@@ -83,12 +83,12 @@ def make_infer_fns(params, model_name):
                       "encodes": enc_keep, "mask": mask_keep, "time_filled": 0,
                       "decoder": {"state": {}}})
         for l in range(hp.num_decoder_layer):
-            p = "decoder/layer_%d/cross_attention/dot_attention/" % l
+            p = "decoder/layer_%d/%s/dot_attention/" % (l, core.cross)
             kv = e.mat("dc%d.kv" % l, B * Ls, 2 * H)
             core._linear(enc_keep, p + "k_map", kv.cols_slice(0, H))
             core._linear(enc_keep, p + "v_map", kv.cols_slice(H, 2 * H))
             lay = {"mk": kv.cols_slice(0, H), "mv": kv.cols_slice(H, 2 * H), "_pp": 0}
-            if core.aan:
+            if core.aan or core.fuse:
                 a = e.buf("dc%d.aan.0" % l, (BK, H), F32)
                 e.zero(a)
                 lay["aan"] = a
@@ -107,7 +107,7 @@ def make_infer_fns(params, model_name):
         state["ts"] = e.buf("bs.ts", (B, 2 * K), torch.float32)
         state["ti"] = e.buf("bs.ti", (B, 2 * K), torch.int32)
         state["graphs"] = {}
-        state["static_ok"] = core.aan          # every launch argument of an AAN step is static
+        state["static_ok"] = core.aan or core.fuse   # every launch argument of an AAN / merged-attention step is static
         return state
 
     def step_static(state, temperature, forbid_value):
@@ -160,12 +160,18 @@ def make_infer_fns(params, model_name):
                 e.lib.call("zk_aan_decode", x.ptr, lay["aan"].data_ptr(), cat.ptr, BK, H,
                            1.0 if time_dev is not None else 1.0 / float(time + 1),
                            time_dev.data_ptr() if time_dev is not None else None, e.stream)
+                if hp.use_ffn:           # transformer_aan.py:176-183
+                    ya = e.mat("dc.ya", BK, H)
+                    e.lib.call("zk_gather_rows", cat.ptr + H * 2, 2 * H * 2, None, ya.ptr, H * 2, BK, H * 2, e.stream)
+                    hh = e.mat("dc.aah", BK, core.F)
+                    core._linear(ya, a + "/ffn_layer/enlarge", hh, act=1)
+                    core._linear(hh, a + "/ffn_layer/output", cat.cols_slice(H, 2 * H))
                 z = e.mat("dc.z", BK, 2 * H)
                 core._linear(cat, a + "/z_project", z)
                 g = e.mat("dc.y", BK, H)
                 e.aan_gate_fwd(z, cat, g, BK, H)
                 x = core._ln_fwd(x, g, a, "dc%d.aa" % l, False, 0.0, 0)
-            else:
+            elif not core.fuse:
                 p = pre + "/self_attention/dot_attention/"
                 qkv = e.mat("dc.qkv", BK, 3 * H)
                 core._linear(x, p + "qkv_map", qkv)
@@ -181,7 +187,7 @@ def make_infer_fns(params, model_name):
                 y = e.mat("dc.y", BK, H)
                 core._linear(att, p + "o_map", y)
                 x = core._ln_fwd(x, y, pre + "/self_attention", "dc%d.sa" % l, False, 0.0, 0)
-            p = pre + "/cross_attention/dot_attention/"
+            p = pre + "/" + core.cross + "/dot_attention/"
             q = e.mat("dc.q", BK, H)
             core._linear(x, p + "q_map", q)
             att = e.mat("dc.att", BK, H)
@@ -190,9 +196,16 @@ def make_infer_fns(params, model_name):
             e.attn_fwd(q, lay["mk"], lay["mv"], att, None, BK, nh, 1, Ls, d, kmask=state["mask"], causal=False,
                        q_pos0=time if time is not None else 0, rpr_k=rk, rpr_v=rv, max_rel=hp.max_relative_position, bsq=H,
                        bsk=Ls * 2 * H, bsv=Ls * 2 * H, kv_group=K)
+            if core.fuse:
+                # func.py:258-272: v_q = v_map(query); cache += v_q; o += cache / (time + 1)
+                vq = e.mat("dc.vq", BK, H)
+                core._linear(x, p + "v_map", vq)
+                e.lib.call("zk_fuse_decode", vq.ptr, lay["aan"].data_ptr(), att.ptr, BK, H,
+                           1.0 if time_dev is not None else 1.0 / float(time + 1),
+                           time_dev.data_ptr() if time_dev is not None else None, e.stream)
             y = e.mat("dc.y", BK, H)
             core._linear(att, p + "o_map", y)
-            x = core._ln_fwd(x, y, pre + "/cross_attention", "dc%d.ca" % l, False, 0.0, 0)
+            x = core._ln_fwd(x, y, pre + "/" + core.cross, "dc%d.ca" % l, False, 0.0, 0)
             x = core._ffn_fwd(x, pre + "/feed_forward", "dc%d.ff" % l, False, 0, False)
         logits = e.mat("dc.logits", BK, core.Vpad, F32)
         e.gemm(x, core.W(core.soft_emb), logits, BK, core.V, H, 0, 1)

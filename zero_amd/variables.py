@@ -56,7 +56,7 @@ def _ffn_specs(prefix, H, F, with_ln=True):
 def variable_specs(params, model_name):
     """[(name, logical_shape, kind, layer)] in the reference's creation order
     (transformer.py:16-33,88-102,184-192; transformer_aan.py:165-192;
-    transformer_rpr.py:54-55,144-146,167-169)."""
+    transformer_rpr.py:54-55,144-146,167-169; transformer_fuse.py:131-160)."""
     H, E, F = params.hidden_size, params.embed_size, params.filter_size
     if H != E:
         raise ValueError("hidden_size must equal embed_size for the Transformer models "
@@ -64,6 +64,7 @@ def variable_specs(params, model_name):
     d = H // params.num_heads
     rpr = model_name == "transformer_rpr"
     aan = model_name == "transformer_aan"
+    fuse = model_name == "transformer_fuse"
     nrel = 2 * params.max_relative_position + 1
     Vs, Vt = params.src_vocab.size(), params.tgt_vocab.size()
     shared = params.shared_source_target_embedding
@@ -77,6 +78,10 @@ def variable_specs(params, model_name):
         specs.append(("tgt_embedding", (Vt, E), "embed", None))
     for l in range(params.num_decoder_layer):
         pre = "decoder/layer_%d" % l
+        if fuse:      # transformer_fuse.py:131-160: merged attention sub-layer + FFN
+            specs += [(n, s, k, l) for n, s, k in _attn_specs(pre + "/fuse_attention", H, False, False, nrel, d)]
+            specs += [(n, s, k, l) for n, s, k in _ffn_specs(pre + "/feed_forward", H, F)]
+            continue
         if aan:
             a = pre + "/average_attention"
             if params.use_ffn:
