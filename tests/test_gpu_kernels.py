@@ -235,7 +235,9 @@ ATT_CASES = [(2, 2, 64, 64, False, False), (3, 2, 37, 53, True, False), (2, 3, 5
              (2, 2, 70, 130, True, False), (1, 2, 130, 130, False, True), (2, 8, 64, 64, True, False)]
 
 
-@pytest.mark.parametrize("impl", [1, 2])
+# impl 1 = reference kernels, 2 = MFMA (single-tile cases take the fused backward), 3 = MFMA backward
+# forced to the two-kernel dQ / dK,dV form (forward falls to the reference kernel)
+@pytest.mark.parametrize("impl", [1, 2, 3])
 @pytest.mark.parametrize("case", ATT_CASES)
 def test_attention_d64(impl, case):
     B, nh, Lq, Lk, um, causal = case
@@ -245,7 +247,7 @@ def test_attention_d64(impl, case):
     assert errs["dq"] < 2.5e-2 and errs["dk"] < 2.5e-2 and errs["dv"] < 2.5e-2, errs
 
 
-@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("impl", [1, 2, 3])
 def test_attention_dropout(impl):
     errs = _attn_case(impl, 2, 2, 64, 64, 64, True, False, drop=0.2)
     print(errs)

@@ -642,6 +642,153 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv_mfma(AttnArgs a, const bf1
   }
 }
 
+// ---- backward, single tile (Lq <= 64 and Lk <= 64): grid (1, nh, B) -> dQ, dK, dV in ONE pass.
+// The two-kernel form above reads Q, K, V, dO twice and recomputes S and dP; at the training
+// shapes of the north star (L = 64) a whole (batch, head) problem is one 64x64 tile, so one
+// workgroup computes P and dS once (wave w owns query rows 16w..16w+15) and all three gradients
+// follow from LDS: dQ = dS K, dK = dS^T Q, dV = P^T dO.  The operand tiles of the first phase are
+// dead by then and their LDS is reused for dS, P^T and dS^T (7 tiles = 64.5 KB -> 2 workgroups/CU).
+__global__ void __launch_bounds__(256) k_attn_bwd_fused64(AttnArgs a, const bf16_t* __restrict__ o, int ldo,
+                                                          const bf16_t* __restrict__ dout, int lddo,
+                                                          const float* __restrict__ lse,
+                                                          bf16_t* __restrict__ dq, int lddq,
+                                                          bf16_t* __restrict__ dk, int lddk,
+                                                          bf16_t* __restrict__ dv, int lddv) {
+  __shared__ __attribute__((aligned(16))) bf16_t sQ[TQ * ALD];    // phase 2: dS   [query][key]
+  __shared__ __attribute__((aligned(16))) bf16_t sK[TQ * ALD];    // phase 2: P^T  [key][query]
+  __shared__ __attribute__((aligned(16))) bf16_t sV[TQ * ALD];    // phase 2: dS^T [key][query]
+  __shared__ __attribute__((aligned(16))) bf16_t sdO[TQ * ALD];
+  __shared__ __attribute__((aligned(16))) bf16_t sKt[TQ * ALD];
+  __shared__ __attribute__((aligned(16))) bf16_t sQt[TQ * ALD];
+  __shared__ __attribute__((aligned(16))) bf16_t sdOt[TQ * ALD];
+  __shared__ float sD[TQ];
+  __shared__ float sL[TQ];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* qb = a.q + (size_t)b * a.bsq + h * AD;
+  const bf16_t* kb = a.k + (size_t)b * a.bsk + h * AD;
+  const bf16_t* vb = a.v + (size_t)b * a.bsv + h * AD;
+  const bf16_t* ob = o + (size_t)b * a.Lq * ldo + h * AD;
+  const bf16_t* dob = dout + (size_t)b * a.Lq * lddo + h * AD;
+  const uint64_t seed = a.thr ? *a.seed : 0;
+
+  stage_direct(sQ, qb, a.ldq, 0, a.Lq, tid);
+  stage_direct(sdO, dob, lddo, 0, a.Lq, tid);
+  stage_direct(sK, kb, a.ldk, 0, a.Lk, tid);
+  stage_direct(sV, vb, a.ldv, 0, a.Lk, tid);
+  if (tid < 128) {
+    stage_trans(sKt, kb, a.ldk, 0, a.Lk, tid);
+  } else {
+    stage_trans(sQt, qb, a.ldq, 0, a.Lq, tid - 128);
+    stage_trans(sdOt, dob, lddo, 0, a.Lq, tid - 128);
+  }
+  {  // D_i = sum_c dO[i][c] * O[i][c]; 4 threads per row
+    const int r = tid >> 2, part = tid & 3;
+    float acc = 0.f;
+    if (r < a.Lq) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float x[8], y[8];
+        unpack8(*reinterpret_cast<const uint4*>(dob + (size_t)r * lddo + part * 16 + u * 8), x);
+        unpack8(*reinterpret_cast<const uint4*>(ob + (size_t)r * ldo + part * 16 + u * 8), y);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc += x[c] * y[c];
+      }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (part == 0) {
+      sD[r] = acc;
+      sL[r] = (r < a.Lq) ? lse[((size_t)b * a.nh + h) * a.Lq + r] : 0.f;
+    }
+  }
+  __syncthreads();
+  // ---- phase 1: P and dS of query rows 16w .. 16w+15 against all 64 keys, kept in registers
+  const int rloc = w * 16 + (lane >> 4) * 4;
+  float pv[4][4], dsv[4][4];
+  {
+    const uint4 q0 = frag(sQ, w * 16, 0, lane), q1 = frag(sQ, w * 16, 1, lane);
+    const uint4 g0 = frag(sdO, w * 16, 0, lane), g1 = frag(sdO, w * 16, 1, lane);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      f32x4_t sc4 = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      sc4 = mfma16(q0, frag(sK, nt * 16, 0, lane), sc4);
+      sc4 = mfma16(q1, frag(sK, nt * 16, 1, lane), sc4);
+      dp = mfma16(g0, frag(sV, nt * 16, 0, lane), dp);
+      dp = mfma16(g1, frag(sV, nt * 16, 1, lane), dp);
+      const int j = nt * 16 + (lane & 15);
+      const bool kvalid = j < a.Lk;
+      float kbias = 0.f;
+      if (kvalid && a.kmask != nullptr && a.kmask[(size_t)b * a.Lk + j] == 0.f) kbias = -a.mask_inf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = rloc + r;
+        float sc = sc4[r] * a.scale + kbias;
+        if (a.causal && j > a.q_pos0 + i) sc -= a.mask_inf;
+        const float p = (kvalid && i < a.Lq) ? __expf(sc - sL[i]) : 0.f;
+        float ms = 1.f;
+        if (a.thr) {
+          const uint64_t idx = (((uint64_t)b * a.nh + h) * a.Lq + i) * a.Lk + j;
+          ms = zk_drop_scale(seed, a.sid, idx, a.thr, a.inv_keep);
+        }
+        pv[nt][r] = p * ms;
+        dsv[nt][r] = p * (dp[r] * ms - sD[i]) * a.scale;
+      }
+    }
+  }
+  __syncthreads();                     // every wave is done reading sQ / sK / sV / sdO
+  bf16_t* sdS = sQ;
+  bf16_t* sPt = sK;
+  bf16_t* sdSt = sV;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int j = nt * 16 + (lane & 15);
+    uint2 pp, dd;
+    pp.x = (uint32_t)f2bf(pv[nt][0]) | ((uint32_t)f2bf(pv[nt][1]) << 16);
+    pp.y = (uint32_t)f2bf(pv[nt][2]) | ((uint32_t)f2bf(pv[nt][3]) << 16);
+    dd.x = (uint32_t)f2bf(dsv[nt][0]) | ((uint32_t)f2bf(dsv[nt][1]) << 16);
+    dd.y = (uint32_t)f2bf(dsv[nt][2]) | ((uint32_t)f2bf(dsv[nt][3]) << 16);
+    *reinterpret_cast<uint2*>(sPt + j * ALD + rloc) = pp;       // 4 consecutive queries of key row j
+    *reinterpret_cast<uint2*>(sdSt + j * ALD + rloc) = dd;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sdS[(rloc + r) * ALD + j] = f2bf(dsv[nt][r]);
+  }
+  __syncthreads();
+  // ---- phase 2: wave w -> dQ rows 16w.. (queries) and dK / dV rows 16w.. (keys)
+  f32x4_t dQ[4], dK[4], dV[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    dQ[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    dK[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    dV[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const uint4 da = frag(sdS, w * 16, kk, lane);
+    const uint4 pa = frag(sPt, w * 16, kk, lane);
+    const uint4 dt = frag(sdSt, w * 16, kk, lane);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      dQ[nb] = mfma16(da, frag(sKt, nb * 16, kk, lane), dQ[nb]);
+      dV[nb] = mfma16(pa, frag(sdOt, nb * 16, kk, lane), dV[nb]);
+      dK[nb] = mfma16(dt, frag(sQt, nb * 16, kk, lane), dK[nb]);
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int c = chan_of_phys(nb * 16 + (lane & 15));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = rloc + r;     // query row for dQ, key row for dK / dV
+      if (i < a.Lq) dq[((size_t)b * a.Lq + i) * lddq + h * AD + c] = f2bf(dQ[nb][r]);
+      if (i < a.Lk) {
+        dk[((size_t)b * a.Lk + i) * lddk + h * AD + c] = f2bf(dK[nb][r]);
+        dv[((size_t)b * a.Lk + i) * lddv + h * AD + c] = f2bf(dV[nb][r]);
+      }
+    }
+  }
+}
+
 // =====================================================================================
 // C-ABI
 // =====================================================================================
@@ -730,7 +877,14 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
   float* Dbuf = (float*)workspace;
   const bool ok = attn_mfma_ok(a, ldo | lddo | lddq | lddk | lddv);
   ZK_CHECK_ARG(impl != 2 || ok, "zk_attn_bwd: MFMA kernel needs d=64, no rpr, ld%%8==0");
-  if (impl == 2 || (impl == 0 && ok)) {
+  ZK_CHECK_ARG(impl != 3 || ok, "zk_attn_bwd: MFMA kernels need d=64, no rpr, ld%%8==0");
+  if ((impl == 0 || impl == 2) && ok && Lq <= TQ && Lk <= TQ) {      // impl 3 forces the two-kernel form
+    hipLaunchKernelGGL(k_attn_bwd_fused64, dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
+                       (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv);
+    ZK_LAUNCH_CHECK();
+    return 0;
+  }
+  if (impl == 2 || impl == 3 || (impl == 0 && ok)) {
     hipLaunchKernelGGL(k_attn_bwd_dq_mfma, dim3((Lq + TQ - 1) / TQ, nh, B), dim3(256), 0, stream, a,
                        (const bf16_t*)out, ldo, (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, Dbuf);
     ZK_LAUNCH_CHECK();
