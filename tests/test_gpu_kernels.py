@@ -600,3 +600,74 @@ def test_gather_rows():
     e.lib.call("zk_gather_rows", src.data_ptr(), 160, idx.data_ptr(), dst.data_ptr(), 256, 4, 32 * 4, e.stream)
     torch.cuda.synchronize()
     assert max_err(dst[:, :32], src[idx.long(), :32]) == 0 and float(dst[:, 32:].abs().max()) == 0
+
+
+# ------------------------------------------------------------------ merged attention / EMA helpers
+@pytest.mark.parametrize("B,L,H", [(3, 7, 64), (2, 64, 512), (5, 1, 16)])
+def test_cumavg_add_fwd_bwd(B, L, H):
+    """func.py:258-275 + 390-398: out = att + W vq with W = row-normalised causal∧valid matrix."""
+    e = eng()
+    vq = rand_bf(B * L, H, seed=1); att = rand_bf(B * L, H, seed=2); dy = rand_bf(B * L, H, seed=3)
+    mask = torch.ones(B, L, device="cuda")
+    for b in range(1, B):
+        mask[b, max(1, L - b):] = 0
+    if L > 3:
+        mask[0, 2] = 0                       # a hole in the middle of a row
+    out = torch.empty_like(att); dvq = torch.empty_like(vq)
+    e.cumavg_add_fwd(mat(vq), mask, mat(att), mat(out), B, L, H)
+    e.cumavg_bwd(mat(dy), mask, mat(dvq), B, L, H)
+    torch.cuda.synchronize()
+    m = mask
+    pair = m[:, None, :] * m[:, :, None] * torch.tril(torch.ones(L, L, device="cuda"))[None]
+    W = torch.softmax(pair + (1 - pair) * -1e8, -1) * pair
+    v = vq.float().view(B, L, H).clone().requires_grad_(True)
+    ref = att.float().view(B, L, H) + W @ v
+    ref.backward(dy.float().view(B, L, H))
+    assert rel_err(out.view(B, L, H), ref) < 6e-3
+    assert rel_err(dvq.view(B, L, H), v.grad) < 6e-3
+    # in place (out aliases att) gives the same result
+    att2 = att.clone()
+    e.cumavg_add_fwd(mat(vq), mask, mat(att2), mat(att2), B, L, H)
+    torch.cuda.synchronize()
+    assert torch.equal(att2, out)
+
+
+def test_fuse_decode_and_add_bf16():
+    e = eng()
+    rows, H = 12, 64
+    vq = rand_bf(rows, H, seed=4); att = rand_bf(rows, H, seed=5)
+    cache = torch.randn(rows, H, device="cuda")
+    ref_cache = cache + vq.float()
+    ref_att = att.float() + ref_cache / 4.0
+    tdev = torch.tensor([3], dtype=torch.int32, device="cuda")
+    c1, a1 = cache.clone(), att.clone()
+    e.lib.call("zk_fuse_decode", vq.data_ptr(), c1.data_ptr(), a1.data_ptr(), rows, H, 0.25, None, e.stream)
+    c2, a2 = cache.clone(), att.clone()
+    e.lib.call("zk_fuse_decode", vq.data_ptr(), c2.data_ptr(), a2.data_ptr(), rows, H, 1.0, tdev.data_ptr(), e.stream)
+    torch.cuda.synchronize()
+    assert max_err(c1, ref_cache) < 1e-6 and rel_err(a1, ref_att) < 5e-3
+    assert torch.equal(c1, c2) and torch.equal(a1, a2)          # host scalar == device time step
+    a = rand_bf(rows, 3 * H, seed=6); b = rand_bf(rows, 2 * H, seed=7)
+    out = torch.zeros(rows, H, dtype=torch.bfloat16, device="cuda")
+    e.lib.call("zk_add_bf16", out.data_ptr(), H, a.data_ptr() + H * 2, 3 * H, b.data_ptr() + H * 2, 2 * H, rows, H,
+               e.stream)
+    torch.cuda.synchronize()
+    assert rel_err(out, a[:, H:2 * H].float() + b[:, H:].float()) < 5e-3
+
+
+def test_ema_kernel_and_skip():
+    e = eng()
+    n = 1000 * 4 + 3
+    p = torch.randn(n, device="cuda"); ema = torch.randn(n, device="cuda")
+    hyper = torch.zeros(12, device="cuda")
+    hyper[6], hyper[8] = 1.5, 0.9
+    want = ema - (1 - 0.9) * (ema - p)
+    got = ema.clone()
+    e.lib.call("zk_ema", got.data_ptr(), p.data_ptr(), hyper.data_ptr(), n, e.stream)
+    torch.cuda.synchronize()
+    assert max_err(got, want) < 1e-6
+    hyper[6] = float("nan")                  # non-finite gradient norm: the update (and the EMA) is skipped
+    got2 = ema.clone()
+    e.lib.call("zk_ema", got2.data_ptr(), p.data_ptr(), hyper.data_ptr(), n, e.stream)
+    torch.cuda.synchronize()
+    assert torch.equal(got2, ema)
