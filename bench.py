@@ -223,7 +223,9 @@ def main():
     src, tgt = synthetic_batch(rank)
     tr.prepare_static({"source": src, "target": tgt})
     tr.core.eng.set_seed(1234 + rank)
-    use_graph = (world == 1) and not args.no_graph
+    # one rank: the whole step is one hipGraph; several ranks: hipGraph segments between the
+    # gradient-bucket hand-offs to RCCL (Trainer._step_segmented)
+    use_graph = not args.no_graph
 
     def barrier():
         if world > 1:
@@ -278,7 +280,7 @@ def main():
                                "B=64 x (src 64 + tgt 64) tokens per GPU, dropout %.2f, label_smooth 0.1, "
                                "fwd+bwd+allreduce+Adam" % args.dropout,
                    "global_batch_tokens": world * B * (LS + LT), "parallelism": "dp%d" % world,
-                   "hip_graph": bool(use_graph)},
+                   "hip_graph": ("whole step" if world == 1 else "segments between all-reduce buckets") if use_graph else False},
         "loss": loss_v, "gnorm": gnorm, "update_skipped": skipped,
         "step_mfma_frac": flops / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12),
     }

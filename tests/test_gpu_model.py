@@ -184,6 +184,30 @@ def test_hipgraph_replay_equals_eager_steps():
     assert abs(runs["eager"][2][0] - runs["graph"][2][0]) < 1e-6 * runs["eager"][2][0]
 
 
+def test_segmented_graph_step_equals_eager(monkeypatch):
+    # the data-parallel step replays hipGraph SEGMENTS cut at every gradient-bucket hand-off
+    # (Trainer._step_segmented); with one rank the hand-offs are no-ops and the result must equal
+    # the eager launch sequence bit for bit
+    from zero_amd.main import Trainer
+    hp, Pn, src, tgt = _setup("transformer_aan")
+    runs = {}
+    for mode in ("eager", "segmented"):
+        monkeypatch.setenv("ZERO_HIP_FORCE_SEGMENTED", "1" if mode == "segmented" else "0")
+        monkeypatch.setenv("ZERO_HIP_GROUP_LAYERS", "1")          # many hand-offs
+        reset_cores()
+        tr = Trainer(hp, initializer=Pn)
+        tr.prepare_static({"source": src, "target": tgt})
+        losses = [float(tr.step_static(use_graph=(mode == "segmented")).cpu()[0]) for _ in range(4)]
+        torch.cuda.synchronize()
+        runs[mode] = (losses, tr.store.export("master")["encoder/layer_0/feed_forward/ffn_layer/enlarge/W_0_0"])
+        if mode == "segmented":
+            plan = [v for k, v in tr._graphs.items() if k[0] == "seg"][0]
+            kinds = [k for k, _ in plan]
+            assert kinds.count("ready") >= 4 and kinds[-1] == "update" and kinds[0] == "graph"
+    assert runs["eager"][0] == runs["segmented"][0]
+    assert np.array_equal(runs["eager"][1], runs["segmented"][1])
+
+
 def test_update_cycle_accumulates_like_cycle_py():
     from zero_amd.main import Trainer
     hp, Pn, src, tgt = _setup("transformer", update_cycle=2)

@@ -1531,6 +1531,12 @@ int zk_graph_end(hipStream_t stream, void** exec_out) {
   hipGraph_t graph = nullptr;
   hipError_t e = hipStreamEndCapture(stream, &graph);
   if (e != hipSuccess) return zk_set_error((int)e, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  size_t n_nodes = 0;
+  if (graph == nullptr || hipGraphGetNodes(graph, nullptr, &n_nodes) != hipSuccess || n_nodes == 0) {
+    if (graph) hipGraphDestroy(graph);      // nothing was captured: a null handle that launches as a no-op
+    *exec_out = nullptr;
+    return 0;
+  }
   hipGraphExec_t exec = nullptr;
   e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
   hipGraphDestroy(graph);
@@ -1539,6 +1545,7 @@ int zk_graph_end(hipStream_t stream, void** exec_out) {
   return 0;
 }
 int zk_graph_launch(void* exec, hipStream_t stream) {
+  if (exec == nullptr) return 0;
   hipError_t e = hipGraphLaunch((hipGraphExec_t)exec, stream);
   if (e != hipSuccess) return zk_set_error((int)e, "hipGraphLaunch: %s", hipGetErrorString(e));
   return 0;

@@ -73,6 +73,7 @@ class _Lib(object):
                 "HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C zero_amd/csrc`). There is no CPU fallback." % LIB_PATH)
         self._dll = ctypes.CDLL(LIB_PATH)
+        self.ncalls = 0
         self.protos = parse_header()
         for name, (restype, argtypes, _) in self.protos.items():
             try:
@@ -89,6 +90,7 @@ class _Lib(object):
 
     def call(self, name, *args):
         """Call an int-returning entry point; raise on a non-zero status."""
+        self.ncalls += 1          # lets callers tell whether anything was enqueued between two points
         rc = getattr(self._dll, name)(*args)
         if rc != 0:
             msg = self._dll.zk_last_error_string()

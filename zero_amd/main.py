@@ -59,6 +59,9 @@ class Trainer(object):
         self.global_step = 0
         self.cycle_counter = 0
         self._graphs = {}
+        # test hook: run the multi-rank (segmented) capture path with a single rank
+        import os as _os
+        self.force_segmented = _os.environ.get("ZERO_HIP_FORCE_SEGMENTED", "0") != "0"
 
     # -- eager path (any shapes) --------------------------------------------------
     def micro_step(self, features):
@@ -89,6 +92,68 @@ class Trainer(object):
         self.core.eng.lib.call("zk_seed_advance", self.core.eng.seed.data_ptr(), 1, self.core.eng.stream)
         return loss
 
+    # -- data-parallel captured path: hipGraph segments between the gradient-bucket hand-offs ----
+    def _step_segmented(self, scale):
+        """Multi-rank step with the launch cost of the single-rank one.  RCCL calls stay outside
+        hipGraphs, so the launch sequence is captured as SEGMENTS: every time the backward reports
+        a finished gradient bucket (``on_ready``) the running capture is closed and a new one is
+        opened; replay = launch segment, hand the finished buckets to the all-reduce (which then
+        overlaps the next segment), ..., wait, launch the captured norm + Adam update."""
+        import ctypes
+        hp, eng = self.params, self.core.eng
+        lib = eng.lib
+        key = ("seg", self.batch["B"], self.batch["Ls"], self.batch["Lt"])
+        plan = self._graphs.get(key)
+        if plan is None:                   # first use of a shape: eager (sizes every scratch buffer)
+            self._graphs[key] = "warm"
+            self.graph.train_fn(self.batch, hp, on_ready=self.reducer.ready)
+            self.reducer.wait()
+            self.train_op.launch_update(scale)
+            lib.call("zk_seed_advance", eng.seed.data_ptr(), 1, eng.stream)
+            return
+        if plan == "warm":
+            stream = torch.cuda.current_stream(eng.device).cuda_stream
+            plan, mark = [], [0]
+
+            def begin():
+                lib.call("zk_graph_begin", stream)
+                mark[0] = lib.ncalls
+
+            def cut():
+                ex = ctypes.c_void_p()
+                lib.call("zk_graph_end", stream, ctypes.byref(ex))
+                return ex
+
+            def on_ready(k):
+                if lib.ncalls == mark[0] and plan and plan[-1][0] == "ready":
+                    plan[-1][1].append(k)          # nothing enqueued since the last hand-off
+                    return
+                plan.append(("graph", cut()))
+                plan.append(("ready", [k]))
+                begin()
+
+            begin()
+            try:
+                self.graph.train_fn(self.batch, hp, on_ready=on_ready)
+            finally:
+                plan.append(("graph", cut()))
+            begin()
+            try:
+                self.train_op.launch_update(scale)
+                lib.call("zk_seed_advance", eng.seed.data_ptr(), 1, eng.stream)
+            finally:
+                plan.append(("update", cut()))
+            self._graphs[key] = plan
+        for kind, what in plan:
+            if kind == "graph":
+                eng.graph_launch(what)
+            elif kind == "ready":
+                for k in what:
+                    self.reducer.ready(k)
+            else:
+                self.reducer.wait()
+                eng.graph_launch(what)
+
     # -- captured path (static shapes, update_cycle == 1) ---------------------------
     def prepare_static(self, features):
         """Upload one batch into the static id buffers; later steps may overwrite the
@@ -116,7 +181,7 @@ class Trainer(object):
         self.lr.step(self.global_step)
         self.train_op.count = 0
         scale = self.train_op.set_hyper(self.lr.get_lr(), world)
-        if world == 1 and use_graph:
+        if world == 1 and use_graph and not self.force_segmented:
             key = (self.batch["B"], self.batch["Ls"], self.batch["Lt"])
             g = self._graphs.get(key)
             if g is None:
@@ -132,6 +197,8 @@ class Trainer(object):
                 g = eng.graph_capture(body)
                 self._graphs[key] = g
             eng.graph_launch(g)
+        elif use_graph and not self.core.use_side and (world > 1 or self.force_segmented):
+            self._step_segmented(scale)
         else:
             self.graph.train_fn(self.batch, hp, on_ready=self.reducer.ready if world > 1 else None)
             self.reducer.wait()
