@@ -58,9 +58,26 @@ def reset_cores():
     reset_stores()
 
 
+def _n_sentences(features):
+    if "B" in features:
+        return features["B"]
+    return int(features["source"].shape[0])
+
+
 def build(model_name):
     def train_fn(features, params, initializer=None, on_ready=None):
         core = get_core(params, model_name, initializer)
+        if _n_sentences(features) == 0:
+            # transformer.py:213-216: a tower without sentences contributes loss 0 (and zero gradients);
+            # it still hands every bucket to the all-reduce so that the other ranks are not left waiting
+            from zero_amd.utils.parallel import layer_buckets
+            core.eng.zero(core.store.grad)
+            if on_ready is not None:
+                for key in layer_buckets(core.store)[1]:
+                    on_ready(key)
+            zero = torch.zeros(1, dtype=torch.float32, device=core.store.device)
+            return {"loss": zero[0], "gradient": core.store.grad, "store": core.store,
+                    "per_sample_loss": zero[:0]}
         batch = features if "B" in features else core.upload(features["source"], features["target"])
         loss, per_sample, _ = core.forward(batch, train=True, save=True)
         core.backward(on_ready)
@@ -72,6 +89,8 @@ def build(model_name):
         params = closing_dropout(params)
         params.label_smooth = 0.0
         core = get_core(params, model_name, initializer)
+        if _n_sentences(features) == 0:
+            return {"score": torch.zeros(0, dtype=torch.float32, device=core.store.device)}
         batch = features if "B" in features else core.upload(features["source"], features["target"])
         _, per_sample, _ = core.forward(batch, train=False, save=False, label_smooth=0.0)
         return {"score": per_sample}
