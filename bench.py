@@ -49,9 +49,11 @@ def synthetic_batch(rank):
     return src, tgt
 
 
-def make_params(dropout=0.1):
+def make_params(dropout=0.1, size="base"):
     hp = transformer_base_params(dropout=dropout, relu_dropout=dropout, residual_dropout=dropout,
                                  attention_dropout=dropout, update_cycle=1, token_size=4096)
+    if size == "big":        # BASELINE configs[2]: Transformer-big widths, same batch / vocabulary
+        hp.override_from_dict(dict(hidden_size=1024, embed_size=1024, filter_size=4096, num_heads=16))
     hp.src_vocab = SyntheticVocab(V)
     hp.tgt_vocab = SyntheticVocab(V)
     return hp
@@ -205,6 +207,8 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--size", choices=["base", "big"], default="base",
+                    help="base = BASELINE configs[1] (the metric's config, default); big = configs[2]")
     args = ap.parse_args()
 
     rank, world, local = parallel.init_distributed()
@@ -217,7 +221,7 @@ def main():
     for kv in os.environ.get("ZERO_HIP_TUNE", "").split(","):     # e.g. ZERO_HIP_TUNE=0:0 (A/B switches)
         if ":" in kv:
             _hip.lib().raw("zk_tune")(int(kv.split(":")[0]), int(kv.split(":")[1]))
-    hp = make_params(args.dropout)
+    hp = make_params(args.dropout, args.size)
     hp.random_seed = 1234   # identical initial replicas on every rank
     tr = Trainer(hp)
     src, tgt = synthetic_batch(rank)
@@ -272,13 +276,14 @@ def main():
     ms = dt / args.steps * 1e3
     flops = train_flops_per_step(hp)
     out = {
-        "metric": "src+tgt tokens/sec training, Transformer-base d=512 L=6",
+        "metric": "src+tgt tokens/sec training, Transformer-%s d=%d L=6" % (args.size, hp.hidden_size),
         "value": tokens / dt, "unit": "src+tgt tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "Transformer-base (d=512, L=6+6, F=2048, h=8, V=32000) training step, "
+        "config": {"workload": "Transformer-%s (d=%d, L=6+6, F=%d, h=%d, V=32000) training step, "
                                "B=64 x (src 64 + tgt 64) tokens per GPU, dropout %.2f, label_smooth 0.1, "
-                               "fwd+bwd+allreduce+Adam" % args.dropout,
+                               "fwd+bwd+allreduce+Adam" % (args.size, hp.hidden_size, hp.filter_size,
+                                                           hp.num_heads, args.dropout),
                    "global_batch_tokens": world * B * (LS + LT), "parallelism": "dp%d" % world,
                    "hip_graph": ("whole step" if world == 1 else "segments between all-reduce buckets") if use_graph else False},
         "loss": loss_v, "gnorm": gnorm, "update_skipped": skipped,
@@ -300,7 +305,7 @@ def main():
                           "tflops": v[0] / v[1] / 1e12} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])},
     }
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(hp)
+        out["cpu_baseline"] = cpu_baseline(hp)     # bounded sample, see cpu_baseline()
     print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
