@@ -68,12 +68,15 @@ int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int t
  * finite 1e8).  lse: fp32 [B,nh,Lq] log-sum-exp saved for the backward (may be NULL).
  * rpr_k/rpr_v: bf16 [2*max_rel+1, d] tables or NULL.  bsq/bsk/bsv: batch strides in
  * elements (0 = L*ld); kv_group: k/v/kmask batch index = b / kv_group (decode: beam-tiled
- * queries attend to un-tiled per-sentence encoder keys, search.py:36-39 never materialised). */
+ * queries attend to un-tiled per-sentence encoder keys, search.py:36-39 never materialised).
+ * pos_dev (device int, may be NULL) carries the decode time step for hipGraph replay: pos_flags bit 0
+ * -> q_pos0 = *pos_dev, bit 1 -> only keys 0..*pos_dev are valid (self-attention over the k/v cache,
+ * func.py:199-205, with Lk = the allocated cache length). */
 int zk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int nh, int Lq,
                 int Lk, int d, int ldq, int ldk, int ldv, int ldo, const float* kmask, int causal,
                 int q_pos0, float scale, float mask_inf, const void* rpr_k, const void* rpr_v, int max_rel,
                 float drop_p, const uint64_t* seed, uint32_t sid, long bsq, long bsk, long bsv, int kv_group,
-                int impl, zk_stream_t stream);
+                int impl, const int* pos_dev, int pos_flags, zk_stream_t stream);
 size_t zk_attn_bwd_workspace(int B, int nh, int Lq);
 int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                 const float* lse, void* dq, void* dk, void* dv, float* drpr_k, float* drpr_v, int B, int nh,
@@ -204,6 +207,12 @@ int zk_cumavg_add_fwd(const void* vq, const float* mask, const void* att, void* 
 int zk_cumavg_bwd(const void* dy, const float* mask, void* dvq, int B, int L, int H, zk_stream_t stream);
 int zk_fuse_decode(const void* vq, float* cache, void* att, int rows, int H, float inv_count, const int* time_dev,
                    zk_stream_t stream);
+/* k/v cache rows with the time step in device memory (hipGraph replay of func.py:199-205 and of the
+   beam reorder search.py:206-209).  mode 0 (append): dst[r][*time_dev] <- src[r] (unit_bytes);
+   mode 1 (reorder): dst[r][0 .. *time_dev) <- src[index[r]][0 .. *time_dev) in units of unit_bytes;
+   max_units bounds the launch. */
+int zk_cache_rows(const void* src, size_t src_stride, const int* index, void* dst, size_t dst_stride, int rows,
+                  size_t unit_bytes, int max_units, const int* time_dev, int mode, zk_stream_t stream);
 /* transformer_aan.py:110-112: cache += x; cat = [x | cache/(t+1)] */
 int zk_aan_decode(const void* x, float* cache, void* cat, int rows, int H, float inv_count, const int* time_dev,
                   zk_stream_t stream);

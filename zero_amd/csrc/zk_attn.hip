@@ -32,7 +32,19 @@ struct AttnArgs {
   float scale; float mask_inf;
   const bf16_t* rpr_k; const bf16_t* rpr_v; int max_rel;   // [2*max_rel+1, d] tables or null
   uint32_t thr; float inv_keep; const uint64_t* seed; uint32_t sid;
+  int ldmask;              // row stride of kmask (= the host-side Lk)
+  // decode step replayed from a hipGraph: the time step lives in device memory.  pos_flags bit 0:
+  // q_pos0 = *pos_dev; bit 1: only keys 0 .. *pos_dev are valid (self-attention over the cache)
+  const int* pos_dev; int pos_flags;
 };
+
+__device__ __forceinline__ void attn_apply_pos(AttnArgs& a) {
+  if (a.pos_dev != nullptr) {
+    const int t = *a.pos_dev;
+    if (a.pos_flags & 1) a.q_pos0 = t;
+    if (a.pos_flags & 2) a.Lk = min(a.Lk, t + 1);
+  }
+}
 
 __device__ __forceinline__ int rel_index(int i_abs, int j, int max_rel) {
   int dlt = i_abs - j;                         // modules/rpr.py:66-75
@@ -43,7 +55,7 @@ __device__ __forceinline__ int rel_index(int i_abs, int j, int max_rel) {
 // additive mask of key j for query i (absolute position), reference semantics
 __device__ __forceinline__ float mask_bias(const AttnArgs& a, int b, int i_abs, int j) {
   float bias = 0.f;
-  if (a.kmask != nullptr && a.kmask[(size_t)(b / a.kv_group) * a.Lk + j] == 0.f) bias -= a.mask_inf;
+  if (a.kmask != nullptr && a.kmask[(size_t)(b / a.kv_group) * a.ldmask + j] == 0.f) bias -= a.mask_inf;
   if (a.causal && j > i_abs) bias -= a.mask_inf;
   return bias;
 }
@@ -70,6 +82,7 @@ __device__ __forceinline__ float naive_score(const AttnArgs& a, int b, int h, in
 __global__ void __launch_bounds__(256) k_attn_fwd_naive(AttnArgs a, bf16_t* __restrict__ out, int ldo,
                                                         float* __restrict__ lse) {
   __shared__ float sp[4][NAIVE_MAXK * 64];
+  attn_apply_pos(a);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 4 + w;
   const long nrows = (long)a.B * a.nh * a.Lq;
@@ -329,6 +342,7 @@ __global__ void __launch_bounds__(256) k_attn_fwd_mfma(AttnArgs a, bf16_t* __res
   __shared__ __attribute__((aligned(16))) bf16_t sK[TQ * ALD];    // K tile, later V^T tile
   __shared__ __attribute__((aligned(16))) bf16_t sP[TQ * (NKT * 64 + 8)];
   constexpr int PLD = NKT * 64 + 8;
+  attn_apply_pos(a);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i0 = blockIdx.x * TQ, h = blockIdx.y, b = blockIdx.z;
   const bf16_t* qb = a.q + (size_t)b * a.bsq + h * AD;
@@ -360,7 +374,7 @@ __global__ void __launch_bounds__(256) k_attn_fwd_mfma(AttnArgs a, bf16_t* __res
     const int j = t * 16 + (lane & 15);
     const bool kvalid = j < a.Lk;
     float kb_ = 0.f;
-    if (kvalid && a.kmask != nullptr && a.kmask[(size_t)(b / a.kv_group) * a.Lk + j] == 0.f) kb_ = -a.mask_inf;
+    if (kvalid && a.kmask != nullptr && a.kmask[(size_t)(b / a.kv_group) * a.ldmask + j] == 0.f) kb_ = -a.mask_inf;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float s = S[t][r] * a.scale + kb_;
@@ -501,7 +515,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dq_mfma(AttnArgs a, const bf16
       const int j = kt * 64 + nt * 16 + (lane & 15);
       const bool kvalid = j < a.Lk;
       float kbias = 0.f;
-      if (kvalid && a.kmask != nullptr && a.kmask[(size_t)(b / a.kv_group) * a.Lk + j] == 0.f) kbias = -a.mask_inf;
+      if (kvalid && a.kmask != nullptr && a.kmask[(size_t)(b / a.kv_group) * a.ldmask + j] == 0.f) kbias = -a.mask_inf;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + rloc + r;
@@ -572,7 +586,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv_mfma(AttnArgs a, const bf1
   for (int r = 0; r < 4; ++r) {
     const int j = j0 + jloc + r;
     kval[r] = j < a.Lk;
-    kbias[r] = (kval[r] && a.kmask != nullptr && a.kmask[(size_t)(b / a.kv_group) * a.Lk + j] == 0.f) ? -a.mask_inf : 0.f;
+    kbias[r] = (kval[r] && a.kmask != nullptr && a.kmask[(size_t)(b / a.kv_group) * a.ldmask + j] == 0.f) ? -a.mask_inf : 0.f;
   }
   const int nqt = (a.Lq + 63) / 64;
   for (int qt = 0; qt < nqt; ++qt) {
@@ -719,7 +733,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_fused64(AttnArgs a, const bf16
       const int j = nt * 16 + (lane & 15);
       const bool kvalid = j < a.Lk;
       float kbias = 0.f;
-      if (kvalid && a.kmask != nullptr && a.kmask[(size_t)b * a.Lk + j] == 0.f) kbias = -a.mask_inf;
+      if (kvalid && a.kmask != nullptr && a.kmask[(size_t)b * a.ldmask + j] == 0.f) kbias = -a.mask_inf;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = rloc + r;
@@ -805,6 +819,7 @@ static int fill_args(AttnArgs* a, const void* q, const void* k, const void* v, i
   a->thr = drop_p > 0.f ? zk_drop_threshold(drop_p) : 0;
   a->inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   a->seed = seed; a->sid = sid;
+  a->ldmask = Lk; a->pos_dev = nullptr; a->pos_flags = 0;
   return 0;
 }
 
@@ -821,7 +836,7 @@ int zk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* l
                 int d, int ldq, int ldk, int ldv, int ldo, const float* kmask, int causal, int q_pos0,
                 float scale, float mask_inf, const void* rpr_k, const void* rpr_v, int max_rel, float drop_p,
                 const uint64_t* seed, uint32_t sid, long bsq, long bsk, long bsv, int kv_group, int impl,
-                hipStream_t stream) {
+                const int* pos_dev, int pos_flags, hipStream_t stream) {
   ZK_CHECK_ARG((rpr_k == nullptr) == (rpr_v == nullptr), "zk_attn_fwd: rpr_k and rpr_v go together");
   ZK_CHECK_ARG(kv_group >= 1, "zk_attn_fwd: kv_group must be >= 1");
   ZK_CHECK_ARG(drop_p == 0.f || seed != nullptr, "zk_attn_fwd: dropout needs a seed pointer");
@@ -834,6 +849,7 @@ int zk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* l
   if (bsk > 0) a.bsk = bsk;
   if (bsv > 0) a.bsv = bsv;
   a.kv_group = kv_group;
+  a.pos_dev = pos_dev; a.pos_flags = pos_dev ? pos_flags : 0;
   const bool ok = attn_mfma_ok(a, ldo) && Lk <= 256 && (a.bsq % 8 == 0) && (a.bsk % 8 == 0) && (a.bsv % 8 == 0) && (((uintptr_t)out & 1) == 0);
   ZK_CHECK_ARG(impl != 2 || ok, "zk_attn_fwd: MFMA kernel needs d=64, no rpr, Lk<=256, ld%%8==0");
   if (impl == 2 || (impl == 0 && ok)) {

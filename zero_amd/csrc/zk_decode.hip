@@ -120,6 +120,24 @@ __global__ void __launch_bounds__(256) k_gather_rows(const uint4* __restrict__ s
     dst[(size_t)r * dst_stride16 + c] = src[s * src_stride16 + c];
 }
 
+// k/v cache maintenance with the step counter read on the device (see zk_cache_rows)
+__global__ void __launch_bounds__(256) k_cache_rows(const uint4* __restrict__ src, size_t src_stride16,
+                                                    const int* __restrict__ index, uint4* __restrict__ dst,
+                                                    size_t dst_stride16, size_t unit16,
+                                                    const int* __restrict__ time_dev, int mode) {
+  const int r = blockIdx.x;
+  const size_t t = (size_t)*time_dev;
+  if (mode == 0) {
+    for (size_t c = (size_t)blockIdx.y * 256 + threadIdx.x; c < unit16; c += (size_t)gridDim.y * 256)
+      dst[(size_t)r * dst_stride16 + t * unit16 + c] = src[(size_t)r * src_stride16 + c];
+  } else {
+    const size_t s = index ? (size_t)index[r] : (size_t)r;
+    const size_t n16 = t * unit16;
+    for (size_t c = (size_t)blockIdx.y * 256 + threadIdx.x; c < n16; c += (size_t)gridDim.y * 256)
+      dst[(size_t)r * dst_stride16 + c] = src[s * src_stride16 + c];
+  }
+}
+
 // cache += x (fp32 running sum); cat = [x | cache * inv_count]
 __global__ void __launch_bounds__(256) k_aan_decode(const bf16_t* __restrict__ x, float* __restrict__ cache,
                                                     bf16_t* __restrict__ cat, int rows, int H, float inv_count,
@@ -197,6 +215,23 @@ int zk_gather_rows(const void* src, size_t src_stride, const int* index, void* d
   if (gy > 64) gy = 64;
   hipLaunchKernelGGL(k_gather_rows, dim3(rows, gy), dim3(256), 0, stream, (const uint4*)src, src_stride / 16, index,
                      (uint4*)dst, dst_stride / 16, row16);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_cache_rows(const void* src, size_t src_stride, const int* index, void* dst, size_t dst_stride, int rows,
+                  size_t unit_bytes, int max_units, const int* time_dev, int mode, hipStream_t stream) {
+  ZK_CHECK_ARG(src_stride % 16 == 0 && dst_stride % 16 == 0 && unit_bytes % 16 == 0,
+               "zk_cache_rows: strides / unit_bytes must be multiples of 16");
+  ZK_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "zk_cache_rows: pointers must be 16-byte aligned");
+  ZK_CHECK_ARG(time_dev != nullptr && (mode == 0 || mode == 1), "zk_cache_rows: time_dev required, mode 0 or 1");
+  if (rows == 0 || unit_bytes == 0) return 0;
+  const size_t unit16 = unit_bytes / 16;
+  const size_t span = mode == 0 ? unit16 : unit16 * (size_t)(max_units > 0 ? max_units : 1);
+  int gy = (int)((span + 255) / 256);
+  if (gy > 64) gy = 64;
+  hipLaunchKernelGGL(k_cache_rows, dim3(rows, gy), dim3(256), 0, stream, (const uint4*)src, src_stride / 16, index,
+                     (uint4*)dst, dst_stride / 16, unit16, time_dev, mode);
   ZK_LAUNCH_CHECK();
   return 0;
 }

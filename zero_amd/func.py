@@ -227,12 +227,13 @@ class Engine(object):
     # ---- func.py:164-286 attention core ----------------------------------------
     def attn_fwd(self, q, k, v, out, lse, B, nh, Lq, Lk, d, kmask=None, causal=False, q_pos0=0,
                  rpr_k=None, rpr_v=None, max_rel=0, drop_p=0.0, sid=0, bsq=0, bsk=0, bsv=0, kv_group=1,
-                 impl=None):
+                 impl=None, pos_dev=None, pos_flags=0):
         self.lib.call(
             "zk_attn_fwd", q.ptr, k.ptr, v.ptr, out.ptr, hip.ptr(lse), B, nh, Lq, Lk, d, q.ld, k.ld, v.ld,
             out.ld, hip.ptr(kmask), 1 if causal else 0, q_pos0, float(d) ** -0.5, zdtype.inf(),
             hip.ptr(rpr_k), hip.ptr(rpr_v), max_rel, float(drop_p), self.seed.data_ptr(), sid,
-            bsq, bsk, bsv, kv_group, self.attn_impl if impl is None else impl, self.stream)
+            bsq, bsk, bsv, kv_group, self.attn_impl if impl is None else impl, hip.ptr(pos_dev), pos_flags,
+            self.stream)
 
     def attn_bwd(self, q, k, v, out, dout, lse, dq, dk, dv, B, nh, Lq, Lk, d, kmask=None, causal=False,
                  rpr_k=None, rpr_v=None, drpr_k=None, drpr_v=None, max_rel=0, drop_p=0.0, sid=0, impl=None):

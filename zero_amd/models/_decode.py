@@ -35,8 +35,9 @@ F32 = torch.float32
 class DecodeState(dict):
     """Nested-dict state with the cache plumbing the search needs."""
 
-    def reorder(self, index_dev):
-        """Gather every per-beam cache by flat beam index [B*K] (device int32)."""
+    def reorder(self, index_dev, time_dev=None):
+        """Gather every per-beam cache by flat beam index [B*K] (device int32).  time_dev: the
+        number of filled cache slots lives in device memory (hipGraph replay)."""
         core = self["_core"]
         e = core.eng
         BK, H, t = self["BK"], core.H, self["time_filled"]
@@ -54,8 +55,12 @@ class DecodeState(dict):
                 for nm in ("k", "v"):
                     src = lay[nm]
                     dst = e.buf("dc%d.%s.%d" % (l, nm, 1 - lay["_pp"]), (BK, Tmax, H))
-                    e.lib.call("zk_gather_rows", src.data_ptr(), Tmax * H * 2, index_dev.data_ptr(),
-                               dst.data_ptr(), Tmax * H * 2, BK, t * H * 2, e.stream)
+                    if time_dev is not None:
+                        e.lib.call("zk_cache_rows", src.data_ptr(), Tmax * H * 2, index_dev.data_ptr(),
+                                   dst.data_ptr(), Tmax * H * 2, BK, H * 2, Tmax, time_dev.data_ptr(), 1, e.stream)
+                    else:
+                        e.lib.call("zk_gather_rows", src.data_ptr(), Tmax * H * 2, index_dev.data_ptr(),
+                                   dst.data_ptr(), Tmax * H * 2, BK, t * H * 2, e.stream)
                     lay[nm] = dst
                 lay["_pp"] = 1 - lay["_pp"]
 
@@ -107,7 +112,9 @@ def make_infer_fns(params, model_name):
         state["ts"] = e.buf("bs.ts", (B, 2 * K), torch.float32)
         state["ti"] = e.buf("bs.ti", (B, 2 * K), torch.int32)
         state["graphs"] = {}
-        state["static_ok"] = core.aan or core.fuse   # every launch argument of an AAN / merged-attention step is static
+        # every launch argument of a step is static: the time step (cache slot, number of valid keys,
+        # relative-position origin) is read from device memory by the kernels
+        state["static_ok"] = True
         return state
 
     def step_static(state, temperature, forbid_value):
@@ -121,8 +128,8 @@ def make_infer_fns(params, model_name):
         g = state["graphs"].get(parity)
 
         def body():
-            state.reorder(state["idx"])
             sb = state["stepbuf"]
+            state.reorder(state["idx"], time_dev=sb[0:1])
             logits, _ = _step_cache(state["tok"], state, None, time_dev=sb[0:1])
             e.beam_topk(logits, state["prev"], state["ts"], state["ti"], state["B"], state["K"], core.V,
                         2 * state["K"], temperature, 1.0, -1, forbid_value, scal_dev=sb[1:3])
@@ -136,7 +143,11 @@ def make_infer_fns(params, model_name):
         else:
             for l in range(hp.num_decoder_layer):      # replay: redo the python-side pointer flips
                 lay = state["decoder"]["state"]["layer_%d" % l]
-                lay["aan"] = e.buf("dc%d.aan.%d" % (l, 1 - lay["_pp"]), (state["BK"], core.H), F32)
+                if "aan" in lay:
+                    lay["aan"] = e.buf("dc%d.aan.%d" % (l, 1 - lay["_pp"]), (state["BK"], core.H), F32)
+                if "k" in lay:
+                    for nm in ("k", "v"):
+                        lay[nm] = e.buf("dc%d.%s.%d" % (l, nm, 1 - lay["_pp"]), (state["BK"], state["Tmax"], core.H))
                 lay["_pp"] = 1 - lay["_pp"]
             e.graph_launch(g)
 
@@ -176,14 +187,20 @@ def make_infer_fns(params, model_name):
                 qkv = e.mat("dc.qkv", BK, 3 * H)
                 core._linear(x, p + "qkv_map", qkv)
                 for nm, c0 in (("k", H), ("v", 2 * H)):
-                    e.lib.call("zk_gather_rows", qkv.ptr + c0 * 2, 3 * H * 2, None,
-                               lay[nm].data_ptr() + time * H * 2, Tmax * H * 2, BK, H * 2, e.stream)
+                    if time_dev is not None:
+                        e.lib.call("zk_cache_rows", qkv.ptr + c0 * 2, 3 * H * 2, None, lay[nm].data_ptr(),
+                                   Tmax * H * 2, BK, H * 2, Tmax, time_dev.data_ptr(), 0, e.stream)
+                    else:
+                        e.lib.call("zk_gather_rows", qkv.ptr + c0 * 2, 3 * H * 2, None,
+                                   lay[nm].data_ptr() + time * H * 2, Tmax * H * 2, BK, H * 2, e.stream)
                 att = e.mat("dc.att", BK, H)
                 rk = core.store.s(p + "rpr_keys/embeddings") if core.rpr else None
                 rv = core.store.s(p + "rpr_values/embeddings") if core.rpr else None
                 e.attn_fwd(qkv.cols_slice(0, H), Mat(lay["k"], BK * Tmax, H), Mat(lay["v"], BK * Tmax, H), att,
-                           None, BK, nh, 1, time + 1, d, kmask=None, causal=False, q_pos0=time, rpr_k=rk,
-                           rpr_v=rv, max_rel=hp.max_relative_position, bsq=3 * H, bsk=Tmax * H, bsv=Tmax * H)
+                           None, BK, nh, 1, Tmax if time_dev is not None else time + 1, d, kmask=None, causal=False,
+                           q_pos0=0 if time_dev is not None else time, rpr_k=rk,
+                           rpr_v=rv, max_rel=hp.max_relative_position, bsq=3 * H, bsk=Tmax * H, bsv=Tmax * H,
+                           pos_dev=time_dev, pos_flags=3)
                 y = e.mat("dc.y", BK, H)
                 core._linear(att, p + "o_map", y)
                 x = core._ln_fwd(x, y, pre + "/self_attention", "dc%d.sa" % l, False, 0.0, 0)
@@ -195,7 +212,7 @@ def make_infer_fns(params, model_name):
             rv = core.store.s(p + "rpr_values/embeddings") if core.rpr else None
             e.attn_fwd(q, lay["mk"], lay["mv"], att, None, BK, nh, 1, Ls, d, kmask=state["mask"], causal=False,
                        q_pos0=time if time is not None else 0, rpr_k=rk, rpr_v=rv, max_rel=hp.max_relative_position, bsq=H,
-                       bsk=Ls * 2 * H, bsv=Ls * 2 * H, kv_group=K)
+                       bsk=Ls * 2 * H, bsv=Ls * 2 * H, kv_group=K, pos_dev=time_dev, pos_flags=1)
             if core.fuse:
                 # func.py:258-272: v_q = v_map(query); cache += v_q; o += cache / (time + 1)
                 vq = e.mat("dc.vq", BK, H)
