@@ -207,6 +207,9 @@ int zk_cumavg_add_fwd(const void* vq, const float* mask, const void* att, void* 
 int zk_cumavg_bwd(const void* dy, const float* mask, void* dvq, int B, int L, int H, zk_stream_t stream);
 int zk_fuse_decode(const void* vq, float* cache, void* att, int rows, int H, float inv_count, const int* time_dev,
                    zk_stream_t stream);
+/* search.py:143-145 (enable_noise_beam_search): logits += Gumbel noise -log(-log(u + eps) + eps), util.py:189-195 */
+int zk_add_gumbel(float* logits, int rows, int V, int ld, float eps, const uint64_t* seed, uint32_t sid,
+                  zk_stream_t stream);
 /* k/v cache rows with the time step in device memory (hipGraph replay of func.py:199-205 and of the
    beam reorder search.py:206-209).  mode 0 (append): dst[r][*time_dev] <- src[r] (unit_bytes);
    mode 1 (reorder): dst[r][0 .. *time_dev) <- src[index[r]][0 .. *time_dev) in units of unit_bytes;

@@ -671,3 +671,20 @@ def test_ema_kernel_and_skip():
     e.lib.call("zk_ema", got2.data_ptr(), p.data_ptr(), hyper.data_ptr(), n, e.stream)
     torch.cuda.synchronize()
     assert torch.equal(got2, ema)
+
+
+def test_gumbel_noise_distribution():
+    """util.py:189-195: -log(-log(u)) has mean = Euler's gamma and variance pi^2/6."""
+    e = eng()
+    rows, V, ld = 64, 5000, 5008
+    logits = torch.zeros(rows, ld, device="cuda")
+    e.set_seed(5)
+    e.lib.call("zk_add_gumbel", logits.data_ptr(), rows, V, ld, 1e-8, e.seed.data_ptr(), 1, e.stream)
+    torch.cuda.synchronize()
+    x = logits[:, :V].double()
+    assert float(logits[:, V:].abs().max()) == 0.0                    # padding columns untouched
+    assert abs(float(x.mean()) - 0.5772) < 0.01 and abs(float(x.var()) - np.pi ** 2 / 6) < 0.03
+    again = torch.zeros(rows, ld, device="cuda")
+    e.lib.call("zk_add_gumbel", again.data_ptr(), rows, V, ld, 1e-8, e.seed.data_ptr(), 1, e.stream)
+    torch.cuda.synchronize()
+    assert torch.equal(again, logits)                                 # counter-based: same seed, same noise

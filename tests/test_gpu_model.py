@@ -354,3 +354,24 @@ def test_sequence_longer_than_the_kernel_limit_fails_loudly():
     with pytest.raises(ZeroHipError):
         registry.get_model(model).train_fn({"source": src, "target": tgt}, hp)
         torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_noise_beam_search_runs_and_is_seeded(graph, monkeypatch):
+    """search.py:143-145 (enable_noise_beam_search): Gumbel-perturbed logits give valid hypotheses,
+    reproducible for a fixed seed and different from the noise-free search."""
+    monkeypatch.setenv("ZERO_HIP_DECODE_GRAPH", graph)
+    from zero_amd.main import tower_infer_graph
+    model = "transformer_aan"
+    hp, Pn, src, tgt = _setup(model, seed=3, beam_size=4)
+    outs = []
+    for noise, seed in ((False, 1), (True, 1), (True, 1), (True, 2)):
+        hp2 = copy.copy(hp); hp2.enable_noise_beam_search = noise
+        reset_cores()
+        core = get_core(hp2, model, Pn)
+        core.eng.set_seed(seed)
+        seqs, scores = tower_infer_graph({"source": src}, registry.get_model(model), hp2)
+        assert np.isfinite(scores).all() and seqs.shape[0] == src.shape[0]
+        outs.append(seqs)
+    assert np.array_equal(outs[1], outs[2])
+    assert not np.array_equal(outs[0], outs[1]) or not np.array_equal(outs[1], outs[3])

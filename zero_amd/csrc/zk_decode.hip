@@ -120,6 +120,19 @@ __global__ void __launch_bounds__(256) k_gather_rows(const uint4* __restrict__ s
     dst[(size_t)r * dst_stride16 + c] = src[s * src_stride16 + c];
 }
 
+// search.py:143-145 + util.py:189-195: logits += -log(-log(u + eps) + eps), u ~ U[0,1) from the
+// counter-based generator (TF's stream cannot be matched; the distribution is)
+__global__ void __launch_bounds__(256) k_add_gumbel(float* __restrict__ logits, int rows, int V, int ld, float eps,
+                                                    const uint64_t* __restrict__ seedp, uint32_t sid) {
+  const uint64_t seed = *seedp;
+  const size_t n = (size_t)rows * V;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / V, c = i % V;
+    const float u = (float)zk_rand_u32(seed, sid, i) * 2.3283064365386963e-10f;   // * 2^-32
+    logits[r * ld + c] += -__logf(-__logf(u + eps) + eps);
+  }
+}
+
 // k/v cache maintenance with the step counter read on the device (see zk_cache_rows)
 __global__ void __launch_bounds__(256) k_cache_rows(const uint4* __restrict__ src, size_t src_stride16,
                                                     const int* __restrict__ index, uint4* __restrict__ dst,
@@ -215,6 +228,18 @@ int zk_gather_rows(const void* src, size_t src_stride, const int* index, void* d
   if (gy > 64) gy = 64;
   hipLaunchKernelGGL(k_gather_rows, dim3(rows, gy), dim3(256), 0, stream, (const uint4*)src, src_stride / 16, index,
                      (uint4*)dst, dst_stride / 16, row16);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_add_gumbel(float* logits, int rows, int V, int ld, float eps, const uint64_t* seed, uint32_t sid,
+                  hipStream_t stream) {
+  ZK_CHECK_ARG(seed != nullptr && ld >= V, "zk_add_gumbel: seed pointer required, ld >= V");
+  const size_t n = (size_t)rows * V;
+  if (n == 0) return 0;
+  size_t g = (n + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(k_add_gumbel, dim3((unsigned)g), dim3(256), 0, stream, logits, rows, V, ld, eps, seed, sid);
   ZK_LAUNCH_CHECK();
   return 0;
 }

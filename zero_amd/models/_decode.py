@@ -28,6 +28,7 @@ import torch
 
 from zero_amd.func import Mat
 from zero_amd.models._factory import get_core
+from zero_amd.utils import dtype as zdtype
 
 F32 = torch.float32
 
@@ -131,6 +132,10 @@ def make_infer_fns(params, model_name):
             sb = state["stepbuf"]
             state.reorder(state["idx"], time_dev=sb[0:1])
             logits, _ = _step_cache(state["tok"], state, None, time_dev=sb[0:1])
+            if hp.enable_noise_beam_search:      # search.py:143-145; a fresh stream position every step
+                e.lib.call("zk_add_gumbel", logits.ptr, state["BK"], core.V, logits.ld, float(zdtype.epsilon()),
+                           e.seed.data_ptr(), 7001, e.stream)
+                e.lib.call("zk_seed_advance", e.seed.data_ptr(), 1, e.stream)
             e.beam_topk(logits, state["prev"], state["ts"], state["ti"], state["B"], state["K"], core.V,
                         2 * state["K"], temperature, 1.0, -1, forbid_value, scal_dev=sb[1:3])
         if g is None:

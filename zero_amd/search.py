@@ -123,6 +123,10 @@ def _beam_search(features, encoding_fn, decoding_fn, params):
             logits, state = decoding_fn(decode_target, state, time)
         # ---- fused log-softmax + penalty + top-2K (search.py:143-176)
         if not static_step:
+            if params.enable_noise_beam_search:      # search.py:143-145
+                e.lib.call("zk_add_gumbel", logits.ptr, B * K, V, logits.ld, float(zdtype.epsilon()),
+                           e.seed.data_ptr(), 7001, e.stream)
+                e.lib.call("zk_seed_advance", e.seed.data_ptr(), 1, e.stream)
             d_prev.copy_(torch.from_numpy(log_probs.reshape(-1)))
             e.beam_topk(logits, d_prev, d_ts, d_ti, B, K, V, 2 * K, params.beam_search_temperature, penalty,
                         eos_id if time < 1 else -1, zdtype.inf())
