@@ -6,7 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zero_amd.func import Engine, Mat
 
 e = Engine("cuda:0")
-T, H, F, V = 4096, 512, 2048, 32000
+T, V = 4096, 32000
+H = int(os.environ.get("GEMM_BENCH_H", "512"))      # 1024 = Transformer-big widths
+F = 4 * H
 SHAPES = [  # name, M, N, K, ta, tb, out_f32, count per step
     ("fwd qkv   ", T, 3 * H, H, 0, 0, 0, 12), ("fwd HxH   ", T, H, H, 0, 0, 0, 36), ("fwd ffn1  ", T, F, H, 0, 0, 0, 12),
     ("fwd ffn2  ", T, H, F, 0, 0, 0, 12), ("logits    ", T, V, H, 0, 1, 1, 1),

@@ -247,15 +247,26 @@ static bool mfma_ok(const void* A, const void* B, int M, int N, int K, int lda, 
 // goal is >= ~3 co-resident workgroups per CU (thread-level parallelism hides the L2 latency)
 // before tile area (arithmetic intensity) is considered.  Large outputs use 128x128; mid-size
 // ones 64x128 / 128x64; small ones 64x64 plus split-K when the epilogue allows it.
+extern int g_tune[8];
 static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, int* splits) {
+  // Measured on MI355X (scripts/gemm_bench.py at base and big widths, profiles/r01_gemm_microbench*.txt):
+  //  * >= 8 M outputs (or a very long K): 128x128 -- most MFMAs per LDS byte, still >= 512 workgroups;
+  //  * 3 M .. 8 M outputs (4096x1024, 4096x1536): 128x64 / 64x128 -- 64x64 leaves 20-35 % on the table
+  //    there (4096x1024x4096: 46 vs 63 us);
+  //  * smaller outputs (4096x512): 64x64 -- more co-resident workgroups beat bigger tiles;
+  //  * split-K when the tiles cannot fill even a quarter of the CUs (with >= 128 tiles and K <= 4096 every
+  //    split measured slower than none: 1024x1024x4096 17.8 us unsplit, 27.4 us split 4), and for the very
+  //    long K of dlogits x E (K = 32000: 2-way split to 1024 workgroups is worth 0.15 ms per step).
   const long out = (long)M * N;
   if (out >= 8L * 1024 * 1024 || (K >= 8192 && M >= 128 && N >= 128)) { *bm = 128; *bn = 128; }
-  else if (out >= 64L * 128 * 640) { if (N >= M) { *bm = 64; *bn = 128; } else { *bm = 128; *bn = 64; } }
+  else if (out >= 3L * 1024 * 1024) { if (N >= M) { *bm = 64; *bn = 128; } else { *bm = 128; *bn = 64; } }
   else { *bm = 64; *bn = 64; }
   const long tiles = (long)((M + *bm - 1) / *bm) * ((N + *bn - 1) / *bn);
   int s = 1;
-  if (allow_split && tiles < 1024 && K >= 1024) {
-    s = (int)((1024 + tiles - 1) / tiles);
+  if (g_tune[1] && allow_split && tiles < 1024 && K >= 1024) s = (int)((1024 + tiles - 1) / tiles);   // A/B: round-1 rule
+  else if (allow_split && tiles < 1024 && K >= 8192) s = (int)((1024 + tiles - 1) / tiles);   // dlogits x E: K = 32000
+  else if (allow_split && tiles <= 96 && K >= 1024) s = (int)((256 + tiles - 1) / tiles);
+  if (s > 1) {
     const int maxs = K / (4 * BK);            // keep >= 4 K-tiles per split
     if (s > maxs) s = maxs;
     if (s > 8) s = 8;
