@@ -381,10 +381,12 @@ int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int t
 }  // extern "C"
 
 // entry used by zk_gemm (zk_gemm.hip)
+extern int g_tune[8];
 int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
                           int bm, int bn, int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags,
                           hipStream_t stream) {
-  const int ns = (sched_flags >> 4) & 15;   // ring-depth override (tuning)
+  int ns = (sched_flags >> 4) & 15;   // ring-depth override (tuning)
+  if (!ns && bm == 64 && bn == 64 && g_tune[3]) ns = g_tune[3];     // A/B: ring depth of the 64x64 tile in-step
   if (ns) {
 #define ZK_NS(BM_, BN_, NS_) return launch_dlds<BM_, BN_, NS_>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream)
     if (bm == 64 && bn == 64) { if (ns == 2) ZK_NS(64, 64, 2); if (ns == 6) ZK_NS(64, 64, 6); if (ns == 8) ZK_NS(64, 64, 8); }
