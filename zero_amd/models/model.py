@@ -1,42 +1,62 @@
 # coding: utf-8
-"""Model registry -- the drop-in boundary of the hot path.
+"""Model registry -- the drop-in boundary of the hot path (reference: models/model.py:11-41).
 
-Same surface as the reference's models/model.py:11-41: modules self-register
-``(train_fn, score_fn, infer_fn)`` under a lower-cased name at import time,
-``get_model`` raises on unknown names, duplicate registration raises.
+Contract kept from the reference: model modules register a ``(train_fn, score_fn, infer_fn)``
+triple under a case-insensitive name when they are imported; looking up an unknown name raises
+``Exception("No supported model <name>")``; registering a name twice raises
+``Exception("Conflict Model Name: <name>")``; the value handed back exposes the three functions as
+attributes ``.train_fn`` / ``.score_fn`` / ``.infer_fn`` (and unpacks like a 3-tuple).
 """
 
 import logging
-from collections import namedtuple
+from typing import Callable, Dict, NamedTuple
 
-# global models defined in Zero
-_total_models = {}
+log = logging.getLogger("zero_amd")
 
 
-class ModelWrapper(namedtuple("ModelTupleWrapper",
-                              ("train_fn", "score_fn", "infer_fn"))):
-    pass
+class ModelWrapper(NamedTuple):
+    train_fn: Callable
+    score_fn: Callable
+    infer_fn: Callable
+
+
+class _Registry(object):
+    """Name -> ModelWrapper, keys normalised to lower case."""
+
+    def __init__(self):
+        self._models: Dict[str, ModelWrapper] = {}
+
+    @staticmethod
+    def _key(name):
+        return str(name).lower()
+
+    def add(self, name, triple):
+        key = self._key(name)
+        if key in self._models:
+            raise Exception("Conflict Model Name: {}".format(key))
+        self._models[key] = triple
+        log.info("Registering model: %s", key)
+
+    def find(self, name):
+        try:
+            return self._models[self._key(name)]
+        except KeyError:
+            raise Exception("No supported model {}".format(self._key(name))) from None
+
+    def names(self):
+        return sorted(self._models)
+
+
+_REGISTRY = _Registry()
 
 
 def model_register(model_name, train_fn, score_fn, infer_fn):
-    model_name = model_name.lower()
-
-    if model_name in _total_models:
-        raise Exception("Conflict Model Name: {}".format(model_name))
-
-    logging.getLogger("zero_amd").info("Registering model: %s", model_name)
-
-    _total_models[model_name] = ModelWrapper(
-        train_fn=train_fn,
-        score_fn=score_fn,
-        infer_fn=infer_fn,
-    )
+    _REGISTRY.add(model_name, ModelWrapper(train_fn, score_fn, infer_fn))
 
 
 def get_model(model_name):
-    model_name = model_name.lower()
+    return _REGISTRY.find(model_name)
 
-    if model_name in _total_models:
-        return _total_models[model_name]
 
-    raise Exception("No supported model {}".format(model_name))
+def registered_models():
+    return _REGISTRY.names()

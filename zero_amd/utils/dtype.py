@@ -1,44 +1,40 @@
 # coding: utf-8
-"""Global numeric constants of the hot path.
+"""Process-wide numeric settings of the hot path (reference: utils/dtype.py:10-43, set from the
+HParams ``default_dtype`` / ``dtype_epsilon`` / ``dtype_inf`` at run.py:397-399).
 
-Mirror of the reference's utils/dtype.py:10-43 (floatx / epsilon=1e-8 /
-inf=1e8, each overridable through run.py:397-399).  ``floatx`` names the
-*storage/compute* contract of the reference (float32 default, float16
-optional); the HIP path always computes in bf16 with fp32 accumulation and
-fp32 master weights (reference dtype.py:55-69 contract), so ``floatx`` is kept
-for config compatibility only.  ``epsilon`` (LayerNorm) and ``inf`` (attention
-mask magnitude, finite on purpose) are parity-critical.
+``epsilon`` is the LayerNorm variance floor and ``inf`` the magnitude of the additive attention
+mask -- finite on purpose: a fully masked row softmaxes to uniform instead of NaN.  Both are
+parity-critical and are passed to the kernels per call.  ``floatx`` names the reference's
+storage/compute type (float32 default, float16 optional); the HIP path always computes in bf16
+with fp32 accumulation over fp32 master weights (the storage contract of dtype.py:55-69), so the
+value is kept for configuration compatibility only.
 """
 
-_FLOATX = 'float32'
-_EPSILON = 1e-8
-_INF = 1e8
-
-
-def epsilon():
-    return _EPSILON
-
-
-def set_epsilon(e):
-    global _EPSILON
-    _EPSILON = float(e)
-
-
-def inf():
-    return _INF
-
-
-def set_inf(e):
-    global _INF
-    _INF = float(e)
+_KNOWN_FLOATX = ("float16", "float32", "float64", "bfloat16")
+_settings = {"floatx": "float32", "epsilon": 1e-8, "inf": 1e8}
 
 
 def floatx():
-    return _FLOATX
+    return _settings["floatx"]
 
 
-def set_floatx(floatx):
-    global _FLOATX
-    if floatx not in {'float16', 'float32', 'float64', 'bfloat16'}:
-        raise ValueError('Unknown floatx type: ' + str(floatx))
-    _FLOATX = str(floatx)
+def epsilon():
+    return _settings["epsilon"]
+
+
+def inf():
+    return _settings["inf"]
+
+
+def set_floatx(name):
+    if name not in _KNOWN_FLOATX:
+        raise ValueError('Unknown floatx type: ' + str(name))
+    _settings["floatx"] = str(name)
+
+
+def set_epsilon(value):
+    _settings["epsilon"] = float(value)
+
+
+def set_inf(value):
+    _settings["inf"] = float(value)
