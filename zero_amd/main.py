@@ -248,7 +248,9 @@ def _evaluate_dev(trainer, dataset, params, target_file, tag):
     trainer.train_op.ema_restore()
     log.info("GStep %s, Scores %s, BLEU %s, Duration %.3f s", tag, np.mean(scores) if scores else 0.0, bleu,
              time.time() - t0)
-    evalu.dump_tanslation(tranes, os.path.join(params.output_dir, "eval-{}.trans.txt".format(tag)), indices=indices)
+    if parallel.rank() == 0:      # every rank decodes the (small) dev set; one of them writes the file
+        evalu.dump_tanslation(tranes, os.path.join(params.output_dir, "eval-{}.trans.txt".format(tag)),
+                              indices=indices)
     return bleu, scores
 
 
