@@ -688,3 +688,19 @@ def test_gumbel_noise_distribution():
     e.lib.call("zk_add_gumbel", again.data_ptr(), rows, V, ld, 1e-8, e.seed.data_ptr(), 1, e.stream)
     torch.cuda.synchronize()
     assert torch.equal(again, logits)                                 # counter-based: same seed, same noise
+
+
+@pytest.mark.parametrize("variant", [2, 4])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_two_wave_workgroups(variant, ta, tb):
+    """The 64x64 tile with two-wave workgroups (A/B variant selected by zk_tune key 4)."""
+    e = eng()
+    old = e.lib.raw("zk_tune")(4, variant)
+    try:
+        for M, N, K in [(128, 128, 64), (200, 264, 136), (72, 40, 24), (64, 512, 1024)]:
+            err, _, _ = _gemm_case(2 | (4 << 8), M, N, K, ta, tb)
+            assert err < 8e-3, (M, N, K, err)
+        assert _gemm_case(2 | (4 << 8), 192, 256, 128, 0, 0, bias=True, act=1, drop=0.3)[0] < 8e-3
+        assert _gemm_case(2 | (4 << 8), 192, 256, 128, 0, 1, residual=True)[0] < 8e-3
+    finally:
+        e.lib.raw("zk_tune")(4, old)

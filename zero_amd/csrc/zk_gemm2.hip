@@ -45,20 +45,20 @@ __device__ __forceinline__ int swz_trans(int k) { return R == 128 ? ((k & 3) << 
 // the K-tail predicate.  Tile rows / column chunks outside the matrix are CLAMPED to a valid
 // row / chunk 0: what they bring in only feeds output rows / columns the epilogue never stores.
 // Only a K tile that crosses kend needs zero fill (both operands), done by the TAIL variant.
-template <int R>
+template <int R, int NW = 4>
 struct DmaPlan {
-  static constexpr int PER_WAVE = R * 8 / 4;      // 16-byte chunks per wave
+  static constexpr int PER_WAVE = R * 8 / NW;     // 16-byte chunks per wave
   static constexpr int NINSTR = PER_WAVE / 64;
   const bf16_t* cur[NINSTR];
   int kofs[NINSTR];
 };
 
-template <int R, bool TRANS>
-__device__ __forceinline__ void dma_plan(DmaPlan<R>& pl, const bf16_t* __restrict__ src, int ld, int row0,
+template <int R, bool TRANS, int NW>
+__device__ __forceinline__ void dma_plan(DmaPlan<R, NW>& pl, const bf16_t* __restrict__ src, int ld, int row0,
                                          int rows_total, int kbeg, int wave, int lane) {
 #pragma unroll
-  for (int j = 0; j < DmaPlan<R>::NINSTR; ++j) {
-    const int P = wave * DmaPlan<R>::PER_WAVE + j * 64 + lane;
+  for (int j = 0; j < DmaPlan<R, NW>::NINSTR; ++j) {
+    const int P = wave * DmaPlan<R, NW>::PER_WAVE + j * 64 + lane;
     if (!TRANS) {
       const int row = P >> 3, pos = P & 7;
       const int c = pos ^ swz_direct(row);
@@ -79,13 +79,13 @@ __device__ __forceinline__ void dma_plan(DmaPlan<R>& pl, const bf16_t* __restric
 
 // issue the LDS-DMA of the next K tile `t` (k range [kbeg + 64 t, ...)) of one operand into `stage`
 // and advance the plan.  TAIL: the tile crosses (or lies past) kend.
-template <int R, bool TRANS, bool TAIL>
-__device__ __forceinline__ void dma_tile(DmaPlan<R>& pl, size_t step, int t, int klen, uint32_t stage_addr, int wave) {
+template <int R, bool TRANS, bool TAIL, int NW>
+__device__ __forceinline__ void dma_tile(DmaPlan<R, NW>& pl, size_t step, int t, int klen, uint32_t stage_addr, int wave) {
 #pragma unroll
-  for (int j = 0; j < DmaPlan<R>::NINSTR; ++j) {
+  for (int j = 0; j < DmaPlan<R, NW>::NINSTR; ++j) {
     const bf16_t* g = pl.cur[j];
     if (TAIL) g = (t * 64 + pl.kofs[j] < klen) ? g : reinterpret_cast<const bf16_t*>(zk_zero_page);
-    glds16(g, stage_addr + (uint32_t)(wave * DmaPlan<R>::PER_WAVE + j * 64) * 16u);
+    glds16(g, stage_addr + (uint32_t)(wave * DmaPlan<R, NW>::PER_WAVE + j * 64) * 16u);
     pl.cur[j] += step;
   }
 }
@@ -135,20 +135,23 @@ struct DldsCfg {
 };
 
 // one BMxBN output tile over k in [kbeg, kend); slab != null: write the fp32 partial tile there
-template <int BM, int BN, int NS, bool TA, bool TB>
+// NW waves per workgroup: 4 (2 x 2 over the tile) or 2 (2 x 1: each wave a BM/2 x BN slab -- two MFMAs per
+// A fragment, half the co-resident-wave LDS footprint per workgroup)
+template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4>
 __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __restrict__ A,
                                           const bf16_t* __restrict__ B, int M, int N, int lda, int ldb, int kbeg,
                                           int kend, int m0, int n0, float* __restrict__ slab, const GemmEpi& e,
                                           int vec_ok) {
-  constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
+  constexpr int NWN = NW / 2;
+  constexpr int WTM = BM / 2, WTN = BN / NWN, TM = WTM / 32, TN = WTN / 32;
   constexpr int STAGE = DldsCfg<BM, BN, NS>::STAGE;
-  constexpr int PER_STAGE = (BM * 8 / 4 + BN * 8 / 4) / 64;  // DMA instructions per wave per stage
+  constexpr int PER_STAGE = (BM * 8 / NW + BN * 8 / NW) / 64;  // DMA instructions per wave per stage
   constexpr int CLD = DldsCfg<BM, BN, NS>::CLD;
   bf16_t* ring = reinterpret_cast<bf16_t*>(smem);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = NW == 4 ? wave >> 1 : wave, wn = NW == 4 ? wave & 1 : 0;
   const int nk = (kend - kbeg + 63) >> 6;
 
   f32x16_t acc[TM][TN];
@@ -159,10 +162,10 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  DmaPlan<BM> planA;
-  DmaPlan<BN> planB;
-  dma_plan<BM, TA>(planA, A, lda, m0, M, kbeg, wave, lane);
-  dma_plan<BN, !TB>(planB, B, ldb, n0, N, kbeg, wave, lane);
+  DmaPlan<BM, NW> planA;
+  DmaPlan<BN, NW> planB;
+  dma_plan<BM, TA, NW>(planA, A, lda, m0, M, kbeg, wave, lane);
+  dma_plan<BN, !TB, NW>(planB, B, ldb, n0, N, kbeg, wave, lane);
   const int klen = kend - kbeg;
   const size_t stepA = TA ? (size_t)64 * lda : (size_t)64;
   const size_t stepB = !TB ? (size_t)64 * ldb : (size_t)64;
@@ -170,11 +173,11 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
   auto issue = [&](int t) {
     const uint32_t st = ring_addr + (uint32_t)((t % NS) * STAGE * 2);
     if (t * 64 + 64 <= klen) {
-      dma_tile<BM, TA, false>(planA, stepA, t, klen, st, wave);
-      dma_tile<BN, !TB, false>(planB, stepB, t, klen, st + BM * 128, wave);
+      dma_tile<BM, TA, false, NW>(planA, stepA, t, klen, st, wave);
+      dma_tile<BN, !TB, false, NW>(planB, stepB, t, klen, st + BM * 128, wave);
     } else {
-      dma_tile<BM, TA, true>(planA, stepA, t, klen, st, wave);
-      dma_tile<BN, !TB, true>(planB, stepB, t, klen, st + BM * 128, wave);
+      dma_tile<BM, TA, true, NW>(planA, stepA, t, klen, st, wave);
+      dma_tile<BN, !TB, true, NW>(planB, stepB, t, klen, st + BM * 128, wave);
     }
   };
   // prologue: tiles 0 .. NS-2 (tiles past the end are all-zero pieces: keeps the DMA count uniform)
@@ -228,7 +231,7 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
   __syncthreads();
   const uint64_t seed = e.thr ? *e.seed : 0;
   constexpr int CPRW = BN / 8;
-  for (int c = tid; c < BM * CPRW; c += 256) {
+  for (int c = tid; c < BM * CPRW; c += NW * 64) {
     const int row = c / CPRW, cc = (c % CPRW) * 8;
     const int gm = m0 + row, gn = n0 + cc;
     if (gm >= M || gn >= N) continue;
@@ -288,8 +291,8 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
   }
 }
 
-template <int BM, int BN, int NS, bool TA, bool TB>
-__global__ void __launch_bounds__(256) k_gemm_dlds(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M,
+template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4>
+__global__ void __launch_bounds__(NW * 64) k_gemm_dlds(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M,
                                                    int N, int K, int lda, int ldb, int kchunk,
                                                    float* __restrict__ slabs, TileSched ts, GemmEpi e, EpiVec ev) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[DldsCfg<BM, BN, NS>::LDS_BYTES];   // the ONLY LDS object
@@ -297,8 +300,8 @@ __global__ void __launch_bounds__(256) k_gemm_dlds(const bf16_t* __restrict__ A,
   tile_of_block(ts, tm_, tn_, z_);
   const int kbeg = z_ * kchunk;
   const int kend = min(K, kbeg + kchunk);
-  gemm_tile<BM, BN, NS, TA, TB>(smem, A, B, M, N, lda, ldb, kbeg, kend, tm_ * BM, tn_ * BN,
-                                slabs ? slabs + (size_t)z_ * M * N : nullptr, e, ev.vec_ok);
+  gemm_tile<BM, BN, NS, TA, TB, NW>(smem, A, B, M, N, lda, ldb, kbeg, kend, tm_ * BM, tn_ * BN,
+                                    slabs ? slabs + (size_t)z_ * M * N : nullptr, e, ev.vec_ok);
 }
 
 // Grouped launch: many independent GEMMs (same transposition flags) in ONE grid -- the deferred
@@ -331,7 +334,7 @@ __global__ void __launch_bounds__(256) k_gemm_grouped(const GroupDesc* __restric
                                 vec_ok);
 }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, int NW = 4>
 static int launch_dlds(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
                        int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags, hipStream_t stream) {
   TileSched ts;
@@ -346,13 +349,13 @@ static int launch_dlds(const bf16_t* A, const bf16_t* B, int M, int N, int K, in
               (e.aux == nullptr || e.ldaux % 8 == 0);
   dim3 grid((unsigned)((long)ts.tiles_m * ts.tiles_n * splits));
   if (!ta && !tb)
-    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, false, false>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
+    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, false, false, NW>), grid, dim3(NW * 64), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
   else if (!ta && tb)
-    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, false, true>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
+    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, false, true, NW>), grid, dim3(NW * 64), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
   else if (ta && !tb)
-    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, true, false>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
+    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, true, false, NW>), grid, dim3(NW * 64), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
   else
-    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, true, true>), grid, dim3(256), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
+    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, true, true, NW>), grid, dim3(NW * 64), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
   ZK_LAUNCH_CHECK();
   return 0;
 }
@@ -387,6 +390,10 @@ int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K,
                           hipStream_t stream) {
   int ns = (sched_flags >> 4) & 15;   // ring-depth override (tuning)
   if (!ns && bm == 64 && bn == 64 && g_tune[3]) ns = g_tune[3];     // A/B: ring depth of the 64x64 tile in-step
+  if (bm == 64 && bn == 64 && g_tune[4] == 2)                       // A/B: two-wave workgroups, ring depth 2
+    return launch_dlds<64, 64, 2, 2>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+  if (bm == 64 && bn == 64 && g_tune[4] == 4)                       // two-wave workgroups, ring depth 4
+    return launch_dlds<64, 64, 4, 2>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
   if (ns) {
 #define ZK_NS(BM_, BN_, NS_) return launch_dlds<BM_, BN_, NS_>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream)
     if (bm == 64 && bn == 64) { if (ns == 2) ZK_NS(64, 64, 2); if (ns == 6) ZK_NS(64, 64, 6); if (ns == 8) ZK_NS(64, 64, 8); }
