@@ -49,9 +49,10 @@ def synthetic_batch(rank):
     return src, tgt
 
 
-def make_params(dropout=0.1, size="base"):
+def make_params(dropout=0.1, size="base", model="transformer"):
     hp = transformer_base_params(dropout=dropout, relu_dropout=dropout, residual_dropout=dropout,
-                                 attention_dropout=dropout, update_cycle=1, token_size=4096)
+                                 attention_dropout=dropout, update_cycle=1, token_size=4096,
+                                 model_name=model)
     if size == "big":        # BASELINE configs[2]: Transformer-big widths, same batch / vocabulary
         hp.override_from_dict(dict(hidden_size=1024, embed_size=1024, filter_size=4096, num_heads=16))
     hp.src_vocab = SyntheticVocab(V)
@@ -207,6 +208,8 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="transformer",
+                    help="registered model name (default: the metric's model); others are side measurements")
     ap.add_argument("--size", choices=["base", "big"], default="base",
                     help="base = BASELINE configs[1] (the metric's config, default); big = configs[2]")
     args = ap.parse_args()
@@ -221,7 +224,7 @@ def main():
     for kv in os.environ.get("ZERO_HIP_TUNE", "").split(","):     # e.g. ZERO_HIP_TUNE=0:0 (A/B switches)
         if ":" in kv:
             _hip.lib().raw("zk_tune")(int(kv.split(":")[0]), int(kv.split(":")[1]))
-    hp = make_params(args.dropout, args.size)
+    hp = make_params(args.dropout, args.size, args.model)
     hp.random_seed = 1234   # identical initial replicas on every rank
     tr = Trainer(hp)
     src, tgt = synthetic_batch(rank)
@@ -280,7 +283,8 @@ def main():
         "value": tokens / dt, "unit": "src+tgt tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "Transformer-%s (d=%d, L=6+6, F=%d, h=%d, V=32000) training step, "
+        "config": {"model_name": args.model,
+                   "workload": "Transformer-%s (d=%d, L=6+6, F=%d, h=%d, V=32000) training step, "
                                "B=64 x (src 64 + tgt 64) tokens per GPU, dropout %.2f, label_smooth 0.1, "
                                "fwd+bwd+allreduce+Adam" % (args.size, hp.hidden_size, hp.filter_size,
                                                            hp.num_heads, args.dropout),

@@ -55,8 +55,8 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
 /* Grouped launch of independent GEMMs with the same ta/tb in one grid (the deferred weight
  * gradients of several layers; the cross-attention k_map / v_map projections of every decoder
  * layer, func.py:206-216).  descs: DEVICE array of nprob records
- *   { const void* A, B; void* C; const float* bias; int M, N, K, lda, ldb, ldc, out_f32,
- *     tile_start, tiles_n, pad; }            (72 bytes)
+ *   { const void* A, B; void* C; const float* bias; const void* res /* bf16 residual or NULL,
+ *     may alias C */; int M, N, K, lda, ldb, ldc, out_f32, tile_start, tiles_n, ldr; }   (80 bytes)
  * tile_start = running sum of ceil(M/T)*ceil(N/T) with T = 128 (tile=1) or 64 (tile=4). */
 int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int tb, int tile,
                     zk_stream_t stream);
@@ -71,19 +71,32 @@ int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int t
  * queries attend to un-tiled per-sentence encoder keys, search.py:36-39 never materialised).
  * pos_dev (device int, may be NULL) carries the decode time step for hipGraph replay: pos_flags bit 0
  * -> q_pos0 = *pos_dev, bit 1 -> only keys 0..*pos_dev are valid (self-attention over the k/v cache,
- * func.py:199-205, with Lk = the allocated cache length). */
+ * func.py:199-205, with Lk = the allocated cache length).
+ * Relative positions on the MFMA kernels (d = 64) are DECOMPOSED (modules/rpr.py:10-75): the caller
+ * computes rpr_gq = Q_h . rpr_k^T (FP32 [B*Lq, rpr_ldg], entry (t, h, r) at t*rpr_ldg + h*rpr_nrp + r)
+ * with a GEMM, the kernel gathers it into the scores and writes rpr_pb = sums of P over the keys of each
+ * relative index (same layout, bf16); the caller finishes O += rpr_pb . rpr_v.  The backward takes
+ * rpr_gq, rpr_gd = dO_h . rpr_v^T (fp32) and writes rpr_pb, rpr_dsb (bf16 bucket sums of P and dS): dQ += dsb . rpr_k,
+ * d rpr_k = dsb^T Q, d rpr_v = pb^T dO are the caller's GEMMs.  Without rpr_gq the reference kernels
+ * apply the tables directly (any head size). */
 int zk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int nh, int Lq,
                 int Lk, int d, int ldq, int ldk, int ldv, int ldo, const float* kmask, int causal,
                 int q_pos0, float scale, float mask_inf, const void* rpr_k, const void* rpr_v, int max_rel,
                 float drop_p, const uint64_t* seed, uint32_t sid, long bsq, long bsk, long bsv, int kv_group,
-                int impl, const int* pos_dev, int pos_flags, zk_stream_t stream);
+                int impl, const int* pos_dev, int pos_flags, const void* rpr_gq, void* rpr_pb, int rpr_ldg,
+                int rpr_nrp, zk_stream_t stream);
 size_t zk_attn_bwd_workspace(int B, int nh, int Lq);
 int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                 const float* lse, void* dq, void* dk, void* dv, float* drpr_k, float* drpr_v, int B, int nh,
                 int Lq, int Lk, int d, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk,
                 int lddv, const float* kmask, int causal, int q_pos0, float scale, float mask_inf,
                 const void* rpr_k, const void* rpr_v, int max_rel, float drop_p, const uint64_t* seed,
-                uint32_t sid, int impl, void* workspace, size_t ws_bytes, zk_stream_t stream);
+                uint32_t sid, int impl, void* workspace, size_t ws_bytes, const void* rpr_gq,
+                const void* rpr_gd, void* rpr_pb, void* rpr_dsb, int rpr_ldg, int rpr_nrp, zk_stream_t stream);
+/* out[i] (+)= sum over s of in[s*stride + i], i < n  (fp32; head-wise partial table gradients of the
+   decomposed rpr path) */
+int zk_sum_slices(float* out, const float* in, int nslices, size_t n, size_t stride, int accumulate,
+                  zk_stream_t stream);
 
 /* ---- transformer.py:16-33 / 88-119 embedding * sqrt(H) + shared bias + timing signal
  * (func.py:341-369; `timing` = host-precomputed fp32 [Lmax,H] table).  shift=1: decoder

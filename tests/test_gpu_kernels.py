@@ -704,3 +704,23 @@ def test_gemm_two_wave_workgroups(variant, ta, tb):
         assert _gemm_case(2 | (4 << 8), 192, 256, 128, 0, 1, residual=True)[0] < 8e-3
     finally:
         e.lib.raw("zk_tune")(4, old)
+
+
+@pytest.mark.parametrize("case", [(2, 2, 64, 64, False, True), (3, 2, 37, 53, True, False), (2, 8, 64, 64, True, False),
+                                  (2, 2, 20, 20, False, True)])
+def test_attention_rpr_on_mfma_kernels(case):
+    """modules/rpr.py on the MFMA path (decomposed: gather of Q.Rk^T, bucket sums of P / dS, table GEMMs)
+    against the autograd reference, forward and backward, incl. both table gradients."""
+    B, nh, Lq, Lk, um, causal = case
+    errs = _attn_case(2, B, nh, Lq, Lk, 64, um, causal, rpr=True)
+    print(case, errs)
+    assert errs["out"] < 1.5e-2 and errs["lse"] < 3e-2
+    assert max(errs[k] for k in ("dq", "dk", "dv", "drk", "drv")) < 3e-2, errs
+
+
+def test_attention_rpr_mfma_forward_long_keys_and_dropout():
+    # forward with several key tiles (backward of such shapes stays on the reference kernels)
+    errs = _attn_case(0, 2, 2, 70, 130, 64, True, False, rpr=True)
+    assert errs["out"] < 1.5e-2 and max(errs[k] for k in ("dq", "dk", "dv", "drk", "drv")) < 3e-2, errs
+    errs = _attn_case(2, 2, 2, 64, 64, 64, True, False, rpr=True, drop=0.2)
+    assert errs["out"] < 1.5e-2 and max(errs[k] for k in ("dq", "dk", "dv", "drk", "drv")) < 3e-2, errs

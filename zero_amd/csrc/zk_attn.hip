@@ -36,6 +36,13 @@ struct AttnArgs {
   // decode step replayed from a hipGraph: the time step lives in device memory.  pos_flags bit 0:
   // q_pos0 = *pos_dev; bit 1: only keys 0 .. *pos_dev are valid (self-attention over the cache)
   const int* pos_dev; int pos_flags;
+  // Relative-position terms on the MFMA path (modules/rpr.py:10-75), decomposed so that the table
+  // products are plain GEMMs done by the caller.  All four are [B*Lq, ldg] (gq, gd fp32; pb, dsb bf16) with the entry of
+  // (token t, head h, relative index r) at t*ldg + h*nrp + r:
+  //   gq  in : Q_h . Rk^T   -> gathered into the scores      gd  in : dO_h . Rv^T -> gathered into dP
+  //   pb  out: sum over keys with relative index r of P (after dropout)   -> O += pb . Rv, dRv = pb^T dO
+  //   dsb out: the same bucket sums of dS                                  -> dQ += dsb . Rk, dRk = dsb^T Q
+  const float* gq; const float* gd; bf16_t* pb; bf16_t* dsb; int ldg; int nrp;
 };
 
 __device__ __forceinline__ void attn_apply_pos(AttnArgs& a) {
@@ -58,6 +65,36 @@ __device__ __forceinline__ float mask_bias(const AttnArgs& a, int b, int i_abs, 
   if (a.kmask != nullptr && a.kmask[(size_t)(b / a.kv_group) * a.ldmask + j] == 0.f) bias -= a.mask_inf;
   if (a.causal && j > i_abs) bias -= a.mask_inf;
   return bias;
+}
+
+// Bucket sums over the relative index for the 16 query rows a wave owns.  `val(row, j)` reads entry
+// (local row, key j) of a [64 x Lk] LDS tile; keys j in [0, Lk).  Interior indices 0 < r < 2m pick the
+// single key j = i_abs - (r - m); r = 0 collects j >= i_abs + m, r = 2m collects j <= i_abs - m
+// (the clipped tails of modules/rpr.py:66-75); r > 2m is padding (0).
+template <typename F>
+__device__ __forceinline__ void rpr_bucket_rows(const AttnArgs& a, bf16_t* __restrict__ dst, int b, int h, int i0,
+                                                int w, int lane, F val) {
+  const int m = a.max_rel;
+  for (int e = lane; e < 16 * a.nrp; e += 64) {
+    const int row = w * 16 + e / a.nrp, r = e % a.nrp;
+    const int i = i0 + row;
+    if (i >= a.Lq) continue;
+    const int ia = a.q_pos0 + i;
+    float acc = 0.f;
+    if (r > 0 && r < 2 * m) {
+      const int j = ia - (r - m);
+      if (j >= 0 && j < a.Lk) acc = val(row, j);
+    } else if (r == 0) {
+      for (int j = max(ia + m, 0); j < a.Lk; ++j) acc += val(row, j);
+    } else if (r == 2 * m) {
+      for (int j = min(ia - m, a.Lk - 1); j >= 0; --j) acc += val(row, j);
+    }
+    dst[((size_t)b * a.Lq + i) * a.ldg + h * a.nrp + r] = f2bf(acc);
+  }
+}
+__device__ __forceinline__ float rpr_gather(const AttnArgs& a, const float* __restrict__ tab, int b, int h, int i,
+                                            int j) {
+  return tab[((size_t)b * a.Lq + i) * a.ldg + h * a.nrp + rel_index(a.q_pos0 + i, j, a.max_rel)];
 }
 
 // =====================================================================================
@@ -377,7 +414,9 @@ __global__ void __launch_bounds__(256) k_attn_fwd_mfma(AttnArgs a, bf16_t* __res
     if (kvalid && a.kmask != nullptr && a.kmask[(size_t)(b / a.kv_group) * a.ldmask + j] == 0.f) kb_ = -a.mask_inf;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float s = S[t][r] * a.scale + kb_;
+      float raw = S[t][r];
+      if (a.gq != nullptr && kvalid && rbase + r < a.Lq) raw += rpr_gather(a, a.gq, b, h, rbase + r, j);
+      float s = raw * a.scale + kb_;
       if (a.causal && j > a.q_pos0 + rbase + r) s -= a.mask_inf;
       s = kvalid ? s : -INFINITY;
       S[t][r] = s;
@@ -416,6 +455,11 @@ __global__ void __launch_bounds__(256) k_attn_fwd_mfma(AttnArgs a, bf16_t* __res
       }
       sP[(w * 16 + (lane >> 4) * 4 + r) * PLD + j] = f2bf(p);
     }
+  }
+  if (a.pb != nullptr) {   // relative-position value term: bucket sums of this wave's own rows of P
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    rpr_bucket_rows(a, a.pb, b, h, i0, w, lane, [&](int row, int j) { return bf2f(sP[row * PLD + j]); });
   }
   // O = P V, V^T staged per key tile into sK
   f32x4_t O[4];
@@ -737,16 +781,19 @@ __global__ void __launch_bounds__(256) k_attn_bwd_fused64(AttnArgs a, const bf16
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = rloc + r;
-        float sc = sc4[r] * a.scale + kbias;
+        const bool live = kvalid && i < a.Lq;
+        float raw = sc4[r], dpr = dp[r];
+        if (a.gq != nullptr && live) { raw += rpr_gather(a, a.gq, b, h, i, j); dpr += rpr_gather(a, a.gd, b, h, i, j); }
+        float sc = raw * a.scale + kbias;
         if (a.causal && j > a.q_pos0 + i) sc -= a.mask_inf;
-        const float p = (kvalid && i < a.Lq) ? __expf(sc - sL[i]) : 0.f;
+        const float p = live ? __expf(sc - sL[i]) : 0.f;
         float ms = 1.f;
         if (a.thr) {
           const uint64_t idx = (((uint64_t)b * a.nh + h) * a.Lq + i) * a.Lk + j;
           ms = zk_drop_scale(seed, a.sid, idx, a.thr, a.inv_keep);
         }
         pv[nt][r] = p * ms;
-        dsv[nt][r] = p * (dp[r] * ms - sD[i]) * a.scale;
+        dsv[nt][r] = p * (dpr * ms - sD[i]) * a.scale;
       }
     }
   }
@@ -768,6 +815,10 @@ __global__ void __launch_bounds__(256) k_attn_bwd_fused64(AttnArgs a, const bf16
     for (int r = 0; r < 4; ++r) sdS[(rloc + r) * ALD + j] = f2bf(dsv[nt][r]);
   }
   __syncthreads();
+  if (a.dsb != nullptr) {   // bucket sums for the relative-position table products (see AttnArgs)
+    rpr_bucket_rows(a, a.dsb, b, h, 0, w, lane, [&](int row, int j) { return bf2f(sdS[row * ALD + j]); });
+    rpr_bucket_rows(a, a.pb, b, h, 0, w, lane, [&](int row, int j) { return bf2f(sPt[j * ALD + row]); });
+  }
   // ---- phase 2: wave w -> dQ rows 16w.. (queries) and dK / dV rows 16w.. (keys)
   f32x4_t dQ[4], dK[4], dV[4];
 #pragma unroll
@@ -820,11 +871,13 @@ static int fill_args(AttnArgs* a, const void* q, const void* k, const void* v, i
   a->inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   a->seed = seed; a->sid = sid;
   a->ldmask = Lk; a->pos_dev = nullptr; a->pos_flags = 0;
+  a->gq = nullptr; a->gd = nullptr; a->pb = nullptr; a->dsb = nullptr; a->ldg = 0; a->nrp = 0;
   return 0;
 }
 
 static bool attn_mfma_ok(const AttnArgs& a, int extra_ld_or) {
-  if (a.d != AD || a.rpr_k != nullptr || a.rpr_v != nullptr) return false;
+  // relative positions run on the MFMA kernels only in the decomposed form (gather tables supplied)
+  if (a.d != AD || ((a.rpr_k != nullptr || a.rpr_v != nullptr) && a.gq == nullptr)) return false;
   if ((a.ldq | a.ldk | a.ldv | extra_ld_or) % 8) return false;
   if ((((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) & 15) != 0) return false;
   return true;
@@ -836,8 +889,12 @@ int zk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* l
                 int d, int ldq, int ldk, int ldv, int ldo, const float* kmask, int causal, int q_pos0,
                 float scale, float mask_inf, const void* rpr_k, const void* rpr_v, int max_rel, float drop_p,
                 const uint64_t* seed, uint32_t sid, long bsq, long bsk, long bsv, int kv_group, int impl,
-                const int* pos_dev, int pos_flags, hipStream_t stream) {
+                const int* pos_dev, int pos_flags, const void* rpr_gq, void* rpr_pb, int rpr_ldg, int rpr_nrp,
+                hipStream_t stream) {
   ZK_CHECK_ARG((rpr_k == nullptr) == (rpr_v == nullptr), "zk_attn_fwd: rpr_k and rpr_v go together");
+  ZK_CHECK_ARG((rpr_gq == nullptr) == (rpr_pb == nullptr), "zk_attn_fwd: rpr_gq and rpr_pb go together");
+  ZK_CHECK_ARG(rpr_gq == nullptr || (rpr_nrp >= 2 * max_rel + 1 && rpr_ldg >= nh * rpr_nrp),
+               "zk_attn_fwd: rpr tables need nrp >= 2*max_rel+1 and ldg >= nh*nrp");
   ZK_CHECK_ARG(kv_group >= 1, "zk_attn_fwd: kv_group must be >= 1");
   ZK_CHECK_ARG(drop_p == 0.f || seed != nullptr, "zk_attn_fwd: dropout needs a seed pointer");
   ZK_CHECK_ARG(Lk >= 1, "zk_attn_fwd: Lk must be >= 1");
@@ -850,6 +907,7 @@ int zk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* l
   if (bsv > 0) a.bsv = bsv;
   a.kv_group = kv_group;
   a.pos_dev = pos_dev; a.pos_flags = pos_dev ? pos_flags : 0;
+  a.gq = (const float*)rpr_gq; a.pb = (bf16_t*)rpr_pb; a.ldg = rpr_ldg; a.nrp = rpr_nrp;
   const bool ok = attn_mfma_ok(a, ldo) && Lk <= 256 && (a.bsq % 8 == 0) && (a.bsk % 8 == 0) && (a.bsv % 8 == 0) && (((uintptr_t)out & 1) == 0);
   ZK_CHECK_ARG(impl != 2 || ok, "zk_attn_fwd: MFMA kernel needs d=64, no rpr, Lk<=256, ld%%8==0");
   if (impl == 2 || (impl == 0 && ok)) {
@@ -881,9 +939,14 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
                 int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, const float* kmask,
                 int causal, int q_pos0, float scale, float mask_inf, const void* rpr_k, const void* rpr_v,
                 int max_rel, float drop_p, const uint64_t* seed, uint32_t sid, int impl, void* workspace,
-                size_t ws_bytes, hipStream_t stream) {
+                size_t ws_bytes, const void* rpr_gq, const void* rpr_gd, void* rpr_pb, void* rpr_dsb, int rpr_ldg,
+                int rpr_nrp, hipStream_t stream) {
   ZK_CHECK_ARG((rpr_k == nullptr) == (rpr_v == nullptr), "zk_attn_bwd: rpr_k and rpr_v go together");
-  ZK_CHECK_ARG(rpr_k == nullptr || (drpr_k != nullptr && drpr_v != nullptr), "zk_attn_bwd: rpr needs grad outputs");
+  ZK_CHECK_ARG(rpr_k == nullptr || rpr_gq != nullptr || (drpr_k != nullptr && drpr_v != nullptr),
+               "zk_attn_bwd: rpr needs grad outputs");
+  ZK_CHECK_ARG(rpr_gq == nullptr || (rpr_gd != nullptr && rpr_pb != nullptr && rpr_dsb != nullptr &&
+                                     rpr_nrp >= 2 * max_rel + 1 && rpr_ldg >= nh * rpr_nrp && Lq <= TQ && Lk <= TQ),
+               "zk_attn_bwd: decomposed rpr needs gq, gd, pb, dsb, nrp >= 2*max_rel+1 and Lq, Lk <= 64");
   ZK_CHECK_ARG(ws_bytes >= zk_attn_bwd_workspace(B, nh, Lq), "zk_attn_bwd: workspace too small");
   ZK_CHECK_ARG(drop_p == 0.f || seed != nullptr, "zk_attn_bwd: dropout needs a seed pointer");
   if (B == 0 || Lq == 0 || Lk == 0) return 0;
@@ -891,7 +954,10 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
   fill_args(&a, q, k, v, ldq, ldk, ldv, B, nh, Lq, Lk, d, kmask, causal, q_pos0, scale, mask_inf, rpr_k, rpr_v,
             max_rel, drop_p, seed, sid);
   float* Dbuf = (float*)workspace;
+  a.gq = (const float*)rpr_gq; a.gd = (const float*)rpr_gd; a.pb = (bf16_t*)rpr_pb; a.dsb = (bf16_t*)rpr_dsb;
+  a.ldg = rpr_ldg; a.nrp = rpr_nrp;
   const bool ok = attn_mfma_ok(a, ldo | lddo | lddq | lddk | lddv);
+  ZK_CHECK_ARG(rpr_gq == nullptr || (ok && impl != 1 && impl != 3), "zk_attn_bwd: decomposed rpr runs on the fused MFMA kernel only");
   ZK_CHECK_ARG(impl != 2 || ok, "zk_attn_bwd: MFMA kernel needs d=64, no rpr, ld%%8==0");
   ZK_CHECK_ARG(impl != 3 || ok, "zk_attn_bwd: MFMA kernels need d=64, no rpr, ld%%8==0");
   if ((impl == 0 || impl == 2) && ok && Lq <= TQ && Lk <= TQ) {      // impl 3 forces the two-kernel form

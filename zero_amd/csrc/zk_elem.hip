@@ -854,6 +854,16 @@ __global__ void __launch_bounds__(256) k_cumavg_bwd(const bf16_t* __restrict__ d
   }
 }
 
+// out[i] (+)= sum_s in[s*n + i]
+__global__ void __launch_bounds__(256) k_sum_slices(float* __restrict__ out, const float* __restrict__ in, int nslices,
+                                                    size_t n, size_t stride, int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float acc = accumulate ? out[i] : 0.f;
+    for (int s = 0; s < nslices; ++s) acc += in[(size_t)s * stride + i];
+    out[i] = acc;
+  }
+}
+
 // out = a + b on bf16 row blocks with independent leading dimensions (cols % 8 == 0)
 __global__ void __launch_bounds__(256) k_add_bf16(bf16_t* __restrict__ out, int ldo, const bf16_t* __restrict__ a,
                                                   int lda, const bf16_t* __restrict__ b, int ldb, int rows, int cols) {
@@ -1352,6 +1362,16 @@ int zk_cumavg_bwd(const void* dy, const float* mask, void* dvq, int B, int L, in
   if (n == 0 || L == 0) return 0;
   hipLaunchKernelGGL(k_cumavg_bwd, dim3((n + 255) / 256), dim3(256), 0, stream, (const bf16_t*)dy, mask,
                      (bf16_t*)dvq, B, L, H);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_sum_slices(float* out, const float* in, int nslices, size_t n, size_t stride, int accumulate,
+                  hipStream_t stream) {
+  if (n == 0 || nslices <= 0) return 0;
+  ZK_CHECK_ARG(stride >= n, "zk_sum_slices: stride must be >= n");
+  hipLaunchKernelGGL(k_sum_slices, dim3(flat_grid(n, 1)), dim3(256), 0, stream, out, in, nslices, n, stride,
+                     accumulate);
   ZK_LAUNCH_CHECK();
   return 0;
 }

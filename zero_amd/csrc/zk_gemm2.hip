@@ -310,8 +310,9 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_dlds(const bf16_t* __restrict_
 // full K per tile and no split-K slabs.  Descriptors live in device memory.
 struct GroupDesc {
   const bf16_t* A; const bf16_t* B; void* C; const float* bias;
-  int M, N, K, lda, ldb, ldc, out_f32, tile_start, tiles_n, pad_;
-};
+  const bf16_t* res;          // optional bf16 residual added in the epilogue (may alias C), row stride ldr
+  int M, N, K, lda, ldb, ldc, out_f32, tile_start, tiles_n, ldr;
+};                            // 80 bytes; mirrored by zero_amd/func.py:_GroupDesc
 
 template <int BM, int BN, int NS, bool TA, bool TB>
 __global__ void __launch_bounds__(256) k_gemm_grouped(const GroupDesc* __restrict__ descs, int nprob) {
@@ -326,10 +327,10 @@ __global__ void __launch_bounds__(256) k_gemm_grouped(const GroupDesc* __restric
   const int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
   GemmEpi e;
   e.C = d.C; e.ldc = d.ldc; e.out_f32 = d.out_f32; e.alpha = 1.f; e.bias = d.bias;
-  e.res = nullptr; e.ldr = 0; e.act = 0; e.aux = nullptr; e.ldaux = 0; e.aux_scale = 1.f;
+  e.res = d.res; e.ldr = d.ldr; e.act = 0; e.aux = nullptr; e.ldaux = 0; e.aux_scale = 1.f;
   e.thr = 0; e.inv_keep = 1.f; e.seed = nullptr; e.sid = 0;
-  const uintptr_t al = (uintptr_t)d.C | (uintptr_t)d.bias;
-  const int vec_ok = ((al & 15) == 0) && (d.ldc % 8 == 0);
+  const uintptr_t al = (uintptr_t)d.C | (uintptr_t)d.bias | (uintptr_t)d.res;
+  const int vec_ok = ((al & 15) == 0) && (d.ldc % 8 == 0) && (d.res == nullptr || d.ldr % 8 == 0);
   gemm_tile<BM, BN, NS, TA, TB>(smem, d.A, d.B, d.M, d.N, d.lda, d.ldb, 0, d.K, tm * BM, tn * BN, nullptr, e,
                                 vec_ok);
 }
@@ -361,7 +362,7 @@ static int launch_dlds(const bf16_t* A, const bf16_t* B, int M, int N, int K, in
 }
 
 extern "C" {
-// descs: device array of `nprob` GroupDesc (72 bytes each, see zk_gemm2.hip) whose tile_start
+// descs: device array of `nprob` GroupDesc (80 bytes each, see zk_gemm2.hip) whose tile_start
 // fields are the running sum of ceil(M/bm)*ceil(N/bn); total_tiles = that sum.
 int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int tb, int tile, hipStream_t stream) {
   ZK_CHECK_ARG(nprob >= 1 && total_tiles >= 1, "zk_gemm_grouped: empty group");

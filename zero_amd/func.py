@@ -27,9 +27,9 @@ from zero_amd.utils import dtype as zdtype
 class _GroupDesc(ctypes.Structure):
     """Mirror of ``struct GroupDesc`` (zero_amd/csrc/zk_gemm2.hip, include/zero_hip.h)."""
     _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p),
-                ("bias", ctypes.c_void_p)] + [(n, ctypes.c_int) for n in
-                                              ("M", "N", "K", "lda", "ldb", "ldc", "out_f32", "tile_start",
-                                               "tiles_n", "pad")]
+                ("bias", ctypes.c_void_p), ("res", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int) for n in ("M", "N", "K", "lda", "ldb", "ldc", "out_f32", "tile_start",
+                                            "tiles_n", "ldr")]
 
 
 class _ColsumDesc(ctypes.Structure):
@@ -152,22 +152,25 @@ class Engine(object):
 
     def gemm_grouped(self, problems, ta, tb, tile=128):
         """One launch for many independent GEMMs with the same ta/tb.
-        problems: list of (A, B, C, M, N, K, bias-or-None) with Mat operands.  The device descriptor
-        table is cached per problem list (buffers are static, so it is built once)."""
-        key = (ta, tb, tile) + tuple((a.ptr, b.ptr, c.ptr, M, N, K, hip.ptr(bias) or 0)
-                                     for a, b, c, M, N, K, bias in problems)
+        problems: list of (A, B, C, M, N, K, bias-or-None[, residual Mat-or-None]) with Mat operands.
+        The device descriptor table is cached per problem list (buffers are static, so it is built
+        once)."""
+        problems = [tuple(p) + (None,) * (8 - len(p)) for p in problems]
+        key = (ta, tb, tile) + tuple((a.ptr, b.ptr, c.ptr, M, N, K, hip.ptr(bias) or 0, r.ptr if r is not None else 0)
+                                     for a, b, c, M, N, K, bias, r in problems)
         cache = self.__dict__.setdefault("_group_cache", {})
         ent = cache.get(key)
         if ent is None:
             arr = (_GroupDesc * len(problems))()
             start = 0
-            for i, (a, b, c, M, N, K, bias) in enumerate(problems):
+            for i, (a, b, c, M, N, K, bias, res) in enumerate(problems):
                 tn = (N + tile - 1) // tile
                 d = arr[i]
                 d.A, d.B, d.C, d.bias = a.ptr, b.ptr, c.ptr, hip.ptr(bias) or 0
+                d.res, d.ldr = (res.ptr, res.ld) if res is not None else (0, 0)
                 d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, a.ld, b.ld, c.ld
                 d.out_f32 = 1 if c.t.dtype == torch.float32 else 0
-                d.tile_start, d.tiles_n, d.pad = start, tn, 0
+                d.tile_start, d.tiles_n = start, tn
                 start += ((M + tile - 1) // tile) * tn
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             ent = (host.to(self.device), len(problems), start)
@@ -225,26 +228,91 @@ class Engine(object):
                       ws.numel(), self.stream)
 
     # ---- func.py:164-286 attention core ----------------------------------------
+    # ---- attention (func.py:218-256; relative positions modules/rpr.py:10-75) -------------------
+    def _rpr_tables(self, rpr_k, rpr_v, max_rel, d):
+        """Zero-padded [nrp, d] bf16 copies of the two relative-position tables (nrp = 2*max_rel+1
+        rounded up to 8) so that they can be GEMM operands with an 8-aligned contraction length."""
+        nrel = 2 * max_rel + 1
+        nrp = (nrel + 7) // 8 * 8
+        pads = []
+        for tag, t in (("k", rpr_k), ("v", rpr_v)):
+            name = "rpr.pad%s.%d" % (tag, t.data_ptr())
+            fresh = name not in self.bufs
+            pad = self.mat(name, nrp, d)
+            if fresh:
+                self.zero(pad.t)           # buffers are uninitialised; the padding rows must stay zero
+            self.lib.call("zk_gather_rows", t.data_ptr(), d * 2, None, pad.ptr, d * 2, nrel, d * 2, self.stream)
+            pads.append(pad)
+        return nrp, pads[0], pads[1]
+
+    def _rpr_mfma(self, impl, d, Lk, rpr_k, lds):
+        impl = self.attn_impl if impl is None else impl
+        return rpr_k is not None and impl in (0, 2) and d == 64 and Lk <= 256 and all(x % 8 == 0 for x in lds)
+
     def attn_fwd(self, q, k, v, out, lse, B, nh, Lq, Lk, d, kmask=None, causal=False, q_pos0=0,
                  rpr_k=None, rpr_v=None, max_rel=0, drop_p=0.0, sid=0, bsq=0, bsk=0, bsv=0, kv_group=1,
                  impl=None, pos_dev=None, pos_flags=0):
+        gq = pb = None
+        ldg = nrp = 0
+        if Lq > 1 and kv_group == 1 and not bsq and self._rpr_mfma(impl, d, Lk, rpr_k, (q.ld, k.ld, v.ld, out.ld)):
+            # decomposed form: scores gather Q_h.Rk^T, the kernel returns the per-index sums of P and
+            # O += pb.Rv finishes the value term -- three grouped GEMM launches around the MFMA kernel
+            T = B * Lq
+            nrp, rk, rv = self._rpr_tables(rpr_k, rpr_v, max_rel, d)
+            ldg = nh * nrp
+            gq = self.mat("rpr.gq.%d" % T, T, ldg, torch.float32)
+            pb = self.mat("rpr.pb.%d" % T, T, ldg)
+            self.gemm_grouped([(q.cols_slice(h * d, (h + 1) * d), rk, gq.cols_slice(h * nrp, (h + 1) * nrp), T, nrp, d, None)
+                               for h in range(nh)], 0, 1, tile=64)
         self.lib.call(
             "zk_attn_fwd", q.ptr, k.ptr, v.ptr, out.ptr, hip.ptr(lse), B, nh, Lq, Lk, d, q.ld, k.ld, v.ld,
             out.ld, hip.ptr(kmask), 1 if causal else 0, q_pos0, float(d) ** -0.5, zdtype.inf(),
             hip.ptr(rpr_k), hip.ptr(rpr_v), max_rel, float(drop_p), self.seed.data_ptr(), sid,
             bsq, bsk, bsv, kv_group, self.attn_impl if impl is None else impl, hip.ptr(pos_dev), pos_flags,
-            self.stream)
+            gq.ptr if gq is not None else None, pb.ptr if pb is not None else None, ldg, nrp, self.stream)
+        if gq is not None:
+            self.gemm_grouped([(pb.cols_slice(h * nrp, (h + 1) * nrp), rv, out.cols_slice(h * d, (h + 1) * d), T, d, nrp,
+                                None, out.cols_slice(h * d, (h + 1) * d)) for h in range(nh)], 0, 0, tile=64)
 
     def attn_bwd(self, q, k, v, out, dout, lse, dq, dk, dv, B, nh, Lq, Lk, d, kmask=None, causal=False,
                  rpr_k=None, rpr_v=None, drpr_k=None, drpr_v=None, max_rel=0, drop_p=0.0, sid=0, impl=None):
         ws_bytes = self.lib.query("zk_attn_bwd_workspace", B, nh, Lq)
         ws = self.workspace(ws_bytes)
+        dec = Lq <= 64 and Lk <= 64 and self._rpr_mfma(
+            impl, d, Lk, rpr_k, (q.ld, k.ld, v.ld, out.ld, dout.ld, dq.ld, dk.ld, dv.ld))
+        tabs = (None, None, None, None)
+        ldg = nrp = 0
+        if dec:
+            T = B * Lq
+            nrp, rk, rv = self._rpr_tables(rpr_k, rpr_v, max_rel, d)
+            ldg = nh * nrp
+            gq = self.mat("rpr.gq.%d" % T, T, ldg, torch.float32)
+            gd = self.mat("rpr.gd.%d" % T, T, ldg, torch.float32)
+            pb, dsb = self.mat("rpr.pb.%d" % T, T, ldg), self.mat("rpr.dsb.%d" % T, T, ldg)
+            heads = range(nh)
+            sl = lambda m, h, w: m.cols_slice(h * w, (h + 1) * w)
+            self.gemm_grouped([(sl(q, h, d), rk, sl(gq, h, nrp), T, nrp, d, None) for h in heads] +
+                              [(sl(dout, h, d), rv, sl(gd, h, nrp), T, nrp, d, None) for h in heads], 0, 1, tile=64)
+            tabs = (gq.ptr, gd.ptr, pb.ptr, dsb.ptr)
         self.lib.call(
             "zk_attn_bwd", q.ptr, k.ptr, v.ptr, out.ptr, dout.ptr, lse.data_ptr(), dq.ptr, dk.ptr, dv.ptr,
             hip.ptr(drpr_k), hip.ptr(drpr_v), B, nh, Lq, Lk, d, q.ld, k.ld, v.ld, out.ld, dout.ld, dq.ld,
             dk.ld, dv.ld, hip.ptr(kmask), 1 if causal else 0, 0, float(d) ** -0.5, zdtype.inf(),
             hip.ptr(rpr_k), hip.ptr(rpr_v), max_rel, float(drop_p), self.seed.data_ptr(), sid,
-            self.attn_impl if impl is None else impl, ws.data_ptr(), ws.numel(), self.stream)
+            self.attn_impl if impl is None else impl, ws.data_ptr(), ws.numel(),
+            tabs[0], tabs[1], tabs[2], tabs[3], ldg, nrp, self.stream)
+        if dec:
+            # dQ += dsb.Rk ; table gradients: per-head partials dsb_h^T Q_h and pb_h^T dO_h, summed over heads
+            self.gemm_grouped([(sl(dsb, h, nrp), rk, sl(dq, h, d), T, d, nrp, None, sl(dq, h, d)) for h in heads],
+                              0, 0, tile=64)
+            part = self.mat("rpr.part", 2 * nh * nrp, d, torch.float32)
+            rows = lambda i: Mat(part.t, nrp, d, d, i * nrp * d)
+            self.gemm_grouped([(sl(dsb, h, nrp), sl(q, h, d), rows(h), nrp, d, T, None) for h in heads] +
+                              [(sl(pb, h, nrp), sl(dout, h, d), rows(nh + h), nrp, d, T, None) for h in heads],
+                              1, 0, tile=64)
+            n = (2 * max_rel + 1) * d
+            self.lib.call("zk_sum_slices", drpr_k.data_ptr(), part.ptr, nh, n, nrp * d, 1, self.stream)
+            self.lib.call("zk_sum_slices", drpr_v.data_ptr(), part.ptr + nh * nrp * d * 4, nh, n, nrp * d, 1, self.stream)
 
     # ---- embedding + timing (transformer.py:16-33, 88-119; func.py:341-369) -------
     def embed_fwd(self, ids, table, bias, out, B, L, H, shift=False, pos0=0, zero_flag=None, drop_p=0.0,
