@@ -707,7 +707,8 @@ def test_gemm_two_wave_workgroups(variant, ta, tb):
 
 
 @pytest.mark.parametrize("case", [(2, 2, 64, 64, False, True), (3, 2, 37, 53, True, False), (2, 8, 64, 64, True, False),
-                                  (2, 2, 20, 20, False, True)])
+                                  (2, 2, 20, 20, False, True), (2, 2, 70, 130, True, False), (1, 2, 130, 130, False, True),
+                                  (2, 2, 100, 40, False, False)])
 def test_attention_rpr_on_mfma_kernels(case):
     """modules/rpr.py on the MFMA path (decomposed: gather of Q.Rk^T, bucket sums of P / dS, table GEMMs)
     against the autograd reference, forward and backward, incl. both table gradients."""
@@ -719,7 +720,7 @@ def test_attention_rpr_on_mfma_kernels(case):
 
 
 def test_attention_rpr_mfma_forward_long_keys_and_dropout():
-    # forward with several key tiles (backward of such shapes stays on the reference kernels)
+    # auto dispatch with several key / query tiles (two-kernel backward), then dropout on the fused one
     errs = _attn_case(0, 2, 2, 70, 130, 64, True, False, rpr=True)
     assert errs["out"] < 1.5e-2 and max(errs[k] for k in ("dq", "dk", "dv", "drk", "drv")) < 3e-2, errs
     errs = _attn_case(2, 2, 2, 64, 64, 64, True, False, rpr=True, drop=0.2)

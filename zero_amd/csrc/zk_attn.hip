@@ -92,6 +92,42 @@ __device__ __forceinline__ void rpr_bucket_rows(const AttnArgs& a, bf16_t* __res
     dst[((size_t)b * a.Lq + i) * a.ldg + h * a.nrp + r] = f2bf(acc);
   }
 }
+// Multi-tile form: entry u of this lane (e = lane + 64 u) accumulates the keys [j0, j0 + 64) of the tile
+// currently in LDS; `val(row, jl)` reads local key jl.  MAXU * 64 >= 16 * nrp entries per wave.
+#define RPR_MAXU 16
+template <typename F>
+__device__ __forceinline__ void rpr_bucket_accum(const AttnArgs& a, float (&acc)[RPR_MAXU], int i0, int j0, int w,
+                                                 int lane, F val) {
+  const int m = a.max_rel;
+#pragma unroll
+  for (int u = 0; u < RPR_MAXU; ++u) {
+    const int e = lane + 64 * u;
+    if (e >= 16 * a.nrp) break;
+    const int row = w * 16 + e / a.nrp, r = e % a.nrp;
+    const int i = i0 + row;
+    if (i >= a.Lq) continue;
+    const int ia = a.q_pos0 + i;
+    const int jend = min(j0 + 64, a.Lk);
+    if (r > 0 && r < 2 * m) {
+      const int j = ia - (r - m);
+      if (j >= j0 && j < jend) acc[u] += val(row, j - j0);
+    } else if (r == 0) {
+      for (int j = max(ia + m, j0); j < jend; ++j) acc[u] += val(row, j - j0);
+    } else if (r == 2 * m) {
+      for (int j = min(ia - m, jend - 1); j >= j0; --j) acc[u] += val(row, j - j0);
+    }
+  }
+}
+__device__ __forceinline__ void rpr_bucket_store(const AttnArgs& a, const float (&acc)[RPR_MAXU], bf16_t* __restrict__ dst,
+                                                 int b, int h, int i0, int w, int lane) {
+#pragma unroll
+  for (int u = 0; u < RPR_MAXU; ++u) {
+    const int e = lane + 64 * u;
+    if (e >= 16 * a.nrp) break;
+    const int i = i0 + w * 16 + e / a.nrp;
+    if (i < a.Lq) dst[((size_t)b * a.Lq + i) * a.ldg + h * a.nrp + e % a.nrp] = f2bf(acc[u]);
+  }
+}
 __device__ __forceinline__ float rpr_gather(const AttnArgs& a, const float* __restrict__ tab, int b, int h, int i,
                                             int j) {
   return tab[((size_t)b * a.Lq + i) * a.ldg + h * a.nrp + rel_index(a.q_pos0 + i, j, a.max_rel)];
@@ -501,10 +537,14 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dq_mfma(AttnArgs a, const bf16
   __shared__ __attribute__((aligned(16))) bf16_t sV[TQ * ALD];
   __shared__ __attribute__((aligned(16))) bf16_t sKt[TQ * ALD];
   __shared__ __attribute__((aligned(16))) bf16_t sdS[TQ * ALD];
+  __shared__ __attribute__((aligned(16))) bf16_t sPd[TQ * ALD];   // dropped P of the tile (relative-position sums only)
   __shared__ float sD[TQ];
   __shared__ float sL[TQ];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i0 = blockIdx.x * TQ, h = blockIdx.y, b = blockIdx.z;
+  float acc_dsb[RPR_MAXU], acc_pb[RPR_MAXU];
+#pragma unroll
+  for (int u = 0; u < RPR_MAXU; ++u) { acc_dsb[u] = 0.f; acc_pb[u] = 0.f; }
   const bf16_t* qb = a.q + (size_t)b * a.bsq + h * AD;
   const bf16_t* kb = a.k + (size_t)(b / a.kv_group) * a.bsk + h * AD;
   const bf16_t* vb = a.v + (size_t)(b / a.kv_group) * a.bsv + h * AD;
@@ -563,19 +603,27 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dq_mfma(AttnArgs a, const bf16
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + rloc + r;
-        float sc = s[r] * a.scale + kbias;
+        float raw = s[r], dpv = dp[r];
+        if (a.gq != nullptr && kvalid && i < a.Lq) { raw += rpr_gather(a, a.gq, b, h, i, j); dpv += rpr_gather(a, a.gd, b, h, i, j); }
+        float sc = raw * a.scale + kbias;
         if (a.causal && j > a.q_pos0 + i) sc -= a.mask_inf;
         const float p = kvalid ? __expf(sc - sL[rloc + r]) : 0.f;
-        float dpv = dp[r];
+        float ms = 1.f;
         if (a.thr) {
           const uint64_t idx = (((uint64_t)b * a.nh + h) * a.Lq + i) * a.Lk + j;
-          dpv *= zk_drop_scale(seed, a.sid, idx, a.thr, a.inv_keep);
+          ms = zk_drop_scale(seed, a.sid, idx, a.thr, a.inv_keep);
         }
+        dpv *= ms;
         const float ds = p * (dpv - sD[rloc + r]) * a.scale;
         sdS[(rloc + r) * ALD + nt * 16 + (lane & 15)] = f2bf(ds);
+        if (a.dsb != nullptr) sPd[(rloc + r) * ALD + nt * 16 + (lane & 15)] = f2bf(i < a.Lq ? p * ms : 0.f);
       }
     }
     __syncthreads();
+    if (a.dsb != nullptr) {   // per-index sums of dS and P over this key tile (rows of this wave)
+      rpr_bucket_accum(a, acc_dsb, i0, kt * 64, w, lane, [&](int row, int jl) { return bf2f(sdS[row * ALD + jl]); });
+      rpr_bucket_accum(a, acc_pb, i0, kt * 64, w, lane, [&](int row, int jl) { return bf2f(sPd[row * ALD + jl]); });
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const uint4 da = frag(sdS, w * 16, kk, lane);
@@ -591,6 +639,10 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dq_mfma(AttnArgs a, const bf16
       const int i = i0 + rloc + r;
       if (i < a.Lq) dq[((size_t)b * a.Lq + i) * lddq + h * AD + c] = f2bf(dQ[nb][r]);
     }
+  }
+  if (a.dsb != nullptr) {
+    rpr_bucket_store(a, acc_dsb, a.dsb, b, h, i0, w, lane);
+    rpr_bucket_store(a, acc_pb, a.pb, b, h, i0, w, lane);
   }
 }
 
@@ -661,7 +713,9 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv_mfma(AttnArgs a, const bf1
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = j0 + jloc + r;
-        float sc = st[r] * a.scale + kbias[r];
+        float raw = st[r], dpr = dpt[r];
+        if (a.gq != nullptr && qvalid && kval[r]) { raw += rpr_gather(a, a.gq, b, h, i, j); dpr += rpr_gather(a, a.gd, b, h, i, j); }
+        float sc = raw * a.scale + kbias[r];
         if (a.causal && j > a.q_pos0 + i) sc -= a.mask_inf;
         const float p = (qvalid && kval[r]) ? __expf(sc - li) : 0.f;
         float ms = 1.f;
@@ -669,7 +723,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv_mfma(AttnArgs a, const bf1
           const uint64_t idx = (((uint64_t)b * a.nh + h) * a.Lq + i) * a.Lk + j;
           ms = zk_drop_scale(seed, a.sid, idx, a.thr, a.inv_keep);
         }
-        const float ds = p * (dpt[r] * ms - Di) * a.scale;
+        const float ds = p * (dpr * ms - Di) * a.scale;
         sPt[(jloc + r) * ALD + il] = f2bf(p * ms);
         sdSt[(jloc + r) * ALD + il] = f2bf(ds);
       }
@@ -893,8 +947,8 @@ int zk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* l
                 hipStream_t stream) {
   ZK_CHECK_ARG((rpr_k == nullptr) == (rpr_v == nullptr), "zk_attn_fwd: rpr_k and rpr_v go together");
   ZK_CHECK_ARG((rpr_gq == nullptr) == (rpr_pb == nullptr), "zk_attn_fwd: rpr_gq and rpr_pb go together");
-  ZK_CHECK_ARG(rpr_gq == nullptr || (rpr_nrp >= 2 * max_rel + 1 && rpr_ldg >= nh * rpr_nrp),
-               "zk_attn_fwd: rpr tables need nrp >= 2*max_rel+1 and ldg >= nh*nrp");
+  ZK_CHECK_ARG(rpr_gq == nullptr || (rpr_nrp >= 2 * max_rel + 1 && rpr_nrp <= 64 && rpr_ldg >= nh * rpr_nrp),
+               "zk_attn_fwd: rpr tables need 2*max_rel+1 <= nrp <= 64 and ldg >= nh*nrp");
   ZK_CHECK_ARG(kv_group >= 1, "zk_attn_fwd: kv_group must be >= 1");
   ZK_CHECK_ARG(drop_p == 0.f || seed != nullptr, "zk_attn_fwd: dropout needs a seed pointer");
   ZK_CHECK_ARG(Lk >= 1, "zk_attn_fwd: Lk must be >= 1");
@@ -945,8 +999,8 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
   ZK_CHECK_ARG(rpr_k == nullptr || rpr_gq != nullptr || (drpr_k != nullptr && drpr_v != nullptr),
                "zk_attn_bwd: rpr needs grad outputs");
   ZK_CHECK_ARG(rpr_gq == nullptr || (rpr_gd != nullptr && rpr_pb != nullptr && rpr_dsb != nullptr &&
-                                     rpr_nrp >= 2 * max_rel + 1 && rpr_ldg >= nh * rpr_nrp && Lq <= TQ && Lk <= TQ),
-               "zk_attn_bwd: decomposed rpr needs gq, gd, pb, dsb, nrp >= 2*max_rel+1 and Lq, Lk <= 64");
+                                     rpr_nrp >= 2 * max_rel + 1 && rpr_nrp <= 64 && rpr_ldg >= nh * rpr_nrp),
+               "zk_attn_bwd: decomposed rpr needs gq, gd, pb, dsb and 2*max_rel+1 <= nrp <= 64");
   ZK_CHECK_ARG(ws_bytes >= zk_attn_bwd_workspace(B, nh, Lq), "zk_attn_bwd: workspace too small");
   ZK_CHECK_ARG(drop_p == 0.f || seed != nullptr, "zk_attn_bwd: dropout needs a seed pointer");
   if (B == 0 || Lq == 0 || Lk == 0) return 0;
@@ -957,7 +1011,7 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
   a.gq = (const float*)rpr_gq; a.gd = (const float*)rpr_gd; a.pb = (bf16_t*)rpr_pb; a.dsb = (bf16_t*)rpr_dsb;
   a.ldg = rpr_ldg; a.nrp = rpr_nrp;
   const bool ok = attn_mfma_ok(a, ldo | lddo | lddq | lddk | lddv);
-  ZK_CHECK_ARG(rpr_gq == nullptr || (ok && impl != 1 && impl != 3), "zk_attn_bwd: decomposed rpr runs on the fused MFMA kernel only");
+  ZK_CHECK_ARG(rpr_gq == nullptr || (ok && impl != 1), "zk_attn_bwd: decomposed rpr runs on the MFMA kernels only");
   ZK_CHECK_ARG(impl != 2 || ok, "zk_attn_bwd: MFMA kernel needs d=64, no rpr, ld%%8==0");
   ZK_CHECK_ARG(impl != 3 || ok, "zk_attn_bwd: MFMA kernels need d=64, no rpr, ld%%8==0");
   if ((impl == 0 || impl == 2) && ok && Lq <= TQ && Lk <= TQ) {      // impl 3 forces the two-kernel form

@@ -245,16 +245,18 @@ class Engine(object):
             pads.append(pad)
         return nrp, pads[0], pads[1]
 
-    def _rpr_mfma(self, impl, d, Lk, rpr_k, lds):
+    def _rpr_mfma(self, impl, d, Lk, rpr_k, lds, max_rel, bwd=False):
+        """Can the relative-position attention run on the MFMA kernels (decomposed form)?"""
         impl = self.attn_impl if impl is None else impl
-        return rpr_k is not None and impl in (0, 2) and d == 64 and Lk <= 256 and all(x % 8 == 0 for x in lds)
+        return rpr_k is not None and impl in ((0, 2, 3) if bwd else (0, 2)) and d == 64 and Lk <= 256 and \
+            2 * max_rel + 1 <= 64 and all(x % 8 == 0 for x in lds)
 
     def attn_fwd(self, q, k, v, out, lse, B, nh, Lq, Lk, d, kmask=None, causal=False, q_pos0=0,
                  rpr_k=None, rpr_v=None, max_rel=0, drop_p=0.0, sid=0, bsq=0, bsk=0, bsv=0, kv_group=1,
                  impl=None, pos_dev=None, pos_flags=0):
         gq = pb = None
         ldg = nrp = 0
-        if Lq > 1 and kv_group == 1 and not bsq and self._rpr_mfma(impl, d, Lk, rpr_k, (q.ld, k.ld, v.ld, out.ld)):
+        if Lq > 1 and kv_group == 1 and not bsq and self._rpr_mfma(impl, d, Lk, rpr_k, (q.ld, k.ld, v.ld, out.ld), max_rel):
             # decomposed form: scores gather Q_h.Rk^T, the kernel returns the per-index sums of P and
             # O += pb.Rv finishes the value term -- three grouped GEMM launches around the MFMA kernel
             T = B * Lq
@@ -278,8 +280,7 @@ class Engine(object):
                  rpr_k=None, rpr_v=None, drpr_k=None, drpr_v=None, max_rel=0, drop_p=0.0, sid=0, impl=None):
         ws_bytes = self.lib.query("zk_attn_bwd_workspace", B, nh, Lq)
         ws = self.workspace(ws_bytes)
-        dec = Lq <= 64 and Lk <= 64 and self._rpr_mfma(
-            impl, d, Lk, rpr_k, (q.ld, k.ld, v.ld, out.ld, dout.ld, dq.ld, dk.ld, dv.ld))
+        dec = self._rpr_mfma(impl, d, 0, rpr_k, (q.ld, k.ld, v.ld, out.ld, dout.ld, dq.ld, dk.ld, dv.ld), max_rel, bwd=True)
         tabs = (None, None, None, None)
         ldg = nrp = 0
         if dec:
