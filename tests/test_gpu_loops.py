@@ -117,3 +117,39 @@ def test_train_eval_score_loops_on_disk(tmp_path):
     assert loops.scorer(p4) == mean_score
     # ... and a 60-step model has learnt something about copying: loss well under the uniform level
     assert mean_score < 0.95 * np.log(params.tgt_vocab.size())
+
+
+def test_cli_train_test_score(tmp_path):
+    """The reference's command line (run.py:241-246, 367-413) end to end in a fresh interpreter:
+    --mode train on files, then --mode test and --mode score from the written param.json."""
+    import subprocess
+    import sys
+    _write_bitext(tmp_path, n=32)
+    out = tmp_path / "cli"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    cfg = tmp_path / "cfg.py"
+    cfg.write_text("dict(hidden_size=32, embed_size=32, filter_size=64, num_heads=2, num_encoder_layer=1,\n"
+                   "     num_decoder_layer=1, model_name='transformer_aan', batch_or_token='batch', batch_size=16,\n"
+                   "     eval_batch_size=8, max_training_steps=12, epoches=100, disp_freq=6, save_freq=6, eval_freq=12,\n"
+                   "     warmup_steps=10, lrate=0.3, lrate_strategy='noam', beam_size=2, decode_length=4, process_num=1,\n"
+                   "     shuffle_batch=False, dropout=0.0, relu_dropout=0.0, residual_dropout=0.0, attention_dropout=0.0)\n")
+    files = ",".join("%s=%s" % (k, tmp_path / v) for k, v in dict(
+        src_vocab_file="vocab.txt", tgt_vocab_file="vocab.txt", src_train_file="train.src", tgt_train_file="train.tgt",
+        src_dev_file="dev.src", tgt_dev_file="dev.tgt", src_test_file="dev.src", tgt_test_file="dev.tgt").items())
+    base = [sys.executable, "-m", "zero_amd.run", "--config", str(cfg)]
+    r = subprocess.run(base + ["--mode", "train", "--parameters", files + ",output_dir=%s" % out],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "best_score" in r.stdout
+    saved = json.loads((out / "param.json").read_text())
+    assert saved["model_name"] == "transformer_aan" and saved["hidden_size"] == 32
+    assert (out / "checkpoint").exists() and (out / "record.json").exists() and (out / "eval-12.trans.txt").exists()
+    r = subprocess.run(base + ["--mode", "test", "--parameters", "output_dir=%s,test_output=%s" % (out, out / "t.txt")],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "bleu" in r.stdout and len((out / "t.txt").read_text().splitlines()) == 8
+    r = subprocess.run(base + ["--mode", "score", "--parameters", "output_dir=%s,test_output=%s" % (out, out / "s.txt")],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len((out / "s.txt").read_text().split()) == 8
