@@ -729,129 +729,199 @@ __global__ void __launch_bounds__(256) k_all_equal(const int* __restrict__ ids, 
 }
 
 // =====================================================================================
-// K5  average attention network: cumulative average over time (transformer_aan.py:92-117)
-//     use_mask=1 (aan_mask=True, func.py:390-398): y_i = m_i * sum_{j<=i} m_j x_j / max(c_i,1)
-//     use_mask=0 (cumsum variant):                  y_i = sum_{j<=i} x_j / (c_i<=0 ? 1 : c_i)
-//     with c_i = sum_{j<=i} m_j.  Writes cat = [x | y]  ([T, 2H]) for the gate GEMM.
-//     O(L*H) scan instead of the reference's [B,L,L]x[B,L,H] matmul.
+// K5  cumulative averages over the time axis (transformer_aan.py:92-108; merged attention func.py:258-275)
+// One block per (sentence, group of 64 eight-channel chunks); its 256 threads split the L time steps into
+// SCAN_SEG segments, so the dependent chain is L/4 long and 4x as many waves are in flight as with one
+// thread per (sentence, chunk): pass 1 reduces each segment, the segment totals are exchanged through LDS,
+// pass 2 re-walks the segment from the right starting value.  O(L*H) instead of the reference's
+// [B,L,L]x[B,L,H] matmul.
+//   forward :  avg_t = w_t * sum_{s<=t} u_s x_s / den(cnt_t)            cnt_t = sum_{s<=t} m_s
+//   backward:  dx_s  = u_s * sum_{t>=s} (w_t / den(cnt_t)) g_t          (the transpose)
+// use_mask (aan_mask, func.py:390-398): u = w = m, den = max(cnt, 1); otherwise (transformer_aan.py:103-108)
+// u = w = 1, den = cnt (1 where cnt <= 0).
 // =====================================================================================
-__global__ void __launch_bounds__(256) k_aan_fwd(const bf16_t* __restrict__ x, const float* __restrict__ mask,
-                                                 bf16_t* __restrict__ cat, int B, int L, int H,
-                                                 int use_mask) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int nc = H / 8;
-  if (idx >= B * nc) return;
-  const int b = idx / nc, c = (idx % nc) * 8;
+#define SCAN_SEG 4
+struct ScanPos {
+  int b, c, sg, t0, t1;
+  bool live;
+};
+__device__ __forceinline__ ScanPos scan_pos(int L, int H) {
+  ScanPos p;
+  p.b = blockIdx.x;
+  const int chunk = blockIdx.y * 64 + (threadIdx.x & 63);
+  p.c = chunk * 8;
+  p.live = p.c < H;
+  p.sg = threadIdx.x >> 6;
+  const int len = (L + SCAN_SEG - 1) / SCAN_SEG;
+  p.t0 = min(L, p.sg * len);
+  p.t1 = min(L, p.t0 + len);
+  return p;
+}
+__device__ __forceinline__ float scan_den(float cnt, int use_mask) {
+  return use_mask ? fmaxf(cnt, 1.f) : (cnt <= 0.f ? 1.f : cnt);
+}
+
+// LOAD(row, c, v[8]) reads x of token row; EMIT(row, c, avg[8]) stores the result of one step
+template <typename LOAD, typename EMIT>
+__device__ __forceinline__ void scan_avg_fwd(const float* __restrict__ mask, int L, int H, int use_mask, LOAD load,
+                                             EMIT emit) {
+  __shared__ float s_part[SCAN_SEG][64][8];
+  __shared__ float s_cnt[SCAN_SEG];
+  const ScanPos p = scan_pos(L, H);
+  const int cl = threadIdx.x & 63;
   float run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float cnt = 0.f;
-  for (int t = 0; t < L; ++t) {
-    const size_t r = (size_t)b * L + t;
+  for (int t = p.t0; t < p.t1; ++t) {
+    const size_t r = (size_t)p.b * L + t;
     const float m = mask[r];
-    const uint4 xv = *reinterpret_cast<const uint4*>(x + r * H + c);
-    float v[8], o[8];
-    unpack8(xv, v);
     cnt += m;
-    const float den = use_mask ? fmaxf(cnt, 1.f) : (cnt <= 0.f ? 1.f : cnt);
-    const float wi = use_mask ? m : 1.f;
+    if (p.live) {
+      float v[8];
+      load(r, p.c, v);
+      const float u = use_mask ? m : 1.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) run[j] += u * v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s_part[p.sg][cl][j] = run[j];
+  if (cl == 0) s_cnt[p.sg] = cnt;
+  __syncthreads();
+  cnt = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) run[j] = 0.f;
+  for (int sg = 0; sg < p.sg; ++sg) {
+    cnt += s_cnt[sg];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) run[j] += s_part[sg][cl][j];
+  }
+  if (!p.live) return;
+  for (int t = p.t0; t < p.t1; ++t) {
+    const size_t r = (size_t)p.b * L + t;
+    const float m = mask[r];
+    float v[8], o[8];
+    load(r, p.c, v);
+    cnt += m;
+    const float u = use_mask ? m : 1.f;
+    const float a = u / scan_den(cnt, use_mask);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      run[j] += wi * v[j];
-      o[j] = (use_mask ? m : 1.f) * run[j] / den;
+      run[j] += u * v[j];
+      o[j] = a * run[j];
     }
-    *reinterpret_cast<uint4*>(cat + r * 2 * H + c) = xv;
-    *reinterpret_cast<uint4*>(cat + r * 2 * H + H + c) = pack8(o);
+    emit(r, p.c, o);
   }
 }
 
+// LOAD(row, c, g[8]) reads the gradient flowing into avg_t; EMIT(row, c, d[8]) receives u_s * reverse sum
+template <typename LOAD, typename EMIT>
+__device__ __forceinline__ void scan_avg_bwd(const float* __restrict__ mask, int L, int H, int use_mask, LOAD load,
+                                             EMIT emit) {
+  __shared__ float s_part[SCAN_SEG][64][8];
+  const ScanPos p = scan_pos(L, H);
+  const int cl = threadIdx.x & 63;
+  float cnt = 0.f;                               // valid steps before this segment
+  for (int t = 0; t < p.t0; ++t) cnt += mask[(size_t)p.b * L + t];
+  float run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int t = p.t0; t < p.t1; ++t) {
+    const size_t r = (size_t)p.b * L + t;
+    const float m = mask[r];
+    cnt += m;
+    if (p.live) {
+      float g[8];
+      load(r, p.c, g);
+      const float a = (use_mask ? m : 1.f) / scan_den(cnt, use_mask);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) run[j] += a * g[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s_part[p.sg][cl][j] = run[j];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) run[j] = 0.f;
+  for (int sg = p.sg + 1; sg < SCAN_SEG; ++sg)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) run[j] += s_part[sg][cl][j];
+  if (!p.live) return;
+  // cnt holds the inclusive count at t1 - 1; walk the segment backwards
+  for (int t = p.t1 - 1; t >= p.t0; --t) {
+    const size_t r = (size_t)p.b * L + t;
+    const float m = mask[r];
+    float g[8], o[8];
+    load(r, p.c, g);
+    const float u = use_mask ? m : 1.f;
+    const float a = u / scan_den(cnt, use_mask);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      run[j] += a * g[j];
+      o[j] = u * run[j];
+    }
+    emit(r, p.c, o);
+    cnt -= m;
+  }
+}
+
+// transformer_aan.py:92-108: cat = [x | average]  ([T, 2H]) for the gate GEMM
+__global__ void __launch_bounds__(256) k_aan_fwd(const bf16_t* __restrict__ x, const float* __restrict__ mask,
+                                                 bf16_t* __restrict__ cat, int B, int L, int H,
+                                                 int use_mask) {
+  scan_avg_fwd(mask, L, H, use_mask,
+               [&](size_t r, int c, float (&v)[8]) { unpack8(*reinterpret_cast<const uint4*>(x + r * H + c), v); },
+               [&](size_t r, int c, const float (&o)[8]) {
+                 *reinterpret_cast<uint4*>(cat + r * 2 * H + c) = *reinterpret_cast<const uint4*>(x + r * H + c);
+                 *reinterpret_cast<uint4*>(cat + r * 2 * H + H + c) = pack8(o);
+               });
+}
+
 // dx_total = ds + dx_gate + dcat[:, :H] + reverse_scan(dy_gate + dcat[:, H:])
-//   reverse scan: dx_j = w_j * sum_{i>=j} a_i * dy_i   with a_i = (use_mask? m_i : 1)/den_i
+// use_mask bit 0: aan_mask; bit 1: dcat[:, H:] is already folded into dyg by the caller (use_ffn)
 __global__ void __launch_bounds__(256) k_aan_bwd(const bf16_t* __restrict__ dcat, const bf16_t* __restrict__ dxg,
                                                  const bf16_t* __restrict__ dyg, const bf16_t* __restrict__ ds,
                                                  const float* __restrict__ mask, bf16_t* __restrict__ dx,
                                                  int B, int L, int H, int use_mask) {
-  const bool skip_dc2 = (use_mask & 2) != 0;   // dcat[:, H:] already folded into dyg by the caller (use_ffn)
-  use_mask &= 1;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int nc = H / 8;
-  if (idx >= B * nc) return;
-  const int b = idx / nc, c = (idx % nc) * 8;
-  float total = 0.f;
-  for (int t = 0; t < L; ++t) total += mask[(size_t)b * L + t];
-  float run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  float cnt = total;
-  for (int t = L - 1; t >= 0; --t) {
-    const size_t r = (size_t)b * L + t;
-    const float m = mask[r];
-    const float den = use_mask ? fmaxf(cnt, 1.f) : (cnt <= 0.f ? 1.f : cnt);
-    const float a = (use_mask ? m : 1.f) / den;
-    float g1[8], g2[8], dc1[8], dc2[8], d0[8], o[8];
-    unpack8(*reinterpret_cast<const uint4*>(dcat + r * 2 * H + c), dc1);
-    unpack8(*reinterpret_cast<const uint4*>(dcat + r * 2 * H + H + c), dc2);
-    unpack8(*reinterpret_cast<const uint4*>(dxg + r * H + c), g1);
-    unpack8(*reinterpret_cast<const uint4*>(dyg + r * H + c), g2);
-    unpack8(*reinterpret_cast<const uint4*>(ds + r * H + c), d0);
-    const float wj = use_mask ? m : 1.f;
+  const bool skip_dc2 = (use_mask & 2) != 0;
+  scan_avg_bwd(mask, L, H, use_mask & 1,
+               [&](size_t r, int c, float (&g)[8]) {
+                 unpack8(*reinterpret_cast<const uint4*>(dyg + r * H + c), g);
+                 if (!skip_dc2) {
+                   float e[8];
+                   unpack8(*reinterpret_cast<const uint4*>(dcat + r * 2 * H + H + c), e);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      run[j] += a * (g2[j] + (skip_dc2 ? 0.f : dc2[j]));
-      o[j] = d0[j] + g1[j] + dc1[j] + wj * run[j];
-    }
-    *reinterpret_cast<uint4*>(dx + r * H + c) = pack8(o);
-    cnt -= m;
-  }
+                   for (int j = 0; j < 8; ++j) g[j] += e[j];
+                 }
+               },
+               [&](size_t r, int c, const float (&o)[8]) {
+                 float g1[8], dc1[8], d0[8], out[8];
+                 unpack8(*reinterpret_cast<const uint4*>(dcat + r * 2 * H + c), dc1);
+                 unpack8(*reinterpret_cast<const uint4*>(dxg + r * H + c), g1);
+                 unpack8(*reinterpret_cast<const uint4*>(ds + r * H + c), d0);
+#pragma unroll
+                 for (int j = 0; j < 8; ++j) out[j] = d0[j] + g1[j] + dc1[j] + o[j];
+                 *reinterpret_cast<uint4*>(dx + r * H + c) = pack8(out);
+               });
 }
 
 // transformer_fuse (func.py:258-275, training branch): the simplified average-attention term that is
-// summed into the cross-attention heads before o_map.  With fuse_mask = attention_bias(mask, "aan")
-// (func.py:390-398):  att[b,t,:] += m_t * sum_{s<=t} m_s vq[b,s,:] / max(sum_{s<=t} m_s, 1).
+// summed into the cross-attention heads before o_map:  out = att + average_mask(vq)   (out may alias att)
 __global__ void __launch_bounds__(256) k_cumavg_add_fwd(const bf16_t* __restrict__ vq, const float* __restrict__ mask,
                                                         const bf16_t* att, bf16_t* out, int B, int L, int H) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int nc = H / 8;
-  if (idx >= B * nc) return;
-  const int b = idx / nc, c = (idx % nc) * 8;
-  float run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  float cnt = 0.f;
-  for (int t = 0; t < L; ++t) {
-    const size_t r = (size_t)b * L + t;
-    const float m = mask[r];
-    float v[8], o[8];
-    unpack8(*reinterpret_cast<const uint4*>(vq + r * H + c), v);
-    unpack8(*reinterpret_cast<const uint4*>(att + r * H + c), o);
-    cnt += m;
-    const float a = m / fmaxf(cnt, 1.f);
+  scan_avg_fwd(mask, L, H, 1,
+               [&](size_t r, int c, float (&v)[8]) { unpack8(*reinterpret_cast<const uint4*>(vq + r * H + c), v); },
+               [&](size_t r, int c, const float (&o)[8]) {
+                 float a[8];
+                 unpack8(*reinterpret_cast<const uint4*>(att + r * H + c), a);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      run[j] += m * v[j];
-      o[j] += a * run[j];
-    }
-    *reinterpret_cast<uint4*>(out + r * H + c) = pack8(o);
-  }
+                 for (int j = 0; j < 8; ++j) a[j] += o[j];
+                 *reinterpret_cast<uint4*>(out + r * H + c) = pack8(a);
+               });
 }
-// its transpose: dvq[b,s,:] = m_s * sum_{t>=s} (m_t / max(cnt_t, 1)) * dy[b,t,:]
+// its transpose
 __global__ void __launch_bounds__(256) k_cumavg_bwd(const bf16_t* __restrict__ dy, const float* __restrict__ mask,
                                                     bf16_t* __restrict__ dvq, int B, int L, int H) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int nc = H / 8;
-  if (idx >= B * nc) return;
-  const int b = idx / nc, c = (idx % nc) * 8;
-  float cnt = 0.f;
-  for (int t = 0; t < L; ++t) cnt += mask[(size_t)b * L + t];
-  float run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int t = L - 1; t >= 0; --t) {
-    const size_t r = (size_t)b * L + t;
-    const float m = mask[r];
-    const float a = m / fmaxf(cnt, 1.f);
-    float g[8], o[8];
-    unpack8(*reinterpret_cast<const uint4*>(dy + r * H + c), g);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      run[j] += a * g[j];
-      o[j] = m * run[j];
-    }
-    *reinterpret_cast<uint4*>(dvq + r * H + c) = pack8(o);
-    cnt -= m;
-  }
+  scan_avg_bwd(mask, L, H, 1,
+               [&](size_t r, int c, float (&g)[8]) { unpack8(*reinterpret_cast<const uint4*>(dy + r * H + c), g); },
+               [&](size_t r, int c, const float (&o)[8]) { *reinterpret_cast<uint4*>(dvq + r * H + c) = pack8(o); });
 }
 
 // out[i] (+)= sum_s in[s*n + i]
@@ -1328,7 +1398,7 @@ int zk_aan_fwd(const void* x, const float* mask, void* cat, int B, int L, int H,
   ZK_CHECK_ARG(H % 8 == 0, "zk_aan_fwd: H=%d must be a multiple of 8", H);
   const int n = B * (H / 8);
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_aan_fwd, dim3((n + 255) / 256), dim3(256), 0, stream, (const bf16_t*)x, mask,
+  hipLaunchKernelGGL(k_aan_fwd, dim3(B, (H / 8 + 63) / 64), dim3(256), 0, stream, (const bf16_t*)x, mask,
                      (bf16_t*)cat, B, L, H, use_mask);
   ZK_LAUNCH_CHECK();
   return 0;
@@ -1339,7 +1409,7 @@ int zk_aan_bwd(const void* dcat, const void* dxg, const void* dyg, const void* d
   ZK_CHECK_ARG(H % 8 == 0, "zk_aan_bwd: H=%d must be a multiple of 8", H);
   const int n = B * (H / 8);
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_aan_bwd, dim3((n + 255) / 256), dim3(256), 0, stream, (const bf16_t*)dcat,
+  hipLaunchKernelGGL(k_aan_bwd, dim3(B, (H / 8 + 63) / 64), dim3(256), 0, stream, (const bf16_t*)dcat,
                      (const bf16_t*)dxg, (const bf16_t*)dyg, (const bf16_t*)ds, mask, (bf16_t*)dx, B, L, H,
                      use_mask);
   ZK_LAUNCH_CHECK();
@@ -1351,7 +1421,7 @@ int zk_cumavg_add_fwd(const void* vq, const float* mask, const void* att, void* 
   ZK_CHECK_ARG(H % 8 == 0, "zk_cumavg_add_fwd: H=%d must be a multiple of 8", H);
   const int n = B * (H / 8);
   if (n == 0 || L == 0) return 0;
-  hipLaunchKernelGGL(k_cumavg_add_fwd, dim3((n + 255) / 256), dim3(256), 0, stream, (const bf16_t*)vq, mask,
+  hipLaunchKernelGGL(k_cumavg_add_fwd, dim3(B, (H / 8 + 63) / 64), dim3(256), 0, stream, (const bf16_t*)vq, mask,
                      (const bf16_t*)att, (bf16_t*)out, B, L, H);
   ZK_LAUNCH_CHECK();
   return 0;
@@ -1360,7 +1430,7 @@ int zk_cumavg_bwd(const void* dy, const float* mask, void* dvq, int B, int L, in
   ZK_CHECK_ARG(H % 8 == 0, "zk_cumavg_bwd: H=%d must be a multiple of 8", H);
   const int n = B * (H / 8);
   if (n == 0 || L == 0) return 0;
-  hipLaunchKernelGGL(k_cumavg_bwd, dim3((n + 255) / 256), dim3(256), 0, stream, (const bf16_t*)dy, mask,
+  hipLaunchKernelGGL(k_cumavg_bwd, dim3(B, (H / 8 + 63) / 64), dim3(256), 0, stream, (const bf16_t*)dy, mask,
                      (bf16_t*)dvq, B, L, H);
   ZK_LAUNCH_CHECK();
   return 0;
