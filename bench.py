@@ -88,7 +88,7 @@ class GemmProfiler(object):
         tf = lambda v: "true" if v else "false"
         if gen == 2:
             ns = 4 if (bm, bn) == (64, 64) else 2
-            return "k_gemm_dlds<%d, %d, %d, %s, %s>" % (bm, bn, ns, tf(ta), tf(tb))
+            return "k_gemm_dlds<%d, %d, %d, %s, %s, 4>" % (bm, bn, ns, tf(ta), tf(tb))   # ..., 4 waves per workgroup
         return "k_gemm_mfma<%d, %d, %s, %s>" % (bm, bn, tf(ta), tf(tb))
 
     def __enter__(self):

@@ -104,8 +104,14 @@ __device__ __forceinline__ uint32_t zk_mix32(uint32_t x) {
   return x;
 }
 __device__ __forceinline__ uint32_t zk_rand_u32(uint64_t seed, uint32_t sid, uint64_t idx) {
-  uint32_t a = zk_mix32((uint32_t)seed ^ (sid * 0x9E3779B1u));
-  uint32_t b = zk_mix32((uint32_t)(seed >> 32) + (uint32_t)(idx >> 32) * 0x85EBCA77u + a);
+  // a and b0 depend on (seed, sid) only: the compiler hoists them out of the per-element loops, so an
+  // element with idx < 2^32 (every dropout site of the path) costs ONE mixer round; the rare high part
+  // takes the extra round.  Values are identical to mixing (seed_hi + idx_hi * C + a) unconditionally.
+  const uint32_t a = zk_mix32((uint32_t)seed ^ (sid * 0x9E3779B1u));
+  const uint32_t hi = (uint32_t)(seed >> 32);
+  uint32_t b = zk_mix32(hi + a);
+  const uint32_t ih = (uint32_t)(idx >> 32);
+  if (__builtin_expect(ih != 0u, 0)) b = zk_mix32(hi + ih * 0x85EBCA77u + a);
   return zk_mix32(((uint32_t)idx) * 0xC2B2AE3Du + b);
 }
 // returns the multiplier to apply: 0 if dropped, 1/(1-p) if kept.  thr = p * 2^32 (clamped).
