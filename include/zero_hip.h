@@ -61,6 +61,19 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
 int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int tb, int tile,
                     zk_stream_t stream);
 
+/* ---- transformer.py:182-216 + util.py:88-103 fused for training: logits = feat . E^T and the label-smoothed
+ * cross entropy WITHOUT materialising the [T, V] logits.  fwd: ce fp32 [T] (may be NULL), lse fp32 [T]
+ * (log-sum-exp of every row, kept for the backward); bwd: recomputes the logits tile by tile and writes
+ * dlogits bf16 [T, ldd] = w_row * (softmax - soft labels) (columns >= V zero), the operand of the two
+ * logits-gradient GEMMs.  feat bf16 [T, K] (ldf); E bf16 [>= V rows, K] (lde).  label smoothing as util.py:88-103
+ * (p = 1 - eps on the gold id, q = eps / (V - 1) elsewhere, normaliser subtracted). */
+size_t zk_logits_ce_workspace(int T, int V);
+int zk_logits_ce_fwd(const void* feat, const void* E, const int* ids, float* ce, float* lse, int T, int V, int K,
+                     int ldf, int lde, float label_smooth, void* workspace, size_t ws_bytes, zk_stream_t stream);
+int zk_logits_ce_bwd(const void* feat, const void* E, const int* ids, const float* w, const float* lse,
+                     void* dlogits, int T, int V, int K, int ldf, int lde, int ldd, float label_smooth,
+                     zk_stream_t stream);
+
 /* ---- func.py:218-256 dot_attention core (+ modules/rpr.py:10-75 relative positions).
  * q/k/v/out: [B*L, ld] bf16, head h at columns [h*d,(h+1)*d) (split/combine_heads,
  * func.py:68-104, folded into addressing).  kmask: fp32 [B,Lk] (1 valid / 0 pad) or NULL;

@@ -725,3 +725,32 @@ def test_attention_rpr_mfma_forward_long_keys_and_dropout():
     assert errs["out"] < 1.5e-2 and max(errs[k] for k in ("dq", "dk", "dv", "drk", "drv")) < 3e-2, errs
     errs = _attn_case(2, 2, 2, 64, 64, 64, True, False, rpr=True, drop=0.2)
     assert errs["out"] < 1.5e-2 and max(errs[k] for k in ("dq", "dk", "dv", "drk", "drv")) < 3e-2, errs
+
+
+@pytest.mark.parametrize("T,V,H,ls", [(70, 300, 64, 0.1), (256, 1000, 128, 0.0), (130, 129, 64, 0.1), (5, 11, 16, 0.1)])
+def test_logits_ce_fused_matches_gemm_plus_ce(T, V, H, ls):
+    """zk_logits_ce_fwd / _bwd against torch: ce, lse and w*(softmax - soft labels)."""
+    e = eng()
+    Vpad = (V + 7) // 8 * 8
+    feat = rand_bf(T, H, seed=1)
+    E = torch.zeros(Vpad, H, dtype=torch.bfloat16, device="cuda")
+    E[:V] = rand_bf(V, H, scale=0.5, seed=2)
+    ids = torch.randint(0, V, (T,), device="cuda", dtype=torch.int32)
+    w = torch.rand(T, device="cuda")
+    w[::7] = 0.0
+    ce = torch.zeros(T, device="cuda"); lse = torch.zeros(T, device="cuda")
+    dl = torch.full((T, Vpad), 7.0, dtype=torch.bfloat16, device="cuda")
+    e.logits_ce_fwd(mat(feat), mat(E), ids, ce, lse, T, V, ls)
+    e.logits_ce_bwd(mat(feat), mat(E), ids, w, lse, mat(dl), T, V, ls)
+    torch.cuda.synchronize()
+    z = feat.float() @ E[:V].float().t()
+    ref_lse = torch.logsumexp(z, -1)
+    p, q = (1 - ls, ls / (V - 1)) if ls > 0 else (1.0, 0.0)
+    norm = -(p * np.log(p) + (V - 1) * q * np.log(q + 1e-20)) if ls > 0 else 0.0
+    zg = z.gather(1, ids.long()[:, None])[:, 0]
+    ref_ce = ref_lse - p * zg - q * (z.sum(-1) - zg) - norm
+    assert max_err(lse, ref_lse) < 2e-3 and max_err(ce, ref_ce) < 3e-3 * max(1.0, float(ref_ce.abs().max()))
+    soft = torch.full_like(z, q); soft.scatter_(1, ids.long()[:, None], p)
+    ref_d = w[:, None] * (torch.softmax(z, -1) - soft)
+    assert rel_err(dl[:, :V], ref_d) < 8e-3
+    assert float(dl[:, V:].float().abs().max()) == 0.0 if Vpad > V else True

@@ -184,6 +184,25 @@ def test_hipgraph_replay_equals_eager_steps():
     assert abs(runs["eager"][2][0] - runs["graph"][2][0]) < 1e-6 * runs["eager"][2][0]
 
 
+def test_fused_logits_cross_entropy_path(monkeypatch):
+    """ZERO_HIP_FUSED_CE=1: same loss and gradients as the default logits GEMM + CE kernels."""
+    model = "transformer"
+    hp, Pn, src, tgt = _setup(model)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("ZERO_HIP_FUSED_CE", flag)
+        reset_cores()
+        out = registry.get_model(model).train_fn({"source": src, "target": tgt}, hp, initializer=Pn)
+        torch.cuda.synchronize()
+        res[flag] = (float(out["loss"].cpu()), out["store"].export("grad"), out["per_sample_loss"].cpu().numpy())
+    assert abs(res["0"][0] - res["1"][0]) / abs(res["0"][0]) < 2e-4
+    assert np.abs(res["0"][2] - res["1"][2]).max() < 2e-3
+    gmax = max(np.linalg.norm(v) for v in res["0"][1].values())
+    for k, a in res["0"][1].items():
+        if np.linalg.norm(a) > 1e-3 * gmax:
+            assert np.linalg.norm(a - res["1"][1][k]) / np.linalg.norm(a) < 3e-2, k
+
+
 def test_segmented_graph_step_equals_eager(monkeypatch):
     # the data-parallel step replays hipGraph SEGMENTS cut at every gradient-bucket hand-off
     # (Trainer._step_segmented); with one rank the hand-offs are no-ops and the result must equal

@@ -134,14 +134,14 @@ struct DldsCfg {
   static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
 };
 
-// one BMxBN output tile over k in [kbeg, kend); slab != null: write the fp32 partial tile there
 // NW waves per workgroup: 4 (2 x 2 over the tile) or 2 (2 x 1: each wave a BM/2 x BN slab -- two MFMAs per
 // A fragment, half the co-resident-wave LDS footprint per workgroup)
+// K loop of one BMxBN tile over k in [kbeg, kend); leaves the fp32 tile in LDS (sC[BM][CLD], smem reused)
+// behind a workgroup barrier, ready for a row-wise epilogue.
 template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4>
-__device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __restrict__ A,
-                                          const bf16_t* __restrict__ B, int M, int N, int lda, int ldb, int kbeg,
-                                          int kend, int m0, int n0, float* __restrict__ slab, const GemmEpi& e,
-                                          int vec_ok) {
+__device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16_t* __restrict__ A,
+                                                 const bf16_t* __restrict__ B, int M, int N, int lda, int ldb,
+                                                 int kbeg, int kend, int m0, int n0) {
   constexpr int NWN = NW / 2;
   constexpr int WTM = BM / 2, WTN = BN / NWN, TM = WTM / 32, TN = WTN / 32;
   constexpr int STAGE = DldsCfg<BM, BN, NS>::STAGE;
@@ -229,6 +229,18 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
       }
     }
   __syncthreads();
+}
+
+// one BMxBN output tile over k in [kbeg, kend); slab != null: write the fp32 partial tile there
+template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4>
+__device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __restrict__ A,
+                                          const bf16_t* __restrict__ B, int M, int N, int lda, int ldb, int kbeg,
+                                          int kend, int m0, int n0, float* __restrict__ slab, const GemmEpi& e,
+                                          int vec_ok) {
+  gemm_tile_to_lds<BM, BN, NS, TA, TB, NW>(smem, A, B, M, N, lda, ldb, kbeg, kend, m0, n0);
+  constexpr int CLD = DldsCfg<BM, BN, NS>::CLD;
+  const int tid = threadIdx.x;
+  const float* sC = reinterpret_cast<const float*>(smem);
   const uint64_t seed = e.thr ? *e.seed : 0;
   constexpr int CPRW = BN / 8;
   for (int c = tid; c < BM * CPRW; c += NW * 64) {
@@ -335,6 +347,103 @@ __global__ void __launch_bounds__(256) k_gemm_grouped(const GroupDesc* __restric
                                 vec_ok);
 }
 
+// =====================================================================================
+// Fused logits + label-smoothed cross entropy (transformer.py:182-216, util.py:88-103) for the training
+// path: the [T, V] fp32 logits (524 MB at the bench shapes) are never written.
+//   forward : every 128x128 logits tile is reduced in its epilogue to one float4 per row
+//             {max, sum exp(z - max), sum z, z_gold (or 0)} over the tile's valid columns -> part[T][tiles_n];
+//             k_ce_combine merges the tiles_n partials of a row into lse and
+//             ce = lse - p z_gold - q (sum z - z_gold) - normalizer.
+//   backward: the tile is recomputed (137 GFLOP is cheaper than reading 524 MB back) and its epilogue writes
+//             dlogits = w_row (exp(z - lse_row) - soft) as bf16, soft = p on the gold column, q elsewhere,
+//             0 in the padding columns >= V: the operand of the two logits-gradient GEMMs.
+// =====================================================================================
+struct CeEpi {
+  const int* ids; const float* lse; const float* w;   // per token row: gold id, log-sum-exp, weight
+  float4* part; bf16_t* dlogits;
+  int V, ldd, tiles_n; float p, q;
+};
+
+template <int PHASE>
+__global__ void __launch_bounds__(256) k_logits_ce(const bf16_t* __restrict__ feat, const bf16_t* __restrict__ E,
+                                                   int T, int K, int ldf, int lde, TileSched ts, CeEpi c) {
+  constexpr int BM = 128, BN = 128, NS = 2;
+  constexpr int CLD = DldsCfg<BM, BN, NS>::CLD;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DldsCfg<BM, BN, NS>::LDS_BYTES];
+  int tm_, tn_, z_;
+  tile_of_block(ts, tm_, tn_, z_);
+  const int m0 = tm_ * BM, n0 = tn_ * BN;
+  gemm_tile_to_lds<BM, BN, NS, false, true>(smem, feat, E, T, c.V, ldf, lde, 0, K, m0, n0);
+  const float* sC = reinterpret_cast<const float*>(smem);
+  const int tid = threadIdx.x;
+  if (PHASE == 1) {
+    const int row = tid >> 1, half = tid & 1;
+    const int gm = m0 + row;
+    const int cbeg = n0 + half * 64;
+    const int nval = min(64, c.V - cbeg);              // valid columns of this half (may be <= 0)
+    const float* zr = sC + row * CLD + half * 64;
+    float m = -INFINITY, sz = 0.f;
+    for (int j = 0; j < nval; ++j) { m = fmaxf(m, zr[j]); sz += zr[j]; }
+    float se = 0.f;
+    for (int j = 0; j < nval; ++j) se += __expf(zr[j] - m);
+    float zg = 0.f;
+    const int gold = gm < T ? c.ids[gm] : -1;
+    if (gold >= cbeg && gold < cbeg + nval) zg = zr[gold - cbeg];
+    // merge the two halves of the row
+    const float m2 = __shfl_xor(m, 1, 64), se2 = __shfl_xor(se, 1, 64);
+    const float mm = fmaxf(m, m2);
+    float tot = 0.f;
+    if (m > -INFINITY) tot += se * __expf(m - mm);
+    if (m2 > -INFINITY) tot += se2 * __expf(m2 - mm);
+    sz += __shfl_xor(sz, 1, 64);
+    zg += __shfl_xor(zg, 1, 64);
+    if (half == 0 && gm < T) c.part[(size_t)gm * c.tiles_n + tn_] = make_float4(mm, tot, sz, zg);
+  } else {
+    constexpr int CPRW = BN / 8;
+    for (int t = tid; t < BM * CPRW; t += 256) {
+      const int row = t / CPRW, cc = (t % CPRW) * 8;
+      const int gm = m0 + row, gn = n0 + cc;
+      if (gm >= T || gn >= c.ldd) continue;
+      const float lse = c.lse[gm], wr = c.w[gm];
+      const int gold = c.ids[gm];
+      const float4 a = *reinterpret_cast<const float4*>(sC + row * CLD + cc);
+      const float4 b = *reinterpret_cast<const float4*>(sC + row * CLD + cc + 4);
+      float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int col = gn + j;
+        v[j] = col < c.V ? wr * (__expf(v[j] - lse) - (col == gold ? c.p : c.q)) : 0.f;
+      }
+      *reinterpret_cast<uint4*>(c.dlogits + (size_t)gm * c.ldd + gn) = pack8(v);
+    }
+  }
+}
+
+// one wave per token row: merge the per-tile partials
+__global__ void __launch_bounds__(256) k_ce_combine(const float4* __restrict__ part, int T, int tiles_n, float p,
+                                                    float q, float normalizer, float* __restrict__ ce,
+                                                    float* __restrict__ lse_out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T) return;
+  float m = -INFINITY;
+  for (int t = lane; t < tiles_n; t += 64) m = fmaxf(m, part[(size_t)row * tiles_n + t].x);
+  m = wave_max(m);
+  float se = 0.f, sz = 0.f, zg = 0.f;
+  for (int t = lane; t < tiles_n; t += 64) {
+    const float4 v = part[(size_t)row * tiles_n + t];
+    if (v.x > -INFINITY) se += v.y * __expf(v.x - m);
+    sz += v.z;
+    zg += v.w;
+  }
+  se = wave_sum(se); sz = wave_sum(sz); zg = wave_sum(zg);
+  if (lane == 0) {
+    const float lse = m + __logf(se);
+    if (lse_out != nullptr) lse_out[row] = lse;
+    if (ce != nullptr) ce[row] = lse - p * zg - q * (sz - zg) - normalizer;
+  }
+}
+
 template <int BM, int BN, int NS, int NW = 4>
 static int launch_dlds(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
                        int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags, hipStream_t stream) {
@@ -379,6 +488,67 @@ int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int t
   if (tile == 1) ZK_GROUP_LAUNCH(128, 128, 2);
   else ZK_GROUP_LAUNCH(64, 64, 4);
 #undef ZK_GROUP_LAUNCH
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+static int ce_check(const void* feat, const void* E, int T, int V, int K, int ldf, int lde) {
+  ZK_CHECK_ARG(T >= 0 && V >= 1 && K >= 8, "zk_logits_ce: bad dims T=%d V=%d K=%d", T, V, K);
+  ZK_CHECK_ARG(K % 8 == 0 && ldf % 8 == 0 && lde % 8 == 0, "zk_logits_ce: K, ldf, lde must be multiples of 8");
+  ZK_CHECK_ARG((((uintptr_t)feat | (uintptr_t)E) & 15) == 0, "zk_logits_ce: operands must be 16-byte aligned");
+  return 0;
+}
+static void ce_smoothing(int V, float label_smooth, float* p, float* q, float* normalizer) {
+  *p = 1.f; *q = 0.f; *normalizer = 0.f;
+  if (label_smooth > 0.f && label_smooth < 1.f) {        // util.py:90-97, fp32 arithmetic
+    const float n = (float)(V - 1);
+    *p = 1.f - label_smooth;
+    *q = label_smooth / n;
+    *normalizer = -(*p * logf(*p) + n * *q * logf(*q + 1e-20f));
+  }
+}
+size_t zk_logits_ce_workspace(int T, int V) { return (size_t)T * ((V + 127) / 128) * sizeof(float4); }
+
+// feat bf16 [T, K] (ldf), E bf16 [>= V rows, K] (lde; the softmax embedding), ids int32 [T].
+// Writes ce fp32 [T] (may be NULL) and lse fp32 [T]; workspace >= zk_logits_ce_workspace(T, V).
+int zk_logits_ce_fwd(const void* feat, const void* E, const int* ids, float* ce, float* lse, int T, int V, int K,
+                     int ldf, int lde, float label_smooth, void* workspace, size_t ws_bytes, hipStream_t stream) {
+  if (int rc = ce_check(feat, E, T, V, K, ldf, lde)) return rc;
+  ZK_CHECK_ARG(lse != nullptr && ids != nullptr, "zk_logits_ce_fwd: ids and lse are required");
+  ZK_CHECK_ARG(ws_bytes >= zk_logits_ce_workspace(T, V), "zk_logits_ce_fwd: workspace too small");
+  if (T == 0) return 0;
+  CeEpi c;
+  c.ids = ids; c.lse = nullptr; c.w = nullptr; c.part = (float4*)workspace; c.dlogits = nullptr;
+  c.V = V; c.ldd = 0; c.tiles_n = (V + 127) / 128;
+  float normalizer;
+  ce_smoothing(V, label_smooth, &c.p, &c.q, &normalizer);
+  TileSched ts;
+  ts.tiles_m = (T + 127) / 128; ts.tiles_n = c.tiles_n; ts.n_major = 1; ts.xcd_remap = 1;
+  hipLaunchKernelGGL(k_logits_ce<1>, dim3((unsigned)((long)ts.tiles_m * ts.tiles_n)), dim3(256), 0, stream,
+                     (const bf16_t*)feat, (const bf16_t*)E, T, K, ldf, lde, ts, c);
+  ZK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_ce_combine, dim3((T + 3) / 4), dim3(256), 0, stream, (const float4*)workspace, T, c.tiles_n,
+                     c.p, c.q, normalizer, ce, lse);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+// dlogits bf16 [T, ldd] (ldd >= V, multiple of 8; columns >= V are written 0) = w_row (softmax - soft labels)
+int zk_logits_ce_bwd(const void* feat, const void* E, const int* ids, const float* w, const float* lse,
+                     void* dlogits, int T, int V, int K, int ldf, int lde, int ldd, float label_smooth,
+                     hipStream_t stream) {
+  if (int rc = ce_check(feat, E, T, V, K, ldf, lde)) return rc;
+  ZK_CHECK_ARG(ids && w && lse && dlogits, "zk_logits_ce_bwd: ids, w, lse, dlogits are required");
+  ZK_CHECK_ARG(ldd >= V && ldd % 8 == 0 && ((uintptr_t)dlogits & 15) == 0, "zk_logits_ce_bwd: ldd=%d must be >= V and a multiple of 8", ldd);
+  if (T == 0) return 0;
+  CeEpi c;
+  c.ids = ids; c.lse = lse; c.w = w; c.part = nullptr; c.dlogits = (bf16_t*)dlogits;
+  c.V = V; c.ldd = ldd; c.tiles_n = (ldd + 127) / 128;
+  float normalizer;
+  ce_smoothing(V, label_smooth, &c.p, &c.q, &normalizer);
+  TileSched ts;
+  ts.tiles_m = (T + 127) / 128; ts.tiles_n = c.tiles_n; ts.n_major = 1; ts.xcd_remap = 1;
+  hipLaunchKernelGGL(k_logits_ce<2>, dim3((unsigned)((long)ts.tiles_m * ts.tiles_n)), dim3(256), 0, stream,
+                     (const bf16_t*)feat, (const bf16_t*)E, T, K, ldf, lde, ts, c);
   ZK_LAUNCH_CHECK();
   return 0;
 }

@@ -372,6 +372,17 @@ class Engine(object):
                       dlogits.ptr if dlogits is not None else None, rows, V, logits.ld, float(label_smooth),
                       self.stream)
 
+    # ---- fused logits + cross entropy (training path; transformer.py:182-216) ------------------
+    def logits_ce_fwd(self, feat, E, ids, ce, lse, T, V, label_smooth):
+        ws_bytes = self.lib.query("zk_logits_ce_workspace", T, V)
+        ws = self.workspace(ws_bytes)
+        self.lib.call("zk_logits_ce_fwd", feat.ptr, E.ptr, ids.data_ptr(), hip.ptr(ce), lse.data_ptr(), T, V,
+                      feat.cols, feat.ld, E.ld, float(label_smooth), ws.data_ptr(), ws.numel(), self.stream)
+
+    def logits_ce_bwd(self, feat, E, ids, w, lse, dlogits, T, V, label_smooth):
+        self.lib.call("zk_logits_ce_bwd", feat.ptr, E.ptr, ids.data_ptr(), w.data_ptr(), lse.data_ptr(),
+                      dlogits.ptr, T, V, feat.cols, feat.ld, E.ld, dlogits.ld, float(label_smooth), self.stream)
+
     def target_stats(self, ids, mask, w, B, L, loss_scale=1.0):
         self.lib.call("zk_target_stats", ids.data_ptr(), hip.ptr(mask), hip.ptr(w), B, L, float(loss_scale),
                       self.stream)

@@ -83,6 +83,11 @@ class TransformerCore(object):
         self._pending_colsums = []     # (dY Mat, bias-gradient view, private partial buffer)
         self._pending_lnred = []       # (partials, rows, H, dgamma, dbeta, dbias_prev)
         self._pending_adds = []        # (fp32 gradient view, fp32 temporary): dst += src after the flush
+        # fused logits + cross entropy (no [T, V] fp32 logits in HBM, recompute in the backward): measured
+        # 224 + 8 us forward and 287 us backward against 291 + 208 us for GEMM + k_ce_fused -- the second
+        # pass over the 137-GFLOP GEMM costs what the saved 1 GB of traffic buys, so it is opt-in (it frees
+        # T*V*4 bytes, which matters for larger batches / vocabularies)
+        self.fused_ce = os.environ.get("ZERO_HIP_FUSED_CE", "0") != "0"
         self._red_id = 0
         self.side = torch.cuda.Stream(self.eng.device) if self.eng.device.type == "cuda" else None
 
@@ -505,16 +510,24 @@ class TransformerCore(object):
         return x, tmask, w
 
     def loss_head(self, batch, feat, w, label_smooth, need_grad):
-        """transformer.py:182-216."""
+        """transformer.py:182-216: logits GEMM + k_ce_fused, or with ZERO_HIP_FUSED_CE=1 the fused form (the
+        [T, V] fp32 logits are never written; the backward recomputes them tile by tile)."""
         e = self.eng
         B, Lt = batch["B"], batch["Lt"]
         Tt = B * Lt
         E = self.W(self.soft_emb)
-        logits = e.mat("logits", Tt, self.Vpad, F32)
-        e.gemm(feat, E, logits, Tt, self.V, self.H, 0, 1)
         ce = e.buf("ce", (Tt,), F32)
-        dlogits = e.mat("dlogits", Tt, self.Vpad) if need_grad else None
-        e.ce_fused(logits, batch["tgt"], w if need_grad else None, ce, dlogits, Tt, self.V, label_smooth)
+        self._fused_ce = self.fused_ce and e.gemm_impl != 1 and self.H % 8 == 0
+        if self._fused_ce:
+            logits, dlogits = None, None
+            lse = e.buf("lse", (Tt,), F32)
+            e.logits_ce_fwd(feat, E, batch["tgt"], ce, lse, Tt, self.V, label_smooth)
+            self._ce_ctx = (lse, w, label_smooth) if need_grad else None
+        else:
+            logits = e.mat("logits", Tt, self.Vpad, F32)
+            e.gemm(feat, E, logits, Tt, self.V, self.H, 0, 1)
+            dlogits = e.mat("dlogits", Tt, self.Vpad) if need_grad else None
+            e.ce_fused(logits, batch["tgt"], w if need_grad else None, ce, dlogits, Tt, self.V, label_smooth)
         per_sample = e.buf("per_sample", (B,), F32)
         loss = e.buf("loss", (1,), F32)
         e.loss_reduce(ce, batch["tgt"], per_sample, loss, B, Lt)
@@ -539,6 +552,10 @@ class TransformerCore(object):
         batch, enc, smask, feat, tmask, dlogits = self._ctx
         B, Ls, Lt = batch["B"], batch["Ls"], batch["Lt"]
         Ts, Tt = B * Ls, B * Lt
+        if dlogits is None:      # fused cross entropy: recompute the logits tiles, write d(loss)/d(logits)
+            lse, w, ls = self._ce_ctx
+            dlogits = e.mat("dlogits", Tt, self.Vpad)
+            e.logits_ce_bwd(feat, self.W(self.soft_emb), batch["tgt"], w, lse, dlogits, Tt, self.V, ls)
         st = self.store
         # embedding tables receive dense gradients (zero rows for unseen ids): untouched rows must
         # read as zero.  The softmax table is fully overwritten by its wgrad GEMM instead.
