@@ -17,7 +17,7 @@ SHAPES = [  # name, M, N, K, ta, tb, out_f32, count per step
     ("wgrad HxH ", H, H, T, 1, 0, 1, 36), ("wgrad qkv ", H, 3 * H, T, 1, 0, 1, 12), ("wgrad ffn1", H, F, T, 1, 0, 1, 12),
     ("wgrad ffn2", F, H, T, 1, 0, 1, 12), ("wgrad lgt ", V, H, T, 1, 0, 1, 1),
 ]
-TILES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64"}
+TILES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "256x128"}
 
 
 def run(M, N, K, ta, tb, f32, impl, reps=20):
@@ -36,7 +36,7 @@ def run(M, N, K, ta, tb, f32, impl, reps=20):
     return s.elapsed_time(t) / reps * 1e3   # us
 
 
-variants = [(0, 0, 0), (0, 64, 0)] + [(t, 0, 0) for t in (1, 2, 3, 4)]   # f=64: generation 1 kernel
+variants = [(0, 0, 0), (0, 64, 0)] + [(t, 0, 0) for t in (1, 2, 3, 4, 5)]   # f=64: generation 1 kernel
 extra_split = [(0, 0, s) for s in (1, 2, 4, 8)]
 print("%-11s %-22s | " % ("shape", "M,N,K") + " | ".join("%12s" % ("%s%s" % (TILES[t], "/gen1" if f & 64 else "")) for t, f, _ in variants))
 tot = {i: 0.0 for i in range(len(variants))}

@@ -132,6 +132,16 @@ def test_gemm_every_tile_shape(impl, tile, ta, tb):
     assert err < 8e-3, (impl, tile, ta, tb, err)
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_256x128_macro_tile(ta, tb):
+    # eight-wave 256x128 tile of the LDS-DMA kernel (impl bits [11:8] = 5): ragged shape with a K tail,
+    # epilogues, and a shape smaller than one tile
+    assert _gemm_case(2 | (5 << 8), 328, 200, 456, ta, tb, bias=True, residual=True)[0] < 8e-3
+    assert _gemm_case(2 | (5 << 8), 600, 384, 128, ta, tb)[0] < 8e-3
+    assert _gemm_case(2 | (5 << 8), 72, 40, 24, ta, tb)[0] < 8e-3
+    assert _gemm_case(2 | (5 << 8), 512, 256, 512, ta, tb, out_f32=True)[0] < 2e-3
+
+
 @pytest.mark.parametrize("ta,tb", [(1, 0), (0, 0), (0, 1)])
 def test_gemm_grouped(ta, tb):
     e = eng()

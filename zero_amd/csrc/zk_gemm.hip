@@ -258,7 +258,8 @@ static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, 
   //    split measured slower than none: 1024x1024x4096 17.8 us unsplit, 27.4 us split 4), and for the very
   //    long K of dlogits x E (K = 32000: 2-way split to 1024 workgroups is worth 0.15 ms per step).
   const long out = (long)M * N;
-  if (out >= 8L * 1024 * 1024 || (K >= 8192 && M >= 128 && N >= 128)) { *bm = 128; *bn = 128; }
+  if (g_tune[5] && out >= (long)g_tune[5] * 1024 * 1024 && M >= 256) { *bm = 256; *bn = 128; }   // A/B: 256x128 macro tile
+  else if (out >= 8L * 1024 * 1024 || (K >= 8192 && M >= 128 && N >= 128)) { *bm = 128; *bn = 128; }
   else if (out >= 3L * 1024 * 1024) { if (N >= M) { *bm = 64; *bn = 128; } else { *bm = 128; *bn = 64; } }
   else if (g_tune[2] == 1) { if (N >= M) { *bm = 64; *bn = 128; } else { *bm = 128; *bn = 64; } }   // A/B switches
   else if (g_tune[2] == 2) { *bm = 128; *bn = 128; }
@@ -355,7 +356,7 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
   const bool plain = (bias == nullptr && residual == nullptr && act == 0 && drop_p == 0.f);
   pick_config(M, N, K, plain ? 1 : 0, &bm, &bn, &splits);
 
-  if (tile_ovr) { const int tb_[5][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}}; bm = tb_[tile_ovr][0]; bn = tb_[tile_ovr][1]; }
+  if (tile_ovr && tile_ovr <= 5) { const int tb_[6][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}}; bm = tb_[tile_ovr][0]; bn = tb_[tile_ovr][1]; }
   if (split_ovr && plain) splits = split_ovr;
   if (splits > 1 && ws_bytes < (size_t)splits * M * N * sizeof(float)) splits = 1;
   int kchunk = K;

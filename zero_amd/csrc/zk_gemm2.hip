@@ -134,16 +134,16 @@ struct DldsCfg {
   static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
 };
 
-// NW waves per workgroup: 4 (2 x 2 over the tile) or 2 (2 x 1: each wave a BM/2 x BN slab -- two MFMAs per
-// A fragment, half the co-resident-wave LDS footprint per workgroup)
+// NW waves per workgroup: 4 (2 x 2 over the tile), 2 (2 x 1: each wave a BM/2 x BN slab) or 8 (4 x 2: the
+// 256x128 macro tile -- 25 % fewer L1->LDS bytes and DMA issues per MFMA than two 128x128 tiles)
 // K loop of one BMxBN tile over k in [kbeg, kend); leaves the fp32 tile in LDS (sC[BM][CLD], smem reused)
 // behind a workgroup barrier, ready for a row-wise epilogue.
 template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4>
 __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16_t* __restrict__ A,
                                                  const bf16_t* __restrict__ B, int M, int N, int lda, int ldb,
                                                  int kbeg, int kend, int m0, int n0) {
-  constexpr int NWN = NW / 2;
-  constexpr int WTM = BM / 2, WTN = BN / NWN, TM = WTM / 32, TN = WTN / 32;
+  constexpr int NWM = NW == 8 ? 4 : 2, NWN = NW / NWM;       // wave grid over the tile: 2x2, 2x1 or 4x2
+  constexpr int WTM = BM / NWM, WTN = BN / NWN, TM = WTM / 32, TN = WTN / 32;
   constexpr int STAGE = DldsCfg<BM, BN, NS>::STAGE;
   constexpr int PER_STAGE = (BM * 8 / NW + BN * 8 / NW) / 64;  // DMA instructions per wave per stage
   constexpr int CLD = DldsCfg<BM, BN, NS>::CLD;
@@ -151,7 +151,7 @@ __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = NW == 4 ? wave >> 1 : wave, wn = NW == 4 ? wave & 1 : 0;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int nk = (kend - kbeg + 63) >> 6;
 
   f32x16_t acc[TM][TN];
@@ -574,6 +574,7 @@ int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K,
   }
   // ring depth 2 for the larger tiles: the measured optimum is MORE workgroups per CU (64 KiB /
   // 48 KiB of LDS each), not deeper prefetch
+  if (bm == 256 && bn == 128) return launch_dlds<256, 128, 2, 8>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
   if (bm == 128 && bn == 128) return launch_dlds<128, 128, 2>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
   if (bm == 128 && bn == 64) return launch_dlds<128, 64, 2>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
   if (bm == 64 && bn == 128) return launch_dlds<64, 128, 2>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
