@@ -401,3 +401,32 @@ def test_noise_beam_search_runs_and_is_seeded(graph, monkeypatch):
         outs.append(seqs)
     assert np.array_equal(outs[1], outs[2])
     assert not np.array_equal(outs[0], outs[1]) or not np.array_equal(outs[1], outs[3])
+
+
+def test_shape_keyed_graph_cache_matches_eager_and_survives_buffer_growth():
+    """Real training feeds batches of varying shape: one captured graph per shape, all dropped when a
+    larger shape makes the engine replace a buffer.  Must equal the eager sequence bit for bit."""
+    from zero_amd.main import Trainer
+    hp, Pn, _, _ = _setup("transformer")
+    rng = np.random.default_rng(9)
+    shapes = [(3, 5, 6), (4, 9, 7), (3, 5, 6), (6, 12, 11), (4, 9, 7), (3, 5, 6), (6, 12, 11), (4, 9, 7), (3, 5, 6),
+              (6, 12, 11), (4, 9, 7), (3, 5, 6)]
+    batches = {}
+    for sh in set(shapes):
+        batches[sh] = make_batch(rng, sh[0], sh[1], sh[2], hp.src_vocab.size(), hp.tgt_vocab.size())
+    runs = {}
+    for mode in (False, True):
+        reset_cores()
+        tr = Trainer(hp, initializer=Pn)
+        losses = []
+        for sh in shapes:
+            src, tgt = batches[sh]
+            tr.prepare_static({"source": src, "target": tgt})
+            losses.append(float(tr.step_static(use_graph=mode).cpu()[0]))
+        torch.cuda.synchronize()
+        runs[mode] = (losses, tr.store.export("master")["decoder/layer_1/feed_forward/ffn_layer/enlarge/W_0_0"])
+        if mode:
+            captured = [k for k, g in tr._graphs.items() if not isinstance(g, str)]
+            assert len(captured) >= 2, tr._graphs.keys()
+    assert runs[False][0] == runs[True][0]
+    assert np.array_equal(runs[False][1], runs[True][1])

@@ -96,6 +96,7 @@ class Engine(object):
         self.gemm_impl = _impl_from_env("ZERO_HIP_GEMM")
         self.attn_impl = _impl_from_env("ZERO_HIP_ATTN")
         self.seed = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.realloc_gen = 0
         self._timing = None
 
     # ---- plumbing -----------------------------------------------------------
@@ -108,6 +109,10 @@ class Engine(object):
         shape = tuple(int(s) for s in shape)
         b = self.bufs.get(name)
         if b is None or b.dtype != dt or b.numel() < int(np.prod(shape)):
+            if b is not None:
+                # a buffer some captured hipGraph may point at is being replaced: holders of graphs compare
+                # this counter before replaying (zero_amd/main.py Trainer)
+                self.realloc_gen += 1
             b = torch.empty(int(np.prod(shape)), dtype=dt, device=self.device)
             self.bufs[name] = b
         return b[:int(np.prod(shape))].view(*shape)

@@ -173,17 +173,40 @@ class Trainer(object):
         cur.wait_stream(ws)
         return loss
 
+    MAX_GRAPHS = 96      # cached step graphs (one per batch shape); least recently used goes first
+
+    def _check_graph_cache(self):
+        """Captured graphs hold raw buffer addresses: drop them all when the engine replaced a buffer
+        (a larger batch shape arrived), and keep the cache bounded."""
+        eng = self.core.eng
+        if getattr(self, "_graph_gen", None) != eng.realloc_gen:
+            for g in self._graphs.values():
+                for h in (g if isinstance(g, list) else [("graph", g)]):
+                    if h[0] in ("graph", "update") and not isinstance(h[1], str):
+                        eng.lib.call("zk_graph_destroy", h[1])
+            self._graphs = {}
+            self._graph_gen = eng.realloc_gen
+        while len(self._graphs) > self.MAX_GRAPHS:
+            key = next(iter(self._graphs))
+            g = self._graphs.pop(key)
+            for h in (g if isinstance(g, list) else [("graph", g)]):
+                if h[0] in ("graph", "update") and not isinstance(h[1], str):
+                    eng.lib.call("zk_graph_destroy", h[1])
+
     def _step_static(self, use_graph):
         hp = self.params
         assert hp.update_cycle == 1, "captured step supports update_cycle == 1"
         world = parallel.world_size()
         eng = self.core.eng
+        self._check_graph_cache()
         self.lr.step(self.global_step)
         self.train_op.count = 0
         scale = self.train_op.set_hyper(self.lr.get_lr(), world)
         if world == 1 and use_graph and not self.force_segmented:
             key = (self.batch["B"], self.batch["Ls"], self.batch["Lt"])
-            g = self._graphs.get(key)
+            g = self._graphs.pop(key, None)
+            if g is not None:
+                self._graphs[key] = g          # most recently used last
             if g is None:
                 # first use of a shape runs eagerly once (sizes every scratch buffer), then
                 # the same launch sequence is captured
@@ -306,7 +329,14 @@ def train(params):
             pending = []
             cum_tokens += int(np.sum(data['tgt'] > 0))
             last = (trainer.cycle_counter + 1) >= params.update_cycle
-            loss = trainer.micro_step({"source": data['src'], "target": data['tgt']})
+            feats = {"source": data['src'], "target": data['tgt']}
+            if params.update_cycle == 1 and data['src'].shape[0] > 0:
+                # one update per batch: the step of every batch SHAPE is captured once and replayed
+                # (eager on first sight, captured on the second, replayed from the third on)
+                trainer.prepare_static(feats)
+                loss = trainer.step_static()
+            else:
+                loss = trainer.micro_step(feats)
             if not last:
                 continue
             gstep = trainer.global_step
