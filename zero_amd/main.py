@@ -104,14 +104,46 @@ class Trainer(object):
         lib = eng.lib
         key = ("seg", self.batch["B"], self.batch["Ls"], self.batch["Lt"])
         plan = self._graphs.get(key)
-        if plan is None:                   # first use of a shape: eager (sizes every scratch buffer)
-            self._graphs[key] = "warm"
+
+        def eager():
             self.graph.train_fn(self.batch, hp, on_ready=self.reducer.ready)
             self.reducer.wait()
             self.train_op.launch_update(scale)
             lib.call("zk_seed_advance", eng.seed.data_ptr(), 1, eng.stream)
-            return
+        if plan is None or getattr(self, "_seg_disabled", False):
+            # first use of a shape: eager (sizes every scratch buffer); also the fallback should a
+            # capture ever fail on a platform (the job then keeps running, only slower)
+            self._graphs.setdefault(key, "warm")
+            return eager()
         if plan == "warm":
+            try:
+                plan = self._capture_segments(scale)
+            except Exception as exc:       # leave capture mode cleanly, run this and later steps eagerly
+                import logging
+                logging.getLogger("zero_amd").warning("segmented hipGraph capture failed (%s); eager steps", exc)
+                try:
+                    ex = ctypes.c_void_p()
+                    lib.call("zk_graph_end", torch.cuda.current_stream(eng.device).cuda_stream, ctypes.byref(ex))
+                except Exception:
+                    pass
+                self._seg_disabled = True
+                return eager()
+            self._graphs[key] = plan
+        for kind, what in plan:
+            if kind == "graph":
+                eng.graph_launch(what)
+            elif kind == "ready":
+                for k in what:
+                    self.reducer.ready(k)
+            else:
+                self.reducer.wait()
+                eng.graph_launch(what)
+
+    def _capture_segments(self, scale):
+        import ctypes
+        hp, eng = self.params, self.core.eng
+        lib = eng.lib
+        if True:
             stream = torch.cuda.current_stream(eng.device).cuda_stream
             plan, mark = [], [0]
 
@@ -143,16 +175,7 @@ class Trainer(object):
                 lib.call("zk_seed_advance", eng.seed.data_ptr(), 1, eng.stream)
             finally:
                 plan.append(("update", cut()))
-            self._graphs[key] = plan
-        for kind, what in plan:
-            if kind == "graph":
-                eng.graph_launch(what)
-            elif kind == "ready":
-                for k in what:
-                    self.reducer.ready(k)
-            else:
-                self.reducer.wait()
-                eng.graph_launch(what)
+            return plan
 
     # -- captured path (static shapes, update_cycle == 1) ---------------------------
     def prepare_static(self, features):
