@@ -430,3 +430,28 @@ def test_shape_keyed_graph_cache_matches_eager_and_survives_buffer_growth():
             assert len(captured) >= 2, tr._graphs.keys()
     assert runs[False][0] == runs[True][0]
     assert np.array_equal(runs[False][1], runs[True][1])
+
+
+def test_accumulation_steps_replayed_from_graphs_match_eager():
+    """update_cycle=3 over batches of two shapes: Trainer.step (captured 'collect' / final graphs per
+    shape) must equal the eager micro_step sequence bit for bit."""
+    from zero_amd.main import Trainer
+    hp, Pn, _, _ = _setup("transformer", update_cycle=3)
+    rng = np.random.default_rng(4)
+    shapes = [(3, 5, 6), (4, 9, 7)] * 9
+    batches = {sh: make_batch(rng, sh[0], sh[1], sh[2], hp.src_vocab.size(), hp.tgt_vocab.size()) for sh in set(shapes)}
+    runs = {}
+    for mode in (False, True):
+        reset_cores()
+        tr = Trainer(hp, initializer=Pn)
+        losses = []
+        for sh in shapes:
+            src, tgt = batches[sh]
+            loss = tr.step({"source": src, "target": tgt}, use_graph=mode)
+            losses.append(float(loss.reshape(-1)[0].cpu()))
+        torch.cuda.synchronize()
+        runs[mode] = (losses, tr.store.export("master")["encoder/layer_1/self_attention/dot_attention/o_map/W_0_0"],
+                      tr.global_step)
+    assert runs[True][2] == runs[False][2] == 6
+    assert runs[False][0] == runs[True][0]
+    assert np.array_equal(runs[False][1], runs[True][1])

@@ -78,6 +78,8 @@ class Trainer(object):
         if not last:
             self.train_op.collect()
             self.cycle_counter += 1
+            # a fresh dropout stream position for every micro batch of the cycle
+            self.core.eng.lib.call("zk_seed_advance", self.core.eng.seed.data_ptr(), 1, self.core.eng.stream)
             return loss
         if hp.update_cycle > 1:
             # reference semantics: one average over N*c micro batches (cycle.py:86-88)
@@ -90,6 +92,75 @@ class Trainer(object):
         self.cycle_counter = 0
         self.global_step += 1
         self.core.eng.lib.call("zk_seed_advance", self.core.eng.seed.data_ptr(), 1, self.core.eng.stream)
+        return loss
+
+    # -- one entry point for the training loop: captured steps whenever the shapes allow ---------
+    def step(self, features, use_graph=True):
+        """One micro step on ``features`` (update on the last one of a cycle), replaying a captured
+        hipGraph per batch shape.  Same arithmetic and bookkeeping as :meth:`micro_step`."""
+        hp = self.params
+        if not use_graph or features["source"].shape[0] == 0 or self.core.use_side:
+            return self.micro_step(features)
+        if hp.update_cycle == 1:
+            self.prepare_static(features)
+            return self.step_static()
+        eng = self.core.eng
+        cur = torch.cuda.current_stream(eng.device)
+        ws = eng.work_stream
+        ws.wait_stream(cur)
+        with torch.cuda.stream(ws):
+            loss = self._step_accumulate(features)
+        cur.wait_stream(ws)
+        return loss
+
+    def _graph_run(self, key, body):
+        eng = self.core.eng
+        g = self._graphs.pop(key, None)
+        if g is None:                       # first sight of a shape: eager, sizes the scratch buffers
+            self._graphs[key] = "warm"
+            body()
+            return
+        if g == "warm":
+            g = eng.graph_capture(body)
+        self._graphs[key] = g
+        eng.graph_launch(g)
+
+    def _step_accumulate(self, features):
+        """update_cycle > 1 (cycle.py:73-92): 'collect' micro steps then the final one."""
+        hp, eng = self.params, self.core.eng
+        world = parallel.world_size()
+        self._check_graph_cache()
+        if self.cycle_counter == 0:
+            self.train_op.zero()
+        last = (self.cycle_counter + 1) >= hp.update_cycle
+        self.lr.step(self.global_step)
+        batch = self.prepare_static(features)
+        shape = (batch["B"], batch["Ls"], batch["Lt"])
+        loss = eng.buf("loss", (1,), torch.float32)
+        if not last:
+            self._graph_run(("acc",) + shape,
+                            lambda: (self.graph.train_fn(batch, hp), self.train_op.collect_launch(),
+                                     eng.lib.call("zk_seed_advance", eng.seed.data_ptr(), 1, eng.stream)))
+            self.train_op.count += 1
+            self.cycle_counter += 1
+            return loss
+        scale = self.train_op.set_hyper(self.lr.get_lr(), world)
+
+        def tail():
+            self.train_op.launch_update(scale)
+            eng.lib.call("zk_seed_advance", eng.seed.data_ptr(), 1, eng.stream)
+        if world == 1:
+            self._graph_run(("fin",) + shape,
+                            lambda: (self.graph.train_fn(batch, hp), self.train_op.add_slots_launch(), tail()))
+        else:       # one exchange per update over the accumulated gradient (cycle.py:86-88)
+            self._graph_run(("finA",) + shape,
+                            lambda: (self.graph.train_fn(batch, hp), self.train_op.add_slots_launch()))
+            self.reducer.all_reduce_everything()
+            self._graph_run(("finB",), tail)
+        self.train_op.count = 0
+        self.store.step += 1
+        self.cycle_counter = 0
+        self.global_step += 1
         return loss
 
     # -- data-parallel captured path: hipGraph segments between the gradient-bucket hand-offs ----
@@ -352,14 +423,9 @@ def train(params):
             pending = []
             cum_tokens += int(np.sum(data['tgt'] > 0))
             last = (trainer.cycle_counter + 1) >= params.update_cycle
-            feats = {"source": data['src'], "target": data['tgt']}
-            if params.update_cycle == 1 and data['src'].shape[0] > 0:
-                # one update per batch: the step of every batch SHAPE is captured once and replayed
-                # (eager on first sight, captured on the second, replayed from the third on)
-                trainer.prepare_static(feats)
-                loss = trainer.step_static()
-            else:
-                loss = trainer.micro_step(feats)
+            # the step of every batch SHAPE is captured once and replayed (eager on first sight,
+            # captured on the second, replayed from the third on), with or without accumulation
+            loss = trainer.step({"source": data['src'], "target": data['tgt']})
             if not last:
                 continue
             gstep = trainer.global_step

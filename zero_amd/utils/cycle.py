@@ -51,12 +51,22 @@ class TrainOp(object):
 
     # cycle.py:73-85
     def collect(self):
+        self.collect_launch()
+        self.count += 1
+
+    def collect_launch(self):
+        """Device side of collect_op (slot += g); graph-capturable, the counter is the caller's."""
         st = self.store
         if st.accum is None:
             st.accum = torch.zeros_like(st.grad)
         self.eng.lib.call("zk_axpby_f32", st.accum.data_ptr(), st.grad.data_ptr(), 1.0, 1.0, st.numel,
                           self.eng.stream)
-        self.count += 1
+
+    def add_slots_launch(self):
+        """g <- g + slot of the final micro step (cycle.py:86-88); graph-capturable."""
+        st = self.store
+        self.eng.lib.call("zk_axpby_f32", st.grad.data_ptr(), st.accum.data_ptr(), 1.0, 1.0, st.numel,
+                          self.eng.stream)
 
     def set_hyper(self, lr, world=1):
         """Host-side scalars of this update (lr is fed per step: main.py:157,292)."""
