@@ -225,6 +225,10 @@ int zk_beam_topk(const float* logits, const float* prev_log_probs, float* topk_s
 /* search.py:198-210 beam reordering: dst row r <- src row index[r] (NULL: r); bytes, multiples of 16 */
 int zk_gather_rows(const void* src, size_t src_stride, const int* index, void* dst, size_t dst_stride, int rows,
                    size_t row_bytes, zk_stream_t stream);
+/* period > 0: rows = n_tables * period stacked tables share one index of length period (the caches of every
+   decoder layer reordered by one launch) */
+int zk_gather_rows_ex(const void* src, size_t src_stride, const int* index, void* dst, size_t dst_stride, int rows,
+                      size_t row_bytes, int period, zk_stream_t stream);
 /* transformer_fuse (func.py:258-275) merged attention: the averaged v_map(query) term summed into the
    cross-attention heads.  train: out = att + cumavg_mask(vq) and its transpose; decode: cache += vq,
    att += cache/(t+1) (func.py:262-272) */
@@ -239,9 +243,9 @@ int zk_add_gumbel(float* logits, int rows, int V, int ld, float eps, const uint6
 /* k/v cache rows with the time step in device memory (hipGraph replay of func.py:199-205 and of the
    beam reorder search.py:206-209).  mode 0 (append): dst[r][*time_dev] <- src[r] (unit_bytes);
    mode 1 (reorder): dst[r][0 .. *time_dev) <- src[index[r]][0 .. *time_dev) in units of unit_bytes;
-   max_units bounds the launch. */
+   max_units bounds the launch; period as in zk_gather_rows_ex. */
 int zk_cache_rows(const void* src, size_t src_stride, const int* index, void* dst, size_t dst_stride, int rows,
-                  size_t unit_bytes, int max_units, const int* time_dev, int mode, zk_stream_t stream);
+                  size_t unit_bytes, int max_units, const int* time_dev, int mode, int period, zk_stream_t stream);
 /* transformer_aan.py:110-112: cache += x; cat = [x | cache/(t+1)] */
 int zk_aan_decode(const void* x, float* cache, void* cat, int rows, int H, float inv_count, const int* time_dev,
                   zk_stream_t stream);

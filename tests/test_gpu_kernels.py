@@ -561,7 +561,8 @@ def test_l2norm_and_adam_tf1_semantics():
 
 
 # ------------------------------------------------------------------ decode tail
-@pytest.mark.parametrize("B,K,V,ld", [(3, 4, 1000, 1000), (2, 1, 37, 40), (5, 4, 32000, 32000), (2, 8, 517, 520)])
+@pytest.mark.parametrize("B,K,V,ld", [(3, 4, 1000, 1000), (2, 1, 37, 40), (5, 4, 32000, 32000), (2, 8, 517, 520),
+                                     (1, 2, 70001, 70008), (2, 3, 9, 16)])   # 70001: one-block-per-row fallback
 def test_beam_topk(B, K, V, ld):
     e = eng()
     logits = torch.zeros(B * K, ld, device="cuda")

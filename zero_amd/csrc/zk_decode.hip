@@ -91,6 +91,113 @@ __global__ void __launch_bounds__(256) k_beam_topk_rows(const float* __restrict_
   block_select(ls, li, cnt, k2, cand_s + (size_t)row * k2, cand_i + (size_t)row * k2, ws, wi, wt);
 }
 
+// ---- chunked form (default): every (sentence, beam) row is split into `nchunks` column chunks, one block
+// each, so that B*K*nchunks blocks read the logits with many loads in flight (the one-block-per-row kernel
+// above keeps ONE dependent load per thread outstanding: 149 us for 128 rows x 32000 at 4 waves per CU).
+// A chunk keeps its keys z/T (minus the EOS ban) in LDS, reduces {max, sum exp} and picks its k2 best by k2
+// block-wide arg-max rounds; within a row the order of the keys is the order of the final scores
+// ((prev + key - lse) / penalty is increasing in key), so nothing is lost before the merge.
+#define TOPK_CHUNK_MAX 8192
+__global__ void __launch_bounds__(256) k_beam_topk_chunks(const float* __restrict__ logits, float* __restrict__ part_ms,
+                                                          float* __restrict__ cand_key, int* __restrict__ cand_v,
+                                                          int V, int ld, int k2, int chunk, int nchunks,
+                                                          float inv_temp, int forbid_id, float forbid_value,
+                                                          const int* __restrict__ scal_dev) {
+  __shared__ float keys[TOPK_CHUNK_MAX];
+  __shared__ float sm[8];
+  __shared__ float ws[4];
+  __shared__ int wi[4];
+  const int row = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+  if (scal_dev != nullptr) forbid_id = scal_dev[1];
+  const int v0 = c * chunk, n = max(0, min(chunk, V - v0));
+  const float* z = logits + (size_t)row * ld + v0;
+  float m = -INFINITY;
+  for (int i = tid; i < n; i += 256) {
+    float key = z[i] * inv_temp;
+    m = fmaxf(m, key);                       // the EOS ban applies after the log-softmax (search.py:148-155)
+    keys[i] = key;
+  }
+  __syncthreads();
+  m = block_max<4>(m, sm);
+  float s = 0.f;
+  for (int i = tid; i < n; i += 256) s += __expf(keys[i] - m);
+  s = block_sum<4>(s, sm);
+  if (tid == 0) {
+    part_ms[((size_t)row * nchunks + c) * 2] = m;
+    part_ms[((size_t)row * nchunks + c) * 2 + 1] = s;
+  }
+  if (forbid_id >= v0 && forbid_id < v0 + n && tid == 0) keys[forbid_id - v0] -= forbid_value;
+  __syncthreads();
+  for (int r = 0; r < k2; ++r) {
+    float bs = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < n; i += 256) {
+      const float key = keys[i];
+      if (key > bs) { bs = key; bi = i; }     // strict: ties keep the lower index (i increases)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float s2 = __shfl_xor(bs, o, 64);
+      const int i2 = __shfl_xor(bi, o, 64);
+      if (better(s2, i2, bs, bi)) { bs = s2; bi = i2; }
+    }
+    if ((tid & 63) == 0) { ws[tid >> 6] = bs; wi[tid >> 6] = bi; }
+    __syncthreads();
+    bs = ws[0]; bi = wi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (better(ws[w], wi[w], bs, bi)) { bs = ws[w]; bi = wi[w]; }
+    if (tid == 0) {
+      const size_t o = ((size_t)row * nchunks + c) * k2 + r;
+      cand_key[o] = bs;
+      cand_v[o] = bi < n ? v0 + bi : 0x7fffffff;
+      if (bi < n) keys[bi] = -INFINITY;
+    }
+    __syncthreads();
+  }
+}
+
+// merge of the chunked form: one block per sentence; thread t owns candidate t of the K*nchunks*k2 (<= 256)
+__global__ void __launch_bounds__(256) k_beam_topk_merge_chunks(const float* __restrict__ part_ms,
+                                                                const float* __restrict__ cand_key,
+                                                                const int* __restrict__ cand_v,
+                                                                const float* __restrict__ prev_lp,
+                                                                float* __restrict__ out_s, int* __restrict__ out_i,
+                                                                int K, int V, int k2, int nchunks, float penalty,
+                                                                const int* __restrict__ scal_dev) {
+  __shared__ float ls[256][TOPK_MAX + 1];
+  __shared__ int li[256][TOPK_MAX + 1];
+  __shared__ float ws[4];
+  __shared__ int wi[4];
+  __shared__ int wt[4];
+  __shared__ float lse[TOPK_MAX];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (scal_dev != nullptr) penalty = __int_as_float(scal_dev[0]);
+  if (tid < K) {
+    const float* pm = part_ms + ((size_t)(b * K + tid) * nchunks) * 2;
+    float m = -INFINITY;
+    for (int c = 0; c < nchunks; ++c) m = fmaxf(m, pm[2 * c]);
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c)
+      if (pm[2 * c] > -INFINITY) s += pm[2 * c + 1] * __expf(pm[2 * c] - m);
+    lse[tid] = m + __logf(s);
+  }
+  __syncthreads();
+  const int per_row = nchunks * k2, n = K * per_row;
+  int cnt = 0;
+  if (tid < n) {
+    const int k = tid / per_row;
+    const size_t o = (size_t)(b * K + k) * per_row + (tid - k * per_row);
+    const int v = cand_v[o];
+    if (v != 0x7fffffff) {
+      ls[tid][0] = (prev_lp[b * K + k] + (cand_key[o] - lse[k])) / penalty;
+      li[tid][0] = k * V + v;
+      cnt = 1;
+    }
+  }
+  block_select(ls, li, cnt, k2, out_s + (size_t)b * k2, out_i + (size_t)b * k2, ws, wi, wt);
+}
+
 // stage 2: one block per sentence merges its K*k2 candidates (ties -> lower flat index)
 __global__ void __launch_bounds__(256) k_beam_topk_merge(const float* __restrict__ cand_s, const int* __restrict__ cand_i,
                                                          float* __restrict__ out_s, int* __restrict__ out_i, int K,
@@ -113,9 +220,11 @@ __global__ void __launch_bounds__(256) k_beam_topk_merge(const float* __restrict
 
 __global__ void __launch_bounds__(256) k_gather_rows(const uint4* __restrict__ src, size_t src_stride16,
                                                      const int* __restrict__ index, uint4* __restrict__ dst,
-                                                     size_t dst_stride16, size_t row16) {
+                                                     size_t dst_stride16, size_t row16, int period) {
   const int r = blockIdx.x;
-  const size_t s = index ? (size_t)index[r] : (size_t)r;
+  // period > 0: `rows / period` stacked tables share one index of length `period` (all layers' caches)
+  const size_t s = index ? (period > 0 ? (size_t)(r / period) * period + index[r % period] : (size_t)index[r])
+                         : (size_t)r;
   for (size_t c = (size_t)blockIdx.y * 256 + threadIdx.x; c < row16; c += (size_t)gridDim.y * 256)
     dst[(size_t)r * dst_stride16 + c] = src[s * src_stride16 + c];
 }
@@ -137,14 +246,15 @@ __global__ void __launch_bounds__(256) k_add_gumbel(float* __restrict__ logits, 
 __global__ void __launch_bounds__(256) k_cache_rows(const uint4* __restrict__ src, size_t src_stride16,
                                                     const int* __restrict__ index, uint4* __restrict__ dst,
                                                     size_t dst_stride16, size_t unit16,
-                                                    const int* __restrict__ time_dev, int mode) {
+                                                    const int* __restrict__ time_dev, int mode, int period) {
   const int r = blockIdx.x;
   const size_t t = (size_t)*time_dev;
   if (mode == 0) {
     for (size_t c = (size_t)blockIdx.y * 256 + threadIdx.x; c < unit16; c += (size_t)gridDim.y * 256)
       dst[(size_t)r * dst_stride16 + t * unit16 + c] = src[(size_t)r * src_stride16 + c];
   } else {
-    const size_t s = index ? (size_t)index[r] : (size_t)r;
+    const size_t s = index ? (period > 0 ? (size_t)(r / period) * period + index[r % period] : (size_t)index[r])
+                           : (size_t)r;
     const size_t n16 = t * unit16;
     for (size_t c = (size_t)blockIdx.y * 256 + threadIdx.x; c < n16; c += (size_t)gridDim.y * 256)
       dst[(size_t)r * dst_stride16 + c] = src[s * src_stride16 + c];
@@ -195,8 +305,14 @@ extern "C" {
 // logits: fp32 [B*K, ld]; prev_log_probs: fp32 [B*K]; outputs fp32/int32 [B, k2]
 // (topk_index = beam*V + symbol).  forbid_id < 0 disables the EOS ban.  scal_dev (device int[2] =
 // {float bits of the length penalty, forbid_id}, or NULL) overrides the two per-step scalars at
-// run time.  workspace: B*K*k2*8 bytes.
-size_t zk_beam_topk_workspace(int B, int K, int k2) { return (size_t)B * K * k2 * 8; }
+// run time.  workspace: zk_beam_topk_workspace(B, K, k2) bytes.
+static int topk_chunks(int K, int V, int k2) {
+  int nc = 256 / (K * k2);                       // merge block: one candidate per thread
+  if (nc > 8) nc = 8;
+  if (nc < 1 || (V + nc - 1) / nc > TOPK_CHUNK_MAX) return 0;   // fall back to one block per row
+  return nc;
+}
+size_t zk_beam_topk_workspace(int B, int K, int k2) { return (size_t)B * K * (8 * k2 * 8 + 8 * 8); }
 int zk_beam_topk(const float* logits, const float* prev_log_probs, float* topk_scores, int* topk_index, int B,
                  int K, int V, int ld, int k2, float temperature, float length_penalty, int forbid_id,
                  float forbid_value, const int* scal_dev, void* workspace, size_t ws_bytes, hipStream_t stream) {
@@ -205,6 +321,21 @@ int zk_beam_topk(const float* logits, const float* prev_log_probs, float* topk_s
   ZK_CHECK_ARG((long)K * V >= k2 && V >= k2, "zk_beam_topk: fewer candidates than k2");
   ZK_CHECK_ARG(ws_bytes >= zk_beam_topk_workspace(B, K, k2), "zk_beam_topk: workspace too small");
   if (B == 0) return 0;
+  const int nc = topk_chunks(K, V, k2);
+  if (nc > 0) {
+    const int chunk = (V + nc - 1) / nc;
+    float* part = (float*)workspace;
+    float* ck = part + (size_t)B * K * nc * 2;
+    int* cv = (int*)(ck + (size_t)B * K * nc * k2);
+    hipLaunchKernelGGL(k_beam_topk_chunks, dim3(B * K, nc), dim3(256), 0, stream, logits, part, ck, cv, V, ld, k2,
+                       chunk, nc, 1.f / temperature, forbid_id, forbid_value, scal_dev);
+    ZK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_beam_topk_merge_chunks, dim3(B), dim3(256), 0, stream, (const float*)part, (const float*)ck,
+                       (const int*)cv, prev_log_probs, topk_scores, topk_index, K, V, k2, nc, length_penalty,
+                       scal_dev);
+    ZK_LAUNCH_CHECK();
+    return 0;
+  }
   float* cs = (float*)workspace;
   int* ci = (int*)(cs + (size_t)B * K * k2);
   hipLaunchKernelGGL(k_beam_topk_rows, dim3(B * K), dim3(256), 0, stream, logits, prev_log_probs, cs, ci, K, V, ld,
@@ -217,8 +348,16 @@ int zk_beam_topk(const float* logits, const float* prev_log_probs, float* topk_s
 }
 
 // dst row r <- src row index[r] (index NULL: r); strides and row_bytes in bytes, multiples of 16
+int zk_gather_rows_ex(const void* src, size_t src_stride, const int* index, void* dst, size_t dst_stride, int rows,
+                      size_t row_bytes, int period, hipStream_t stream);
 int zk_gather_rows(const void* src, size_t src_stride, const int* index, void* dst, size_t dst_stride, int rows,
                    size_t row_bytes, hipStream_t stream) {
+  return zk_gather_rows_ex(src, src_stride, index, dst, dst_stride, rows, row_bytes, 0, stream);
+}
+// period > 0: rows = n_tables * period; table t gathers src row t*period + index[r] (one launch for the caches
+// of every decoder layer, search.py:206-209)
+int zk_gather_rows_ex(const void* src, size_t src_stride, const int* index, void* dst, size_t dst_stride, int rows,
+                      size_t row_bytes, int period, hipStream_t stream) {
   ZK_CHECK_ARG(src_stride % 16 == 0 && dst_stride % 16 == 0 && row_bytes % 16 == 0,
                "zk_gather_rows: strides / row_bytes must be multiples of 16");
   ZK_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "zk_gather_rows: pointers must be 16-byte aligned");
@@ -226,8 +365,9 @@ int zk_gather_rows(const void* src, size_t src_stride, const int* index, void* d
   const size_t row16 = row_bytes / 16;
   int gy = (int)((row16 + 255) / 256);
   if (gy > 64) gy = 64;
+  ZK_CHECK_ARG(period >= 0 && (period == 0 || rows % period == 0), "zk_gather_rows: rows must be a multiple of period");
   hipLaunchKernelGGL(k_gather_rows, dim3(rows, gy), dim3(256), 0, stream, (const uint4*)src, src_stride / 16, index,
-                     (uint4*)dst, dst_stride / 16, row16);
+                     (uint4*)dst, dst_stride / 16, row16, period);
   ZK_LAUNCH_CHECK();
   return 0;
 }
@@ -245,7 +385,7 @@ int zk_add_gumbel(float* logits, int rows, int V, int ld, float eps, const uint6
 }
 
 int zk_cache_rows(const void* src, size_t src_stride, const int* index, void* dst, size_t dst_stride, int rows,
-                  size_t unit_bytes, int max_units, const int* time_dev, int mode, hipStream_t stream) {
+                  size_t unit_bytes, int max_units, const int* time_dev, int mode, int period, hipStream_t stream) {
   ZK_CHECK_ARG(src_stride % 16 == 0 && dst_stride % 16 == 0 && unit_bytes % 16 == 0,
                "zk_cache_rows: strides / unit_bytes must be multiples of 16");
   ZK_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "zk_cache_rows: pointers must be 16-byte aligned");
@@ -255,8 +395,9 @@ int zk_cache_rows(const void* src, size_t src_stride, const int* index, void* ds
   const size_t span = mode == 0 ? unit16 : unit16 * (size_t)(max_units > 0 ? max_units : 1);
   int gy = (int)((span + 255) / 256);
   if (gy > 64) gy = 64;
+  ZK_CHECK_ARG(period >= 0 && (period == 0 || rows % period == 0), "zk_cache_rows: rows must be a multiple of period");
   hipLaunchKernelGGL(k_cache_rows, dim3(rows, gy), dim3(256), 0, stream, (const uint4*)src, src_stride / 16, index,
-                     (uint4*)dst, dst_stride / 16, unit16, time_dev, mode);
+                     (uint4*)dst, dst_stride / 16, unit16, time_dev, mode, period);
   ZK_LAUNCH_CHECK();
   return 0;
 }

@@ -38,32 +38,45 @@ class DecodeState(dict):
 
     def reorder(self, index_dev, time_dev=None):
         """Gather every per-beam cache by flat beam index [B*K] (device int32).  time_dev: the
-        number of filled cache slots lives in device memory (hipGraph replay)."""
+        number of filled cache slots lives in device memory (hipGraph replay).  The caches of all
+        layers are slabs of one buffer, so each kind (aan / k / v) is ONE launch."""
         core = self["_core"]
         e = core.eng
         BK, H, t = self["BK"], core.H, self["time_filled"]
-        for l in range(core.hp.num_decoder_layer):
+        nl = core.hp.num_decoder_layer
+        pp = self["_pp"]
+        lay0 = self["decoder"]["state"]["layer_0"]
+        if "aan" in lay0:
+            src = e.buf("dc.aan.%d" % pp, (nl, BK, H), F32)
+            dst = e.buf("dc.aan.%d" % (1 - pp), (nl, BK, H), F32)
+            e.lib.call("zk_gather_rows_ex", src.data_ptr(), H * 4, index_dev.data_ptr(), dst.data_ptr(), H * 4,
+                       nl * BK, H * 4, BK, e.stream)
+        if "k" in lay0:
+            Tmax = self["Tmax"]
+            for nm in ("k", "v"):
+                src = e.buf("dc.%s.%d" % (nm, pp), (nl, BK, Tmax, H))
+                dst = e.buf("dc.%s.%d" % (nm, 1 - pp), (nl, BK, Tmax, H))
+                if time_dev is not None:
+                    e.lib.call("zk_cache_rows", src.data_ptr(), Tmax * H * 2, index_dev.data_ptr(), dst.data_ptr(),
+                               Tmax * H * 2, nl * BK, H * 2, Tmax, time_dev.data_ptr(), 1, BK, e.stream)
+                else:
+                    e.lib.call("zk_gather_rows_ex", src.data_ptr(), Tmax * H * 2, index_dev.data_ptr(),
+                               dst.data_ptr(), Tmax * H * 2, nl * BK, t * H * 2, BK, e.stream)
+        self["_pp"] = 1 - pp
+        self.bind_caches()
+
+    def bind_caches(self):
+        """Point every layer's cache entries at the current ping-pong half."""
+        core = self["_core"]
+        e = core.eng
+        BK, H, nl, pp = self["BK"], core.H, core.hp.num_decoder_layer, self["_pp"]
+        for l in range(nl):
             lay = self["decoder"]["state"]["layer_%d" % l]
             if "aan" in lay:
-                src = lay["aan"]
-                dst = e.buf("dc%d.aan.%d" % (l, 1 - lay["_pp"]), (BK, H), F32)
-                e.lib.call("zk_gather_rows", src.data_ptr(), H * 4, index_dev.data_ptr(), dst.data_ptr(), H * 4,
-                           BK, H * 4, e.stream)
-                lay["aan"] = dst
-                lay["_pp"] = 1 - lay["_pp"]
+                lay["aan"] = e.buf("dc.aan.%d" % pp, (nl, BK, H), F32)[l]
             if "k" in lay:
-                Tmax = self["Tmax"]
                 for nm in ("k", "v"):
-                    src = lay[nm]
-                    dst = e.buf("dc%d.%s.%d" % (l, nm, 1 - lay["_pp"]), (BK, Tmax, H))
-                    if time_dev is not None:
-                        e.lib.call("zk_cache_rows", src.data_ptr(), Tmax * H * 2, index_dev.data_ptr(),
-                                   dst.data_ptr(), Tmax * H * 2, BK, H * 2, Tmax, time_dev.data_ptr(), 1, e.stream)
-                    else:
-                        e.lib.call("zk_gather_rows", src.data_ptr(), Tmax * H * 2, index_dev.data_ptr(),
-                                   dst.data_ptr(), Tmax * H * 2, BK, t * H * 2, e.stream)
-                    lay[nm] = dst
-                lay["_pp"] = 1 - lay["_pp"]
+                    lay[nm] = e.buf("dc.%s.%d" % (nm, pp), (nl, BK, self["Tmax"], H))[l]
 
 
 def make_infer_fns(params, model_name):
@@ -93,25 +106,40 @@ def make_infer_fns(params, model_name):
             kv = e.mat("dc%d.kv" % l, B * Ls, 2 * H)
             core._linear(enc_keep, p + "k_map", kv.cols_slice(0, H))
             core._linear(enc_keep, p + "v_map", kv.cols_slice(H, 2 * H))
-            lay = {"mk": kv.cols_slice(0, H), "mv": kv.cols_slice(H, 2 * H), "_pp": 0}
+            lay = {"mk": kv.cols_slice(0, H), "mv": kv.cols_slice(H, 2 * H)}
             if core.aan or core.fuse:
-                a = e.buf("dc%d.aan.0" % l, (BK, H), F32)
-                e.zero(a)
-                lay["aan"] = a
+                lay["aan"] = None
             else:
-                lay["k"] = e.buf("dc%d.k.0" % l, (BK, max_steps, H))
-                lay["v"] = e.buf("dc%d.v.0" % l, (BK, max_steps, H))
+                lay["k"] = lay["v"] = None
             state["decoder"]["state"]["layer_%d" % l] = lay
+        state["_pp"] = 0
+        nl = hp.num_decoder_layer
+        if core.aan or core.fuse:
+            e.zero(e.buf("dc.aan.0", (nl, BK, H), F32))
+            e.buf("dc.aan.1", (nl, BK, H), F32)
+        else:
+            for nm in ("k", "v"):
+                for half in (0, 1):
+                    e.buf("dc.%s.%d" % (nm, half), (nl, BK, max_steps, H))
+        state.bind_caches()
         state["zero_flag"] = e.buf("dc.zflag", (1,), torch.int32)
         # per-step scalars live in device memory ({time, float bits of the length penalty, EOS-ban id}):
         # a captured decode-step graph reads the current values at replay time
-        state["stepbuf"] = e.buf("dc.stepbuf", (4,), torch.int32)
-        state["stepbuf_host"] = torch.zeros(4, dtype=torch.int32).pin_memory()
-        state["tok"] = e.buf("bs.tok", (BK,), torch.int32)
-        state["prev"] = e.buf("bs.prev", (BK,), torch.float32)
-        state["idx"] = e.buf("bs.idx", (BK,), torch.int32)
-        state["ts"] = e.buf("bs.ts", (B, 2 * K), torch.float32)
-        state["ti"] = e.buf("bs.ti", (B, 2 * K), torch.int32)
+        # what the host hands to a (replayed) step -- last tokens, previous log-probs, beam reorder index and
+        # the per-step scalars {time, float bits of the length penalty, EOS-ban id} -- is ONE pinned buffer
+        # and one async copy; what comes back (top-2K scores and flat indices) is one copy as well
+        pack = e.buf("bs.pack", (3 * BK + 4,), torch.int32)
+        state["pack_dev"] = pack
+        state["pack_host"] = torch.zeros(3 * BK + 4, dtype=torch.int32).pin_memory()
+        state["tok"] = pack[0:BK]
+        state["prev"] = pack[BK:2 * BK].view(torch.float32)
+        state["idx"] = pack[2 * BK:3 * BK]
+        state["stepbuf"] = pack[3 * BK:3 * BK + 4]
+        out = e.buf("bs.out", (2, B, 2 * K), torch.int32)
+        state["out_dev"] = out
+        state["out_host"] = torch.zeros(2, B, 2 * K, dtype=torch.int32).pin_memory()
+        state["ts"] = out[0].view(torch.float32)
+        state["ti"] = out[1]
         state["graphs"] = {}
         # every launch argument of a step is static: the time step (cache slot, number of valid keys,
         # relative-position origin) is read from device memory by the kernels
@@ -125,7 +153,7 @@ def make_infer_fns(params, model_name):
         ping-pong parity), so after one eager pass per parity it is captured into a hipGraph."""
         core = state["_core"]
         e = core.eng
-        parity = state["decoder"]["state"]["layer_0"]["_pp"]
+        parity = state["_pp"]
         g = state["graphs"].get(parity)
 
         def body():
@@ -146,14 +174,8 @@ def make_infer_fns(params, model_name):
             state["graphs"][parity] = e.graph_capture(body)
             e.graph_launch(state["graphs"][parity])
         else:
-            for l in range(hp.num_decoder_layer):      # replay: redo the python-side pointer flips
-                lay = state["decoder"]["state"]["layer_%d" % l]
-                if "aan" in lay:
-                    lay["aan"] = e.buf("dc%d.aan.%d" % (l, 1 - lay["_pp"]), (state["BK"], core.H), F32)
-                if "k" in lay:
-                    for nm in ("k", "v"):
-                        lay[nm] = e.buf("dc%d.%s.%d" % (l, nm, 1 - lay["_pp"]), (state["BK"], state["Tmax"], core.H))
-                lay["_pp"] = 1 - lay["_pp"]
+            state["_pp"] = 1 - state["_pp"]           # replay: redo the python-side pointer flip
+            state.bind_caches()
             e.graph_launch(g)
 
     def _step_cache(target, state, time, time_dev=None):
@@ -194,7 +216,7 @@ def make_infer_fns(params, model_name):
                 for nm, c0 in (("k", H), ("v", 2 * H)):
                     if time_dev is not None:
                         e.lib.call("zk_cache_rows", qkv.ptr + c0 * 2, 3 * H * 2, None, lay[nm].data_ptr(),
-                                   Tmax * H * 2, BK, H * 2, Tmax, time_dev.data_ptr(), 0, e.stream)
+                                   Tmax * H * 2, BK, H * 2, Tmax, time_dev.data_ptr(), 0, 0, e.stream)
                     else:
                         e.lib.call("zk_gather_rows", qkv.ptr + c0 * 2, 3 * H * 2, None,
                                    lay[nm].data_ptr() + time * H * 2, Tmax * H * 2, BK, H * 2, e.stream)

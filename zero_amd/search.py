@@ -91,7 +91,11 @@ def _beam_search(features, encoding_fn, decoding_fn, params):
     static_step = cache_mode and state.get("static_ok", False) and hasattr(decoding_fn, "step_static") \
         and os.environ.get("ZERO_HIP_DECODE_GRAPH", "1") != "0"
     if static_step:
-        d_idx.copy_(torch.arange(B * K, dtype=torch.int32))     # step 0: identity reorder
+        BK = B * K
+        pack = state["pack_host"].numpy()             # pinned; shares memory with the tensor
+        pack[2 * BK:3 * BK] = np.arange(BK, dtype=np.int32)     # step 0: identity reorder
+        out_host = state["out_host"]
+        out_np = out_host.numpy()
     while True:
         # ---- search.py:85-113
         max_lp = np.power((f32(5.) + max_target_length) / f32(6.), f32(alpha)).astype(f32)
@@ -107,11 +111,11 @@ def _beam_search(features, encoding_fn, decoding_fn, params):
         if static_step:
             if time >= state["Tmax"]:
                 raise RuntimeError("decode step %d exceeds the allocated cache length %d" % (time, state["Tmax"]))
-            d_tok.copy_(torch.from_numpy(seq[:, :, -1].reshape(-1).astype(np.int32)), non_blocking=True)
-            d_prev.copy_(torch.from_numpy(log_probs.reshape(-1)), non_blocking=True)
-            hb = state["stepbuf_host"]
-            hb[0], hb[1], hb[2] = time, int(np.float32(penalty).view(np.int32)), (eos_id if time < 1 else -1)
-            state["stepbuf"].copy_(hb, non_blocking=True)
+            pack[0:BK] = seq[:, :, -1].reshape(-1)
+            pack[BK:2 * BK] = log_probs.reshape(-1).view(np.int32)
+            pack[3 * BK], pack[3 * BK + 1], pack[3 * BK + 2] = \
+                time, int(np.float32(penalty).view(np.int32)), (eos_id if time < 1 else -1)
+            state["pack_dev"].copy_(state["pack_host"], non_blocking=True)
             decoding_fn.step_static(state, params.beam_search_temperature, zdtype.inf())
             logits = None
         elif cache_mode:
@@ -130,8 +134,13 @@ def _beam_search(features, encoding_fn, decoding_fn, params):
             d_prev.copy_(torch.from_numpy(log_probs.reshape(-1)))
             e.beam_topk(logits, d_prev, d_ts, d_ti, B, K, V, 2 * K, params.beam_search_temperature, penalty,
                         eos_id if time < 1 else -1, zdtype.inf())
-        topk_scores = d_ts.cpu().numpy().astype(f32)
-        topk_idx = d_ti.cpu().numpy().astype(np.int64)
+        if static_step:
+            out_host.copy_(state["out_dev"])           # one D2H for scores and indices (synchronises)
+            topk_scores = out_np[0].view(f32).copy()
+            topk_idx = out_np[1].astype(np.int64)
+        else:
+            topk_scores = d_ts.cpu().numpy().astype(f32)
+            topk_idx = d_ti.cpu().numpy().astype(np.int64)
         beam_idx = topk_idx // V
         sym_idx = topk_idx % V
         bpos = np.arange(B)[:, None]
@@ -155,9 +164,11 @@ def _beam_search(features, encoding_fn, decoding_fn, params):
         seq, log_probs, scores = alive_seq, alive_lp, alive_scores
         if cache_mode:
             flat_idx = (np.arange(B)[:, None] * K + alive_beam).reshape(-1).astype(np.int32)
-            d_idx.copy_(torch.from_numpy(flat_idx), non_blocking=static_step)
-            if not static_step:
-                state.reorder(d_idx)        # (the static step reorders at its own start)
+            if static_step:
+                pack[2 * BK:3 * BK] = flat_idx          # travels with the next step's inputs; it reorders first
+            else:
+                d_idx.copy_(torch.from_numpy(flat_idx))
+                state.reorder(d_idx)
         time += 1
 
     any_fin = fin_flags.any(axis=1)
