@@ -20,3 +20,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _fixed_seeds():
+    """Every test sees the same random data whatever ran before it (several tolerances are checked
+    against randomly drawn operands)."""
+    import random
+    import numpy as np
+    import torch
+    random.seed(1234)
+    np.random.seed(1234)
+    torch.manual_seed(1234)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(1234)
+    yield
