@@ -314,3 +314,26 @@ def test_recorder_round_trip(tmp_path):
     r.save_to_json(p)
     r2 = Recorder(); r2.load_from_json(p)
     assert r2.step == 12 and r2.valid_script_scores == [[10, 3.5]] and r2.epoch == 1 and r2.lidx == -1
+
+
+def test_checkpoint_averaging(tmp_path):
+    """scripts/checkpoint_averaging.py: newest N of the run, float64 mean, global_step reset, json copied."""
+    from zero_amd.scripts import checkpoint_averaging as ca
+    from zero_amd.utils.saver import Saver
+    run = tmp_path / "run"; run.mkdir()
+    (run / "param.json").write_text('{"hidden_size": 8}')
+    sv = Saver(checkpoints=5, output_dir=str(run))
+    for step in (10, 20, 30, 40):
+        sv.save({"s/w": np.full((2, 3), float(step), np.float32), "s/h": np.full(4, step, np.float16),
+                 "global_step": np.array(step, np.int64)}, step)
+    out = tmp_path / "avg"
+    used = ca.average(str(run), 3, str(out))
+    assert [os.path.basename(p) for p in used] == ["model-40", "model-30", "model-20"]
+    got = bundle.load_checkpoint(str(out / "average-0"))
+    assert got["s/w"].dtype == np.float32 and np.allclose(got["s/w"], 30.0) and got["s/h"].dtype == np.float16
+    assert int(got["global_step"]) == 0 and (out / "param.json").exists()
+    assert Saver(output_dir=str(out)).restore()["s/w"].shape == (2, 3)
+    ca.main(["--path", str(run), "--checkpoints", "10", "--output", str(tmp_path / "avg2")])
+    assert np.allclose(bundle.load_checkpoint(str(tmp_path / "avg2" / "average-0"))["s/w"], 25.0)
+    with pytest.raises(ValueError):
+        ca.get_checkpoints(str(tmp_path / "nowhere"))
