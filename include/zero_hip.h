@@ -237,6 +237,15 @@ int zk_cumavg_add_fwd(const void* vq, const float* mask, const void* att, void* 
 int zk_cumavg_bwd(const void* dy, const float* mask, void* dvq, int B, int L, int H, zk_stream_t stream);
 int zk_fuse_decode(const void* vq, float* cache, void* att, int rows, int H, float inv_count, const int* time_dev,
                    zk_stream_t stream);
+/* Host side of a beam-search step in C (pure host code, no device work): the stop test of search.py:85-113
+   and the alive / finished bookkeeping of search.py:168-228 on int32 [B, K, Tcap] sequence buffers. */
+int zk_beam_host_should_stop(int B, int K, const float* log_probs, const float* fin_scores,
+                             const unsigned char* fin_flags, const float* max_target_length, const int* mtl_i,
+                             int time, float alpha);
+int zk_beam_host_step(int B, int K, int V, int Tcap, int time, const float* topk_scores, const int* topk_idx,
+                      int* seq, int* fin_seq, float* log_probs, float* scores, float* fin_scores,
+                      unsigned char* fin_flags, const int* mtl_i, int eos_id, int pad_id, float penalty,
+                      int* flat_idx, int* next_tok);
 /* search.py:143-145 (enable_noise_beam_search): logits += Gumbel noise -log(-log(u + eps) + eps), util.py:189-195 */
 int zk_add_gumbel(float* logits, int rows, int V, int ld, float eps, const uint64_t* seed, uint32_t sid,
                   zk_stream_t stream);

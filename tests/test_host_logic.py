@@ -122,3 +122,72 @@ def test_trim_columns_is_remove_invalid_seq():
     from zero_amd.models._core import trim_columns
     assert trim_columns(np.zeros((2, 3), dtype=np.int64)).shape == (2, 1)
     assert trim_columns(np.array([[4, 2, 0, 0], [5, 6, 2, 0]])).shape == (2, 3)
+
+
+def test_beam_host_step_in_c_matches_the_numpy_bookkeeping():
+    """zk_beam_host_step / zk_beam_host_should_stop (pure host C in libzero_hip.so) against the numpy
+    statements of search.py:85-113,168-228 used by the eager / dev search: random survivors incl. exact
+    ties, EOS symbols and length caps, several steps in a row."""
+    import ctypes
+    from zero_amd import hip
+    lib = hip.lib()
+    f32 = np.float32
+    F32_MIN = np.finfo(np.float32).min
+    rng = np.random.default_rng(5)
+    B, K, V, eos, pad, alpha = 5, 3, 50, 2, 0, 0.6
+    Tcap = 12
+    mtl = np.array([3, 9, 9, 2, 9], dtype=f32); mtl_i = mtl.astype(np.int32)
+
+    def top_k(x, k):
+        idx = np.argsort(-x, axis=-1, kind="stable")[..., :k]
+        return np.take_along_axis(x, idx, axis=-1), idx
+    # numpy state
+    seq = np.full((B, K, 1), pad, dtype=np.int64); fin_seq = np.zeros_like(seq)
+    log_probs = np.tile(np.array([[0.] + [F32_MIN] * (K - 1)], dtype=f32), (B, 1)); scores = np.zeros_like(log_probs)
+    fin_scores = np.full((B, K), F32_MIN, dtype=f32); fin_flags = np.zeros((B, K), dtype=bool)
+    # C state
+    c_seq = np.full((B, K, Tcap), pad, dtype=np.int32); c_fin = np.zeros((B, K, Tcap), dtype=np.int32)
+    c_lp = log_probs.copy(); c_sc = scores.copy(); c_fs = fin_scores.copy(); c_ff = np.zeros((B, K), dtype=np.uint8)
+    c_idx = np.zeros(B * K, np.int32); c_tok = np.zeros(B * K, np.int32)
+    P = lambda a: ctypes.c_void_p(a.ctypes.data)
+    for time in range(8):
+        max_lp = np.power((f32(5.) + mtl) / f32(6.), f32(alpha)).astype(f32)
+        worst = (fin_scores * fin_flags.astype(f32)).min(axis=1) + (f32(1.) - fin_flags.any(axis=1).astype(f32)) * F32_MIN
+        want_stop = bool((worst > log_probs[:, 0] / max_lp).all()) or not bool((time < mtl_i).any())
+        got_stop = lib.raw("zk_beam_host_should_stop")(B, K, P(c_lp), P(c_fs), P(c_ff), P(mtl), P(mtl_i), time, alpha)
+        assert bool(got_stop) == want_stop
+        if want_stop:
+            break
+        penalty = f32(np.power(f32((f32(5.) + f32(time + 1)) / f32(6.)), f32(alpha)))
+        ts = np.sort(rng.standard_normal((B, 2 * K)).astype(f32) * 3 - time, axis=1)[:, ::-1].copy()
+        ts[0, 1] = ts[0, 0]                                              # an exact tie
+        ti = rng.integers(0, K * V, (B, 2 * K)).astype(np.int32)
+        ti[1, 0] = 1 * V + eos; ti[2, 3] = 0 * V + eos                   # some EOS symbols
+        # ---- numpy (search.py:168-228 as in zero_amd/search.py)
+        beam_idx = ti.astype(np.int64) // V; sym = ti.astype(np.int64) % V
+        bpos = np.arange(B)[:, None]
+        curr_seq = np.concatenate([seq[bpos, beam_idx], sym[:, :, None]], axis=2)
+        curr_fin = (sym == eos) | (time >= mtl_i)[:, None]
+        with np.errstate(over="ignore"):
+            alive_scores, alive_idx = top_k(ts + curr_fin.astype(f32) * F32_MIN, K)
+            alive_lp = (alive_scores * penalty).astype(f32)
+            cfs = ts + (f32(1.) - curr_fin.astype(f32)) * F32_MIN
+        all_flags = np.concatenate([fin_flags, curr_fin], axis=1); all_scores = np.concatenate([fin_scores, cfs], axis=1)
+        fin_scores, fin_idx = top_k(all_scores, K)
+        fin_flags = all_flags[bpos, fin_idx]
+        all_seq = np.concatenate([np.concatenate([fin_seq, np.full((B, K, 1), pad, dtype=seq.dtype)], axis=2), curr_seq], axis=1)
+        fin_seq = all_seq[bpos, fin_idx]
+        flat = (np.arange(B)[:, None] * K + beam_idx[bpos, alive_idx]).reshape(-1)
+        seq, log_probs, scores = curr_seq[bpos, alive_idx], alive_lp, alive_scores
+        # ---- C
+        rc = lib.raw("zk_beam_host_step")(B, K, V, Tcap, time, P(ts), P(ti), P(c_seq), P(c_fin), P(c_lp), P(c_sc), P(c_fs),
+                                          P(c_ff), P(mtl_i), eos, pad, float(penalty), P(c_idx), P(c_tok))
+        assert rc == 0
+        n = time + 2
+        assert np.array_equal(c_seq[:, :, :n], seq) and np.array_equal(c_fin[:, :, :n], fin_seq)
+        assert np.array_equal(c_lp.view(np.int32), log_probs.view(np.int32))          # bit-exact fp32
+        assert np.array_equal(c_sc.view(np.int32), scores.view(np.int32))
+        assert np.array_equal(c_fs.view(np.int32), fin_scores.view(np.int32))
+        assert np.array_equal(c_ff.astype(bool), fin_flags)
+        assert np.array_equal(c_idx, flat) and np.array_equal(c_tok, seq[:, :, -1].reshape(-1))
+    assert time >= 3

@@ -7,6 +7,7 @@
 // search.py:198-210: beam reordering of the per-beam caches = row gather.
 // transformer_aan.py:110-112: decode-time cumulative average, cache in HBM (fp32).
 #include "zk_common.h"
+#include <alloca.h>
 
 #define TOPK_MAX 16
 
@@ -421,6 +422,122 @@ int zk_fuse_decode(const void* vq, float* cache, void* att, int rows, int H, flo
   hipLaunchKernelGGL(k_fuse_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)vq, cache,
                      (bf16_t*)att, rows, H, inv_count, time_dev);
   ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side of one beam-search step (search.py:85-113 and 168-228) in C: the 2K survivors of every
+// sentence come back from the GPU and the alive / finished sets are updated here in ~2 us instead of
+// ~25 small numpy calls (~130 us, a fifth of a decode step).  Plain fp32 arithmetic in the reference's
+// order; tf.nn.top_k ties -> lower index.  Pure host code.
+// ---------------------------------------------------------------------------------------------
+static const float kF32Min = -3.4028234663852886e38f;
+
+// search.py:85-113: stop when every sentence's worst finished score beats its best alive bound, or when
+// no sentence may grow any more.  Returns 1 to stop.
+int zk_beam_host_should_stop(int B, int K, const float* log_probs, const float* fin_scores,
+                             const unsigned char* fin_flags, const float* max_target_length, const int* mtl_i,
+                             int time, float alpha) {
+  bool bound = true, length = false;
+  for (int b = 0; b < B; ++b) {
+    const float max_lp = powf((5.f + max_target_length[b]) / 6.f, alpha);
+    const float best_alive = log_probs[b * K] / max_lp;
+    float worst = INFINITY;
+    bool any = false;
+    for (int k = 0; k < K; ++k) {
+      const float f = fin_flags[b * K + k] ? 1.f : 0.f;
+      worst = fminf(worst, fin_scores[b * K + k] * f);
+      any = any || fin_flags[b * K + k];
+    }
+    worst = worst + (1.f - (any ? 1.f : 0.f)) * kF32Min;
+    if (!(worst > best_alive)) bound = false;
+    if (time < mtl_i[b]) length = true;
+  }
+  return (bound || !length) ? 1 : 0;
+}
+
+// descending, ties -> lower index (np.argsort(-x, kind="stable")[:k])
+static void host_top_k(const float* x, int n, int k, int* idx) {
+  bool used[64];
+  for (int i = 0; i < n; ++i) used[i] = false;
+  for (int r = 0; r < k; ++r) {
+    int best = -1;
+    for (int i = 0; i < n; ++i) {
+      if (used[i]) continue;
+      if (best < 0 || x[i] > x[best]) best = i;        // strict: the first of equal values wins
+    }
+    idx[r] = best;
+    used[best] = true;
+  }
+}
+
+// seq / fin_seq: int32 [B, K, Tcap], the first `len` entries of every row valid (len = time + 1 on entry,
+// time + 2 on exit).  topk_idx = beam * V + symbol.  Outputs the next step's tokens, log-probs, scores and
+// the flat beam index (b * K + source beam) of every alive hypothesis.
+int zk_beam_host_step(int B, int K, int V, int Tcap, int time, const float* topk_scores, const int* topk_idx,
+                      int* seq, int* fin_seq, float* log_probs, float* scores, float* fin_scores,
+                      unsigned char* fin_flags, const int* mtl_i, int eos_id, int pad_id, float penalty,
+                      int* flat_idx, int* next_tok) {
+  const int K2 = 2 * K, len = time + 1;
+  if (K < 1 || K2 + K > 64 || len + 1 > Tcap) return -1;
+  int cur[64], beam[64], aidx[64], fidx[64];
+  float masked[64], allsc[64];
+  unsigned char cfin[64], allfl[64];
+  int* tmp = (int*)alloca((size_t)(K2 + K) * (len + 1) * sizeof(int) * 2);
+  int* new_alive = tmp;                                   // [K][len+1]
+  int* new_fin = tmp + (size_t)K * (len + 1);             // [K][len+1]
+  for (int b = 0; b < B; ++b) {
+    const float* ts = topk_scores + (size_t)b * K2;
+    const int* ti = topk_idx + (size_t)b * K2;
+    int* sq = seq + (size_t)b * K * Tcap;
+    int* fs = fin_seq + (size_t)b * K * Tcap;
+    const bool at_cap = time >= mtl_i[b];
+    for (int c = 0; c < K2; ++c) {
+      beam[c] = ti[c] / V;
+      cur[c] = ti[c] % V;
+      cfin[c] = (cur[c] == eos_id) || at_cap;
+      masked[c] = ts[c] + (cfin[c] ? 1.f : 0.f) * kF32Min;
+    }
+    // alive (search.py:192-210)
+    host_top_k(masked, K2, K, aidx);
+    for (int k = 0; k < K; ++k) {
+      const int c = aidx[k];
+      for (int t = 0; t < len; ++t) new_alive[k * (len + 1) + t] = sq[beam[c] * Tcap + t];
+      new_alive[k * (len + 1) + len] = cur[c];
+      scores[b * K + k] = masked[c];
+      log_probs[b * K + k] = masked[c] * penalty;
+      flat_idx[b * K + k] = b * K + beam[c];
+      next_tok[b * K + k] = cur[c];
+    }
+    // finished (search.py:212-228): previous K finished | the 2K candidates
+    for (int k = 0; k < K; ++k) { allsc[k] = fin_scores[b * K + k]; allfl[k] = fin_flags[b * K + k]; }
+    for (int c = 0; c < K2; ++c) {
+      allsc[K + c] = ts[c] + (1.f - (cfin[c] ? 1.f : 0.f)) * kF32Min;
+      allfl[K + c] = cfin[c];
+    }
+    host_top_k(allsc, K + K2, K, fidx);
+    for (int k = 0; k < K; ++k) {
+      const int j = fidx[k];
+      if (j < K) {
+        for (int t = 0; t < len; ++t) new_fin[k * (len + 1) + t] = fs[j * Tcap + t];
+        new_fin[k * (len + 1) + len] = pad_id;
+      } else {
+        const int c = j - K;
+        for (int t = 0; t < len; ++t) new_fin[k * (len + 1) + t] = sq[beam[c] * Tcap + t];
+        new_fin[k * (len + 1) + len] = cur[c];
+      }
+      masked[k] = allsc[j];                                // reuse as the new finished scores
+      cfin[k] = allfl[j];
+    }
+    for (int k = 0; k < K; ++k) {
+      fin_scores[b * K + k] = masked[k];
+      fin_flags[b * K + k] = cfin[k];
+      for (int t = 0; t <= len; ++t) {
+        sq[k * Tcap + t] = new_alive[k * (len + 1) + t];
+        fs[k * Tcap + t] = new_fin[k * (len + 1) + t];
+      }
+    }
+  }
   return 0;
 }
 

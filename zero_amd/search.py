@@ -90,6 +90,8 @@ def _beam_search(features, encoding_fn, decoding_fn, params):
     # replayed as a hipGraph; per-step scalars travel through a small device buffer
     static_step = cache_mode and state.get("static_ok", False) and hasattr(decoding_fn, "step_static") \
         and os.environ.get("ZERO_HIP_DECODE_GRAPH", "1") != "0"
+    if static_step and K <= 16 and os.environ.get("ZERO_HIP_DECODE_HOST_C", "1") != "0":
+        return _beam_search_static(state, decoding_fn, params, B, K, V, eos_id, pad_id, alpha, max_target_length)
     if static_step:
         BK = B * K
         pack = state["pack_host"].numpy()             # pinned; shares memory with the tensor
@@ -173,6 +175,61 @@ def _beam_search(features, encoding_fn, decoding_fn, params):
 
     any_fin = fin_flags.any(axis=1)
     final_seqs = np.where(any_fin[:, None, None], fin_seq, seq)
+    final_scores = np.where(any_fin[:, None], fin_scores, scores)
+    return {"seq": final_seqs[:, :, 1:], "score": final_scores, "steps": time}
+
+
+def _beam_search_static(state, decoding_fn, params, B, K, V, eos_id, pad_id, alpha, max_target_length):
+    """The cache-mode search with the whole device step replayed from a hipGraph and the host bookkeeping
+    of search.py:85-113,168-228 done by two C calls (zk_beam_host_should_stop / zk_beam_host_step) on
+    int32 [B, K, Tcap] sequence buffers.  Same arithmetic as the numpy path of _beam_search (kept for the
+    eager / dev modes; the tests hold the two against the same oracle)."""
+    import ctypes
+    f32 = np.float32
+    core = state["_core"]
+    lib = core.eng.lib
+    BK = B * K
+    Tcap = int(state["Tmax"]) + 2
+    seq = np.full((B, K, Tcap), pad_id, dtype=np.int32)
+    fin_seq = np.zeros((B, K, Tcap), dtype=np.int32)
+    log_probs = np.tile(np.array([[0.] + [F32_MIN] * (K - 1)], dtype=f32), (B, 1))
+    scores = np.zeros((B, K), dtype=f32)
+    fin_scores = np.full((B, K), F32_MIN, dtype=f32)
+    fin_flags = np.zeros((B, K), dtype=np.uint8)
+    mtl = np.ascontiguousarray(max_target_length, dtype=f32)
+    mtl_i = mtl.astype(np.int32)
+    pack = state["pack_host"].numpy()             # pinned: [tok | prev log-probs | reorder index | step scalars]
+    pack[0:BK] = pad_id                            # BOS = pad id (search.py:50)
+    pack[2 * BK:3 * BK] = np.arange(BK, dtype=np.int32)
+    out_host = state["out_host"]
+    out_np = out_host.numpy()
+    P = lambda a: ctypes.c_void_p(a.ctypes.data)
+    tok, prev, idx = pack[0:BK], pack[BK:2 * BK], pack[2 * BK:3 * BK]
+    p_seq, p_fin, p_lp, p_sc, p_fs, p_ff = P(seq), P(fin_seq), P(log_probs), P(scores), P(fin_scores), P(fin_flags)
+    p_mtl, p_mtli, p_ts, p_ti, p_idx, p_tok = P(mtl), P(mtl_i), P(out_np[0]), P(out_np[1]), P(idx), P(tok)
+    stop = lib.raw("zk_beam_host_should_stop")
+    step = lib.raw("zk_beam_host_step")
+    time = 0
+    while True:
+        if stop(B, K, p_lp, p_fs, p_ff, p_mtl, p_mtli, time, float(alpha)):
+            break
+        if time >= state["Tmax"]:
+            raise RuntimeError("decode step %d exceeds the allocated cache length %d" % (time, state["Tmax"]))
+        penalty = f32(np.power(f32((f32(5.) + f32(time + 1)) / f32(6.)), f32(alpha)))
+        prev[:] = log_probs.reshape(-1).view(np.int32)
+        pack[3 * BK], pack[3 * BK + 1], pack[3 * BK + 2] = \
+            time, int(penalty.view(np.int32)), (eos_id if time < 1 else -1)
+        state["pack_dev"].copy_(state["pack_host"], non_blocking=True)
+        decoding_fn.step_static(state, params.beam_search_temperature, zdtype.inf())
+        out_host.copy_(state["out_dev"])           # one D2H for scores and indices (synchronises)
+        rc = step(B, K, V, Tcap, time, p_ts, p_ti, p_seq, p_fin, p_lp, p_sc, p_fs, p_ff, p_mtli, eos_id, pad_id,
+                  float(penalty), p_idx, p_tok)
+        if rc != 0:
+            raise RuntimeError("zk_beam_host_step failed (rc=%d)" % rc)
+        time += 1
+    any_fin = fin_flags.any(axis=1)
+    n = time + 1
+    final_seqs = np.where(any_fin[:, None, None], fin_seq[:, :, :n], seq[:, :, :n]).astype(np.int64)
     final_scores = np.where(any_fin[:, None], fin_scores, scores)
     return {"seq": final_seqs[:, :, 1:], "score": final_scores, "steps": time}
 
