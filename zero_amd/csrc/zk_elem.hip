@@ -1604,8 +1604,18 @@ int zk_spin(uint32_t usec, hipStream_t stream) {
   return 0;
 }
 
+__global__ void __launch_bounds__(256) k_zero16(uint4* __restrict__ p, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+    p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
 int zk_zero(void* p, size_t bytes, hipStream_t stream) {
   if (bytes == 0) return 0;
+  if ((((uintptr_t)p | bytes) & 15) == 0) {      // a kernel node, not a memset node (hipGraph replays)
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(k_zero16, dim3(flat_grid(n16, 1)), dim3(256), 0, stream, (uint4*)p, n16);
+    ZK_LAUNCH_CHECK();
+    return 0;
+  }
   hipError_t e = hipMemsetAsync(p, 0, bytes, stream);
   if (e != hipSuccess) return zk_set_error((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
   return 0;

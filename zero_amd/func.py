@@ -125,12 +125,16 @@ class Engine(object):
         key = self.stream
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes:
+            if ws is not None:
+                self.realloc_gen += 1          # captured graphs point at the old scratch (see buf())
             ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=self.device)
             self._ws[key] = ws
         return ws
 
     def timing(self, length, H):
         if self._timing is None or self._timing.shape[0] < length or self._timing.shape[1] != H:
+            if self._timing is not None:
+                self.realloc_gen += 1          # captured graphs read the old table
             n = max(256, int(length))
             self._timing = torch.from_numpy(timing_table(n, H)).to(self.device)
         return self._timing
