@@ -173,10 +173,25 @@ def _beam_search(features, encoding_fn, decoding_fn, params):
                 state.reorder(d_idx)
         time += 1
 
+    if cache_mode:
+        _release_graphs(state)
     any_fin = fin_flags.any(axis=1)
     final_seqs = np.where(any_fin[:, None, None], fin_seq, seq)
     final_scores = np.where(any_fin[:, None], fin_scores, scores)
     return {"seq": final_seqs[:, :, 1:], "score": final_scores, "steps": time}
+
+
+def _release_graphs(state):
+    """The decode-step graphs of a batch die with it (they point at this batch's cache layout)."""
+    graphs = state.get("graphs") if hasattr(state, "get") else None
+    if not graphs:
+        return
+    core = state["_core"]
+    torch.cuda.current_stream(core.eng.device).synchronize()
+    for g in graphs.values():
+        if not isinstance(g, str):
+            core.eng.lib.call("zk_graph_destroy", g)
+    graphs.clear()
 
 
 def _beam_search_static(state, decoding_fn, params, B, K, V, eos_id, pad_id, alpha, max_target_length):
@@ -227,6 +242,7 @@ def _beam_search_static(state, decoding_fn, params, B, K, V, eos_id, pad_id, alp
         if rc != 0:
             raise RuntimeError("zk_beam_host_step failed (rc=%d)" % rc)
         time += 1
+    _release_graphs(state)
     any_fin = fin_flags.any(axis=1)
     n = time + 1
     final_seqs = np.where(any_fin[:, None, None], fin_seq[:, :, :n], seq[:, :, :n]).astype(np.int64)
