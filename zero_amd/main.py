@@ -351,6 +351,10 @@ def _restore(trainer, saver, path=None):
     if step is not None and path is None:
         trainer.global_step = step
         trainer.store.step = step
+    if trainer.train_op.ema is not None:
+        from zero_amd.utils.saver import assign_flat
+        assign_flat(trainer.store, trainer.train_op.ema, trainer.params.scope_name or "model", tensors,
+                    "/ExponentialMovingAverage")
     log.info("restored %d variables (%d missing)", len(got), len(missing))
     return True
 
@@ -398,7 +402,7 @@ def train(params):
 
     def checkpoint(gstep, score=None):
         if rank == 0:
-            saver.save(collect_tensors(trainer.store, scope, gstep, params), gstep, score)
+            saver.save(collect_tensors(trainer.store, scope, gstep, params, ema=trainer.train_op.ema), gstep, score)
             rec.save_to_json(os.path.join(params.output_dir, "record.json"))
 
     start_time, cum_tokens = time.time(), 0

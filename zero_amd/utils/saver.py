@@ -63,9 +63,13 @@ def _remove(directory, name):
             os.remove(p)
 
 
-def collect_tensors(store, scope, global_step, hparams=None):
-    """The checkpoint content of one replica: parameters, Adam slots, step."""
+def collect_tensors(store, scope, global_step, hparams=None, ema=None):
+    """The checkpoint content of one replica: parameters, Adam slots, step, and (``ema``: the flat shadow
+    buffer of TrainOp) the ExponentialMovingAverage shadows under TF's slot name."""
     out = {}
+    if ema is not None:
+        for name, arr in store.export(ema).items():
+            out["%s/%s/ExponentialMovingAverage" % (scope, name)] = arr
     for which, suffix in (("master", ""), ("m", "/Adam"), ("v", "/Adam_1")):
         for name, arr in store.export(which).items():
             out["%s/%s%s" % (scope, name, suffix)] = arr
@@ -74,6 +78,24 @@ def collect_tensors(store, scope, global_step, hparams=None):
         out["beta1_power"] = np.array(hparams.beta1 ** (store.step + 1), dtype=np.float32)
         out["beta2_power"] = np.array(hparams.beta2 ** (store.step + 1), dtype=np.float32)
     return out
+
+
+def assign_flat(store, flat, scope, tensors, suffix):
+    """Fill a flat buffer laid out like the parameters from ``<scope>/<name><suffix>`` entries."""
+    import torch
+    n = 0
+    for name in store.names():
+        key = "%s/%s%s" % (scope, name, suffix)
+        if key in tensors and tuple(tensors[key].shape) == store.lshape[name]:
+            dst = store._view(flat, name)
+            t = torch.as_tensor(np.asarray(tensors[key], dtype=np.float32))
+            dst.zero_()
+            if t.dim() == 2:
+                dst[:t.shape[0], :t.shape[1]].copy_(t)
+            else:
+                dst.copy_(t)
+            n += 1
+    return n
 
 
 def assign_tensors(store, scope, tensors):

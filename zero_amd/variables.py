@@ -214,8 +214,9 @@ class VariableStore(object):
             self.shadow.copy_(self.master.to(torch.bfloat16))
 
     def export(self, which="master"):
-        """{name: np.ndarray (logical shape)} of master / grad / m / v."""
-        flat = getattr(self, which)
+        """{name: np.ndarray (logical shape)} of master / grad / m / v (or of any flat buffer laid out
+        like them, e.g. the EMA shadows)."""
+        flat = getattr(self, which) if isinstance(which, str) else which
         out = OrderedDict()
         for name in self.offsets:
             t = self._view(flat, name)
