@@ -193,8 +193,10 @@ int zk_aan_gate_bwd(const void* dg, const void* z, const void* cat, void* dz, vo
                     int H, zk_stream_t stream);
 
 /* ---- utils/cycle.py:86-101 + tf.train.AdamOptimizer (main.py:178-181) on flat buffers.
- * hyper (device fp32[8]): lr_t, beta1, beta2, eps, grad_scale, clip_norm(0=off), gnorm(in),
- * skipped(out).  zk_l2norm: out[0] = scale*||x||_2; zk_adam's pnorm_out = ||p|| before the update.                                   */
+ * hyper (device fp32[12]): lr_t, beta1, beta2, eps, grad_scale, clip_norm(0=off), gnorm(in), skipped(out),
+ * EMA decay (zk_ema), gnorm upper bound of safe_nan (main.py:325-329; 0 = off), 2 reserved.
+ * zk_l2norm: out[0] = scale*||x||_2; zk_adam's pnorm_out = ||p|| before the update.  The update (and the EMA)
+ * is skipped, and hyper[7] set, when gnorm is not finite or exceeds the bound. */
 size_t zk_norm_workspace(void);
 int zk_l2norm(const float* x, size_t n, float scale, float* out, void* workspace, size_t ws_bytes,
               zk_stream_t stream);

@@ -533,7 +533,7 @@ def test_l2norm_and_adam_tf1_semantics():
     p = torch.randn(n_pad, device="cuda"); g = torch.randn(n_pad, device="cuda") * 0.1
     m = torch.rand(n_pad, device="cuda") * 0.01; v = torch.rand(n_pad, device="cuda") * 0.001
     sh = torch.zeros(n_pad, dtype=torch.bfloat16, device="cuda")
-    hyper = torch.zeros(8, device="cuda")
+    hyper = torch.zeros(12, device="cuda")
     ws = torch.empty(e.lib.query("zk_norm_workspace"), dtype=torch.uint8, device="cuda")
     e.lib.call("zk_l2norm", g.data_ptr(), n, 0.5, hyper.data_ptr() + 24, ws.data_ptr(), ws.numel(), e.stream)
     torch.cuda.synchronize()
@@ -562,6 +562,17 @@ def test_l2norm_and_adam_tf1_semantics():
                hyper.data_ptr(), None, None, 0, e.stream)
     torch.cuda.synchronize()
     assert float(hyper[7]) == 1.0 and max_err(p, pb) == 0
+    # safe_nan (main.py:325-329): a finite norm above hyper[9] skips the update as well
+    hyper[6], hyper[7], hyper[9] = 5.0, 0.0, 4.0
+    e.lib.call("zk_adam", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr(), n,
+               hyper.data_ptr(), None, None, 0, e.stream)
+    torch.cuda.synchronize()
+    assert float(hyper[7]) == 1.0 and max_err(p, pb) == 0
+    hyper[7], hyper[9] = 0.0, 6.0
+    e.lib.call("zk_adam", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr(), n,
+               hyper.data_ptr(), None, None, 0, e.stream)
+    torch.cuda.synchronize()
+    assert float(hyper[7]) == 0.0 and max_err(p, pb) > 0
 
 
 # ------------------------------------------------------------------ decode tail

@@ -1006,6 +1006,7 @@ __global__ void __launch_bounds__(256) k_aan_gate_bwd(const bf16_t* __restrict__
 //     lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed on the host and read from `hyper`)
 //     hyper (device floats): [0] lr_t  [1] beta1  [2] beta2  [3] eps  [4] grad_scale
 //                            [5] clip_norm (0 = off)  [6] gnorm (in)  [7] skipped-flag (out)
+//                            [8] EMA decay  [9] gnorm upper bound of safe_nan (0 = off)   -- 12 floats in all
 //     The bf16 shadow copy used by the GEMMs is refreshed in the same pass
 //     (utils/dtype.py:55-69 fp32 storage / low-precision compute contract).
 // =====================================================================================
@@ -1041,7 +1042,8 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
   float pacc = 0.f;   // sum of squares of the parameters BEFORE this update (tf.global_norm(variables))
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
   const float gs = hyper[4], clip = hyper[5], gnorm = hyper[6];
-  if (!(gnorm == gnorm) || fabsf(gnorm) == INFINITY) {  // NaN/Inf guard (main.py:316-319)
+  // NaN/Inf guard (main.py:316-319); hyper[9] > 0: also skip when gnorm exceeds it (safe_nan, main.py:325-329)
+  if (!(gnorm == gnorm) || fabsf(gnorm) == INFINITY || (hyper[9] > 0.f && gnorm > hyper[9])) {
     if (blockIdx.x == 0 && threadIdx.x == 0) hyper[7] = 1.f;
     return;
   }
@@ -1107,7 +1109,7 @@ __global__ void __launch_bounds__(256) k_axpy_f32(float* __restrict__ y, const f
 __global__ void __launch_bounds__(256) k_ema(float* __restrict__ ema, const float* __restrict__ p,
                                              const float* __restrict__ hyper, size_t n) {
   const float gnorm = hyper[6], d = hyper[8];
-  if (!(gnorm == gnorm) || fabsf(gnorm) == INFINITY) return;
+  if (!(gnorm == gnorm) || fabsf(gnorm) == INFINITY || (hyper[9] > 0.f && gnorm > hyper[9])) return;
   const size_t n4 = n / 4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     float4 e = reinterpret_cast<float4*>(ema)[i];

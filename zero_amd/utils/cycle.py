@@ -27,7 +27,9 @@ class TrainOp(object):
     def __init__(self, store, params, engine):
         self.store, self.hp, self.eng = store, params, engine
         dev = store.device
-        self.hyper = torch.zeros(12, dtype=torch.float32, device=dev)   # [0:6] host scalars, 6 gnorm, 7 skipped, 8 ema decay
+        self.hyper = torch.zeros(12, dtype=torch.float32, device=dev)   # [0:6] host scalars, 6 gnorm, 7 skipped, 8 ema decay, 9 gnorm bound
+        if getattr(params, "safe_nan", False) and getattr(params, "gnorm_upper_bound", 0.) > 0.:
+            self.hyper[9] = float(params.gnorm_upper_bound)      # main.py:325-329: update skipped above it
         self.hyper_host = torch.zeros(6, dtype=torch.float32).pin_memory() if dev.type == "cuda" \
             else torch.zeros(6, dtype=torch.float32)
         self.ema_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" \
