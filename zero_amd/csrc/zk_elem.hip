@@ -1047,6 +1047,7 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
     if (blockIdx.x == 0 && threadIdx.x == 0) hyper[7] = 1.f;
     return;
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) hyper[7] = 0.f;   // the flag describes THIS update
   float f = gs;
   if (clip > 0.f) f *= clip / fmaxf(gnorm, clip);  // tf.clip_by_global_norm
   const size_t n4 = n / 4;
