@@ -23,9 +23,9 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, use_graph):
+def _worker(rank, world, port, out_dir, use_graph, overlap="1"):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), ZERO_HIP_GROUP_LAYERS="1")
+                      MASTER_PORT=str(port), ZERO_HIP_GROUP_LAYERS="1", ZERO_HIP_OVERLAP_UPDATE=overlap)
     from tests.common import make_hp, make_batch
     from zero_amd.utils import parallel
     from zero_amd.main import Trainer
@@ -44,16 +44,18 @@ def _worker(rank, world, port, out_dir, use_graph):
     for _ in range(3):
         losses.append(float(tr.step_static(use_graph=use_graph).cpu()[0]))
     torch.cuda.synchronize()
-    np.savez(os.path.join(out_dir, "r%d_%d.npz" % (rank, int(use_graph))), loss=np.array(losses),
+    g_, p_, bad_ = tr.train_op.stats()
+    np.savez(os.path.join(out_dir, "r%d_%d%s.npz" % (rank, int(use_graph), "" if overlap == "1" else "_plain")),
+             loss=np.array(losses), gnorm=np.array([g_, p_]),
              grad=tr.store.grad.cpu().numpy(), master=tr.store.master.cpu().numpy(),
              kinds=np.array([k for k, _ in next((v for k, v in tr._graphs.items() if k[0] == "seg"), [])] or ["none"]))
     torch.distributed.destroy_process_group()
 
 
-def _run(world, out_dir, use_graph):
+def _run(world, out_dir, use_graph, overlap="1"):
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, out_dir, use_graph)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out_dir, use_graph, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -65,8 +67,13 @@ def test_two_rank_step_on_one_gpu(tmp_path):
     out = str(tmp_path)
     _run(2, out, True)
     _run(2, out, False)
+    _run(2, out, True, overlap="0")
     g = [np.load(os.path.join(out, "r%d_1.npz" % r)) for r in range(2)]
     e = [np.load(os.path.join(out, "r%d_0.npz" % r)) for r in range(2)]
+    plain = [np.load(os.path.join(out, "r%d_1_plain.npz" % r)) for r in range(2)]
+    # per-bucket updates behind their own all-reduce == wait-for-all, norm, one Adam pass
+    assert np.array_equal(g[0]["master"], plain[0]["master"]) and np.array_equal(g[0]["loss"], plain[0]["loss"])
+    assert abs(g[0]["gnorm"][0] - plain[0]["gnorm"][0]) <= 1e-6 * plain[0]["gnorm"][0]
     assert "ready" in list(g[0]["kinds"]) and list(g[0]["kinds"])[-1] == "update"
     # replicas stay identical, segmented replay == eager multi-rank step
     assert np.array_equal(g[0]["master"], g[1]["master"]) and np.array_equal(e[0]["master"], e[1]["master"])

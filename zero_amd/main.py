@@ -62,6 +62,8 @@ class Trainer(object):
         # test hook: run the multi-rank (segmented) capture path with a single rank
         import os as _os
         self.force_segmented = _os.environ.get("ZERO_HIP_FORCE_SEGMENTED", "0") != "0"
+        # data parallelism: update each gradient bucket behind its own all-reduce (see _reduced_update)
+        self.overlap_update = _os.environ.get("ZERO_HIP_OVERLAP_UPDATE", "1") != "0"
 
     # -- eager path (any shapes) --------------------------------------------------
     def micro_step(self, features):
@@ -178,9 +180,7 @@ class Trainer(object):
 
         def eager():
             self.graph.train_fn(self.batch, hp, on_ready=self.reducer.ready)
-            self.reducer.wait()
-            self.train_op.launch_update(scale)
-            lib.call("zk_seed_advance", eng.seed.data_ptr(), 1, eng.stream)
+            self._reduced_update(scale, None)
         if plan is None or getattr(self, "_seg_disabled", False):
             # first use of a shape: eager (sizes every scratch buffer); also the fallback should a
             # capture ever fail on a platform (the job then keeps running, only slower)
@@ -207,8 +207,32 @@ class Trainer(object):
                 for k in what:
                     self.reducer.ready(k)
             else:
-                self.reducer.wait()
-                eng.graph_launch(what)
+                self._reduced_update(scale, what)
+
+    def _reduced_update(self, scale, update_graph):
+        """Everything after the last gradient hand-off.  When the update does not depend on the global norm
+        (no clipping, no safe_nan) every bucket is updated as soon as its own all-reduce has finished, so
+        the Adam pass hides behind the collectives still in flight; otherwise wait for all, then the
+        (captured) norm + Adam."""
+        eng = self.core.eng
+        top = self.train_op
+        if self.overlap_update and parallel.world_size() > 1 and top.can_update_by_range():
+            top.begin_update_by_range()
+            done = 0
+            for lo, hi in self.reducer.drain():
+                top.launch_update_range(lo, hi)
+                done += hi - lo
+            if done != self.store.numel:          # a variable group nobody reported: never leave it stale
+                raise RuntimeError("gradient buckets covered %d of %d elements" % (done, self.store.numel))
+            top.finish_update_by_range(scale)
+            eng.lib.call("zk_seed_advance", eng.seed.data_ptr(), 1, eng.stream)
+            return
+        self.reducer.wait()
+        if update_graph is not None:
+            eng.graph_launch(update_graph)
+        else:
+            top.launch_update(scale)
+            eng.lib.call("zk_seed_advance", eng.seed.data_ptr(), 1, eng.stream)
 
     def _capture_segments(self, scale):
         import ctypes
@@ -316,9 +340,11 @@ class Trainer(object):
             eng.graph_launch(g)
         elif use_graph and not self.core.use_side and (world > 1 or self.force_segmented):
             self._step_segmented(scale)
+        elif world > 1:
+            self.graph.train_fn(self.batch, hp, on_ready=self.reducer.ready)
+            self._reduced_update(scale, None)
         else:
-            self.graph.train_fn(self.batch, hp, on_ready=self.reducer.ready if world > 1 else None)
-            self.reducer.wait()
+            self.graph.train_fn(self.batch, hp)
             self.train_op.launch_update(scale)
             eng.lib.call("zk_seed_advance", eng.seed.data_ptr(), 1, eng.stream)
         self.store.step += 1

@@ -101,6 +101,37 @@ class TrainOp(object):
         if self.ema is not None:
             lib.call("zk_ema", self.ema.data_ptr(), st.master.data_ptr(), self.hyper.data_ptr(), st.numel, s)
 
+    # -- data parallelism: the update of a gradient bucket as soon as ITS all-reduce is done ----------
+    def can_update_by_range(self):
+        """Per-bucket updates need an update that does not depend on the global gradient norm: no
+        clipping (cycle.py:98-101 with clip_grad_norm = 0.0) and no safe_nan skip."""
+        hp = self.hp
+        clip = hp.clip_grad_norm or None
+        return not isinstance(clip, float) and not getattr(hp, "safe_nan", False)
+
+    def begin_update_by_range(self):
+        """hyper[6] (the norm the Adam kernel guards on) is only known after the last bucket: a finite
+        placeholder lets the per-bucket updates through; finish_update_by_range() writes the real value."""
+        self.hyper[6:7].fill_(1.0)
+
+    def launch_update_range(self, lo, hi):
+        """TF1 Adam on elements [lo, hi) of the flat buffers (bucket boundaries are 64-element aligned)."""
+        st, lib, s = self.store, self.eng.lib, self.eng.stream
+        n = hi - lo
+        lib.call("zk_adam", st.master.data_ptr() + lo * 4, st.grad.data_ptr() + lo * 4, st.m.data_ptr() + lo * 4,
+                 st.v.data_ptr() + lo * 4, st.shadow.data_ptr() + lo * 2, n, self.hyper.data_ptr(), None, None, 0, s)
+
+    def finish_update_by_range(self, scale):
+        """Global gradient norm (logging + the NaN report of main.py:316-319; the update has been applied,
+        as in the reference without safe_nan), parameter norm, EMA."""
+        st, lib, s = self.store, self.eng.lib, self.eng.stream
+        nb = self._ws.numel() // 2
+        lib.call("zk_l2norm", st.grad.data_ptr(), st.numel, scale, self.hyper.data_ptr() + 6 * 4,
+                 self._ws.data_ptr(), nb, s)
+        lib.call("zk_l2norm", st.master.data_ptr(), st.numel, 1.0, self.pnorm.data_ptr(), self._ws.data_ptr() + nb, nb, s)
+        if self.ema is not None:
+            lib.call("zk_ema", self.ema.data_ptr(), st.master.data_ptr(), self.hyper.data_ptr(), st.numel, s)
+
     # cycle.py:120-127: evaluate with the averaged weights, then put the raw ones back
     def ema_backup(self):
         if self.ema is not None:
@@ -132,4 +163,5 @@ class TrainOp(object):
     def stats(self):
         """(gradient_norm, parameter_norm, skipped) -- forces a sync; call at display time."""
         h = self.hyper.cpu()
-        return float(h[6]), float(self.pnorm.cpu()[0]), bool(h[7] != 0)
+        g = float(h[6])
+        return g, float(self.pnorm.cpu()[0]), bool(h[7] != 0) or not math.isfinite(g)

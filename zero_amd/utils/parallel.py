@@ -96,14 +96,22 @@ class GradientAllReduce(object):
             return
         lo, hi = self._open
         self._open = None
-        self.pending.append(dist.all_reduce(self.store.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        self.pending.append((lo, hi, dist.all_reduce(self.store.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True)))
 
     def wait(self):
         """Flush the tail and make the current stream wait for every bucket."""
+        for _ in self.drain():
+            pass
+
+    def drain(self):
+        """Flush the tail, then yield (lo, hi) of every bucket in launch order as soon as the current stream
+        has been made to wait for ITS all-reduce: work queued per bucket (the Adam update of that range)
+        overlaps the collectives still in flight."""
         self.flush()
-        for w in self.pending:
+        pending, self.pending = self.pending, []
+        for lo, hi, w in pending:
             w.wait()
-        self.pending = []
+            yield lo, hi
 
     def all_reduce_everything(self):
         """Unbucketed path (used after gradient accumulation: one exchange per update,
