@@ -99,3 +99,25 @@ def test_two_rank_step_on_one_gpu(tmp_path):
     # step 1 of the two-rank job started from the same weights: its per-rank losses average to l0
     both = 0.5 * (g[0]["loss"][0] + g[1]["loss"][0])
     assert abs(both - l0) / abs(l0) < 2e-3, (both, l0)
+
+
+def test_bench_contract_with_two_ranks_on_one_gpu():
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per process),
+    with the gloo backend and both ranks on cuda:0: one JSON line from rank 0 with the N-rank fields."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, ZERO_DIST_BACKEND="gloo", ZERO_SINGLE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["higher_is_better"] is True
+    assert out["config"]["parallelism"] == "dp2" and out["config"]["global_batch_tokens"] == 2 * 64 * 128
+    assert out["value"] > 0 and np.isfinite(out["loss"]) and not out["update_skipped"]
+    assert "roofline" in out and "cpu_baseline" not in out          # the CPU baseline is a 1-rank field

@@ -32,7 +32,11 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # ZERO_DIST_BACKEND=gloo + ZERO_SINGLE_DEVICE=1: several ranks on ONE GPU (RCCL refuses that), the
+            # way the GPU tests and a 1-GPU box exercise the multi-rank step end to end
+            backend = os.environ.get("ZERO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if os.environ.get("ZERO_SINGLE_DEVICE", "0") != "0":
+            local = 0
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
