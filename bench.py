@@ -84,11 +84,12 @@ class GemmProfiler(object):
 
     def _name(self, M, N, K, ta, tb, out_f32, plain):
         code = self.eng.lib.raw("zk_gemm_plan")(M, N, K, out_f32, plain)
-        gen, bm, bn = code & 255, (code >> 8) & 255, (code >> 16) & 255
+        gen, bm, bn = code & 255, (code >> 8) & 255, (code >> 16) & 255   # [27:24] split-K, [30:28] producer waves
         tf = lambda v: "true" if v else "false"
         if gen == 2:
             ns = 4 if (bm, bn) == (64, 64) else 2
-            return "k_gemm_dlds<%d, %d, %d, %s, %s, 4>" % (bm, bn, ns, tf(ta), tf(tb))   # ..., 4 waves per workgroup
+            # ..., 4 compute waves, producer waves per workgroup
+            return "k_gemm_dlds<%d, %d, %d, %s, %s, 4, %d>" % (bm, bn, ns, tf(ta), tf(tb), (code >> 28) & 7)
         return "k_gemm_mfma<%d, %d, %s, %s>" % (bm, bn, tf(ta), tf(tb))
 
     def __enter__(self):
@@ -104,7 +105,7 @@ class GemmProfiler(object):
 
         def timed_grouped(problems, ta, tb, tile=128):
             tf = lambda v: "true" if v else "false"
-            name = "k_gemm_grouped<%d, %d, %d, %s, %s>" % (tile, tile, 2 if tile == 128 else 4, tf(ta), tf(tb))
+            name = "k_gemm_grouped<%d, %d, %d, %s, %s, 0>" % (tile, tile, 2 if tile == 128 else 4, tf(ta), tf(tb))
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             self._grouped(problems, ta, tb, tile=tile)

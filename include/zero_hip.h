@@ -45,7 +45,7 @@ const char* zk_last_error_string(void);
  *   (aux>0)*aux_scale (ReLU+dropout backward through the saved activation).          */
 size_t zk_gemm_workspace(int M, int N, int K);
 size_t zk_gemm_workspace_split(int M, int N, int splits);
-int zk_gemm_plan(int M, int N, int K, int out_f32, int plain);  /* gen | bm<<8 | bn<<16 | splits<<24 chosen by impl=0 */
+int zk_gemm_plan(int M, int N, int K, int out_f32, int plain);  /* gen | bm<<8 | bn<<16 | splits<<24 | producer waves<<28 chosen by impl=0 */
 int zk_gemm_set_generation(int gen);   /* 1 = register-staged kernel, 2 = LDS-DMA ring kernel (default) */
 int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
             int ta, int tb, int out_f32, float alpha, const float* bias, const void* residual, int ldr,

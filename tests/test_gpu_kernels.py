@@ -732,6 +732,51 @@ def test_gemm_two_wave_workgroups(variant, ta, tb):
         e.lib.raw("zk_tune")(4, old)
 
 
+@pytest.mark.parametrize("tile,tune", [(4, 0), (4, 2), (4, 4), (4, 8), (1, 0), (1, 2 << 4), (1, 4 << 4), (1, 8 << 4),
+                                       (1, (4 << 4) | 256), (2, 4 << 12), (3, 8 << 12)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_producer_wave_workgroups(tile, tune, ta, tb):
+    """Producer-wave workgroups of the gen-2 GEMM (zk_tune key 6; 0x44 is the default): every variant against
+    the fp32 reference over ragged / K-tail / split-free shapes and the fused epilogues, and the epilogue-free
+    result bit-identical to the variant without producer waves (same MFMA order)."""
+    e = eng()
+    old = e.lib.raw("zk_tune")(6, tune)
+    try:
+        impl = 2 | (tile << 8) | (1 << 16)
+        for M, N, K in [(128, 128, 64), (200, 264, 136), (72, 40, 24), (256, 512, 1024), (136, 136, 72)]:
+            err, _, _ = _gemm_case(impl, M, N, K, ta, tb)
+            assert err < 8e-3, (M, N, K, err)
+        assert _gemm_case(impl, 192, 256, 128, ta, tb, bias=True, act=1, drop=0.3)[0] < 8e-3
+        assert _gemm_case(impl, 192, 256, 128, ta, tb, residual=True)[0] < 8e-3
+        M, N, K = 384, 256, 200
+        A = torch.randn((K, M) if ta else (M, K), device="cuda").bfloat16()
+        B = torch.randn((N, K) if tb else (K, N), device="cuda").bfloat16()
+        outs = []
+        for t in (tune, 0):
+            e.lib.raw("zk_tune")(6, t)
+            C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            e.gemm(Mat(A, *A.shape), Mat(B, *B.shape), Mat(C, M, N), M, N, K, ta, tb, impl=impl)
+            torch.cuda.synchronize()
+            outs.append(C)
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        e.lib.raw("zk_tune")(6, old)
+
+
+def test_gemm_plan_reports_producer_waves():
+    """zk_gemm_plan labels the instance that runs: bits [30:28] carry the producer waves of the tile class."""
+    e = eng()
+    plan = e.lib.raw("zk_gemm_plan")
+    old = e.lib.raw("zk_tune")(6, 0x44)
+    try:
+        code = plan(4096, 512, 512, 0, 1)
+        assert (code & 255, (code >> 8) & 255, (code >> 16) & 255, (code >> 28) & 7) == (2, 64, 64, 4)
+        e.lib.raw("zk_tune")(6, 0)
+        assert (plan(4096, 512, 512, 0, 1) >> 28) & 7 == 0
+    finally:
+        e.lib.raw("zk_tune")(6, old)
+
+
 @pytest.mark.parametrize("case", [(2, 2, 64, 64, False, True), (3, 2, 37, 53, True, False), (2, 8, 64, 64, True, False),
                                   (2, 2, 20, 20, False, True), (2, 2, 70, 130, True, False), (1, 2, 130, 130, False, True),
                                   (2, 2, 100, 40, False, False)])

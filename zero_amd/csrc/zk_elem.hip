@@ -1214,7 +1214,7 @@ size_t zk_add_ln_bwd_workspace(int rows, int H) {
   return (size_t)g * 3 * H * sizeof(float);
 }
 
-int g_tune[8] = {1, 0, 0, 0, 0, 0, 0, 0};   // [0] wide LayerNorm backward kernel; [1] GEMM: legacy split-K rule (A/B)
+int g_tune[8] = {1, 0, 0, 0, 0, 0, 0x44, 0};   // [0] wide LayerNorm backward kernel; [1] GEMM: legacy split-K rule (A/B)
 static int ln_bwd_blocks(int rows) {
   int g = (rows + 15) / 16;
   if (g > 256) g = 256;

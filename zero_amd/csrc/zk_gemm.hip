@@ -280,6 +280,7 @@ static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, 
   *splits = s;
 }
 
+int zk_gemm_dlds_pw(int bm, int bn);
 int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
                           int bm, int bn, int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags,
                           hipStream_t stream);
@@ -301,14 +302,14 @@ size_t zk_gemm_workspace(int M, int N, int K) {
   if (s < 2 && K >= 1024) s = 2;
   return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
-// Which kernel would impl=0 pick?  Returns gen | bm<<8 | bn<<16 | splits<<24 (for labelling
-// measurements with the kernel instance that actually runs).
+// Which kernel would impl=0 pick?  Returns gen | bm<<8 | bn<<16 | splits<<24 | producer waves<<28 (for
+// labelling measurements with the kernel instance that actually runs).
 int zk_gemm_plan(int M, int N, int K, int out_f32, int plain) {
   int bm, bn, s;
   pick_config(M, N, K, plain ? 1 : 0, &bm, &bn, &s);
   int gen = g_default_gen;
   if (gen == 2 && out_f32 && K <= 512 && (long)M * N >= 64L * 1024 * 1024) gen = 1;
-  return gen | (bm << 8) | (bn << 16) | (s << 24);
+  return gen | (bm << 8) | (bn << 16) | (s << 24) | ((gen == 2 ? zk_gemm_dlds_pw(bm, bn) : 0) << 28);
 }
 
 // workspace for an explicit split-K override (tuning)

@@ -19,6 +19,16 @@
 typedef short v4s_t __attribute__((ext_vector_type(4)));
 
 __device__ __attribute__((aligned(16))) uint4 zk_zero_page[4];   // source of out-of-range pieces
+// In-kernel timeline (diagnostic build only: make TRACE=1, scripts/trace_gemm.py): wave 0 of workgroup 301
+// stamps s_memtime at the phase boundaries of the K loop (ZK_T, one row per K step) and of the kernel (ZK_E).
+#ifdef ZK_GEMM_TRACE
+__device__ unsigned long long zk_trace_buf[8192];
+#define ZK_E(slot) do { if (blockIdx.x == 301 && threadIdx.x == 0) zk_trace_buf[4096 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define ZK_T(slot) do { if (tr_on) zk_trace_buf[tr_i * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ZK_E(slot) do { } while (0)
+#define ZK_T(slot) do { } while (0)
+#endif
 
 // LDS-DMA issued from inline asm: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every
 // ds_read that may alias an LDS-DMA it knows about, which would drain the ring each K step.  The
@@ -122,6 +132,8 @@ __device__ __forceinline__ bf16x8_t load_frag(const bf16_t* stage, int r0, int k
   }
 }
 
+extern int g_tune[8];   // A/B switches (zk_tune, zk_elem.hip)
+
 struct EpiVec {
   int vec_ok;   // 16-byte vector epilogue allowed (alignment checked on the host)
 };
@@ -134,26 +146,34 @@ struct DldsCfg {
   static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
 };
 
-// NW waves per workgroup: 4 (2 x 2 over the tile), 2 (2 x 1: each wave a BM/2 x BN slab) or 8 (4 x 2: the
-// 256x128 macro tile -- 25 % fewer L1->LDS bytes and DMA issues per MFMA than two 128x128 tiles)
+// NW compute waves per workgroup: 4 (2 x 2 over the tile), 2 (2 x 1: each wave a BM/2 x BN slab) or 8 (4 x 2: the
+// 256x128 macro tile -- 25 % fewer L1->LDS bytes and DMA issues per MFMA than two 128x128 tiles).
+// PW > 0: PW extra PRODUCER waves (wave index >= NW) issue every LDS-DMA of the workgroup and the NW compute
+// waves issue none.  Reason (profiles/r01_gemm_kloop_trace.txt): a global_load_lds stalls its wave ~100 cycles
+// while the CU's texture-address path is busy, and a stalled wave cannot issue its MFMAs, so with PW = 0 the
+// DMA-issue time and the MFMA time of a K step add up inside a workgroup; with producer waves they overlap.
 // K loop of one BMxBN tile over k in [kbeg, kend); leaves the fp32 tile in LDS (sC[BM][CLD], smem reused)
 // behind a workgroup barrier, ready for a row-wise epilogue.
-template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4>
+template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0>
 __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16_t* __restrict__ A,
                                                  const bf16_t* __restrict__ B, int M, int N, int lda, int ldb,
                                                  int kbeg, int kend, int m0, int n0) {
   constexpr int NWM = NW == 8 ? 4 : 2, NWN = NW / NWM;       // wave grid over the tile: 2x2, 2x1 or 4x2
   constexpr int WTM = BM / NWM, WTN = BN / NWN, TM = WTM / 32, TN = WTN / 32;
   constexpr int STAGE = DldsCfg<BM, BN, NS>::STAGE;
-  constexpr int PER_STAGE = (BM * 8 / NW + BN * 8 / NW) / 64;  // DMA instructions per wave per stage
+  constexpr int NDW = PW ? PW : NW;                          // waves that issue the DMA
+  constexpr int PER_STAGE = (BM * 8 / NDW + BN * 8 / NDW) / 64;  // DMA instructions per issuing wave per stage
   constexpr int CLD = DldsCfg<BM, BN, NS>::CLD;
   bf16_t* ring = reinterpret_cast<bf16_t*>(smem);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = PW > 0 && wave >= NW;
+  const int dwave = PW ? wave - NW : wave;                   // index among the issuing waves
   const int wm = wave / NWN, wn = wave % NWN;
   const int nk = (kend - kbeg + 63) >> 6;
 
+  ZK_E(0);
   f32x16_t acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -162,10 +182,12 @@ __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  DmaPlan<BM, NW> planA;
-  DmaPlan<BN, NW> planB;
-  dma_plan<BM, TA, NW>(planA, A, lda, m0, M, kbeg, wave, lane);
-  dma_plan<BN, !TB, NW>(planB, B, ldb, n0, N, kbeg, wave, lane);
+  DmaPlan<BM, NDW> planA;
+  DmaPlan<BN, NDW> planB;
+  if (PW == 0 || producer) {
+    dma_plan<BM, TA, NDW>(planA, A, lda, m0, M, kbeg, dwave, lane);
+    dma_plan<BN, !TB, NDW>(planB, B, ldb, n0, N, kbeg, dwave, lane);
+  }
   const int klen = kend - kbeg;
   const size_t stepA = TA ? (size_t)64 * lda : (size_t)64;
   const size_t stepB = !TB ? (size_t)64 * ldb : (size_t)64;
@@ -173,22 +195,15 @@ __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16
   auto issue = [&](int t) {
     const uint32_t st = ring_addr + (uint32_t)((t % NS) * STAGE * 2);
     if (t * 64 + 64 <= klen) {
-      dma_tile<BM, TA, false, NW>(planA, stepA, t, klen, st, wave);
-      dma_tile<BN, !TB, false, NW>(planB, stepB, t, klen, st + BM * 128, wave);
+      dma_tile<BM, TA, false, NDW>(planA, stepA, t, klen, st, dwave);
+      dma_tile<BN, !TB, false, NDW>(planB, stepB, t, klen, st + BM * 128, dwave);
     } else {
-      dma_tile<BM, TA, true, NW>(planA, stepA, t, klen, st, wave);
-      dma_tile<BN, !TB, true, NW>(planB, stepB, t, klen, st + BM * 128, wave);
+      dma_tile<BM, TA, true, NDW>(planA, stepA, t, klen, st, dwave);
+      dma_tile<BN, !TB, true, NDW>(planB, stepB, t, klen, st + BM * 128, dwave);
     }
   };
-  // prologue: tiles 0 .. NS-2 (tiles past the end are all-zero pieces: keeps the DMA count uniform)
-#pragma unroll
-  for (int s = 0; s < NS - 1; ++s) issue(s);
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed once at most NS-2 later tiles of this wave are still in flight
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PER_STAGE) : "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    issue(kt + NS - 1);                         // refill the stage everybody finished reading
+  // MFMAs of K tile kt out of its ring stage
+  auto compute = [&](int kt) {
     const bf16_t* sA = ring + (kt % NS) * STAGE;
     const bf16_t* sB = sA + BM * 64;
     // fragments of k-slice kk+1 are read while the MFMAs of slice kk run (two register sets)
@@ -211,39 +226,169 @@ __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
     }
+  };
+  [[maybe_unused]] const bool tr_on = (blockIdx.x == 301) && (tid == 0);
+  if (PW > 0) {
+    // invariant at the barrier of step kt: tile kt has landed (the producers waited for it) and every compute
+    // wave is done with tile kt-1, whose stage the producers refill next.  Both roles pass nk barriers.
+    if (producer) {
+#pragma unroll
+      for (int s = 0; s < NS - 1; ++s) issue(s);
+      for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PER_STAGE) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        issue(kt + NS - 1);
+      }
+    } else {
+      ZK_E(1);
+      for (int kt = 0; kt < nk; ++kt) {
+        [[maybe_unused]] const int tr_i = kt;
+        ZK_T(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        ZK_T(2);
+        compute(kt);
+        __builtin_amdgcn_sched_barrier(0);
+        ZK_T(4);
+      }
+    }
+  } else {
+    // prologue: tiles 0 .. NS-2 (tiles past the end are all-zero pieces: keeps the DMA count uniform)
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s);
+    __builtin_amdgcn_sched_barrier(0);
+    ZK_E(1);
+    for (int kt = 0; kt < nk; ++kt) {
+      [[maybe_unused]] const int tr_i = kt;
+      ZK_T(0);
+      // tile kt has landed once at most NS-2 later tiles of this wave are still in flight
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PER_STAGE) : "memory");
+      ZK_T(1);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      ZK_T(2);
+      issue(kt + NS - 1);                         // refill the stage everybody finished reading
+      __builtin_amdgcn_sched_barrier(0);
+      ZK_T(3);
+      compute(kt);
+      __builtin_amdgcn_sched_barrier(0);
+      ZK_T(4);
+    }
   }
   // ---- epilogue through LDS
+  ZK_E(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (all-zero) pieces have landed
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   float* sC = reinterpret_cast<float*>(smem);
+  if (!producer) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = wn * WTN + j * 32 + (lane & 31);
+      for (int j = 0; j < TN; ++j) {
+        const int col = wn * WTN + j * 32 + (lane & 31);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        sC[row * CLD + col] = acc[i][j][r];
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          sC[row * CLD + col] = acc[i][j][r];
+        }
       }
-    }
+  }
   __syncthreads();
+  ZK_E(3);
 }
 
 // one BMxBN output tile over k in [kbeg, kend); slab != null: write the fp32 partial tile there
-template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4>
+template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0>
 __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __restrict__ A,
                                           const bf16_t* __restrict__ B, int M, int N, int lda, int ldb, int kbeg,
                                           int kend, int m0, int n0, float* __restrict__ slab, const GemmEpi& e,
                                           int vec_ok) {
-  gemm_tile_to_lds<BM, BN, NS, TA, TB, NW>(smem, A, B, M, N, lda, ldb, kbeg, kend, m0, n0);
+  gemm_tile_to_lds<BM, BN, NS, TA, TB, NW, PW>(smem, A, B, M, N, lda, ldb, kbeg, kend, m0, n0);
   constexpr int CLD = DldsCfg<BM, BN, NS>::CLD;
+  constexpr int NT = (NW + PW) * 64;
   const int tid = threadIdx.x;
   const float* sC = reinterpret_cast<const float*>(smem);
   const uint64_t seed = e.thr ? *e.seed : 0;
   constexpr int CPRW = BN / 8;
-  for (int c = tid; c < BM * CPRW; c += NW * 64) {
+  // Fast path (interior tile, 16-byte epilogue, no split-K slab): every thread's chunks sit in the same 8
+  // columns (NT is a multiple of CPRW), so the loop is fully unrolled with all LDS reads first, then all
+  // residual / mask loads, then the arithmetic and the stores -- the latencies overlap instead of adding up
+  // once per chunk (the rolled loop below cost ~1200 cycles per chunk, profiles/r01_gemm_kloop_trace.txt).
+  if (slab == nullptr && vec_ok && m0 + BM <= M && n0 + BN <= N) {
+    static_assert(NT % CPRW == 0, "a thread's chunks must share their columns");
+    constexpr int CH = BM * CPRW, ITER = (CH + NT - 1) / NT;
+    const int cc = (tid % CPRW) * 8, gn = n0 + cc, row0 = tid / CPRW;
+    constexpr int RSTEP = NT / CPRW;
+    float v[ITER][8];
+    uint4 rres[ITER], raux[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int row = min(row0 + it * RSTEP, BM - 1);
+      const float4 a = *reinterpret_cast<const float4*>(sC + row * CLD + cc);
+      const float4 b = *reinterpret_cast<const float4*>(sC + row * CLD + cc + 4);
+      v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
+      v[it][4] = b.x; v[it][5] = b.y; v[it][6] = b.z; v[it][7] = b.w;
+    }
+    if (e.res) {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int gm = m0 + min(row0 + it * RSTEP, BM - 1);
+        rres[it] = *reinterpret_cast<const uint4*>(e.res + (size_t)gm * e.ldr + gn);
+      }
+    }
+    if (e.act == 2) {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int gm = m0 + min(row0 + it * RSTEP, BM - 1);
+        raux[it] = *reinterpret_cast<const uint4*>(e.aux + (size_t)gm * e.ldaux + gn);
+      }
+    }
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (e.bias) {
+      const float4 a = *reinterpret_cast<const float4*>(e.bias + gn);
+      const float4 b = *reinterpret_cast<const float4*>(e.bias + gn + 4);
+      bv[0] = a.x; bv[1] = a.y; bv[2] = a.z; bv[3] = a.w; bv[4] = b.x; bv[5] = b.y; bv[6] = b.z; bv[7] = b.w;
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int row = row0 + it * RSTEP;
+      if (CH % NT != 0 && row >= BM) break;
+      const int gm = m0 + row;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[it][j] = v[it][j] * e.alpha + bv[j];
+      if (e.res) {
+        float rv[8];
+        unpack8(rres[it], rv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[it][j] += rv[j];
+      }
+      if (e.act == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[it][j] = fmaxf(v[it][j], 0.f);
+      } else if (e.act == 2) {
+        float av[8];
+        unpack8(raux[it], av);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[it][j] = av[j] > 0.f ? v[it][j] * e.aux_scale : 0.f;
+      }
+      if (e.thr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[it][j] *= zk_drop_scale(seed, e.sid, (uint64_t)gm * N + gn + j, e.thr, e.inv_keep);
+      }
+      if (e.out_f32) {
+        float* d = reinterpret_cast<float*>(e.C) + (size_t)gm * e.ldc + gn;
+        reinterpret_cast<float4*>(d)[0] = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
+        reinterpret_cast<float4*>(d)[1] = make_float4(v[it][4], v[it][5], v[it][6], v[it][7]);
+      } else {
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)gm * e.ldc + gn) = pack8(v[it]);
+      }
+    }
+    return;
+  }
+  for (int c = tid; c < BM * CPRW; c += NT) {
     const int row = c / CPRW, cc = (c % CPRW) * 8;
     const int gm = m0 + row, gn = n0 + cc;
     if (gm >= M || gn >= N) continue;
@@ -303,8 +448,8 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
   }
 }
 
-template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4>
-__global__ void __launch_bounds__(NW * 64) k_gemm_dlds(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M,
+template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0>
+__global__ void __launch_bounds__((NW + PW) * 64) k_gemm_dlds(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M,
                                                    int N, int K, int lda, int ldb, int kchunk,
                                                    float* __restrict__ slabs, TileSched ts, GemmEpi e, EpiVec ev) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[DldsCfg<BM, BN, NS>::LDS_BYTES];   // the ONLY LDS object
@@ -312,8 +457,10 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_dlds(const bf16_t* __restrict_
   tile_of_block(ts, tm_, tn_, z_);
   const int kbeg = z_ * kchunk;
   const int kend = min(K, kbeg + kchunk);
-  gemm_tile<BM, BN, NS, TA, TB, NW>(smem, A, B, M, N, lda, ldb, kbeg, kend, tm_ * BM, tn_ * BN,
+  gemm_tile<BM, BN, NS, TA, TB, NW, PW>(smem, A, B, M, N, lda, ldb, kbeg, kend, tm_ * BM, tn_ * BN,
                                     slabs ? slabs + (size_t)z_ * M * N : nullptr, e, ev.vec_ok);
+  __builtin_amdgcn_sched_barrier(0);
+  ZK_E(4);
 }
 
 // Grouped launch: many independent GEMMs (same transposition flags) in ONE grid -- the deferred
@@ -326,8 +473,8 @@ struct GroupDesc {
   int M, N, K, lda, ldb, ldc, out_f32, tile_start, tiles_n, ldr;
 };                            // 80 bytes; mirrored by zero_amd/func.py:_GroupDesc
 
-template <int BM, int BN, int NS, bool TA, bool TB>
-__global__ void __launch_bounds__(256) k_gemm_grouped(const GroupDesc* __restrict__ descs, int nprob) {
+template <int BM, int BN, int NS, bool TA, bool TB, int PW = 0>
+__global__ void __launch_bounds__((4 + PW) * 64) k_gemm_grouped(const GroupDesc* __restrict__ descs, int nprob) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[DldsCfg<BM, BN, NS>::LDS_BYTES];
   const int nb = gridDim.x, bid = blockIdx.x;
   const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
@@ -343,8 +490,8 @@ __global__ void __launch_bounds__(256) k_gemm_grouped(const GroupDesc* __restric
   e.thr = 0; e.inv_keep = 1.f; e.seed = nullptr; e.sid = 0;
   const uintptr_t al = (uintptr_t)d.C | (uintptr_t)d.bias | (uintptr_t)d.res;
   const int vec_ok = ((al & 15) == 0) && (d.ldc % 8 == 0) && (d.res == nullptr || d.ldr % 8 == 0);
-  gemm_tile<BM, BN, NS, TA, TB>(smem, d.A, d.B, d.M, d.N, d.lda, d.ldb, 0, d.K, tm * BM, tn * BN, nullptr, e,
-                                vec_ok);
+  gemm_tile<BM, BN, NS, TA, TB, 4, PW>(smem, d.A, d.B, d.M, d.N, d.lda, d.ldb, 0, d.K, tm * BM, tn * BN, nullptr, e,
+                                       vec_ok);
 }
 
 // =====================================================================================
@@ -444,7 +591,7 @@ __global__ void __launch_bounds__(256) k_ce_combine(const float4* __restrict__ p
   }
 }
 
-template <int BM, int BN, int NS, int NW = 4>
+template <int BM, int BN, int NS, int NW = 4, int PW = 0>
 static int launch_dlds(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
                        int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags, hipStream_t stream) {
   TileSched ts;
@@ -459,13 +606,13 @@ static int launch_dlds(const bf16_t* A, const bf16_t* B, int M, int N, int K, in
               (e.aux == nullptr || e.ldaux % 8 == 0);
   dim3 grid((unsigned)((long)ts.tiles_m * ts.tiles_n * splits));
   if (!ta && !tb)
-    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, false, false, NW>), grid, dim3(NW * 64), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
+    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, false, false, NW, PW>), grid, dim3((NW + PW) * 64), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
   else if (!ta && tb)
-    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, false, true, NW>), grid, dim3(NW * 64), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
+    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, false, true, NW, PW>), grid, dim3((NW + PW) * 64), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
   else if (ta && !tb)
-    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, true, false, NW>), grid, dim3(NW * 64), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
+    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, true, false, NW, PW>), grid, dim3((NW + PW) * 64), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
   else
-    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, true, true, NW>), grid, dim3(NW * 64), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
+    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, true, true, NW, PW>), grid, dim3((NW + PW) * 64), 0, stream, A, B, M, N, K, lda, ldb, kchunk, slabs, ts, e, ev);
   ZK_LAUNCH_CHECK();
   return 0;
 }
@@ -478,15 +625,17 @@ int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int t
   ZK_CHECK_ARG(tile == 1 || tile == 4, "zk_gemm_grouped: tile must be 1 (128x128) or 4 (64x64)");
   const GroupDesc* d = (const GroupDesc*)descs;
   dim3 grid((unsigned)total_tiles);
-#define ZK_GROUP_LAUNCH(BM_, BN_, NS_)                                                                          \
+#define ZK_GROUP_LAUNCH(BM_, BN_, NS_, PW_)                                                                     \
   do {                                                                                                         \
-    if (!ta && !tb) hipLaunchKernelGGL((k_gemm_grouped<BM_, BN_, NS_, false, false>), grid, dim3(256), 0, stream, d, nprob); \
-    else if (!ta && tb) hipLaunchKernelGGL((k_gemm_grouped<BM_, BN_, NS_, false, true>), grid, dim3(256), 0, stream, d, nprob); \
-    else if (ta && !tb) hipLaunchKernelGGL((k_gemm_grouped<BM_, BN_, NS_, true, false>), grid, dim3(256), 0, stream, d, nprob); \
-    else hipLaunchKernelGGL((k_gemm_grouped<BM_, BN_, NS_, true, true>), grid, dim3(256), 0, stream, d, nprob);     \
+    const dim3 blk((4 + PW_) * 64);                                                                            \
+    if (!ta && !tb) hipLaunchKernelGGL((k_gemm_grouped<BM_, BN_, NS_, false, false, PW_>), grid, blk, 0, stream, d, nprob); \
+    else if (!ta && tb) hipLaunchKernelGGL((k_gemm_grouped<BM_, BN_, NS_, false, true, PW_>), grid, blk, 0, stream, d, nprob); \
+    else if (ta && !tb) hipLaunchKernelGGL((k_gemm_grouped<BM_, BN_, NS_, true, false, PW_>), grid, blk, 0, stream, d, nprob); \
+    else hipLaunchKernelGGL((k_gemm_grouped<BM_, BN_, NS_, true, true, PW_>), grid, blk, 0, stream, d, nprob);     \
   } while (0)
-  if (tile == 1) ZK_GROUP_LAUNCH(128, 128, 2);
-  else ZK_GROUP_LAUNCH(64, 64, 4);
+  const bool pw = (g_tune[6] >> 16) & 1;          // producer-wave workgroups (see gemm_tile_to_lds)
+  if (tile == 1) { if (pw) ZK_GROUP_LAUNCH(128, 128, 2, 4); else ZK_GROUP_LAUNCH(128, 128, 2, 0); }
+  else { if (pw) ZK_GROUP_LAUNCH(64, 64, 4, 4); else ZK_GROUP_LAUNCH(64, 64, 4, 0); }
 #undef ZK_GROUP_LAUNCH
   ZK_LAUNCH_CHECK();
   return 0;
@@ -552,10 +701,29 @@ int zk_logits_ce_bwd(const void* feat, const void* E, const int* ids, const floa
   ZK_LAUNCH_CHECK();
   return 0;
 }
+#ifdef ZK_GEMM_TRACE
+int zk_debug_trace_read(unsigned long long* out, int n) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(zk_trace_buf), sizeof(unsigned long long) * n);
+}
+#endif
 }  // extern "C"
 
+// Producer waves of the gen-2 kernel for a bm x bn tile: tuning key 6 holds one nibble per tile class
+// (64x64 | 128x128 << 4 | 128x64 and 64x128 << 12; bit 8: ring depth 3 for 128x128; bit 16: grouped launches).
+// Default 0x44 -- in-step A/B on the bench configuration: 5.41 -> 5.32 ms (profiles/r01_gemm_producer_waves.txt).
+int zk_gemm_dlds_pw(int bm, int bn) {
+  const int t = g_tune[6];
+  int pw = 0;
+  if (bm == 64 && bn == 64) pw = t & 15;
+  else if (bm == 128 && bn == 128) pw = (t >> 4) & 15;
+  else if ((bm == 128 && bn == 64) || (bm == 64 && bn == 128)) pw = (t >> 12) & 15;
+  const bool deep128 = bm == 128 && bn == 128 && ((t >> 8) & 1);
+  if (pw == 2) return (bm == bn && !deep128) ? 2 : 0;      // instantiated: 64x64 and 128x128 with ring depth 2
+  return (pw == 4 || pw == 8) ? pw : 0;
+}
+
 // entry used by zk_gemm (zk_gemm.hip)
-extern int g_tune[8];
 int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
                           int bm, int bn, int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags,
                           hipStream_t stream) {
@@ -565,6 +733,16 @@ int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K,
     return launch_dlds<64, 64, 2, 2>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
   if (bm == 64 && bn == 64 && g_tune[4] == 4)                       // two-wave workgroups, ring depth 4
     return launch_dlds<64, 64, 4, 2>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+  if (!ns) {                                                        // producer-wave workgroups (default for 64x64, 128x128)
+    const int t = g_tune[6], pw = zk_gemm_dlds_pw(bm, bn), ns3 = (t >> 8) & 1;
+#define ZK_PW(BM_, BN_, NS_, PW_) return launch_dlds<BM_, BN_, NS_, 4, PW_>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream)
+    if (bm == 64 && bn == 64) { if (pw == 2) ZK_PW(64, 64, 4, 2); if (pw == 4) ZK_PW(64, 64, 4, 4); if (pw == 8) ZK_PW(64, 64, 4, 8); }
+    if (bm == 128 && bn == 128 && !ns3) { if (pw == 2) ZK_PW(128, 128, 2, 2); if (pw == 4) ZK_PW(128, 128, 2, 4); if (pw == 8) ZK_PW(128, 128, 2, 8); }
+    if (bm == 128 && bn == 128 && ns3) { if (pw == 4) ZK_PW(128, 128, 3, 4); if (pw == 8) ZK_PW(128, 128, 3, 8); }
+    if (bm == 128 && bn == 64) { if (pw == 4) ZK_PW(128, 64, 2, 4); if (pw == 8) ZK_PW(128, 64, 2, 8); }
+    if (bm == 64 && bn == 128) { if (pw == 4) ZK_PW(64, 128, 2, 4); if (pw == 8) ZK_PW(64, 128, 2, 8); }
+#undef ZK_PW
+  }
   if (ns) {
 #define ZK_NS(BM_, BN_, NS_) return launch_dlds<BM_, BN_, NS_>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream)
     if (bm == 64 && bn == 64) { if (ns == 2) ZK_NS(64, 64, 2); if (ns == 6) ZK_NS(64, 64, 6); if (ns == 8) ZK_NS(64, 64, 8); }
