@@ -308,7 +308,7 @@ int zk_gemm_plan(int M, int N, int K, int out_f32, int plain) {
   int bm, bn, s;
   pick_config(M, N, K, plain ? 1 : 0, &bm, &bn, &s);
   int gen = g_default_gen;
-  if (gen == 2 && out_f32 && K <= 512 && (long)M * N >= 64L * 1024 * 1024) gen = 1;
+  if (!g_tune[7] && gen == 2 && out_f32 && K <= 512 && (long)M * N >= 64L * 1024 * 1024) gen = 1;
   return gen | (bm << 8) | (bn << 16) | (s << 24) | ((gen == 2 ? zk_gemm_dlds_pw(bm, bn) : 0) << 28);
 }
 
@@ -334,7 +334,7 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
   // measured (scripts/gemm_bench.py): a huge fp32 output with a short K loop (the logits GEMM) is
   // epilogue-bound; the register-staged kernel keeps 2 workgroups per CU and overlaps one's
   // epilogue with the other's K loop
-  else if (impl == 0 && gen == 2 && out_f32 && K <= 512 && (long)M * N >= 64L * 1024 * 1024) gen = 1;
+  else if (!g_tune[7] && impl == 0 && gen == 2 && out_f32 && K <= 512 && (long)M * N >= 64L * 1024 * 1024) gen = 1;
   if (M == 0 || N == 0) return 0;
   GemmEpi e;
   e.C = C; e.ldc = ldc; e.out_f32 = out_f32; e.alpha = alpha; e.bias = bias;
