@@ -248,6 +248,26 @@ int zk_beam_host_step(int B, int K, int V, int Tcap, int time, const float* topk
                       int* seq, int* fin_seq, float* log_probs, float* scores, float* fin_scores,
                       unsigned char* fin_flags, const int* mtl_i, int eos_id, int pad_id, float penalty,
                       int* flat_idx, int* next_tok);
+/* The same two statements with the search state RESIDENT ON THE DEVICE, as the first and the last node of
+   the decode-step graph (no host round trip per step; replaces the per-step session.run boundary of
+   search.py:60-275 / main.py:399-460).  ctrl int32[4]: [0] steps taken (= next time step), [1] stopped,
+   [2] error (the step ran into the cache cap Tmax).  stepbuf int32[>=3]: [0] time, [1] length penalty of the
+   step (fp32 bits), [2] banned symbol or -1 -- the per-step scalars the other kernels of the graph read.
+   pen_table[t] = ((5 + t + 1) / 6)^alpha for t < Tcap and max_lp[b] = ((5 + max_target_length[b]) / 6)^alpha
+   are computed by the caller in fp32.  prepare: stop test of the coming step; when it fires the state is
+   frozen (advance becomes a no-op), otherwise it publishes the step scalars.  advance: alive / finished
+   update from the step's [B, 2K] survivors; writes the next step's tokens, log-probs (prev) and flat beam
+   indices.  seq / fin_seq: int32 [B, K, Tcap]; fin_flags: int32 [B, K].  K <= 16, 2*K*Tcap*4 <= 64 KiB. */
+int zk_beam_dev_prepare(int* ctrl, int* stepbuf, const float* pen_table, const float* max_lp, const int* mtl_i,
+                        const float* topk_scores, const int* topk_idx, int* seq, int* fin_seq, float* log_probs,
+                        float* scores, float* fin_scores, int* fin_flags, int* flat_idx, int* next_tok,
+                        float* prev, int B, int K, int V, int Tcap, int Tmax, int eos_id, int pad_id,
+                        zk_stream_t stream);
+int zk_beam_dev_advance(int* ctrl, int* stepbuf, const float* pen_table, const float* max_lp, const int* mtl_i,
+                        const float* topk_scores, const int* topk_idx, int* seq, int* fin_seq, float* log_probs,
+                        float* scores, float* fin_scores, int* fin_flags, int* flat_idx, int* next_tok,
+                        float* prev, int B, int K, int V, int Tcap, int Tmax, int eos_id, int pad_id,
+                        zk_stream_t stream);
 /* search.py:143-145 (enable_noise_beam_search): logits += Gumbel noise -log(-log(u + eps) + eps), util.py:189-195 */
 int zk_add_gumbel(float* logits, int rows, int V, int ld, float eps, const uint64_t* seed, uint32_t sid,
                   zk_stream_t stream);

@@ -296,6 +296,67 @@ def test_beam_search_token_ids(model, K):
         assert np.array_equal(outs["cache"][0], outs["dev"][0])
 
 
+@pytest.mark.parametrize("model", MODELS)
+@pytest.mark.parametrize("K", [1, 4, 8])
+def test_device_resident_search_equals_host_bookkeeping(model, K, monkeypatch):
+    """search.py:85-113,168-228 on the device (zk_beam_dev_prepare / zk_beam_dev_advance inside the step graph,
+    stop flag polled every few replays) against the host-C bookkeeping and the numpy statements: all K
+    hypotheses, their scores and the step count, bit for bit, whatever the polling interval (replays past the
+    stop must not change the frozen state)."""
+    from zero_amd.main import tower_infer_graph
+    from zero_amd import search
+    hp, Pn, src, tgt = _setup(model, seed=5, beam_size=K)
+    Pn["tgt_embedding"] = (Pn["tgt_embedding"] * 6.0).astype(np.float32)
+    hp = copy.copy(hp); hp.beam_size = K; hp.search_mode = "cache"
+    outs = {}
+    for name, env in (("numpy", {"ZERO_HIP_DECODE_HOST_C": "0"}),
+                      ("host_c", {"ZERO_HIP_DECODE_DEVICE_BOOK": "0"}),
+                      ("dev1", {"ZERO_HIP_DECODE_POLL": "1"}), ("dev4", {}), ("dev7", {"ZERO_HIP_DECODE_POLL": "7"})):
+        for k in ("ZERO_HIP_DECODE_HOST_C", "ZERO_HIP_DECODE_DEVICE_BOOK", "ZERO_HIP_DECODE_POLL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        reset_cores()
+        get_core(hp, model, Pn)
+        enc, dec = registry.get_model(model).infer_fn(hp)
+        outs[name] = search.beam_search({"source": src}, enc, dec, hp)
+    ref = outs["host_c"]
+    assert ref["steps"] > 2
+    for name in ("numpy", "dev1", "dev4", "dev7"):
+        o = outs[name]
+        assert o["steps"] == ref["steps"], (name, o["steps"], ref["steps"])
+        assert np.array_equal(o["seq"], ref["seq"]), name
+        assert np.array_equal(o["score"], ref["score"]), name
+
+
+@pytest.mark.parametrize("model", ["transformer", "transformer_aan"])
+def test_decode_graphs_across_batches_of_changing_shape(model):
+    """After the first batch the step graphs are captured without an eager pass (the scratch exists); batches
+    that grow a buffer fall back to the eager pass.  A sequence of batches on ONE engine must give exactly
+    what each batch gives on a fresh engine."""
+    from zero_amd import search
+    hp, Pn, _, _ = _setup(model, seed=7, beam_size=4)
+    Pn["tgt_embedding"] = (Pn["tgt_embedding"] * 6.0).astype(np.float32)
+    hp = copy.copy(hp); hp.beam_size = 4; hp.search_mode = "cache"
+    rng = np.random.default_rng(11)
+    shapes = [(4, 7), (4, 9), (4, 5), (6, 12), (3, 12), (4, 30), (4, 7)]
+    batches = [make_batch(rng, b, l, 3, hp.src_vocab.size(), hp.tgt_vocab.size())[0] for b, l in shapes]
+
+    def run(src):
+        enc, dec = registry.get_model(model).infer_fn(hp)
+        return search.beam_search({"source": src}, enc, dec, hp)
+    fresh = []
+    for src in batches:
+        reset_cores(); get_core(hp, model, Pn)
+        fresh.append(run(src))
+    reset_cores(); core = get_core(hp, model, Pn)
+    for i, src in enumerate(batches):
+        o = run(src)
+        assert o["steps"] == fresh[i]["steps"], i
+        assert np.array_equal(o["seq"], fresh[i]["seq"]) and np.array_equal(o["score"], fresh[i]["score"]), i
+    assert core.__dict__.get("_decode_warm_rows", 0) >= 16
+
+
 def test_aan_use_ffn_variant():
     """transformer_aan.py:176-183: an FFN between the cumulative average and the gate (use_ffn=True,
     off by default in run.py:119): loss / gradients of the extra ffn_layer variables, beam ids."""

@@ -431,6 +431,134 @@ int zk_fuse_decode(const void* vq, float* cache, void* att, int rows, int H, flo
 // ~25 small numpy calls (~130 us, a fifth of a decode step).  Plain fp32 arithmetic in the reference's
 // order; tf.nn.top_k ties -> lower index.  Pure host code.
 // ---------------------------------------------------------------------------------------------
+// Device-resident search bookkeeping: the same statements as zk_beam_host_step / zk_beam_host_should_stop
+// below, run as the first (prepare) and last (advance) node of the decode-step graph, so a step needs no
+// host round trip; the host only polls ctrl[1] every few replays.  Once the stop test fires the state is
+// frozen (advance is a no-op), so replays issued past the stop change nothing.
+//   ctrl int32[4]: [0] steps taken = next time step, [1] stopped, [2] error (time ran into the cache cap)
+struct BeamDev {
+  int* ctrl; int* stepbuf;               // stepbuf: [0] time, [1] penalty (fp32 bits), [2] banned symbol or -1
+  const float* pen_table;                // ((5 + t + 1) / 6)^alpha for t < Tcap, computed on the host in fp32
+  const float* max_lp; const int* mtl_i; // per sentence: ((5 + max_target_length) / 6)^alpha, int(max_target_length)
+  const float* topk_scores; const int* topk_idx;   // [B, 2K] survivors of this step
+  int* seq; int* fin_seq;                // [B, K, Tcap]
+  float* log_probs; float* scores; float* fin_scores; int* fin_flags;   // [B, K]
+  int* flat_idx; int* next_tok; float* prev;       // [B*K] inputs of the next step
+  int B, K, V, Tcap, Tmax, eos_id, pad_id;
+};
+#define ZK_F32MIN (-3.4028234663852886e38f)
+
+__global__ void __launch_bounds__(256) k_beam_prepare(BeamDev d) {
+  __shared__ int s_bound_fail, s_length;
+  if (d.ctrl[1]) return;
+  if (threadIdx.x == 0) { s_bound_fail = 0; s_length = 0; }
+  __syncthreads();
+  const int time = d.ctrl[0];
+  for (int b = threadIdx.x; b < d.B; b += blockDim.x) {       // search.py:85-113
+    const float best_alive = d.log_probs[b * d.K] / d.max_lp[b];
+    float worst = INFINITY;
+    bool any = false;
+    for (int k = 0; k < d.K; ++k) {
+      const bool f = d.fin_flags[b * d.K + k] != 0;
+      worst = fminf(worst, d.fin_scores[b * d.K + k] * (f ? 1.f : 0.f));
+      any = any || f;
+    }
+    worst = worst + (1.f - (any ? 1.f : 0.f)) * ZK_F32MIN;
+    if (!(worst > best_alive)) atomicOr(&s_bound_fail, 1);
+    if (time < d.mtl_i[b]) atomicOr(&s_length, 1);
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  if (!s_bound_fail || !s_length) { d.ctrl[1] = 1; return; }
+  if (time >= d.Tmax) { d.ctrl[1] = 1; d.ctrl[2] = 1; return; }
+  d.stepbuf[0] = time;
+  d.stepbuf[1] = __float_as_int(d.pen_table[time]);
+  d.stepbuf[2] = time < 1 ? d.eos_id : -1;
+  d.ctrl[0] = time + 1;
+}
+
+// descending, ties -> lower index (np.argsort(-x, kind="stable")[:k])
+__device__ inline void dev_top_k(const float* x, int n, int k, int* idx) {
+  unsigned long long used = 0ull;
+  for (int r = 0; r < k; ++r) {
+    int best = -1;
+    for (int i = 0; i < n; ++i) {
+      if ((used >> i) & 1ull) continue;
+      if (best < 0 || x[i] > x[best]) best = i;
+    }
+    idx[r] = best;
+    used |= 1ull << best;
+  }
+}
+
+// one block per sentence; dynamic LDS: 2 * K * Tcap ints (the sentence's alive and finished rows)
+__global__ void __launch_bounds__(128) k_beam_advance(BeamDev d) {
+  extern __shared__ int s_rows[];
+  __shared__ int s_beam[32], s_cur[32], s_aidx[16], s_fidx[16];
+  if (d.ctrl[1]) return;
+  const int b = blockIdx.x, K = d.K, K2 = 2 * d.K, Tcap = d.Tcap;
+  const int time = d.stepbuf[0], len = time + 1;
+  int* sq = d.seq + (size_t)b * K * Tcap;
+  int* fs = d.fin_seq + (size_t)b * K * Tcap;
+  int* l_seq = s_rows;
+  int* l_fin = s_rows + K * Tcap;
+  for (int i = threadIdx.x; i < K * len; i += blockDim.x) {
+    const int k = i / len, t = i - k * len;
+    l_seq[k * Tcap + t] = sq[k * Tcap + t];
+    l_fin[k * Tcap + t] = fs[k * Tcap + t];
+  }
+  if (threadIdx.x == 0) {
+    const float penalty = __int_as_float(d.stepbuf[1]);
+    const float* ts = d.topk_scores + (size_t)b * K2;
+    const int* ti = d.topk_idx + (size_t)b * K2;
+    float masked[32], allsc[48];
+    int allfl[48], cfin[32], aidx[16], fidx[16];
+    const bool at_cap = time >= d.mtl_i[b];
+    for (int c = 0; c < K2; ++c) {
+      const int beam = ti[c] / d.V, cur = ti[c] % d.V;
+      s_beam[c] = beam; s_cur[c] = cur;
+      cfin[c] = (cur == d.eos_id) || at_cap;
+      masked[c] = ts[c] + (cfin[c] ? 1.f : 0.f) * ZK_F32MIN;
+    }
+    dev_top_k(masked, K2, K, aidx);                       // alive (search.py:192-210)
+    for (int k = 0; k < K; ++k) {
+      const int c = aidx[k];
+      s_aidx[k] = c;
+      d.scores[b * K + k] = masked[c];
+      const float lp = masked[c] * penalty;
+      d.log_probs[b * K + k] = lp;
+      d.prev[b * K + k] = lp;
+      d.flat_idx[b * K + k] = b * K + s_beam[c];
+      d.next_tok[b * K + k] = s_cur[c];
+    }
+    for (int k = 0; k < K; ++k) { allsc[k] = d.fin_scores[b * K + k]; allfl[k] = d.fin_flags[b * K + k]; }
+    for (int c = 0; c < K2; ++c) {                        // finished (search.py:212-228)
+      allsc[K + c] = ts[c] + (1.f - (cfin[c] ? 1.f : 0.f)) * ZK_F32MIN;
+      allfl[K + c] = cfin[c];
+    }
+    dev_top_k(allsc, K + K2, K, fidx);
+    for (int k = 0; k < K; ++k) {
+      const int j = fidx[k];
+      s_fidx[k] = j;
+      masked[k] = allsc[j];
+      cfin[k] = allfl[j];
+    }
+    for (int k = 0; k < K; ++k) { d.fin_scores[b * K + k] = masked[k]; d.fin_flags[b * K + k] = cfin[k]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K * (len + 1); i += blockDim.x) {
+    const int k = i / (len + 1), t = i - k * (len + 1);
+    const int c = s_aidx[k];
+    sq[k * Tcap + t] = t < len ? l_seq[s_beam[c] * Tcap + t] : s_cur[c];
+    const int j = s_fidx[k];
+    int v;
+    if (j < K) v = t < len ? l_fin[j * Tcap + t] : d.pad_id;
+    else v = t < len ? l_seq[s_beam[j - K] * Tcap + t] : s_cur[j - K];
+    fs[k * Tcap + t] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 static const float kF32Min = -3.4028234663852886e38f;
 
 // search.py:85-113: stop when every sentence's worst finished score beats its best alive bound, or when
@@ -541,4 +669,45 @@ int zk_beam_host_step(int B, int K, int V, int Tcap, int time, const float* topk
   return 0;
 }
 
+
+// Device-resident search state (see BeamDev above).  All pointers are device memory; `state` points at one
+// int32/fp32 arena laid out by the caller:  the entry points take the pieces explicitly so the layout stays
+// the caller's business.  prepare: <<<1, 256>>>, advance: <<<B, 128, 2*K*Tcap*4>>>.
+static int beam_dev_fill(BeamDev* d, int* ctrl, int* stepbuf, const float* pen_table, const float* max_lp,
+                         const int* mtl_i, const float* topk_scores, const int* topk_idx, int* seq, int* fin_seq,
+                         float* log_probs, float* scores, float* fin_scores, int* fin_flags, int* flat_idx,
+                         int* next_tok, float* prev, int B, int K, int V, int Tcap, int Tmax, int eos_id, int pad_id) {
+  ZK_CHECK_ARG(B >= 1 && K >= 1 && K <= 16 && V >= 1 && Tcap >= 2, "zk_beam_dev: bad dims B=%d K=%d V=%d Tcap=%d", B, K, V, Tcap);
+  ZK_CHECK_ARG((size_t)2 * K * Tcap * sizeof(int) <= 64 * 1024, "zk_beam_dev: K*Tcap=%d rows do not fit LDS", K * Tcap);
+  ZK_CHECK_ARG(ctrl && stepbuf && pen_table && max_lp && mtl_i && topk_scores && topk_idx && seq && fin_seq && log_probs &&
+               scores && fin_scores && fin_flags && flat_idx && next_tok && prev, "zk_beam_dev: null pointer");
+  d->ctrl = ctrl; d->stepbuf = stepbuf; d->pen_table = pen_table; d->max_lp = max_lp; d->mtl_i = mtl_i;
+  d->topk_scores = topk_scores; d->topk_idx = topk_idx; d->seq = seq; d->fin_seq = fin_seq;
+  d->log_probs = log_probs; d->scores = scores; d->fin_scores = fin_scores; d->fin_flags = fin_flags;
+  d->flat_idx = flat_idx; d->next_tok = next_tok; d->prev = prev;
+  d->B = B; d->K = K; d->V = V; d->Tcap = Tcap; d->Tmax = Tmax; d->eos_id = eos_id; d->pad_id = pad_id;
+  return 0;
+}
+#define ZK_BEAM_DEV_ARGS                                                                                         \
+  int* ctrl, int* stepbuf, const float* pen_table, const float* max_lp, const int* mtl_i,                         \
+  const float* topk_scores, const int* topk_idx, int* seq, int* fin_seq, float* log_probs, float* scores,        \
+  float* fin_scores, int* fin_flags, int* flat_idx, int* next_tok, float* prev, int B, int K, int V, int Tcap,   \
+  int Tmax, int eos_id, int pad_id
+#define ZK_BEAM_DEV_PASS                                                                                         \
+  ctrl, stepbuf, pen_table, max_lp, mtl_i, topk_scores, topk_idx, seq, fin_seq, log_probs, scores, fin_scores,   \
+  fin_flags, flat_idx, next_tok, prev, B, K, V, Tcap, Tmax, eos_id, pad_id
+int zk_beam_dev_prepare(ZK_BEAM_DEV_ARGS, hipStream_t stream) {
+  BeamDev d;
+  if (int rc = beam_dev_fill(&d, ZK_BEAM_DEV_PASS)) return rc;
+  hipLaunchKernelGGL(k_beam_prepare, dim3(1), dim3(256), 0, stream, d);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+int zk_beam_dev_advance(ZK_BEAM_DEV_ARGS, hipStream_t stream) {
+  BeamDev d;
+  if (int rc = beam_dev_fill(&d, ZK_BEAM_DEV_PASS)) return rc;
+  hipLaunchKernelGGL(k_beam_advance, dim3(B), dim3(128), (size_t)2 * K * Tcap * sizeof(int), stream, d);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
 }  // extern "C"

@@ -156,8 +156,12 @@ def make_infer_fns(params, model_name):
         parity = state["_pp"]
         g = state["graphs"].get(parity)
 
+        book = state.get("book")          # device-resident search bookkeeping (search._beam_search_device)
+
         def body():
             sb = state["stepbuf"]
+            if book is not None:
+                e.lib.call("zk_beam_dev_prepare", *book, e.stream)
             state.reorder(state["idx"], time_dev=sb[0:1])
             logits, _ = _step_cache(state["tok"], state, None, time_dev=sb[0:1])
             if hp.enable_noise_beam_search:      # search.py:143-145; a fresh stream position every step
@@ -166,6 +170,27 @@ def make_infer_fns(params, model_name):
                 e.lib.call("zk_seed_advance", e.seed.data_ptr(), 1, e.stream)
             e.beam_topk(logits, state["prev"], state["ts"], state["ti"], state["B"], state["K"], core.V,
                         2 * state["K"], temperature, 1.0, -1, forbid_value, scal_dev=sb[1:3])
+            if book is not None:
+                e.lib.call("zk_beam_dev_advance", *book, e.stream)
+        if g is None and core.__dict__.get("_decode_warm_rows", 0) >= state["BK"]:
+            # A batch of at least this many beam rows has already been decoded on this engine, so the step's
+            # scratch buffers exist: capture straight away instead of spending an eager pass first.  If the
+            # capture does hit an allocation after all (a larger source length can grow a workspace), undo
+            # the python-side ping-pong flip of the aborted pass and take the eager route below.
+            pp0, gen0 = state["_pp"], e.realloc_gen
+            try:
+                gexec = e.graph_capture(body)
+                if e.realloc_gen != gen0:
+                    e.lib.call("zk_graph_destroy", gexec)
+                    raise RuntimeError("buffer replaced during capture")
+                state["graphs"][parity] = gexec
+                e.graph_launch(gexec)
+                return
+            except Exception:
+                torch.cuda.synchronize(e.device)
+                state["_pp"] = pp0
+                state.bind_caches()
+                core._decode_warm_rows = 0
         if g is None:
             state["graphs"][parity] = "warm"
             body()

@@ -91,6 +91,9 @@ def _beam_search(features, encoding_fn, decoding_fn, params):
     static_step = cache_mode and state.get("static_ok", False) and hasattr(decoding_fn, "step_static") \
         and os.environ.get("ZERO_HIP_DECODE_GRAPH", "1") != "0"
     if static_step and K <= 16 and os.environ.get("ZERO_HIP_DECODE_HOST_C", "1") != "0":
+        Tcap = int(state["Tmax"]) + 2
+        if os.environ.get("ZERO_HIP_DECODE_DEVICE_BOOK", "1") != "0" and 2 * K * Tcap * 4 <= 64 * 1024:
+            return _beam_search_device(state, decoding_fn, params, B, K, V, eos_id, pad_id, alpha, max_target_length)
         return _beam_search_static(state, decoding_fn, params, B, K, V, eos_id, pad_id, alpha, max_target_length)
     if static_step:
         BK = B * K
@@ -187,6 +190,9 @@ def _release_graphs(state):
     if not graphs:
         return
     core = state["_core"]
+    if all(not isinstance(g, str) for g in graphs.values()):
+        # a whole batch ran from captured graphs: the step's scratch exists for this many beam rows
+        core._decode_warm_rows = max(core.__dict__.get("_decode_warm_rows", 0), state["BK"])
     torch.cuda.current_stream(core.eng.device).synchronize()
     for g in graphs.values():
         if not isinstance(g, str):
@@ -245,6 +251,70 @@ def _beam_search_static(state, decoding_fn, params, B, K, V, eos_id, pad_id, alp
     _release_graphs(state)
     any_fin = fin_flags.any(axis=1)
     n = time + 1
+    final_seqs = np.where(any_fin[:, None, None], fin_seq[:, :, :n], seq[:, :, :n]).astype(np.int64)
+    final_scores = np.where(any_fin[:, None], fin_scores, scores)
+    return {"seq": final_seqs[:, :, 1:], "score": final_scores, "steps": time}
+
+
+def _beam_search_device(state, decoding_fn, params, B, K, V, eos_id, pad_id, alpha, max_target_length):
+    """The cache-mode search with the bookkeeping of search.py:85-113,168-228 RESIDENT ON THE DEVICE
+    (zk_beam_dev_prepare / zk_beam_dev_advance are the first and last node of the step graph): a decode step
+    needs no host round trip; the host replays the graph ZERO_HIP_DECODE_POLL (default 4) times between reads of
+    the stop flag.  Once the stop test fires the state is frozen, so the replays past it change nothing and the
+    result is the one of _beam_search_static (tests hold the two equal, bit for bit)."""
+    f32 = np.float32
+    core = state["_core"]
+    e = core.eng
+    BK = B * K
+    Tcap = int(state["Tmax"]) + 2
+    mtl = np.ascontiguousarray(max_target_length, dtype=f32)
+    # one int32 arena: [ctrl 4 | pen_table Tcap | max_lp B | mtl_i B | log_probs | scores | fin_scores |
+    #                   fin_flags (BK each) | seq | fin_seq (BK*Tcap each)]
+    sizes = [4, Tcap, B, B, BK, BK, BK, BK, BK * Tcap, BK * Tcap]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+    host = torch.zeros(int(offs[-1]), dtype=torch.int32).pin_memory()
+    h = host.numpy()
+    part = lambda i: h[offs[i]:offs[i + 1]]
+    part(1).view(f32)[:] = [f32(np.power(f32((f32(5.) + f32(t + 1)) / f32(6.)), f32(alpha))) for t in range(Tcap)]
+    part(2).view(f32)[:] = [f32(np.power(f32((f32(5.) + m) / f32(6.)), f32(alpha))) for m in mtl]
+    part(3)[:] = mtl.astype(np.int32)
+    part(4).view(f32)[:] = np.tile(np.array([0.] + [F32_MIN] * (K - 1), dtype=f32), B)
+    part(6).view(f32)[:] = F32_MIN
+    part(8)[:] = pad_id                               # seq; fin_seq starts at zeros (search.py:52-57)
+    dev = e.buf("bs.book", (int(offs[-1]),), torch.int32)
+    dev.copy_(host, non_blocking=True)
+    d = lambda i: dev[offs[i]:offs[i + 1]].data_ptr()
+    pack = state["pack_host"].numpy()
+    pack[0:BK] = pad_id                               # BOS = pad id (search.py:50)
+    pack[BK:2 * BK] = part(4)                         # previous log-probs of step 0
+    pack[2 * BK:3 * BK] = np.arange(BK, dtype=np.int32)
+    state["pack_dev"].copy_(state["pack_host"], non_blocking=True)
+    state["book"] = (d(0), state["stepbuf"].data_ptr(), d(1), d(2), d(3), state["ts"].data_ptr(), state["ti"].data_ptr(),
+                     d(8), d(9), d(4), d(5), d(6), d(7), state["idx"].data_ptr(), state["tok"].data_ptr(),
+                     state["prev"].data_ptr(), B, K, V, Tcap, int(state["Tmax"]), eos_id, pad_id)
+    poll = max(1, int(os.environ.get("ZERO_HIP_DECODE_POLL", "4")))
+    ctrl_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+    ctrl_dev = dev[0:4]
+    launched = 0
+    while True:
+        for _ in range(poll):
+            decoding_fn.step_static(state, params.beam_search_temperature, zdtype.inf())
+        launched += poll
+        ctrl_host.copy_(ctrl_dev)                     # synchronises
+        if int(ctrl_host[1]) or launched > Tcap + poll:
+            break
+    _release_graphs(state)
+    state.pop("book", None)
+    if int(ctrl_host[2]) or not int(ctrl_host[1]):
+        raise RuntimeError("decode step %d exceeds the allocated cache length %d" % (int(ctrl_host[0]), state["Tmax"]))
+    host.copy_(dev)
+    time = int(h[0])
+    n = time + 1
+    seq = part(8).reshape(B, K, Tcap)
+    fin_seq = part(9).reshape(B, K, Tcap)
+    scores, fin_scores = part(5).view(f32).reshape(B, K), part(6).view(f32).reshape(B, K)
+    fin_flags = part(7).reshape(B, K) != 0
+    any_fin = fin_flags.any(axis=1)
     final_seqs = np.where(any_fin[:, None, None], fin_seq[:, :, :n], seq[:, :, :n]).astype(np.int64)
     final_scores = np.where(any_fin[:, None], fin_scores, scores)
     return {"seq": final_seqs[:, :, 1:], "score": final_scores, "steps": time}
