@@ -395,6 +395,55 @@ __device__ __forceinline__ void stage_trans(bf16_t* dst, const bf16_t* src, int 
   }
 }
 __device__ __forceinline__ int chan_of_phys(int q) { return (q & 7) * 8 + (q >> 3); }
+// The same staging in two halves -- all global loads of a prologue are issued before the first LDS store, so
+// their latencies overlap instead of adding up (one stage_* call after another measured ~1500 cycles each).
+// Branch-free: rows past the end are clamped for the address and zeroed by a select.
+struct DirectRegs { uint4 v[2]; };
+__device__ __forceinline__ void load_direct(DirectRegs& R, const bf16_t* src, int ld, int row0, int nrows, int tid) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int t = tid + it * 256;
+    const int r = row0 + (t >> 3), c = (t & 7) * 8;
+    const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)min(r, nrows - 1) * ld + c);
+    R.v[it] = r < nrows ? v : make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+__device__ __forceinline__ void store_direct(bf16_t* dst, const DirectRegs& R, int tid) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int t = tid + it * 256;
+    *reinterpret_cast<uint4*>(dst + (t >> 3) * ALD + (t & 7) * 8) = R.v[it];
+  }
+}
+struct TransRegs { uint4 v[4]; };
+__device__ __forceinline__ void load_trans(TransRegs& R, const bf16_t* src, int ld, int row0, int nrows, int t128) {
+  const int dc = t128 & 7, rq = t128 >> 3;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int r = row0 + rq * 4 + u;
+    const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)min(r, nrows - 1) * ld + dc * 8);
+    R.v[u] = r < nrows ? v : make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+__device__ __forceinline__ void store_trans(bf16_t* dst, const TransRegs& R, int t128) {
+  const int dc = t128 & 7, rq = t128 >> 3;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint2 o;
+    o.x = half_of4(R.v[0], i) | (half_of4(R.v[1], i) << 16);
+    o.y = half_of4(R.v[2], i) | (half_of4(R.v[3], i) << 16);
+    *reinterpret_cast<uint2*>(dst + (i * 8 + dc) * ALD + rq * 4) = o;
+  }
+}
+// [64 rows][64 channels] bf16 tile in LDS (row stride ALD) -> global rows [0, nrows), 16 bytes per thread and store
+__device__ __forceinline__ void store_tile_rows(const bf16_t* tile, bf16_t* dst, size_t ld, int nrows, int tid) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int t = tid + it * 256;
+    const int r = t >> 3, c = (t & 7) * 8;
+    if (r < nrows) *reinterpret_cast<uint4*>(dst + (size_t)r * ld + c) = *reinterpret_cast<const uint4*>(tile + r * ALD + c);
+  }
+}
 
 __device__ __forceinline__ float quad16_max(float v) {
   v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
@@ -423,12 +472,28 @@ __global__ void __launch_bounds__(256) k_attn_fwd_mfma(AttnArgs a, bf16_t* __res
   const bf16_t* vb = a.v + (size_t)(b / a.kv_group) * a.bsv + h * AD;
   const uint64_t seed = a.thr ? *a.seed : 0;
 
-  stage_direct(sQ, qb, a.ldq, i0, a.Lq, tid);
+  // the loads that do not depend on anything computed here are issued together: Q, the first K tile, the first
+  // V tile (kept in registers until P is ready) and the key mask -- one memory round trip instead of four
+  DirectRegs rQ, rK;
+  TransRegs rVt;
+  load_direct(rQ, qb, a.ldq, i0, a.Lq, tid);
+  load_direct(rK, kb, a.ldk, 0, a.Lk, tid);
+  if (tid < 128) load_trans(rVt, vb, a.ldv, 0, a.Lk, tid);
+  float kbias[NKT * 4];
+#pragma unroll
+  for (int t = 0; t < NKT * 4; ++t) {
+    const int j = t * 16 + (lane & 15);
+    kbias[t] = (a.kmask != nullptr && a.kmask[(size_t)(b / a.kv_group) * a.ldmask + min(j, a.Lk - 1)] == 0.f) ? -a.mask_inf : 0.f;
+  }
+  store_direct(sQ, rQ, tid);
+  store_direct(sK, rK, tid);
   f32x4_t S[NKT * 4];
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
-    __syncthreads();   // previous tile's readers are done with sK (and sQ is visible on kt==0)
-    stage_direct(sK, kb, a.ldk, kt * 64, a.Lk, tid);
+    if (kt > 0) {
+      __syncthreads();   // previous tile's readers are done with sK
+      stage_direct(sK, kb, a.ldk, kt * 64, a.Lk, tid);
+    }
     __syncthreads();
     const uint4 q0 = frag(sQ, w * 16, 0, lane), q1 = frag(sQ, w * 16, 1, lane);
 #pragma unroll
@@ -446,8 +511,7 @@ __global__ void __launch_bounds__(256) k_attn_fwd_mfma(AttnArgs a, bf16_t* __res
   for (int t = 0; t < NKT * 4; ++t) {
     const int j = t * 16 + (lane & 15);
     const bool kvalid = j < a.Lk;
-    float kb_ = 0.f;
-    if (kvalid && a.kmask != nullptr && a.kmask[(size_t)(b / a.kv_group) * a.ldmask + j] == 0.f) kb_ = -a.mask_inf;
+    const float kb_ = kvalid ? kbias[t] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float raw = S[t][r];
@@ -504,7 +568,8 @@ __global__ void __launch_bounds__(256) k_attn_fwd_mfma(AttnArgs a, bf16_t* __res
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
     __syncthreads();   // sK readers done / sP complete
-    stage_trans(sK, vb, a.ldv, kt * 64, a.Lk, tid);
+    if (kt == 0) { if (tid < 128) store_trans(sK, rVt, tid); }
+    else stage_trans(sK, vb, a.ldv, kt * 64, a.Lk, tid);
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -514,15 +579,15 @@ __global__ void __launch_bounds__(256) k_attn_fwd_mfma(AttnArgs a, bf16_t* __res
       for (int nb = 0; nb < 4; ++nb) O[nb] = mfma16(pa, frag(sK, nb * 16, kk, lane), O[nb]);
     }
   }
+  // O through LDS (sQ is dead) so that every thread stores 16 bytes of a row
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
     const int c = chan_of_phys(nb * 16 + (lane & 15));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = rbase + r;
-      if (i < a.Lq) out[((size_t)b * a.Lq + i) * ldo + h * AD + c] = f2bf(O[nb][r]);
-    }
+    for (int r = 0; r < 4; ++r) sQ[(w * 16 + (lane >> 4) * 4 + r) * ALD + c] = f2bf(O[nb][r]);
   }
+  __syncthreads();
+  store_tile_rows(sQ, out + ((size_t)b * a.Lq + i0) * ldo + h * AD, ldo, a.Lq - i0, tid);
 }
 
 // ---- backward A: grid (ceil(Lq/64), nh, B) -> dQ, Dbuf
@@ -784,34 +849,60 @@ __global__ void __launch_bounds__(256) k_attn_bwd_fused64(AttnArgs a, const bf16
   const bf16_t* dob = dout + (size_t)b * a.Lq * lddo + h * AD;
   const uint64_t seed = a.thr ? *a.seed : 0;
 
-  stage_direct(sQ, qb, a.ldq, 0, a.Lq, tid);
-  stage_direct(sdO, dob, lddo, 0, a.Lq, tid);
-  stage_direct(sK, kb, a.ldk, 0, a.Lk, tid);
-  stage_direct(sV, vb, a.ldv, 0, a.Lk, tid);
+  // every global load of the prologue first (tiles, the O / dO rows of D_i, lse, the key mask), then the LDS stores
+  DirectRegs rQ, rdO, rK, rV;
+  TransRegs t0, t1;
+  load_direct(rQ, qb, a.ldq, 0, a.Lq, tid);
+  load_direct(rdO, dob, lddo, 0, a.Lq, tid);
+  load_direct(rK, kb, a.ldk, 0, a.Lk, tid);
+  load_direct(rV, vb, a.ldv, 0, a.Lk, tid);
   if (tid < 128) {
-    stage_trans(sKt, kb, a.ldk, 0, a.Lk, tid);
+    load_trans(t0, kb, a.ldk, 0, a.Lk, tid);
   } else {
-    stage_trans(sQt, qb, a.ldq, 0, a.Lq, tid - 128);
-    stage_trans(sdOt, dob, lddo, 0, a.Lq, tid - 128);
+    load_trans(t0, qb, a.ldq, 0, a.Lq, tid - 128);
+    load_trans(t1, dob, lddo, 0, a.Lq, tid - 128);
   }
-  {  // D_i = sum_c dO[i][c] * O[i][c]; 4 threads per row
-    const int r = tid >> 2, part = tid & 3;
+  const int dr = tid >> 2, dpart = tid & 3;          // D_i = sum_c dO[i][c] * O[i][c]; 4 threads per row
+  const int drc = min(dr, a.Lq - 1);
+  uint4 dx[2], dy[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    dx[u] = *reinterpret_cast<const uint4*>(dob + (size_t)drc * lddo + dpart * 16 + u * 8);
+    dy[u] = *reinterpret_cast<const uint4*>(ob + (size_t)drc * ldo + dpart * 16 + u * 8);
+  }
+  const float lse_r = lse[((size_t)b * a.nh + h) * a.Lq + drc];
+  float kbias4[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int j = nt * 16 + (lane & 15);
+    kbias4[nt] = (a.kmask != nullptr && a.kmask[(size_t)b * a.ldmask + min(j, a.Lk - 1)] == 0.f) ? -a.mask_inf : 0.f;
+  }
+  store_direct(sQ, rQ, tid);
+  store_direct(sdO, rdO, tid);
+  store_direct(sK, rK, tid);
+  store_direct(sV, rV, tid);
+  if (tid < 128) {
+    store_trans(sKt, t0, tid);
+  } else {
+    store_trans(sQt, t0, tid - 128);
+    store_trans(sdOt, t1, tid - 128);
+  }
+  {
     float acc = 0.f;
-    if (r < a.Lq) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        float x[8], y[8];
-        unpack8(*reinterpret_cast<const uint4*>(dob + (size_t)r * lddo + part * 16 + u * 8), x);
-        unpack8(*reinterpret_cast<const uint4*>(ob + (size_t)r * ldo + part * 16 + u * 8), y);
+    for (int u = 0; u < 2; ++u) {
+      float x[8], y[8];
+      unpack8(dx[u], x);
+      unpack8(dy[u], y);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc += x[c] * y[c];
-      }
+      for (int c = 0; c < 8; ++c) acc += x[c] * y[c];
     }
+    if (dr >= a.Lq) acc = 0.f;
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
-    if (part == 0) {
-      sD[r] = acc;
-      sL[r] = (r < a.Lq) ? lse[((size_t)b * a.nh + h) * a.Lq + r] : 0.f;
+    if (dpart == 0) {
+      sD[dr] = acc;
+      sL[dr] = (dr < a.Lq) ? lse_r : 0.f;
     }
   }
   __syncthreads();
@@ -830,8 +921,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_fused64(AttnArgs a, const bf16
       dp = mfma16(g1, frag(sV, nt * 16, 1, lane), dp);
       const int j = nt * 16 + (lane & 15);
       const bool kvalid = j < a.Lk;
-      float kbias = 0.f;
-      if (kvalid && a.kmask != nullptr && a.kmask[(size_t)b * a.ldmask + j] == 0.f) kbias = -a.mask_inf;
+      const float kbias = kvalid ? kbias4[nt] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = rloc + r;
@@ -893,19 +983,25 @@ __global__ void __launch_bounds__(256) k_attn_bwd_fused64(AttnArgs a, const bf16
       dK[nb] = mfma16(dt, frag(sQt, nb * 16, kk, lane), dK[nb]);
     }
   }
+  // results through LDS ([row][channel] tiles over the transposed operands, which are dead now) so that every
+  // thread stores 16 bytes instead of 48 scattered 2-byte elements
+  __syncthreads();
+  bf16_t* oQ = sKt; bf16_t* oK = sQt; bf16_t* oV = sdOt;
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
     const int c = chan_of_phys(nb * 16 + (lane & 15));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = rloc + r;     // query row for dQ, key row for dK / dV
-      if (i < a.Lq) dq[((size_t)b * a.Lq + i) * lddq + h * AD + c] = f2bf(dQ[nb][r]);
-      if (i < a.Lk) {
-        dk[((size_t)b * a.Lk + i) * lddk + h * AD + c] = f2bf(dK[nb][r]);
-        dv[((size_t)b * a.Lk + i) * lddv + h * AD + c] = f2bf(dV[nb][r]);
-      }
+      oQ[i * ALD + c] = f2bf(dQ[nb][r]);
+      oK[i * ALD + c] = f2bf(dK[nb][r]);
+      oV[i * ALD + c] = f2bf(dV[nb][r]);
     }
   }
+  __syncthreads();
+  store_tile_rows(oQ, dq + (size_t)b * a.Lq * lddq + h * AD, lddq, a.Lq, tid);
+  store_tile_rows(oK, dk + (size_t)b * a.Lk * lddk + h * AD, lddk, a.Lk, tid);
+  store_tile_rows(oV, dv + (size_t)b * a.Lk * lddv + h * AD, lddv, a.Lk, tid);
 }
 
 // =====================================================================================
@@ -962,7 +1058,7 @@ int zk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* l
   a.kv_group = kv_group;
   a.pos_dev = pos_dev; a.pos_flags = pos_dev ? pos_flags : 0;
   a.gq = (const float*)rpr_gq; a.pb = (bf16_t*)rpr_pb; a.ldg = rpr_ldg; a.nrp = rpr_nrp;
-  const bool ok = attn_mfma_ok(a, ldo) && Lk <= 256 && (a.bsq % 8 == 0) && (a.bsk % 8 == 0) && (a.bsv % 8 == 0) && (((uintptr_t)out & 1) == 0);
+  const bool ok = attn_mfma_ok(a, ldo) && Lk <= 256 && (a.bsq % 8 == 0) && (a.bsk % 8 == 0) && (a.bsv % 8 == 0) && (((uintptr_t)out & 15) == 0);
   ZK_CHECK_ARG(impl != 2 || ok, "zk_attn_fwd: MFMA kernel needs d=64, no rpr, Lk<=256, ld%%8==0");
   if (impl == 2 || (impl == 0 && ok)) {
     dim3 grid((Lq + TQ - 1) / TQ, nh, B);
@@ -1010,7 +1106,8 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
   float* Dbuf = (float*)workspace;
   a.gq = (const float*)rpr_gq; a.gd = (const float*)rpr_gd; a.pb = (bf16_t*)rpr_pb; a.dsb = (bf16_t*)rpr_dsb;
   a.ldg = rpr_ldg; a.nrp = rpr_nrp;
-  const bool ok = attn_mfma_ok(a, ldo | lddo | lddq | lddk | lddv);
+  const bool ok = attn_mfma_ok(a, ldo | lddo | lddq | lddk | lddv) &&
+                  ((((uintptr_t)out | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0);   // 16-byte row accesses
   ZK_CHECK_ARG(rpr_gq == nullptr || (ok && impl != 1), "zk_attn_bwd: decomposed rpr runs on the MFMA kernels only");
   ZK_CHECK_ARG(impl != 2 || ok, "zk_attn_bwd: MFMA kernel needs d=64, no rpr, ld%%8==0");
   ZK_CHECK_ARG(impl != 3 || ok, "zk_attn_bwd: MFMA kernels need d=64, no rpr, ld%%8==0");
