@@ -99,62 +99,102 @@ __global__ void __launch_bounds__(256) k_beam_topk_rows(const float* __restrict_
 // block-wide arg-max rounds; within a row the order of the keys is the order of the final scores
 // ((prev + key - lse) / penalty is increasing in key), so nothing is lost before the merge.
 #define TOPK_CHUNK_MAX 8192
+// NV float4 of keys per thread, register-resident: element e of the chunk belongs to thread (e / 4) % 256, slot
+// (e / 1024) * 4 + e % 4, so a thread's slots are in increasing element order (ties must keep the lower index).
+// Timeline of the LDS version (s_memtime stamps, 4000-key chunks): 10 900 cycles of 4-byte loads, 8 arg-max rounds
+// of 3 600 cycles each -- dominated by the owner's 16 dependent LDS reads when it rescans its keys.
+template <int NV>
 __global__ void __launch_bounds__(256) k_beam_topk_chunks(const float* __restrict__ logits, float* __restrict__ part_ms,
                                                           float* __restrict__ cand_key, int* __restrict__ cand_v,
                                                           int V, int ld, int k2, int chunk, int nchunks,
                                                           float inv_temp, int forbid_id, float forbid_value,
                                                           const int* __restrict__ scal_dev) {
-  __shared__ float keys[TOPK_CHUNK_MAX];
   __shared__ float sm[8];
-  __shared__ float ws[4];
-  __shared__ int wi[4];
+  __shared__ float ws[8];
+  __shared__ int wi[8];
   const int row = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
   if (scal_dev != nullptr) forbid_id = scal_dev[1];
   const int v0 = c * chunk, n = max(0, min(chunk, V - v0));
   const float* z = logits + (size_t)row * ld + v0;
-  float m = -INFINITY;
-  for (int i = tid; i < n; i += 256) {
-    float key = z[i] * inv_temp;
-    m = fmaxf(m, key);                       // the EOS ban applies after the log-softmax (search.py:148-155)
-    keys[i] = key;
+  const bool vec = (((uintptr_t)z) & 15) == 0;
+  float key[NV * 4];
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int e = 4 * (tid + 256 * u);
+    if (vec && e + 3 < n) {
+      const float4 x = *reinterpret_cast<const float4*>(z + e);
+      key[u * 4 + 0] = x.x * inv_temp; key[u * 4 + 1] = x.y * inv_temp;
+      key[u * 4 + 2] = x.z * inv_temp; key[u * 4 + 3] = x.w * inv_temp;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) key[u * 4 + q] = (e + q < n) ? z[e + q] * inv_temp : -INFINITY;
+    }
   }
-  __syncthreads();
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NV * 4; ++i) m = fmaxf(m, key[i]);        // the EOS ban applies after the log-softmax (search.py:148-155)
   m = block_max<4>(m, sm);
   float s = 0.f;
-  for (int i = tid; i < n; i += 256) s += __expf(keys[i] - m);
+#pragma unroll
+  for (int u = 0; u < NV; ++u)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (4 * (tid + 256 * u) + q < n) s += __expf(key[u * 4 + q] - m);
   s = block_sum<4>(s, sm);
   if (tid == 0) {
     part_ms[((size_t)row * nchunks + c) * 2] = m;
     part_ms[((size_t)row * nchunks + c) * 2 + 1] = s;
   }
-  if (forbid_id >= v0 && forbid_id < v0 + n && tid == 0) keys[forbid_id - v0] -= forbid_value;
-  __syncthreads();
+  if (forbid_id >= v0 && forbid_id < v0 + n) {
+    const int e = forbid_id - v0;
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (4 * (tid + 256 * u) + q == e) key[u * 4 + q] -= forbid_value;
+  }
+  // k2 arg-max rounds over the per-thread bests; only the winner's owner rescans (registers)
+  float my_bs;
+  int my_bi;
+  auto rescan = [&]() {
+    my_bs = -INFINITY; my_bi = 0x7fffffff;
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (key[u * 4 + q] > my_bs) { my_bs = key[u * 4 + q]; my_bi = 4 * (tid + 256 * u) + q; }   // strict: ties keep the lower index
+  };
+  rescan();
   for (int r = 0; r < k2; ++r) {
-    float bs = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int i = tid; i < n; i += 256) {
-      const float key = keys[i];
-      if (key > bs) { bs = key; bi = i; }     // strict: ties keep the lower index (i increases)
-    }
+    float bs = my_bs;
+    int bi = my_bi;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float s2 = __shfl_xor(bs, o, 64);
       const int i2 = __shfl_xor(bi, o, 64);
       if (better(s2, i2, bs, bi)) { bs = s2; bi = i2; }
     }
-    if ((tid & 63) == 0) { ws[tid >> 6] = bs; wi[tid >> 6] = bi; }
+    float* wsr = ws + (r & 1) * 4;                    // double-buffered: one barrier per round
+    int* wir = wi + (r & 1) * 4;
+    if ((tid & 63) == 0) { wsr[tid >> 6] = bs; wir[tid >> 6] = bi; }
     __syncthreads();
-    bs = ws[0]; bi = wi[0];
+    bs = wsr[0]; bi = wir[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w)
-      if (better(ws[w], wi[w], bs, bi)) { bs = ws[w]; bi = wi[w]; }
+      if (better(wsr[w], wir[w], bs, bi)) { bs = wsr[w]; bi = wir[w]; }
     if (tid == 0) {
       const size_t o = ((size_t)row * nchunks + c) * k2 + r;
       cand_key[o] = bs;
       cand_v[o] = bi < n ? v0 + bi : 0x7fffffff;
-      if (bi < n) keys[bi] = -INFINITY;
     }
-    __syncthreads();
+    if (bi < n && ((bi >> 2) & 255) == tid) {
+#pragma unroll
+      for (int u = 0; u < NV; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (4 * (tid + 256 * u) + q == bi) key[u * 4 + q] = -INFINITY;
+      rescan();
+    }
   }
 }
 
@@ -310,7 +350,7 @@ extern "C" {
 static int topk_chunks(int K, int V, int k2) {
   int nc = 256 / (K * k2);                       // merge block: one candidate per thread
   if (nc > 8) nc = 8;
-  if (nc < 1 || (V + nc - 1) / nc > TOPK_CHUNK_MAX) return 0;   // fall back to one block per row
+  if (nc < 1 || (V + nc - 1) / nc + 3 > TOPK_CHUNK_MAX) return 0;   // fall back to one block per row
   return nc;
 }
 size_t zk_beam_topk_workspace(int B, int K, int k2) { return (size_t)B * K * (8 * k2 * 8 + 8 * 8); }
@@ -324,12 +364,16 @@ int zk_beam_topk(const float* logits, const float* prev_log_probs, float* topk_s
   if (B == 0) return 0;
   const int nc = topk_chunks(K, V, k2);
   if (nc > 0) {
-    const int chunk = (V + nc - 1) / nc;
+    const int chunk = ((V + nc - 1) / nc + 3) & ~3;       // multiple of 4: every chunk starts 16-byte aligned
     float* part = (float*)workspace;
     float* ck = part + (size_t)B * K * nc * 2;
     int* cv = (int*)(ck + (size_t)B * K * nc * k2);
-    hipLaunchKernelGGL(k_beam_topk_chunks, dim3(B * K, nc), dim3(256), 0, stream, logits, part, ck, cv, V, ld, k2,
-                       chunk, nc, 1.f / temperature, forbid_id, forbid_value, scal_dev);
+    if (chunk <= 4096)
+      hipLaunchKernelGGL(k_beam_topk_chunks<4>, dim3(B * K, nc), dim3(256), 0, stream, logits, part, ck, cv, V, ld, k2,
+                         chunk, nc, 1.f / temperature, forbid_id, forbid_value, scal_dev);
+    else
+      hipLaunchKernelGGL(k_beam_topk_chunks<8>, dim3(B * K, nc), dim3(256), 0, stream, logits, part, ck, cv, V, ld, k2,
+                         chunk, nc, 1.f / temperature, forbid_id, forbid_value, scal_dev);
     ZK_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_beam_topk_merge_chunks, dim3(B), dim3(256), 0, stream, (const float*)part, (const float*)ck,
                        (const int*)cv, prev_log_probs, topk_scores, topk_index, K, V, k2, nc, length_penalty,
@@ -491,62 +535,66 @@ __device__ inline void dev_top_k(const float* x, int n, int k, int* idx) {
   }
 }
 
-// one block per sentence; dynamic LDS: 2 * K * Tcap ints (the sentence's alive and finished rows)
+// one block per sentence; dynamic LDS: 2 * K * Tcap ints (the sentence's alive and finished rows).
+// The candidate fields are loaded and derived by 2K threads in parallel and the per-beam results written by K
+// threads; only the two top-k selections (at most 16 of 48 values) run on one thread.
 __global__ void __launch_bounds__(128) k_beam_advance(BeamDev d) {
   extern __shared__ int s_rows[];
-  __shared__ int s_beam[32], s_cur[32], s_aidx[16], s_fidx[16];
+  __shared__ int s_beam[32], s_cur[32], s_cfin[32], s_aidx[16], s_fidx[16], s_allfl[48];
+  __shared__ float s_masked[32], s_allsc[48];
   if (d.ctrl[1]) return;
-  const int b = blockIdx.x, K = d.K, K2 = 2 * d.K, Tcap = d.Tcap;
+  const int b = blockIdx.x, K = d.K, K2 = 2 * d.K, Tcap = d.Tcap, tid = threadIdx.x;
   const int time = d.stepbuf[0], len = time + 1;
   int* sq = d.seq + (size_t)b * K * Tcap;
   int* fs = d.fin_seq + (size_t)b * K * Tcap;
   int* l_seq = s_rows;
   int* l_fin = s_rows + K * Tcap;
-  for (int i = threadIdx.x; i < K * len; i += blockDim.x) {
+  if (tid < K2) {                                          // candidates (search.py:168-190)
+    const float ts = d.topk_scores[(size_t)b * K2 + tid];
+    const int ti = d.topk_idx[(size_t)b * K2 + tid];
+    const int cur = ti % d.V;
+    const bool fin = (cur == d.eos_id) || (time >= d.mtl_i[b]);
+    s_beam[tid] = ti / d.V; s_cur[tid] = cur; s_cfin[tid] = fin;
+    s_masked[tid] = ts + (fin ? 1.f : 0.f) * ZK_F32MIN;
+    s_allsc[K + tid] = ts + (1.f - (fin ? 1.f : 0.f)) * ZK_F32MIN;
+    s_allfl[K + tid] = fin;
+  } else if (tid >= 64 && tid < 64 + K) {                  // previous finished set
+    s_allsc[tid - 64] = d.fin_scores[b * K + tid - 64];
+    s_allfl[tid - 64] = d.fin_flags[b * K + tid - 64];
+  }
+  for (int i = tid; i < K * len; i += blockDim.x) {
     const int k = i / len, t = i - k * len;
     l_seq[k * Tcap + t] = sq[k * Tcap + t];
     l_fin[k * Tcap + t] = fs[k * Tcap + t];
   }
-  if (threadIdx.x == 0) {
-    const float penalty = __int_as_float(d.stepbuf[1]);
-    const float* ts = d.topk_scores + (size_t)b * K2;
-    const int* ti = d.topk_idx + (size_t)b * K2;
-    float masked[32], allsc[48];
-    int allfl[48], cfin[32], aidx[16], fidx[16];
-    const bool at_cap = time >= d.mtl_i[b];
-    for (int c = 0; c < K2; ++c) {
-      const int beam = ti[c] / d.V, cur = ti[c] % d.V;
-      s_beam[c] = beam; s_cur[c] = cur;
-      cfin[c] = (cur == d.eos_id) || at_cap;
-      masked[c] = ts[c] + (cfin[c] ? 1.f : 0.f) * ZK_F32MIN;
-    }
-    dev_top_k(masked, K2, K, aidx);                       // alive (search.py:192-210)
-    for (int k = 0; k < K; ++k) {
-      const int c = aidx[k];
-      s_aidx[k] = c;
-      d.scores[b * K + k] = masked[c];
-      const float lp = masked[c] * penalty;
-      d.log_probs[b * K + k] = lp;
-      d.prev[b * K + k] = lp;
-      d.flat_idx[b * K + k] = b * K + s_beam[c];
-      d.next_tok[b * K + k] = s_cur[c];
-    }
-    for (int k = 0; k < K; ++k) { allsc[k] = d.fin_scores[b * K + k]; allfl[k] = d.fin_flags[b * K + k]; }
-    for (int c = 0; c < K2; ++c) {                        // finished (search.py:212-228)
-      allsc[K + c] = ts[c] + (1.f - (cfin[c] ? 1.f : 0.f)) * ZK_F32MIN;
-      allfl[K + c] = cfin[c];
-    }
-    dev_top_k(allsc, K + K2, K, fidx);
-    for (int k = 0; k < K; ++k) {
-      const int j = fidx[k];
-      s_fidx[k] = j;
-      masked[k] = allsc[j];
-      cfin[k] = allfl[j];
-    }
-    for (int k = 0; k < K; ++k) { d.fin_scores[b * K + k] = masked[k]; d.fin_flags[b * K + k] = cfin[k]; }
+  __syncthreads();
+  if (tid == 0) {                                          // alive (search.py:192-210)
+    float x[32]; int idx[16];
+    for (int c = 0; c < K2; ++c) x[c] = s_masked[c];
+    dev_top_k(x, K2, K, idx);
+    for (int k = 0; k < K; ++k) s_aidx[k] = idx[k];
+  } else if (tid == 64) {                                  // finished (search.py:212-228): previous K | 2K candidates
+    float x[48]; int idx[16];
+    for (int c = 0; c < K + K2; ++c) x[c] = s_allsc[c];
+    dev_top_k(x, K + K2, K, idx);
+    for (int k = 0; k < K; ++k) s_fidx[k] = idx[k];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < K * (len + 1); i += blockDim.x) {
+  if (tid < K) {
+    const int c = s_aidx[tid];
+    const float penalty = __int_as_float(d.stepbuf[1]);
+    d.scores[b * K + tid] = s_masked[c];
+    const float lp = s_masked[c] * penalty;
+    d.log_probs[b * K + tid] = lp;
+    d.prev[b * K + tid] = lp;
+    d.flat_idx[b * K + tid] = b * K + s_beam[c];
+    d.next_tok[b * K + tid] = s_cur[c];
+  } else if (tid >= 64 && tid < 64 + K) {
+    const int j = s_fidx[tid - 64];
+    d.fin_scores[b * K + tid - 64] = s_allsc[j];
+    d.fin_flags[b * K + tid - 64] = s_allfl[j];
+  }
+  for (int i = tid; i < K * (len + 1); i += blockDim.x) {
     const int k = i / (len + 1), t = i - k * (len + 1);
     const int c = s_aidx[k];
     sq[k * Tcap + t] = t < len ? l_seq[s_beam[c] * Tcap + t] : s_cur[c];
