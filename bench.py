@@ -80,7 +80,7 @@ class GemmProfiler(object):
     def __init__(self, engine):
         self.eng = engine
         self.records = []
-        self._gemm, self._grouped = engine.gemm, engine.gemm_grouped
+        self._gemm, self._grouped, self._kseg = engine.gemm, engine.gemm_grouped, engine.gemm_kseg
 
     def _name(self, M, N, K, ta, tb, out_f32, plain):
         code = self.eng.lib.raw("zk_gemm_plan")(M, N, K, out_f32, plain)
@@ -111,11 +111,18 @@ class GemmProfiler(object):
             self._grouped(problems, ta, tb, tile=tile)
             e.record()
             self.records.append((name, sum(2.0 * p[3] * p[4] * p[5] for p in problems), s, e))
-        self.eng.gemm, self.eng.gemm_grouped = timed, timed_grouped
+        def timed_kseg(segments, C, M, N, kseg, tb, residual=None):
+            name = "k_gemm_kseg<64, 64, 4, %s, 4>" % ("true" if tb else "false")
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            self._kseg(segments, C, M, N, kseg, tb, residual=residual)
+            e.record()
+            self.records.append((name, 2.0 * M * N * kseg * len(segments), s, e))
+        self.eng.gemm, self.eng.gemm_grouped, self.eng.gemm_kseg = timed, timed_grouped, timed_kseg
         return self
 
     def __exit__(self, *a):
-        self.eng.gemm, self.eng.gemm_grouped = self._gemm, self._grouped
+        self.eng.gemm, self.eng.gemm_grouped, self.eng.gemm_kseg = self._gemm, self._grouped, self._kseg
 
     def calibrate(self):
         """Cost of one event pair itself: brackets around 1 and around 33 one-thread kernels,

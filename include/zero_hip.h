@@ -47,6 +47,13 @@ size_t zk_gemm_workspace(int M, int N, int K);
 size_t zk_gemm_workspace_split(int M, int N, int splits);
 int zk_gemm_plan(int M, int N, int K, int out_f32, int plain);  /* gen | bm<<8 | bn<<16 | splits<<24 | producer waves<<28 chosen by impl=0 */
 int zk_gemm_set_generation(int gen);   /* 1 = register-staged kernel, 2 = LDS-DMA ring kernel (default) */
+/* K-segmented GEMM: C bf16 [M, ldc] = sum_s A_s [M, kseg] x B_s (+ bf16 residual, may alias C) in ONE launch --
+   gradient contributions that the reference accumulates with add_n over the users of a tensor (the encoder
+   output feeds the cross-attention K / V projections of every decoder layer, transformer.py:120-160).
+   a_segs / b_segs: host arrays of nseg (<= 16) device pointers, all segments share lda / ldb;
+   tb = 1: B_s is [N, ldb] with K contiguous, tb = 0: [kseg, ldb].  kseg % 64 == 0. */
+int zk_gemm_kseg(const void* const* a_segs, const void* const* b_segs, int nseg, int kseg, void* C, int M, int N,
+                 int lda, int ldb, int ldc, int tb, const void* residual, int ldr, zk_stream_t stream);
 int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
             int ta, int tb, int out_f32, float alpha, const float* bias, const void* residual, int ldr,
             int act, const void* aux, int ldaux, float aux_scale, float drop_p, const uint64_t* seed,

@@ -763,6 +763,29 @@ def test_gemm_producer_wave_workgroups(tile, tune, ta, tb):
         e.lib.raw("zk_tune")(6, old)
 
 
+@pytest.mark.parametrize("tb", [0, 1])
+@pytest.mark.parametrize("shape", [(4096, 512, 512, 12), (200, 264, 128, 3), (72, 40, 64, 1), (130, 512, 192, 16)])
+def test_gemm_k_segmented(tb, shape):
+    """zk_gemm_kseg: C = sum_s A_s B_s with every segment its own matrix, against the fp32 sum of products;
+    with and without the residual (which may alias C)."""
+    e = eng()
+    M, N, kseg, nseg = shape
+    A = [rand_bf(M, kseg, seed=10 + i) for i in range(nseg)]
+    Bm = [rand_bf(*((N, kseg) if tb else (kseg, N)), seed=40 + i) for i in range(nseg)]
+    C = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    e.gemm_kseg([(mat(a), mat(b)) for a, b in zip(A, Bm)], mat(C), M, N, kseg, tb)
+    torch.cuda.synchronize()
+    ref = sum(a.float() @ (b.float().t() if tb else b.float()) for a, b in zip(A, Bm))
+    assert rel_err(C, ref) < 8e-3
+    R = rand_bf(M, N, seed=99)
+    C2 = R.clone()
+    e.gemm_kseg([(mat(a), mat(b)) for a, b in zip(A, Bm)], mat(C2), M, N, kseg, tb, residual=mat(C2))
+    torch.cuda.synchronize()
+    assert rel_err(C2, ref + R.float()) < 8e-3
+    with pytest.raises(hip.ZeroHipError):
+        e.gemm_kseg([(mat(A[0]), mat(Bm[0]))] * 17, mat(C), M, N, kseg, tb)
+
+
 def test_gemm_plan_reports_producer_waves():
     """zk_gemm_plan labels the instance that runs: bits [30:28] carry the producer waves of the tile class."""
     e = eng()

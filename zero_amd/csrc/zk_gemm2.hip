@@ -146,6 +146,16 @@ struct DldsCfg {
   static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
 };
 
+// K-segmented GEMM: C = sum_s A_s B_s with every A_s / B_s its own matrix (same shape and leading dimension), e.g.
+// the gradient of the encoder output, which every decoder layer's cross-attention K and V projection feeds
+// (12 segments of K = 512 in one launch instead of 12 dependent GEMMs accumulating in place).
+#define ZK_KSEG_MAX 16
+struct KSegDesc {
+  const bf16_t* A[ZK_KSEG_MAX];
+  const bf16_t* B[ZK_KSEG_MAX];
+  int nseg, tps;               // segments, 64-deep K tiles per segment
+};
+
 // NW compute waves per workgroup: 4 (2 x 2 over the tile), 2 (2 x 1: each wave a BM/2 x BN slab) or 8 (4 x 2: the
 // 256x128 macro tile -- 25 % fewer L1->LDS bytes and DMA issues per MFMA than two 128x128 tiles).
 // PW > 0: PW extra PRODUCER waves (wave index >= NW) issue every LDS-DMA of the workgroup and the NW compute
@@ -154,10 +164,10 @@ struct DldsCfg {
 // DMA-issue time and the MFMA time of a K step add up inside a workgroup; with producer waves they overlap.
 // K loop of one BMxBN tile over k in [kbeg, kend); leaves the fp32 tile in LDS (sC[BM][CLD], smem reused)
 // behind a workgroup barrier, ready for a row-wise epilogue.
-template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0>
+template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0, bool KSEG = false>
 __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16_t* __restrict__ A,
                                                  const bf16_t* __restrict__ B, int M, int N, int lda, int ldb,
-                                                 int kbeg, int kend, int m0, int n0) {
+                                                 int kbeg, int kend, int m0, int n0, const KSegDesc* ks = nullptr) {
   constexpr int NWM = NW == 8 ? 4 : 2, NWN = NW / NWM;       // wave grid over the tile: 2x2, 2x1 or 4x2
   constexpr int WTM = BM / NWM, WTN = BN / NWN, TM = WTM / 32, TN = WTN / 32;
   constexpr int STAGE = DldsCfg<BM, BN, NS>::STAGE;
@@ -184,15 +194,29 @@ __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16
 
   DmaPlan<BM, NDW> planA;
   DmaPlan<BN, NDW> planB;
-  if (PW == 0 || producer) {
+  if (!KSEG && (PW == 0 || producer)) {
     dma_plan<BM, TA, NDW>(planA, A, lda, m0, M, kbeg, dwave, lane);
     dma_plan<BN, !TB, NDW>(planB, B, ldb, n0, N, kbeg, dwave, lane);
   }
+  [[maybe_unused]] int seg_left = 0, seg_id = 0;   // KSEG: K tiles left in the current segment, next segment
   const int klen = kend - kbeg;
   const size_t stepA = TA ? (size_t)64 * lda : (size_t)64;
   const size_t stepB = !TB ? (size_t)64 * ldb : (size_t)64;
   const uint32_t ring_addr = lds_addr(ring);
   auto issue = [&](int t) {
+    if (KSEG) {                                   // tiles are issued in order: re-plan at every segment start
+      if (seg_left == 0) {
+        if (seg_id < ks->nseg) {
+          dma_plan<BM, TA, NDW>(planA, ks->A[seg_id], lda, m0, M, 0, dwave, lane);
+          dma_plan<BN, !TB, NDW>(planB, ks->B[seg_id], ldb, n0, N, 0, dwave, lane);
+          ++seg_id;
+          seg_left = ks->tps;
+        } else {
+          seg_left = 0x40000000;                  // past the last segment: only all-zero tail pieces follow
+        }
+      }
+      --seg_left;
+    }
     const uint32_t st = ring_addr + (uint32_t)((t % NS) * STAGE * 2);
     if (t * 64 + 64 <= klen) {
       dma_tile<BM, TA, false, NDW>(planA, stepA, t, klen, st, dwave);
@@ -300,12 +324,12 @@ __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16
 }
 
 // one BMxBN output tile over k in [kbeg, kend); slab != null: write the fp32 partial tile there
-template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0>
+template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0, bool KSEG = false>
 __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __restrict__ A,
                                           const bf16_t* __restrict__ B, int M, int N, int lda, int ldb, int kbeg,
                                           int kend, int m0, int n0, float* __restrict__ slab, const GemmEpi& e,
-                                          int vec_ok) {
-  gemm_tile_to_lds<BM, BN, NS, TA, TB, NW, PW>(smem, A, B, M, N, lda, ldb, kbeg, kend, m0, n0);
+                                          int vec_ok, const KSegDesc* ks = nullptr) {
+  gemm_tile_to_lds<BM, BN, NS, TA, TB, NW, PW, KSEG>(smem, A, B, M, N, lda, ldb, kbeg, kend, m0, n0, ks);
   constexpr int CLD = DldsCfg<BM, BN, NS>::CLD;
   constexpr int NT = (NW + PW) * 64;
   const int tid = threadIdx.x;
@@ -461,6 +485,16 @@ __global__ void __launch_bounds__((NW + PW) * 64) k_gemm_dlds(const bf16_t* __re
                                     slabs ? slabs + (size_t)z_ * M * N : nullptr, e, ev.vec_ok);
   __builtin_amdgcn_sched_barrier(0);
   ZK_E(4);
+}
+
+template <int BM, int BN, int NS, bool TB, int PW>
+__global__ void __launch_bounds__((4 + PW) * 64) k_gemm_kseg(KSegDesc ks, int M, int N, int lda, int ldb, TileSched ts,
+                                                             GemmEpi e, EpiVec ev) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DldsCfg<BM, BN, NS>::LDS_BYTES];
+  int tm_, tn_, z_;
+  tile_of_block(ts, tm_, tn_, z_);
+  gemm_tile<BM, BN, NS, false, TB, 4, PW, true>(smem, nullptr, nullptr, M, N, lda, ldb, 0, ks.nseg * ks.tps * 64,
+                                                tm_ * BM, tn_ * BN, nullptr, e, ev.vec_ok, &ks);
 }
 
 // Grouped launch: many independent GEMMs (same transposition flags) in ONE grid -- the deferred
@@ -640,6 +674,42 @@ int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int t
   ZK_LAUNCH_CHECK();
   return 0;
 }
+// C bf16 [M, ldc] = sum_s A_s [M, kseg] (lda) x B_s (+ residual bf16 [M, ldr], may alias C).
+//   tb = 1: B_s is [N, ldb] with K contiguous (dgrad through W stored [in, out]);  tb = 0: B_s is [kseg, ldb].
+// a_segs / b_segs: HOST arrays of nseg (<= 16) device pointers; kseg a multiple of 64; 16-byte aligned operands,
+// leading dimensions multiples of 8.
+int zk_gemm_kseg(const void* const* a_segs, const void* const* b_segs, int nseg, int kseg, void* C, int M, int N,
+                 int lda, int ldb, int ldc, int tb, const void* residual, int ldr, hipStream_t stream) {
+  ZK_CHECK_ARG(nseg >= 1 && nseg <= ZK_KSEG_MAX, "zk_gemm_kseg: nseg=%d out of range (<= %d)", nseg, ZK_KSEG_MAX);
+  ZK_CHECK_ARG(kseg >= 64 && kseg % 64 == 0, "zk_gemm_kseg: kseg=%d must be a positive multiple of 64", kseg);
+  ZK_CHECK_ARG(M >= 0 && N >= 1 && C != nullptr, "zk_gemm_kseg: bad output");
+  ZK_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && (residual == nullptr || ldr % 8 == 0) && (tb || N % 8 == 0),
+               "zk_gemm_kseg: leading dimensions must be multiples of 8");
+  if (M == 0) return 0;
+  KSegDesc ks;
+  uintptr_t al = (uintptr_t)C | (uintptr_t)residual;
+  for (int i = 0; i < nseg; ++i) {
+    ks.A[i] = (const bf16_t*)a_segs[i]; ks.B[i] = (const bf16_t*)b_segs[i];
+    ZK_CHECK_ARG(a_segs[i] != nullptr && b_segs[i] != nullptr, "zk_gemm_kseg: null segment %d", i);
+    al |= (uintptr_t)a_segs[i] | (uintptr_t)b_segs[i];
+  }
+  ZK_CHECK_ARG((al & 15) == 0, "zk_gemm_kseg: operands must be 16-byte aligned");
+  for (int i = nseg; i < ZK_KSEG_MAX; ++i) { ks.A[i] = ks.A[0]; ks.B[i] = ks.B[0]; }
+  ks.nseg = nseg; ks.tps = kseg / 64;
+  GemmEpi e;
+  e.C = C; e.ldc = ldc; e.out_f32 = 0; e.alpha = 1.f; e.bias = nullptr; e.res = (const bf16_t*)residual; e.ldr = ldr;
+  e.act = 0; e.aux = nullptr; e.ldaux = 0; e.aux_scale = 1.f; e.thr = 0; e.inv_keep = 1.f; e.seed = nullptr; e.sid = 0;
+  TileSched ts;
+  ts.tiles_m = (M + 63) / 64; ts.tiles_n = (N + 63) / 64; ts.n_major = ((long)N > (long)M) ? 1 : 0; ts.xcd_remap = 1;
+  EpiVec ev;
+  ev.vec_ok = 1;
+  dim3 grid((unsigned)((long)ts.tiles_m * ts.tiles_n));
+  if (tb) hipLaunchKernelGGL((k_gemm_kseg<64, 64, 4, true, 4>), grid, dim3(512), 0, stream, ks, M, N, lda, ldb, ts, e, ev);
+  else hipLaunchKernelGGL((k_gemm_kseg<64, 64, 4, false, 4>), grid, dim3(512), 0, stream, ks, M, N, lda, ldb, ts, e, ev);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
 static int ce_check(const void* feat, const void* E, int T, int V, int K, int ldf, int lde) {
   ZK_CHECK_ARG(T >= 0 && V >= 1 && K >= 8, "zk_logits_ce: bad dims T=%d V=%d K=%d", T, V, K);
   ZK_CHECK_ARG(K % 8 == 0 && ldf % 8 == 0 && lde % 8 == 0, "zk_logits_ce: K, ldf, lde must be multiples of 8");

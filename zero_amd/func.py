@@ -159,6 +159,18 @@ class Engine(object):
             float(drop_p), self.seed.data_ptr(), sid,
             self.gemm_impl if impl is None else impl, ws.data_ptr(), ws.numel(), self.stream)
 
+    def gemm_kseg(self, segments, C, M, N, kseg, tb, residual=None):
+        """C = sum over (A_s, B_s) in segments of A_s @ B_s (B_s transposed when tb) in one launch
+        (zk_gemm_kseg).  All A_s share a leading dimension, all B_s too."""
+        n = len(segments)
+        a = (ctypes.c_void_p * n)(*[s[0].ptr for s in segments])
+        b = (ctypes.c_void_p * n)(*[s[1].ptr for s in segments])
+        lda, ldb = segments[0][0].ld, segments[0][1].ld
+        assert all(s[0].ld == lda and s[1].ld == ldb for s in segments)
+        self.lib.call("zk_gemm_kseg", a, b, n, kseg, C.ptr, M, N, lda, ldb, C.ld, tb,
+                      residual.ptr if residual is not None else None, residual.ld if residual is not None else 0,
+                      self.stream)
+
     def gemm_grouped(self, problems, ta, tb, tile=128):
         """One launch for many independent GEMMs with the same ta/tb.
         problems: list of (A, B, C, M, N, K, bias-or-None[, residual Mat-or-None]) with Mat operands.

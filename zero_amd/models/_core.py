@@ -83,6 +83,9 @@ class TransformerCore(object):
         self._pending_colsums = []     # (dY Mat, bias-gradient view, private partial buffer)
         self._pending_lnred = []       # (partials, rows, H, dgamma, dbeta, dbias_prev)
         self._pending_adds = []        # (fp32 gradient view, fp32 temporary): dst += src after the flush
+        self._mem_segs = []            # (dK or dV, W) pairs of the cross-attention memory side (see _finish_mem_grad)
+        # encoder-output gradient by one K-segmented GEMM (needs the MFMA path: H a multiple of 64, aligned rows)
+        self.kseg_mem = os.environ.get("ZERO_HIP_KSEG_MEM", "1") != "0"
         # fused logits + cross entropy (no [T, V] fp32 logits in HBM, recompute in the backward): measured
         # 224 + 8 us forward and 287 us backward against 291 + 208 us for GEMM + k_ce_fused -- the second
         # pass over the 137-GFLOP GEMM costs what the saved 1 GB of traffic buys, so it is opt-in (it frees
@@ -117,6 +120,19 @@ class TransformerCore(object):
             adds = self._pending_adds
             self._pending_adds = []
             self._side(lambda: [self._accumulate(dst, src) for dst, src in adds])
+
+    def _use_kseg(self):
+        return self.kseg_mem and self.H % 64 == 0 and self.eng.gemm_impl == 0
+
+    def _finish_mem_grad(self, d_mem):
+        """d_mem = sum over decoder layers of dK_l W_k,l^T + dV_l W_v,l^T: one zk_gemm_kseg launch per 16 segments
+        (12 segments of K = H for six layers) instead of a chain of 2 L in-place GEMMs."""
+        segs, self._mem_segs = self._mem_segs, []
+        first = True
+        for i in range(0, len(segs), 16):
+            self.eng.gemm_kseg(segs[i:i + 16], d_mem, d_mem.rows, self.H, self.H, 1,
+                               residual=None if first else d_mem)
+            first = False
 
     def _accumulate(self, dst, src):
         """dst += src (fp32 gradient views of equal size)."""
@@ -371,9 +387,17 @@ class TransformerCore(object):
                    drpr_v=self.gb(p + "rpr_values/embeddings") if self.rpr else None,
                    max_rel=hp.max_relative_position, drop_p=hp.attention_dropout, sid=sid0)
         self._linear_bwd(x_in, dq, p + "q_map", dx=dx_out, residual=ds)
-        # memory side: gradients of all decoder layers accumulate in d_mem (in place)
-        self._linear_bwd(mem, dkv.cols_slice(0, H), p + "k_map", dx=d_mem, residual=d_mem)
-        self._linear_bwd(mem, dkv.cols_slice(H, 2 * H), p + "v_map", dx=d_mem, residual=d_mem)
+        # memory side: the gradients of all decoder layers add up in d_mem.  Default: every layer only records its
+        # (dK, W_k) / (dV, W_v) pair and ONE K-segmented GEMM sums them after the decoder (see _finish_mem_grad);
+        # otherwise each layer accumulates in place.
+        if self._use_kseg():
+            self._linear_bwd(mem, dkv.cols_slice(0, H), p + "k_map")
+            self._linear_bwd(mem, dkv.cols_slice(H, 2 * H), p + "v_map")
+            self._mem_segs += [(dkv.cols_slice(0, H), self.W(p + "k_map/W_0_0")),
+                               (dkv.cols_slice(H, 2 * H), self.W(p + "v_map/W_0_0"))]
+        else:
+            self._linear_bwd(mem, dkv.cols_slice(0, H), p + "k_map", dx=d_mem, residual=d_mem)
+            self._linear_bwd(mem, dkv.cols_slice(H, 2 * H), p + "v_map", dx=d_mem, residual=d_mem)
         if fuse_tmask is not None:
             # query side of the shared v_map: transpose of the averaging, then dgrad into dx and
             # wgrad / bias-grad ADDED to what the memory side wrote
@@ -578,7 +602,8 @@ class TransformerCore(object):
         else:
             self._side(lambda: e.gemm(dlogits, feat, gE, self.Vpad, H, Tt, 1, 0))
         d_enc = e.mat("g.denc", Ts, H)
-        e.zero(d_enc.t)
+        if not self._use_kseg():
+            e.zero(d_enc.t)
         NE = hp.num_encoder_layer
 
         def layer_input(side, l, kind):
@@ -631,6 +656,8 @@ class TransformerCore(object):
             self._side(lambda: on_ready(self.soft_emb))
         if self.tgt_emb != self.soft_emb and self.tgt_emb != self.src_emb:
             self._side(lambda: on_ready(self.tgt_emb))
+        if self._use_kseg():
+            self._finish_mem_grad(d_enc)
         # encoder
         Q = [d_enc, e.mat("ge.p1", Ts, H)]
         cur = 0
