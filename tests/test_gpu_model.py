@@ -311,7 +311,7 @@ def test_device_resident_search_equals_host_bookkeeping(model, K, monkeypatch):
     outs = {}
     for name, env in (("numpy", {"ZERO_HIP_DECODE_HOST_C": "0"}),
                       ("host_c", {"ZERO_HIP_DECODE_DEVICE_BOOK": "0"}),
-                      ("dev1", {"ZERO_HIP_DECODE_POLL": "1"}), ("dev4", {}), ("dev7", {"ZERO_HIP_DECODE_POLL": "7"})):
+                      ("dev_default", {}), ("dev4", {"ZERO_HIP_DECODE_POLL": "4"}), ("dev7", {"ZERO_HIP_DECODE_POLL": "7"})):
         for k in ("ZERO_HIP_DECODE_HOST_C", "ZERO_HIP_DECODE_DEVICE_BOOK", "ZERO_HIP_DECODE_POLL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -322,7 +322,7 @@ def test_device_resident_search_equals_host_bookkeeping(model, K, monkeypatch):
         outs[name] = search.beam_search({"source": src}, enc, dec, hp)
     ref = outs["host_c"]
     assert ref["steps"] > 2
-    for name in ("numpy", "dev1", "dev4", "dev7"):
+    for name in ("numpy", "dev_default", "dev4", "dev7"):
         o = outs[name]
         assert o["steps"] == ref["steps"], (name, o["steps"], ref["steps"])
         assert np.array_equal(o["seq"], ref["seq"]), name
