@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <vector>
 
-__global__ void __launch_bounds__(64) k_barrier(int* cnt, unsigned long long* out, int iters, int groups, int* xcc_ids) {
+__global__ void __launch_bounds__(512) k_barrier(int* cnt, unsigned long long* out, int iters, int groups, int* xcc_ids) {
+  extern __shared__ int lds_pad[];                           // occupies LDS like a GEMM workgroup would
+  if (threadIdx.x == 0) lds_pad[0] = 0;
   const int g = blockIdx.x % groups, gsize = gridDim.x / groups;
   if (threadIdx.x == 0) {
     unsigned xcc;
@@ -31,21 +33,26 @@ __global__ void __launch_bounds__(64) k_barrier(int* cnt, unsigned long long* ou
 int main() {
   setvbuf(stdout, nullptr, _IONBF, 0);
   int* cnt; unsigned long long* out; int* xcc;
-  if (hipMalloc(&cnt, 8 * 64 * 4) != hipSuccess || hipMalloc(&out, 256 * 8) != hipSuccess || hipMalloc(&xcc, 256 * 4) != hipSuccess) return 1;
+  if (hipMalloc(&cnt, 8 * 64 * 4) != hipSuccess || hipMalloc(&out, 512 * 8) != hipSuccess || hipMalloc(&xcc, 512 * 4) != hipSuccess) return 1;
   const int iters = 200;
-  for (int groups : {1, 8}) {
-    for (int rep = 0; rep < 2; ++rep) {
-      (void)hipMemset(cnt, 0, 8 * 64 * 4);
-      hipLaunchKernelGGL(k_barrier, dim3(256), dim3(64), 0, 0, cnt, out, iters, groups, xcc);
-      (void)hipDeviceSynchronize();
+  // (workgroups, threads, dynamic LDS bytes): one 64-thread workgroup per CU; two 512-thread, 64-KiB workgroups per CU
+  const int cfg[2][3] = {{256, 64, 0}, {512, 512, 65536}};
+  for (int c = 0; c < 2; ++c) {
+    const int nwg = cfg[c][0];
+    for (int groups : {1, 8}) {
+      for (int rep = 0; rep < 2; ++rep) {
+        (void)hipMemset(cnt, 0, 8 * 64 * 4);
+        hipLaunchKernelGGL(k_barrier, dim3(nwg), dim3(cfg[c][1]), cfg[c][2], 0, cnt, out, iters, groups, xcc);
+        (void)hipDeviceSynchronize();
+      }
+      std::vector<unsigned long long> h(nwg); std::vector<int> x(nwg);
+      (void)hipMemcpy(h.data(), out, nwg * 8, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(x.data(), xcc, nwg * 4, hipMemcpyDeviceToHost);
+      double a = 0; for (auto v : h) a += v; a /= nwg;
+      int match = 0; for (int b = 0; b < nwg; ++b) match += (x[b] == b % 8);
+      printf("%d workgroups x %d threads, %d group(s) of %3d: %.0f cycles per barrier (%.2f us at 2.4 GHz); blockIdx %% 8 == XCC_ID for %d of %d\n",
+             nwg, cfg[c][1], groups, nwg / groups, a / iters, a / iters / 2400.0, match, nwg);
     }
-    std::vector<unsigned long long> h(256); std::vector<int> x(256);
-    (void)hipMemcpy(h.data(), out, 256 * 8, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(x.data(), xcc, 256 * 4, hipMemcpyDeviceToHost);
-    double a = 0; for (auto v : h) a += v; a /= 256;
-    int match = 0; for (int b = 0; b < 256; ++b) match += (x[b] == b % 8);
-    printf("%d group(s) of %3d workgroups: %.0f cycles per barrier (%.2f us at 2.4 GHz); blockIdx %% 8 == XCC_ID for %d of 256 workgroups\n",
-           groups, 256 / groups, a / iters, a / iters / 2400.0, match);
   }
   return 0;
 }
