@@ -337,3 +337,24 @@ def test_checkpoint_averaging(tmp_path):
     assert np.allclose(bundle.load_checkpoint(str(tmp_path / "avg2" / "average-0"))["s/w"], 25.0)
     with pytest.raises(ValueError):
         ca.get_checkpoints(str(tmp_path / "nowhere"))
+
+
+def test_vocab_and_vocabulary_preparation_match_the_reference(tmp_path):
+    """vocab.py: the preparation tool (count, sort by falling frequency with first-seen ties, cut to --size), loading,
+    to_id / to_tokens incl. unknown tokens and out-of-range ids, reserved ids -- against outputs of the reference's
+    own module on seeded corpora (tests/golden/reference_vocab.json, made by tests/golden/make_vocab_golden.py)."""
+    import json
+    from zero_amd.vocab import Vocab, main as vocab_main
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vocab.json")))["cases"]
+    assert len(cases) >= 6
+    for i, c in enumerate(cases):
+        src, out = tmp_path / ("corpus%d.txt" % i), tmp_path / ("vocab%d.txt" % i)
+        src.write_text("\n".join(c["corpus"]) + ("\n" if c["corpus"] else ""))
+        argv = [str(src), str(out)] + ([] if c["size"] >= 1e6 else ["--size", str(int(c["size"]))])
+        vocab_main(argv)
+        assert out.read_text() == c["vocab_file"], i
+        v = Vocab(str(out))
+        assert v.size() == c["loaded_size"]
+        assert v.to_id(c["probe"]) == c["to_id"] and v.to_id(c["probe"], append_eos=False) == c["to_id_no_eos"]
+        assert v.to_tokens(c["ids"]) == c["to_tokens"]
+        assert (v.eos(), v.pad()) == (c["eos"], c["pad"]) == (2, 0)
