@@ -201,14 +201,27 @@ int zk_aan_gate_bwd(const void* dg, const void* z, const void* cat, void* dz, vo
 
 /* ---- utils/cycle.py:86-101 + tf.train.AdamOptimizer (main.py:178-181) on flat buffers.
  * hyper (device fp32[12]): lr_t, beta1, beta2, eps, grad_scale, clip_norm(0=off), gnorm(in), skipped(out),
- * EMA decay (zk_ema), gnorm upper bound of safe_nan (main.py:325-329; 0 = off), 2 reserved.
+ * EMA decay (zk_ema), gnorm upper bound of safe_nan (main.py:325-329; 0 = off), [10] STICKY count of updates that
+ * were skipped or saw a non-finite gradient norm (never cleared by the kernels: the loop reads it before every
+ * display / checkpoint, main.py:316-319), 1 reserved.
  * zk_l2norm: out[0] = scale*||x||_2; zk_adam's pnorm_out = ||p|| before the update.  The update (and the EMA)
- * is skipped, and hyper[7] set, when gnorm is not finite or exceeds the bound. */
+ * is skipped, and hyper[7] set, when gnorm is not finite or exceeds the bound.
+ * zk_adam_step: the whole update of a step.  norm_free = 1 (cycle.py:98-101: clip_grad_norm 0.0, and no safe_nan --
+ * the update does not depend on the global norm, which is only reported): gradient norm -> hyper[6] (+ flags),
+ * TF1 Adam, bf16 shadow refresh and parameter norm in ONE pass over the flat buffers (the reference fetches
+ * train_op and gradient_norm together, main.py:309-312); norm_free = 0: hyper[6] must hold the norm (zk_l2norm).
+ * seed (device uint64, may be NULL): the dropout step seed, advanced by one in the same launch.
+ * zk_norm_flag: fold a norm that zk_l2norm wrote to hyper[6] AFTER per-bucket updates into hyper[7] / hyper[10]. */
 size_t zk_norm_workspace(void);
 int zk_l2norm(const float* x, size_t n, float scale, float* out, void* workspace, size_t ws_bytes,
               zk_stream_t stream);
 int zk_adam(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n, float* hyper,
             float* pnorm_out, void* workspace, size_t ws_bytes, zk_stream_t stream);
+size_t zk_adam_step_workspace(void);
+int zk_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n, float* hyper,
+                 float* pnorm_out, uint64_t* seed, int norm_free, void* workspace, size_t ws_bytes,
+                 zk_stream_t stream);
+int zk_norm_flag(float* hyper, zk_stream_t stream);
 int zk_cast_f32_bf16(const float* x, void* y, size_t n, zk_stream_t stream);
 int zk_cast_bf16_f32(const void* x, float* y, size_t n, zk_stream_t stream);
 int zk_zero(void* p, size_t bytes, zk_stream_t stream);
@@ -221,6 +234,24 @@ int zk_tune(int key, int value);   /* A/B switches for measurements; key 0 = wid
    the Adam update when hyper[6] (gradient norm) is not finite */
 int zk_ema(float* ema, const float* p, const float* hyper, size_t n, zk_stream_t stream);
 int zk_axpby_f32(float* y, const float* x, float a, float b, size_t n, zk_stream_t stream);
+
+/* ---- utils/parallel.py:134-208 average_gradients -> RCCL sum collectives over xGMI on the caller's stream (the 1/N
+ * of the tower mean is zk_adam_step's grad_scale).  The communicator is an opaque handle OWNED BY THE CALLER:
+ * rank 0 draws a 128-byte id (zk_comm_unique_id) and ships it to the other ranks by its own means (here: the
+ * torch.distributed store), every rank calls zk_comm_init (collective; the current HIP device is the rank's GPU) and
+ * later zk_comm_destroy.  librccl is dlopen()ed on first use: zk_comm_available() = 0 on a box without it.
+ * dtype: 0 fp32, 1 bf16 (all-gather also 2 = int32).  Errors: 1000 + ncclResult_t. */
+int zk_comm_available(void);
+int zk_comm_unique_id(void* id128);
+int zk_comm_init(const void* id128, int nranks, int rank, void** comm_out);
+int zk_comm_destroy(void* comm);
+int zk_comm_size(const void* comm);
+int zk_comm_allreduce(void* comm, void* buf, size_t count, int dtype, zk_stream_t stream);
+/* n in-place all-reduces in ONE RCCL group; bufs / counts are HOST arrays */
+int zk_comm_allreduce_multi(void* comm, void* const* bufs, const size_t* counts, int n, int dtype,
+                            zk_stream_t stream);
+/* recv[r*count .. (r+1)*count) <- send of rank r (row-sparse source-embedding gradient, parallel.py:142-181) */
+int zk_comm_allgather(void* comm, const void* send, void* recv, size_t count, int dtype, zk_stream_t stream);
 
 /* dropout plumbing */
 int zk_dropout_mask(float* out, size_t n, float drop_p, const uint64_t* seed, uint32_t sid, zk_stream_t stream);

@@ -182,6 +182,62 @@ class Cfg(object):
     """dtype.py:12-15 constants + run-time switches of the restatement."""
     eps = 1e-8
     inf = 1e8
+    # Storage model of the MI355X build (a property of the CHECKER, not of the reference): when set, every
+    # tensor the HIP path keeps in HBM as bf16 -- matrix weights read by the GEMMs, the output of every
+    # linear / attention / LayerNorm / embedding, the softmax probabilities that feed P.V, and the gradients
+    # of those tensors in the backward -- is rounded to bf16 (round to nearest even) at the same point; all
+    # arithmetic and every accumulation stay fp32.  Lets the GPU tests assert a tight per-variable gradient
+    # tolerance instead of the 12 % the pure-fp32 comparison needs.
+    store_bf16 = False
+
+
+def _bf16(x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+class _RoundBoth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16(g)
+
+
+class _RoundFwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16(g)
+
+
+def _st(x):
+    """activation stored as bf16 (value and its gradient)."""
+    return _RoundBoth.apply(x) if Cfg.store_bf16 else x
+
+
+def _st_fwd(x):
+    """value rounded (bf16 shadow weights, probabilities), gradient kept fp32."""
+    return _RoundFwd.apply(x) if Cfg.store_bf16 else x
+
+
+def _st_bwd(x):
+    """value kept fp32 (scores / logits live in registers or fp32), gradient stored bf16."""
+    return _RoundBwd.apply(x) if Cfg.store_bf16 else x
 
 
 def dropout(x, p, training=True):
@@ -193,12 +249,12 @@ def dropout(x, p, training=True):
 
 def linear(x, P, scope, bias=True):
     """func.py:14-65 (single input, single output, no ln)."""
-    W = P[scope + "/W_0_0"]
+    W = _st_fwd(P[scope + "/W_0_0"])
     shp = x.shape
     o = torch.matmul(x.reshape(-1, shp[-1]), W)
     if bias:
         o = o + P[scope + "/b_0"]
-    return o.reshape(*shp[:-1], W.shape[1])
+    return _st(o.reshape(*shp[:-1], W.shape[1]))
 
 
 def split_heads(x, n):
@@ -277,14 +333,14 @@ def dot_attention(query, memory, mem_mask, H, P, scope, num_heads, cache=None,
         logits = torch.matmul(q, k.transpose(-1, -2))
     if mem_mask is not None:
         logits = logits + mem_mask
-    weights = torch.softmax(logits, dim=-1)
-    dweights = dropout(weights, drop, training)
+    weights = torch.softmax(_st_bwd(logits), dim=-1)
+    dweights = _st_fwd(dropout(weights, drop, training))
     if use_rpr:
         r = rel_pos_embeddings(P, scope + "/rpr_values", q_len, k.shape[2], max_rel, r_lst)
         o = relative_attention_inner(dweights, v, r, False)
     else:
         o = torch.matmul(dweights, v)
-    o = combine_heads(o)
+    o = _st(combine_heads(o))
     if fuse_mask is not None:
         v_q = linear(query, P, scope + "/v_map")        # shares v_map with the memory side
         if cache is not None and 'aan' in cache:
@@ -293,7 +349,7 @@ def dot_attention(query, memory, mem_mask, H, P, scope, num_heads, cache=None,
             aan_o = torch.matmul(fuse_mask, v_q)
         if cache is not None:
             cache['aan'] = v_q if 'aan' not in cache else v_q + cache['aan']
-        o = o + aan_o
+        o = _st(o + aan_o)
     o = linear(o, P, scope + "/o_map")
     return {'weights': weights, 'output': o, 'cache': cache}
 
@@ -304,7 +360,7 @@ def layer_norm(x, P, scope):
     offset = P[scope + "/layer_norm/offset"]
     mean = x.mean(-1, keepdim=True)
     var = ((x - mean) ** 2).mean(-1, keepdim=True)
-    return scale * (x - mean) * torch.rsqrt(var + Cfg.eps) + offset
+    return _st(scale * (x - mean) * torch.rsqrt(var + Cfg.eps) + offset)
 
 
 def residual_fn(x, y, drop=None, training=True):
@@ -402,10 +458,10 @@ def encoder(source, hp, P, model_name, training=True):
     H = hp.hidden_size
     mask = (source != 0).to(dt)
     source, mask = remove_invalid_seq(source, mask)
-    x = P[_emb_name(hp, "src")][source] * (H ** 0.5)
+    x = _st_fwd(P[_emb_name(hp, "src")])[source] * (H ** 0.5)
     x = x + P["bias"]
     x = x + timing_signal(x.shape[1], x.shape[2], dt)
-    x = dropout(x, hp.dropout, training)
+    x = _st(dropout(x, hp.dropout, training))
     rpr = model_name == "transformer_rpr"
     for l in range(hp.num_encoder_layer):
         pre = "encoder/layer_%d" % l
@@ -450,7 +506,7 @@ def decoder(target, state, hp, P, model_name, training=True):
     is_training = ('decoder' not in state)
     if is_training:
         target, mask = remove_invalid_seq(target, mask)
-    inputs = P[_emb_name(hp, "tgt")][target] * (H ** 0.5)
+    inputs = _st_fwd(P[_emb_name(hp, "tgt")])[target] * (H ** 0.5)
     inputs = inputs + P["bias"]
     if is_training:
         inputs = F.pad(inputs, (0, 0, 1, 0))[:, :-1, :]
@@ -460,7 +516,7 @@ def decoder(target, state, hp, P, model_name, training=True):
             inputs = torch.zeros_like(inputs)
         mask = torch.ones_like(mask)
         inputs = inputs + timing_signal(1, inputs.shape[2], dt, time=state['time'])
-    x = dropout(inputs, hp.dropout, training)
+    x = _st(dropout(inputs, hp.dropout, training))
     rpr = model_name == "transformer_rpr"
     aan = model_name == "transformer_aan"
     dstep = None if is_training else state['time']
@@ -481,12 +537,12 @@ def decoder(target, state, hp, P, model_name, training=True):
             continue
         if aan:
             assert [s.lower() for s in hp.strategies] == ["aan"]
-            y = average_attention(x, mask, state, l, hp, is_training)
+            y = _st(average_attention(x, mask, state, l, hp, is_training))
             if hp.use_ffn:
                 y = ffn_layer(y, P, pre + "/average_attention", hp.relu_dropout, training)
             z = linear(torch.cat([x, y], dim=-1), P, pre + "/average_attention/z_project")
             i, f = torch.split(z, H, dim=-1)
-            y = torch.sigmoid(i) * x + torch.sigmoid(f) * y
+            y = _st(torch.sigmoid(i) * x + torch.sigmoid(f) * y)
             x = layer_norm(residual_fn(x, y, hp.residual_dropout, training), P, pre + "/average_attention")
         else:
             r = dot_attention(x, None, attention_bias(mask.shape[1], "causal").to(dt), H, P,
@@ -511,7 +567,7 @@ def decoder(target, state, hp, P, model_name, training=True):
     if 'dev_decode' in state:
         feature = x[:, -1, :]
     feature = feature.reshape(-1, hp.embed_size)
-    logits = torch.matmul(feature, P[_emb_name(hp, "softmax")].t())
+    logits = _st_bwd(torch.matmul(feature, _st_fwd(P[_emb_name(hp, "softmax")]).t()))
     logits32 = logits  # tf.cast(logits, tf.float32): the restatement already runs >= fp32
     if 'dev_decode' in state or not is_training:
         # loss tensors are built by the reference graph but never fetched on

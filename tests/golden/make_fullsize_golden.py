@@ -1,0 +1,105 @@
+# coding: utf-8
+"""Full-size oracle fixtures (run in the BUILD container only).
+
+The HIP path is otherwise only compared with the oracle at toy sizes; the shapes that select the
+benchmark's kernels (64x64 producer-wave tiles, the 12-segment K-segmented GEMM, the grouped weight
+gradients incl. the logits problem, split-K) need a comparison at the BASELINE sizes.  The oracle
+(oracle/ref_torch.py, fp32 torch-CPU restatement; PARITY UNPINNED -- TF1 never ran) takes minutes at
+these sizes, so its outputs are committed here and the `-m gpu` tests compare against them:
+
+  base_synth_seed1234.npz  BASELINE configs[1]: d=512, F=2048, h=8, 6+6 layers, V=32000, B=64 x (64+64),
+                           dropout 0, label smoothing 0.1
+  enc12_synth_seed1234.npz BASELINE configs[4], the part the reference has code for: the same model with
+                           num_encoder_layer=12 (transformer.py:35-69)
+  big_synth_seed1234.npz   BASELINE configs[2] widths: d=1024, F=4096, h=16, 6+6 layers
+  aan_base_beam.npz        BASELINE configs[3] subset: transformer_aan, d=512, 64 sentences, beam 1 and 4
+
+Parameters are NOT stored (77-242 M floats): both sides regenerate them from
+``oracle.ref_torch.init_params(hp, model, seed)`` + ``tests.common.perturb`` (numpy Generator streams are
+stable across platforms); `param_probe` pins that the regenerated values are the ones used here.
+
+Each training fixture holds, for the fp32 oracle and for the oracle under the bf16 storage model
+(``Cfg.store_bf16``: tensors the HIP path keeps as bf16 are rounded at the same points, arithmetic fp32):
+loss, per-sentence loss, global gradient norm, the L2 norm of every variable's gradient, and three
+gradient slices.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_torch as rt  # noqa: E402
+from tests.common import perturb  # noqa: E402
+from tests.fullsize import (fullsize_hp, fullsize_batch, fullsize_params, param_probe, SLICES,  # noqa: E402
+                            beam_hp, beam_sources)
+
+
+def train_fixture(name, **kw):
+    hp = fullsize_hp(**kw)
+    model = hp.model_name
+    Pn = fullsize_params(hp, model)
+    src, tgt = fullsize_batch()
+    out = {"param_probe": param_probe(Pn)}
+    for tag, flag in (("f32", False), ("bf16", True)):
+        rt.Cfg.store_bf16 = flag
+        t0 = time.time()
+        P = rt.to_torch(Pn, torch.float32, requires_grad=True)
+        r = rt.train_fn({"source": torch.tensor(src), "target": torch.tensor(tgt)}, hp, P, model, training=False)
+        r["loss"].backward()
+        rt.Cfg.store_bf16 = False
+        names = list(P.keys())
+        gn = np.array([float(P[k].grad.double().norm()) if P[k].grad is not None else 0.0 for k in names])
+        out[tag + "_loss"] = np.float64(r["loss"].item())
+        out[tag + "_per_sample"] = r["per_sample_loss"].detach().numpy().astype(np.float32)
+        out[tag + "_gnorm"] = np.float64(np.sqrt((gn ** 2).sum()))
+        out[tag + "_grad_norms"] = gn
+        for i, (k, rs, cs) in enumerate(SLICES):
+            out["%s_slice%d" % (tag, i)] = P[k].grad[rs[0]:rs[1], cs[0]:cs[1]].numpy().astype(np.float32)
+        print("%s %s: loss %.6f gnorm %.6f (%.0f s)" % (name, tag, out[tag + "_loss"], out[tag + "_gnorm"],
+                                                       time.time() - t0), flush=True)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+def beam_fixture():
+    hp = beam_hp()
+    model = hp.model_name
+    Pn = fullsize_params(hp, model)
+    P = rt.to_torch(Pn)
+    src = beam_sources()
+    out = {"param_probe": param_probe(Pn), "source": src}
+    enc, dec = rt.infer_fn(hp, P, model)
+    for K in (1, 4):
+        hp.beam_size = K
+        t0 = time.time()
+        seqs, scores = [], []
+        for i in range(0, src.shape[0], 32):
+            r = rt.beam_search({"source": torch.tensor(src[i:i + 32])}, enc, dec, hp)
+            seqs.append(np.asarray(r["seq"])); scores.append(np.asarray(r["score"]))
+        L = max(s.shape[-1] for s in seqs)
+        seqs = [np.pad(s, [(0, 0)] * (s.ndim - 1) + [(0, L - s.shape[-1])]) for s in seqs]
+        out["seqs_k%d" % K] = np.concatenate(seqs, 0).astype(np.int32)
+        out["scores_k%d" % K] = np.concatenate(scores, 0).astype(np.float32)
+        # margin between the best two candidates is what decides whether bf16 can flip a token: keep the
+        # best-hypothesis score gap to the runner-up for the report
+        print("beam %d: %s (%.0f s)" % (K, out["seqs_k%d" % K].shape, time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(HERE, "aan_base_beam.npz"), **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(os.cpu_count())
+    which = sys.argv[1:] or ["base", "enc12", "big", "beam"]
+    if "base" in which:
+        train_fixture("base_synth_seed1234")
+    if "enc12" in which:
+        train_fixture("enc12_synth_seed1234", num_encoder_layer=12)
+    if "big" in which:
+        train_fixture("big_synth_seed1234", hidden_size=1024, embed_size=1024, filter_size=4096, num_heads=16)
+    if "beam" in which:
+        beam_fixture()

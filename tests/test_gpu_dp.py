@@ -121,3 +121,28 @@ def test_bench_contract_with_two_ranks_on_one_gpu():
     assert out["config"]["parallelism"] == "dp2" and out["config"]["global_batch_tokens"] == 2 * 64 * 128
     assert out["value"] > 0 and np.isfinite(out["loss"]) and not out["update_skipped"]
     assert "roofline" in out and "cpu_baseline" not in out          # the CPU baseline is a 1-rank field
+
+
+def test_rccl_communicator_through_the_c_abi_single_rank():
+    """zk_comm_* (include/zero_hip.h; utils/parallel.py:134-208 -> RCCL): the one-GPU box can only hold a
+    one-rank communicator (RCCL refuses two ranks on a device), which still exercises dlopen, the id, init,
+    the collectives on the side stream, the event hand-back and destroy; a sum over one rank is the identity."""
+    from zero_amd.utils import parallel
+    comm = parallel.RcclComm("cuda:0")
+    assert comm.world == 1 and comm.lib.raw("zk_comm_size")(comm.handle) == 1
+    x = torch.randn(1 << 20, device="cuda:0")
+    ref = x.clone()
+    ev = comm.all_reduce(x)
+    torch.cuda.current_stream().wait_event(ev)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    xb = torch.randn(4099, device="cuda:0").to(torch.bfloat16)
+    refb = xb.clone()
+    torch.cuda.current_stream().wait_event(comm.all_reduce(xb))
+    ids = torch.arange(777, dtype=torch.int32, device="cuda:0")
+    out = torch.empty_like(ids)
+    torch.cuda.current_stream().wait_event(comm.all_gather(ids, out))
+    torch.cuda.synchronize()
+    assert torch.equal(xb, refb) and torch.equal(out, ids)
+    comm.close()
+    comm.close()          # idempotent

@@ -162,6 +162,53 @@ def test_adam_update_matches_oracle_given_same_gradients():
         assert np.abs(new[k] - P[k].numpy()).max() < 1e-6, k
 
 
+def test_norm_free_update_equals_norm_first_update_and_counts_bad_steps():
+    """zk_adam_step: with clip_grad_norm = 0.0 and no safe_nan (cycle.py:98-101) the gradient norm is accumulated
+    inside the Adam pass (norm_free = 1); weights, m, v, shadow, gnorm and pnorm must equal the two-pass form
+    (zk_l2norm + zk_adam) bit for bit / to fp32 summation order, the seed must advance by one, and a non-finite
+    gradient must show in the per-update flag AND in the sticky counter that a later good update does not clear."""
+    from zero_amd.main import Trainer, tower_train_graph
+    hp, Pn, src, tgt = _setup("transformer")
+    reset_cores()
+    tr = Trainer(hp, initializer=Pn)
+    assert tr.train_op.can_update_by_range()
+    tr.lr.step(0)
+    tower_train_graph({"source": src, "target": tgt}, tr.graph, hp, None)
+    torch.cuda.synchronize()
+    st, top, eng = tr.store, tr.train_op, tr.core.eng
+    snap = {k: getattr(st, k).clone() for k in ("master", "grad", "m", "v", "shadow")}
+    seed0 = int(eng.seed.cpu()[0])
+    scale = top.set_hyper(tr.lr.get_lr(), 1)
+    top.launch_update(scale)                      # norm-free single pass
+    torch.cuda.synchronize()
+    one = {k: getattr(st, k).clone() for k in ("master", "m", "v", "shadow")}
+    g1, p1, bad1 = top.stats()
+    assert int(eng.seed.cpu()[0]) == seed0 + 1 and not bad1 and top.bad_updates() == 0
+    for k, v in snap.items():
+        getattr(st, k).copy_(v)
+    lib, s = eng.lib, eng.stream
+    lib.call("zk_l2norm", st.grad.data_ptr(), st.numel, scale, top.hyper.data_ptr() + 24, top._ws.data_ptr(),
+             top._ws.numel(), s)
+    lib.call("zk_adam", st.master.data_ptr(), st.grad.data_ptr(), st.m.data_ptr(), st.v.data_ptr(),
+             st.shadow.data_ptr(), st.numel, top.hyper.data_ptr(), top.pnorm.data_ptr(), top._ws.data_ptr(),
+             top._ws.numel(), s)
+    torch.cuda.synchronize()
+    g2, p2, bad2 = top.stats()
+    for k in one:
+        assert torch.equal(one[k], getattr(st, k)), k
+    assert abs(g1 - g2) <= 2e-6 * g2 and abs(p1 - p2) <= 2e-6 * p2 and not bad2
+    # a NaN gradient: reported for that update and remembered afterwards
+    st.grad[5] = float("nan")
+    top.launch_update(scale)
+    torch.cuda.synchronize()
+    assert top.stats()[2] and top.bad_updates() == 1
+    for k, v in snap.items():
+        getattr(st, k).copy_(v)
+    top.launch_update(scale)
+    torch.cuda.synchronize()
+    assert not top.stats()[2] and top.bad_updates() == 1
+
+
 def test_hipgraph_replay_equals_eager_steps():
     # the captured step (forward + backward + norm + Adam in one hipGraph) must reproduce the eager
     # launch sequence exactly, update after update

@@ -1034,22 +1034,35 @@ __global__ void __launch_bounds__(256) k_norm_final(const float* __restrict__ pa
   if (threadIdx.x == 0) out[0] = scale * sqrtf(acc);
 }
 
+// GSQ = false: the update depends on the global norm (clipping, safe_nan bound): hyper[6] holds it (zk_l2norm ran).
+// GSQ = true : norm-free update (cycle.py:98-101 with clip_grad_norm = 0.0, no safe_nan -- the recipe): the gradient
+//              norm is only reported (main.py:316-319, the log line), so its sum of squares is accumulated in THIS
+//              pass over the gradient (gsq partials; k_norm_final2 writes hyper[6] and the flags afterwards) instead
+//              of a pass of its own over the 308 MB.  The update is applied whatever the norm turns out to be --
+//              exactly what the reference does without safe_nan (train_op and the norm are fetched together).
+// seed (may be NULL): the per-step dropout seed is advanced here (one launch fewer per step).
+template <bool GSQ>
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g,
                                               float* __restrict__ m, float* __restrict__ v,
                                               bf16_t* __restrict__ shadow, size_t n,
-                                              float* __restrict__ hyper, float* __restrict__ psq) {
+                                              float* __restrict__ hyper, float* __restrict__ psq,
+                                              float* __restrict__ gsq, uint64_t* __restrict__ seed) {
   __shared__ float sm_[8];
   float pacc = 0.f;   // sum of squares of the parameters BEFORE this update (tf.global_norm(variables))
+  float gacc = 0.f;   // sum of squares of the scaled gradient (GSQ)
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
   const float gs = hyper[4], clip = hyper[5], gnorm = hyper[6];
-  // NaN/Inf guard (main.py:316-319); hyper[9] > 0: also skip when gnorm exceeds it (safe_nan, main.py:325-329)
-  if (!(gnorm == gnorm) || fabsf(gnorm) == INFINITY || (hyper[9] > 0.f && gnorm > hyper[9])) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) hyper[7] = 1.f;
-    return;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) hyper[7] = 0.f;   // the flag describes THIS update
+  if (seed != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *seed += 1;
   float f = gs;
-  if (clip > 0.f) f *= clip / fmaxf(gnorm, clip);  // tf.clip_by_global_norm
+  if (!GSQ) {
+    // NaN/Inf guard (main.py:316-319); hyper[9] > 0: also skip when gnorm exceeds it (safe_nan, main.py:325-329)
+    if (!(gnorm == gnorm) || fabsf(gnorm) == INFINITY || (hyper[9] > 0.f && gnorm > hyper[9])) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) { hyper[7] = 1.f; hyper[10] += 1.f; }   // [10]: sticky count
+      return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) hyper[7] = 0.f;   // the flag describes THIS update
+    if (clip > 0.f) f *= clip / fmaxf(gnorm, clip);  // tf.clip_by_global_norm
+  }
   const size_t n4 = n / 4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -1061,6 +1074,7 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float gj = G[j] * f;
+      if (GSQ) gacc += gj * gj;
       M[j] = b1 * M[j] + (1.f - b1) * gj;
       Vv[j] = b2 * Vv[j] + (1.f - b2) * gj * gj;
       P[j] -= lr * M[j] / (sqrtf(Vv[j]) + eps);
@@ -1073,6 +1087,7 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
   }
   for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float gj = g[i] * f;
+    if (GSQ) gacc += gj * gj;
     pacc += p[i] * p[i];
     m[i] = b1 * m[i] + (1.f - b1) * gj;
     v[i] = b2 * v[i] + (1.f - b2) * gj * gj;
@@ -1083,6 +1098,36 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
     pacc = block_sum<4>(pacc, sm_);
     if (threadIdx.x == 0) psq[blockIdx.x] = pacc;
   }
+  if (GSQ && gsq != nullptr) {
+    gacc = block_sum<4>(gacc, sm_);
+    if (threadIdx.x == 0) gsq[blockIdx.x] = gacc;
+  }
+}
+// finishes k_adam<true>: gnorm = sqrt(sum gsq) -> hyper[6], the per-update flag hyper[7] and the sticky count
+// hyper[10] of non-finite norms; pnorm = sqrt(sum psq) -> pnorm_out.  One block.
+__global__ void __launch_bounds__(256) k_norm_final2(const float* __restrict__ psq, const float* __restrict__ gsq,
+                                                     int n, float* __restrict__ hyper, float* __restrict__ pnorm_out) {
+  __shared__ float sm[8];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) { a += gsq[i]; if (psq != nullptr) b += psq[i]; }
+  a = block_sum<4>(a, sm);
+  b = block_sum<4>(b, sm);
+  if (threadIdx.x == 0) {
+    const float gn = sqrtf(a);
+    hyper[6] = gn;
+    const bool bad = !(gn == gn) || fabsf(gn) == INFINITY;
+    hyper[7] = bad ? 1.f : 0.f;
+    if (bad) hyper[10] += 1.f;
+    if (pnorm_out != nullptr) pnorm_out[0] = sqrtf(b);
+  }
+}
+// hyper[6] was written by zk_l2norm on a path whose update does not look at it (per-bucket updates of the
+// data-parallel step): record a non-finite norm in the per-update flag and the sticky count.
+__global__ void k_norm_flag(float* __restrict__ hyper) {
+  const float gn = hyper[6];
+  const bool bad = !(gn == gn) || fabsf(gn) == INFINITY;
+  hyper[7] = bad ? 1.f : 0.f;
+  if (bad) hyper[10] += 1.f;
 }
 
 __global__ void __launch_bounds__(256) k_cast_f32_bf16(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
@@ -1509,12 +1554,49 @@ int zk_adam(float* p, const float* g, float* m, float* v, void* shadow, size_t n
   if (n == 0) return 0;
   const int grid = flat_grid(n, 4);
   float* psq = pnorm_out ? (float*)workspace : nullptr;
-  hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n, hyper, psq);
+  hipLaunchKernelGGL(k_adam<false>, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n, hyper, psq,
+                     (float*)nullptr, (uint64_t*)nullptr);
   ZK_LAUNCH_CHECK();
   if (pnorm_out) {
     hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, stream, (const float*)psq, grid, 1.f, pnorm_out);
     ZK_LAUNCH_CHECK();
   }
+  return 0;
+}
+size_t zk_adam_step_workspace(void) { return 2 * 2048 * sizeof(float); }
+// The whole update of one step in two launches.  norm_free = 1 (cycle.py:98-101 with clip_grad_norm 0.0 and no
+// safe_nan): gradient norm (-> hyper[6], flag hyper[7], sticky count hyper[10]), TF1 Adam, bf16 shadow and parameter
+// norm in ONE pass over the buffers + a one-block finish.  norm_free = 0: hyper[6] must already hold the gradient norm
+// (zk_l2norm); the update is skipped when it is not finite / above hyper[9].  seed (device uint64, may be NULL) += 1.
+int zk_adam_step(float* p, const float* g, float* m, float* v, void* shadow, size_t n, float* hyper,
+                 float* pnorm_out, uint64_t* seed, int norm_free, void* workspace, size_t ws_bytes,
+                 hipStream_t stream) {
+  ZK_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+               "zk_adam_step: buffers must be 16-byte aligned");
+  ZK_CHECK_ARG(ws_bytes >= zk_adam_step_workspace(), "zk_adam_step: workspace too small");
+  ZK_CHECK_ARG(hyper != nullptr, "zk_adam_step: hyper is required");
+  if (n == 0) return 0;
+  const int grid = flat_grid(n, 4);
+  float* psq = (float*)workspace;
+  float* gsq = psq + 2048;
+  if (norm_free) {
+    hipLaunchKernelGGL(k_adam<true>, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n, hyper, psq, gsq, seed);
+    ZK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_norm_final2, dim3(1), dim3(256), 0, stream, (const float*)psq, (const float*)gsq, grid, hyper,
+                       pnorm_out);
+  } else {
+    hipLaunchKernelGGL(k_adam<false>, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n, hyper, psq,
+                       (float*)nullptr, seed);
+    ZK_LAUNCH_CHECK();
+    if (pnorm_out) hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, stream, (const float*)psq, grid, 1.f, pnorm_out);
+  }
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+int zk_norm_flag(float* hyper, hipStream_t stream) {
+  ZK_CHECK_ARG(hyper != nullptr, "zk_norm_flag: hyper is required");
+  hipLaunchKernelGGL(k_norm_flag, dim3(1), dim3(1), 0, stream, hyper);
+  ZK_LAUNCH_CHECK();
   return 0;
 }
 

@@ -64,6 +64,23 @@ class Trainer(object):
         self.force_segmented = _os.environ.get("ZERO_HIP_FORCE_SEGMENTED", "0") != "0"
         # data parallelism: update each gradient bucket behind its own all-reduce (see _reduced_update)
         self.overlap_update = _os.environ.get("ZERO_HIP_OVERLAP_UPDATE", "1") != "0"
+        self.reseed()
+
+    def reseed(self):
+        """Position the dropout / Gumbel-noise stream: high word = params.random_seed mixed with the rank (every
+        data-parallel replica draws its own masks, as every tower of the reference has its own dropout ops), low
+        word = number of micro steps taken so far, so a resumed run continues the stream instead of replaying
+        it from step 0.  The device advances the low word by one per micro step."""
+        hp = self.params
+        hi = (int(getattr(hp, "random_seed", 1234)) * 0x9E3779B1 + parallel.rank() * 0x85EBCA77 + 0x165667B1) & 0x7FFFFFFF
+        micro = (self.global_step * max(1, int(hp.update_cycle)) + self.cycle_counter) & 0xFFFFFFFF
+        self.core.eng.set_seed((hi << 32) | micro)
+
+    def rollback_skipped_update(self):
+        """main.py:320-332 (safe_nan): a skipped update does not run train_op, so global_step, Adam's t and the
+        learning-rate schedule do not advance."""
+        self.global_step -= 1
+        self.store.step -= 1
 
     # -- eager path (any shapes) --------------------------------------------------
     def micro_step(self, features):
@@ -92,8 +109,7 @@ class Trainer(object):
             self.reducer.wait()
             self.train_op.apply(self.lr.get_lr(), world)
         self.cycle_counter = 0
-        self.global_step += 1
-        self.core.eng.lib.call("zk_seed_advance", self.core.eng.seed.data_ptr(), 1, self.core.eng.stream)
+        self.global_step += 1          # (the update launch advanced the dropout seed)
         return loss
 
     # -- one entry point for the training loop: captured steps whenever the shapes allow ---------
@@ -150,7 +166,6 @@ class Trainer(object):
 
         def tail():
             self.train_op.launch_update(scale)
-            eng.lib.call("zk_seed_advance", eng.seed.data_ptr(), 1, eng.stream)
         if world == 1:
             self._graph_run(("fin",) + shape,
                             lambda: (self.graph.train_fn(batch, hp), self.train_op.add_slots_launch(), tail()))
@@ -232,7 +247,6 @@ class Trainer(object):
             eng.graph_launch(update_graph)
         else:
             top.launch_update(scale)
-            eng.lib.call("zk_seed_advance", eng.seed.data_ptr(), 1, eng.stream)
 
     def _capture_segments(self, scale):
         import ctypes
@@ -267,7 +281,6 @@ class Trainer(object):
             begin()
             try:
                 self.train_op.launch_update(scale)
-                lib.call("zk_seed_advance", eng.seed.data_ptr(), 1, eng.stream)
             finally:
                 plan.append(("update", cut()))
             return plan
@@ -334,7 +347,6 @@ class Trainer(object):
                 def body():
                     self.graph.train_fn(self.batch, hp)
                     self.train_op.launch_update(scale)
-                    eng.lib.call("zk_seed_advance", eng.seed.data_ptr(), 1, eng.stream)
                 g = eng.graph_capture(body)
                 self._graphs[key] = g
             eng.graph_launch(g)
@@ -346,7 +358,6 @@ class Trainer(object):
         else:
             self.graph.train_fn(self.batch, hp)
             self.train_op.launch_update(scale)
-            eng.lib.call("zk_seed_advance", eng.seed.data_ptr(), 1, eng.stream)
         self.store.step += 1
         self.global_step += 1
         return eng.buf("loss", (1,), torch.float32)
@@ -374,9 +385,12 @@ def _restore(trainer, saver, path=None):
     got, missing, step = assign_tensors(trainer.store, trainer.params.scope_name or "model", tensors)
     for name in missing:
         log.warning("%s is missed", name)
-    if step is not None and path is None:
+    if step is not None:
+        # tf.train.Saver restores global_step and Adam's beta powers together with the slots, also from
+        # ``pretrained_model`` (main.py:221-226, saver.py:131-170): warm m / v keep their bias correction
         trainer.global_step = step
         trainer.store.step = step
+        trainer.reseed()
     if trainer.train_op.ema is not None:
         from zero_amd.utils.saver import assign_flat
         assign_flat(trainer.store, trainer.train_op.ema, trainer.params.scope_name or "model", tensors,
@@ -432,6 +446,7 @@ def train(params):
             rec.save_to_json(os.path.join(params.output_dir, "record.json"))
 
     start_time, cum_tokens = time.time(), 0
+    bad_seen = trainer.train_op.bad_updates()
     pending = []
     for epoch in range(rec.epoch, params.epoches + 1):
         rec.epoch = epoch
@@ -459,14 +474,23 @@ def train(params):
             if not last:
                 continue
             gstep = trainer.global_step
-            if gstep % params.disp_freq == 0 or params.safe_nan:
+            will_save = gstep > 0 and (gstep % params.save_freq == 0 or gstep % params.eval_freq == 0)
+            if gstep % params.disp_freq == 0 or params.safe_nan or will_save:
                 gnorm, pnorm, skipped = trainer.train_op.stats()
                 loss_v = float(loss.reshape(-1)[0].cpu()) if hasattr(loss, "cpu") else float(loss)
-                if skipped or not np.isfinite(loss_v) or not np.isfinite(gnorm):
-                    log.error("Nan or Inf raised! Loss %s GNorm %s.", loss_v, gnorm)
+                # the device counts every skipped / non-finite update (sticky): nothing that happened between two
+                # reads is lost, and it is read before anything is written to disk
+                bad_total = trainer.train_op.bad_updates()
+                bad_new, bad_seen = bad_total > bad_seen, bad_total
+                if skipped or bad_new or not np.isfinite(loss_v) or not np.isfinite(gnorm):
                     if not params.safe_nan:          # main.py:316-319
+                        log.error("Nan or Inf raised! Loss %s GNorm %s.", loss_v, gnorm)
                         rec.estop = True
                         break
+                    if skipped:                      # main.py:320-332: the step is passed, global_step stays
+                        log.error("Nan or Inf raised, GStep %s is passed! Loss %s GNorm %s.", gstep, loss_v, gnorm)
+                        trainer.rollback_skipped_update()
+                        continue
                 if gstep % params.disp_freq == 0:
                     now = time.time()
                     log.info("Epoch %d, GStep %d~%d, LStep %d~%d, Loss %.3f, GNorm %.3f, PNorm %.3f, Lr %.5f, "

@@ -25,9 +25,17 @@ from zero_amd.vocab import Vocab
 
 
 def save_parameters(params, output_dir):
+    """run.py:250-272.  With data parallelism every process runs this CLI: only rank 0 writes, through a temporary
+    file + rename, so that no other rank (or a restarted job) ever reads a torn param.json."""
+    from zero_amd.utils import parallel
+    if parallel.rank() != 0:
+        return
     os.makedirs(output_dir, exist_ok=True)
-    with open(os.path.join(output_dir, "param.json"), "w") as writer:
+    path = os.path.join(output_dir, "param.json")
+    tmp = "%s.tmp.%d" % (path, os.getpid())
+    with open(tmp, "w") as writer:
         writer.write(params.to_json())
+    os.replace(tmp, path)
 
 
 def load_parameters(params, output_dir):
@@ -36,6 +44,14 @@ def load_parameters(params, output_dir):
         with open(name, "r") as reader:
             params.parse_json(reader.readline())
     return params
+
+
+def _parse_dict_call(text):
+    node = ast.parse(text.strip(), mode="eval").body
+    if not (isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id == "dict"
+            and not node.args):
+        raise ValueError("--config file must hold a dict literal or a dict(k=v, ...) expression")
+    return {kw.arg: ast.literal_eval(kw.value) for kw in node.keywords}
 
 
 def build_params(parameters="", config=""):
@@ -48,9 +64,9 @@ def build_params(parameters="", config=""):
         try:
             cfg = ast.literal_eval(text.strip())
         except (ValueError, SyntaxError):
-            # the reference eval()s a ``dict(k=v, ...)`` expression (run.py:371); evaluate it with
-            # no builtins except dict
-            cfg = eval(text, {"__builtins__": {}, "dict": dict})  # noqa: S307
+            # the reference eval()s a ``dict(k=v, ...)`` expression (run.py:371); accept exactly that shape --
+            # one call of ``dict`` with literal keyword values -- without evaluating any code
+            cfg = _parse_dict_call(text)
         params.override_from_dict(cfg)
     if params.output_dir:
         params = load_parameters(params, params.output_dir)
@@ -114,6 +130,7 @@ def main(argv=None):
     parallel.init_distributed()
     if args.mode == "train" and params.src_train_file:
         save_parameters(params, params.output_dir or ".")
+        parallel.barrier()           # nobody reads param.json / record.json before rank 0 has written them
         setup_recorder(params)
         print(json.dumps({"best_score": loops.train(params)}))
     elif args.mode == "test" and params.src_test_file:

@@ -27,7 +27,9 @@ class TrainOp(object):
     def __init__(self, store, params, engine):
         self.store, self.hp, self.eng = store, params, engine
         dev = store.device
-        self.hyper = torch.zeros(12, dtype=torch.float32, device=dev)   # [0:6] host scalars, 6 gnorm, 7 skipped, 8 ema decay, 9 gnorm bound
+        # [0:6] host scalars, 6 gnorm, 7 skipped (this update), 8 ema decay, 9 gnorm bound, 10 sticky count of
+        # skipped / non-finite updates (only ever incremented on the device; see bad_updates())
+        self.hyper = torch.zeros(12, dtype=torch.float32, device=dev)
         if getattr(params, "safe_nan", False) and getattr(params, "gnorm_upper_bound", 0.) > 0.:
             self.hyper[9] = float(params.gnorm_upper_bound)      # main.py:325-329: update skipped above it
         self.hyper_host = torch.zeros(6, dtype=torch.float32).pin_memory() if dev.type == "cuda" \
@@ -40,7 +42,8 @@ class TrainOp(object):
             self.ema = store.master.clone()      # shadows start at the variables' initial values
         self.pnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.count = 0
-        self._ws = torch.empty(hip.lib().query("zk_norm_workspace") * 2, dtype=torch.uint8, device=dev)
+        self._ws = torch.empty(max(hip.lib().query("zk_norm_workspace") * 2, hip.lib().query("zk_adam_step_workspace")),
+                               dtype=torch.uint8, device=dev)
 
     # cycle.py:58-71
     def zero(self):
@@ -88,16 +91,21 @@ class TrainOp(object):
             self.hyper[8:9].copy_(self.ema_host, non_blocking=True)
         return scale
 
-    def launch_update(self, scale):
-        """Device side of train_op; graph-capturable (reads scalars from self.hyper)."""
+    def launch_update(self, scale, advance_seed=True):
+        """Device side of train_op; graph-capturable (reads scalars from self.hyper).  Also advances the
+        dropout step seed (same launch).  When the update does not depend on the global norm (no clipping,
+        no safe_nan -- cycle.py:98-101 with the recipe's clip_grad_norm = 0.0) the gradient norm is only
+        reported, and it is accumulated inside the Adam pass instead of a pass of its own."""
         st, lib, s = self.store, self.eng.lib, self.eng.stream
-        nb = self._ws.numel() // 2
-        lib.call("zk_l2norm", st.grad.data_ptr(), st.numel, scale, self.hyper.data_ptr() + 6 * 4,
-                 self._ws.data_ptr(), nb, s)
+        norm_free = self.can_update_by_range()
+        if not norm_free:
+            lib.call("zk_l2norm", st.grad.data_ptr(), st.numel, scale, self.hyper.data_ptr() + 6 * 4,
+                     self._ws.data_ptr(), self._ws.numel(), s)
         # parameter norm (cycle.py:95) is accumulated inside the Adam pass over the same data
-        lib.call("zk_adam", st.master.data_ptr(), st.grad.data_ptr(), st.m.data_ptr(), st.v.data_ptr(),
+        lib.call("zk_adam_step", st.master.data_ptr(), st.grad.data_ptr(), st.m.data_ptr(), st.v.data_ptr(),
                  st.shadow.data_ptr(), st.numel, self.hyper.data_ptr(), self.pnorm.data_ptr(),
-                 self._ws.data_ptr() + nb, nb, s)
+                 self.eng.seed.data_ptr() if advance_seed else None, 1 if norm_free else 0,
+                 self._ws.data_ptr(), self._ws.numel(), s)
         if self.ema is not None:
             lib.call("zk_ema", self.ema.data_ptr(), st.master.data_ptr(), self.hyper.data_ptr(), st.numel, s)
 
@@ -128,6 +136,7 @@ class TrainOp(object):
         nb = self._ws.numel() // 2
         lib.call("zk_l2norm", st.grad.data_ptr(), st.numel, scale, self.hyper.data_ptr() + 6 * 4,
                  self._ws.data_ptr(), nb, s)
+        lib.call("zk_norm_flag", self.hyper.data_ptr(), s)      # non-finite norm -> flag + sticky count
         lib.call("zk_l2norm", st.master.data_ptr(), st.numel, 1.0, self.pnorm.data_ptr(), self._ws.data_ptr() + nb, nb, s)
         if self.ema is not None:
             lib.call("zk_ema", self.ema.data_ptr(), st.master.data_ptr(), self.hyper.data_ptr(), st.numel, s)
@@ -161,7 +170,13 @@ class TrainOp(object):
         return scale
 
     def stats(self):
-        """(gradient_norm, parameter_norm, skipped) -- forces a sync; call at display time."""
+        """(gradient_norm, parameter_norm, skipped) of the LAST update -- forces a sync; call at display time."""
         h = self.hyper.cpu()
         g = float(h[6])
         return g, float(self.pnorm.cpu()[0]), bool(h[7] != 0) or not math.isfinite(g)
+
+    def bad_updates(self):
+        """Number of updates so far that were skipped or saw a non-finite gradient norm (sticky device counter:
+        nothing between two reads is lost).  Forces a sync; the loop reads it before every display and every
+        checkpoint (main.py:316-319 checks every step, which here would serialise host and device)."""
+        return int(self.hyper[10:11].cpu()[0])

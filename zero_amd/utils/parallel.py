@@ -16,6 +16,7 @@ Equality with the reference's tower average: mean over ranks of per-rank gradien
 same number of sentences (loss is a mean of per-sentence means, transformer.py:210-211).
 """
 
+import ctypes
 import os
 
 import torch
@@ -71,6 +72,108 @@ def layer_buckets(store):
     return {k: tuple(v) for k, v in ends.items()}, order
 
 
+class RcclComm(object):
+    """RCCL through the C-ABI (``zk_comm_*``, zero_amd/csrc/zk_comm.hip): the communicator handle is owned by this
+    object; collectives are enqueued on a side HIP stream of its own, ordered after the compute stream's
+    position at call time, and hand back a HIP event the consumer stream waits on.
+
+    The rendezvous uses whatever ``torch.distributed`` group is up (gloo is enough): rank 0 draws the 128-byte id,
+    ``broadcast_object_list`` ships it.  With a single process the id stays local (used by the GPU test)."""
+
+    def __init__(self, device=None):
+        from zero_amd import hip
+        self.lib = hip.lib()
+        if not self.lib.raw("zk_comm_available")():
+            raise hip.ZeroHipError("librccl is not loadable: %s" % self.lib.raw("zk_last_error_string")().decode())
+        self.rank, self.world = rank(), world_size()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        uid = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            self.lib.call("zk_comm_unique_id", uid)
+        if self.world > 1:
+            box = [bytes(uid.raw)]
+            dist.broadcast_object_list(box, src=0)
+            uid = ctypes.create_string_buffer(box[0], 128)
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            self.lib.call("zk_comm_init", uid, self.world, self.rank, ctypes.byref(self.handle))
+        self.stream = torch.cuda.Stream(self.device)
+
+    def _after_compute(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.stream.wait_event(ev)
+
+    def all_reduce(self, t):
+        """In-place sum over the ranks of a contiguous fp32 / bf16 tensor; returns the completion event."""
+        assert t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)
+        self._after_compute()
+        self.lib.call("zk_comm_allreduce", self.handle, t.data_ptr(), t.numel(), 0 if t.dtype == torch.float32 else 1,
+                      self.stream.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        return done
+
+    def all_gather(self, send, recv):
+        code = {torch.float32: 0, torch.bfloat16: 1, torch.int32: 2}[send.dtype]
+        assert recv.numel() == send.numel() * self.world and recv.dtype == send.dtype
+        self._after_compute()
+        self.lib.call("zk_comm_allgather", self.handle, send.data_ptr(), recv.data_ptr(), send.numel(), code,
+                      self.stream.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        return done
+
+    def close(self):
+        if self.handle is not None and self.handle.value:
+            self.stream.synchronize()
+            self.lib.call("zk_comm_destroy", self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _EventWork(object):
+    """torch.distributed Work look-alike over a HIP event (the RCCL transport)."""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
+_TRANSPORT = {}
+
+
+def transport():
+    """``ZERO_HIP_COMM=rccl``: collectives go through the C-ABI communicator (``zk_comm_*``) on its own side
+    stream; default ``torch``: ``torch.distributed`` (whose ``nccl`` backend IS RCCL on ROCm, and which is the only
+    choice for the gloo tests).  Both are sum all-reduces of the same buckets; results are identical.  The direct
+    transport has only ever been exercised with ONE rank on the 1-GPU test box (tests/test_gpu_dp.py), so it is
+    opt-in until an 8-GPU run has seen it; any failure to set it up falls back to torch.distributed."""
+    if "t" not in _TRANSPORT:
+        t = None
+        if os.environ.get("ZERO_HIP_COMM", "torch").lower() == "rccl" and torch.cuda.is_available() \
+                and (not dist.is_initialized() or dist.get_backend() != "gloo" or os.environ.get("ZERO_SINGLE_DEVICE", "0") == "0"):
+            try:
+                t = RcclComm()
+            except Exception as exc:      # noqa: BLE001 -- never lose the job to the optional transport
+                import logging
+                logging.getLogger("zero_amd").warning("direct RCCL transport unavailable (%s); torch.distributed", exc)
+        _TRANSPORT["t"] = t
+    return _TRANSPORT["t"]
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
 class GradientAllReduce(object):
     """Bucketed, overlapped sum all-reduce of ``store.grad``."""
 
@@ -80,6 +183,12 @@ class GradientAllReduce(object):
         self.ranges, _ = layer_buckets(store)
         self.pending = []
         self._open = None   # (lo, hi) of the bucket being filled (adjacent ranges only)
+
+    def _all_reduce(self, t):
+        tr = transport()
+        if tr is not None:
+            return _EventWork(tr.all_reduce(t))
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
     def ready(self, key):
         """Called by the backward when every gradient under ``key`` is final."""
@@ -100,7 +209,7 @@ class GradientAllReduce(object):
             return
         lo, hi = self._open
         self._open = None
-        self.pending.append((lo, hi, dist.all_reduce(self.store.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True)))
+        self.pending.append((lo, hi, self._all_reduce(self.store.grad[lo:hi])))
 
     def wait(self):
         """Flush the tail and make the current stream wait for every bucket."""
@@ -121,7 +230,7 @@ class GradientAllReduce(object):
         """Unbucketed path (used after gradient accumulation: one exchange per update,
         cycle.py:86-88 semantics)."""
         if world_size() > 1:
-            dist.all_reduce(self.store.grad, op=dist.ReduceOp.SUM)
+            self._all_reduce(self.store.grad).wait()
 
 
 def average_scalar(t):

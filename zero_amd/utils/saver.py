@@ -181,11 +181,12 @@ class Saver(object):
         scores = [v[1] for v in self.topk_scores]
         if not scores or len(scores) < self.best_checkpoints or metric_score > min(scores):
             self._dump(self.output_best_dir, step, tensors)
-            self.topk_scores.append((name, float(metric_score)))
+            # the same step saved again replaces its entry; whatever falls out of the top k is deleted,
+            # the checkpoint just written included (ties rank by insertion order)
+            self.topk_scores = [v for v in self.topk_scores if v[0] != name] + [(name, float(metric_score))]
             ranked = sorted(self.topk_scores, key=lambda x: x[1])
             for gone, _ in ranked[:-self.best_checkpoints]:
-                if gone != name:
-                    _remove(self.output_best_dir, gone)
+                _remove(self.output_best_dir, gone)
             self.topk_scores = ranked[-self.best_checkpoints:]
             _write_state(self.output_best_dir, [n for n, _ in self.topk_scores])
             with open(os.path.join(self.output_best_dir, "topk_checkpoint"), "w") as w:
