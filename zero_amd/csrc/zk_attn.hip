@@ -838,14 +838,13 @@ __global__ void __launch_bounds__(256) k_attn_bwd_fused64(AttnArgs a, const bf16
   __shared__ __attribute__((aligned(16))) bf16_t sKt[TQ * ALD];
   __shared__ __attribute__((aligned(16))) bf16_t sQt[TQ * ALD];
   __shared__ __attribute__((aligned(16))) bf16_t sdOt[TQ * ALD];
-  __shared__ float sD[TQ];
   __shared__ float sL[TQ];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
   const bf16_t* qb = a.q + (size_t)b * a.bsq + h * AD;
   const bf16_t* kb = a.k + (size_t)b * a.bsk + h * AD;
   const bf16_t* vb = a.v + (size_t)b * a.bsv + h * AD;
-  const bf16_t* ob = o + (size_t)b * a.Lq * ldo + h * AD;
+  (void)o; (void)ldo;
   const bf16_t* dob = dout + (size_t)b * a.Lq * lddo + h * AD;
   const uint64_t seed = a.thr ? *a.seed : 0;
 
@@ -862,14 +861,12 @@ __global__ void __launch_bounds__(256) k_attn_bwd_fused64(AttnArgs a, const bf16
     load_trans(t0, qb, a.ldq, 0, a.Lq, tid - 128);
     load_trans(t1, dob, lddo, 0, a.Lq, tid - 128);
   }
-  const int dr = tid >> 2, dpart = tid & 3;          // D_i = sum_c dO[i][c] * O[i][c]; 4 threads per row
+  // D_i = sum_j P_ij dP_ij is taken from the P and dP this workgroup computes anyway (whole rows live in one tile),
+  // not from rowsum(dO o O) over the stored bf16 O: no O / dO row loads, and sum_j dS_ij = 0 holds to fp32 rounding
+  // (with the bf16 O the rows of dS kept a common offset ~2^-9 |dO.O| that leaked mean(K) into dQ -- 30 % of the
+  // tiny q_map / k_map gradients of the 12-layer-encoder configuration, tests/test_gpu_fullsize.py)
+  const int dr = tid >> 2, dpart = tid & 3;
   const int drc = min(dr, a.Lq - 1);
-  uint4 dx[2], dy[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    dx[u] = *reinterpret_cast<const uint4*>(dob + (size_t)drc * lddo + dpart * 16 + u * 8);
-    dy[u] = *reinterpret_cast<const uint4*>(ob + (size_t)drc * ldo + dpart * 16 + u * 8);
-  }
   const float lse_r = lse[((size_t)b * a.nh + h) * a.Lq + drc];
   float kbias4[4];
 #pragma unroll
@@ -887,29 +884,13 @@ __global__ void __launch_bounds__(256) k_attn_bwd_fused64(AttnArgs a, const bf16
     store_trans(sQt, t0, tid - 128);
     store_trans(sdOt, t1, tid - 128);
   }
-  {
-    float acc = 0.f;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      float x[8], y[8];
-      unpack8(dx[u], x);
-      unpack8(dy[u], y);
-#pragma unroll
-      for (int c = 0; c < 8; ++c) acc += x[c] * y[c];
-    }
-    if (dr >= a.Lq) acc = 0.f;
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    if (dpart == 0) {
-      sD[dr] = acc;
-      sL[dr] = (dr < a.Lq) ? lse_r : 0.f;
-    }
-  }
+  if (dpart == 0) sL[dr] = (dr < a.Lq) ? lse_r : 0.f;
   __syncthreads();
   // ---- phase 1: P and dS of query rows 16w .. 16w+15 against all 64 keys, kept in registers
   const int rloc = w * 16 + (lane >> 4) * 4;
   float pv[4][4], dsv[4][4];
   {
+    float pu[4][4], dpv[4][4], Di[4] = {0.f, 0.f, 0.f, 0.f};
     const uint4 q0 = frag(sQ, w * 16, 0, lane), q1 = frag(sQ, w * 16, 1, lane);
     const uint4 g0 = frag(sdO, w * 16, 0, lane), g1 = frag(sdO, w * 16, 1, lane);
 #pragma unroll
@@ -937,9 +918,23 @@ __global__ void __launch_bounds__(256) k_attn_bwd_fused64(AttnArgs a, const bf16
           ms = zk_drop_scale(seed, a.sid, idx, a.thr, a.inv_keep);
         }
         pv[nt][r] = p * ms;
-        dsv[nt][r] = p * (dpr * ms - sD[i]) * a.scale;
+        pu[nt][r] = p;
+        dpv[nt][r] = dpr * ms;
+        Di[r] += p * dpr * ms;
       }
     }
+    // a query row's 64 keys sit in the 16 lanes of its group x 4 key tiles
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      Di[r] += __shfl_xor(Di[r], 1, 64);
+      Di[r] += __shfl_xor(Di[r], 2, 64);
+      Di[r] += __shfl_xor(Di[r], 4, 64);
+      Di[r] += __shfl_xor(Di[r], 8, 64);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dsv[nt][r] = pu[nt][r] * (dpv[nt][r] - Di[r]) * a.scale;
   }
   __syncthreads();                     // every wave is done reading sQ / sK / sV / sdO
   bf16_t* sdS = sQ;
