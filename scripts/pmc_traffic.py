@@ -27,5 +27,10 @@ for name in sorted(set(fetch) | set(write)):
     out[name] = {"launches": max(fn, wn),
                  "fetch_bytes_per_launch": 2.0 * 1024.0 * fk / max(fn, 1),
                  "write_bytes_per_launch": 1024.0 * wk / max(wn, 1)}
-print(json.dumps({"note": "FETCH_SIZE KB x2 (gfx950 correction), WRITE_SIZE KB x1; per-launch averages over "
+import subprocess, datetime
+try:
+    commit = open(".head_commit").read().strip()   # written by scripts/gpu.sh before the snapshot travels
+except OSError:
+    commit = None
+print(json.dumps({"commit": commit, "date": datetime.datetime.utcnow().strftime("%Y-%m-%d"), "note": "FETCH_SIZE KB x2 (gfx950 correction), WRITE_SIZE KB x1; per-launch averages over "
                           "bench.py --steps 2 --warmup 2 --no-graph", "kernels": out}, indent=1))

@@ -1,9 +1,11 @@
 """Summarise a rocprofv3 --kernel-trace rocpd database: per-kernel totals (like --stats)."""
 import sqlite3, sys
 db = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof/r1_results.db"
-steps = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
 con = sqlite3.connect(db)
 cur = con.cursor()
+# steps in the trace: every step (warm-up, timed, instrumented passes of bench.py) launches the Adam kernel once
+steps = float(sys.argv[2]) if len(sys.argv) > 2 else float(
+    cur.execute("select count(*) from kernels where name like '%k_adam%'").fetchone()[0] or 1)
 rows = cur.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
                    "from kernels where name not like 'k_spin%' group by name order by 3 desc").fetchall()   # k_spin: bench.py's measurement aid
 tot = sum(r[2] for r in rows)

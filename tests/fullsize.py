@@ -14,6 +14,8 @@ SLICES = [
     ("encoder/layer_0/self_attention/dot_attention/qkv_map/W_0_0", (0, 48), (500, 548)),
     ("decoder/layer_5/feed_forward/ffn_layer/output/W_0_0", (1000, 1048), (100, 148)),
     ("tgt_embedding", (0, 64), (0, 64)),
+    ("decoder/layer_0/feed_forward/ffn_layer/enlarge/W_0_0", (100, 148), (700, 748)),
+    ("encoder/layer_3/self_attention/dot_attention/o_map/W_0_0", (0, 48), (0, 48)),
 ]
 
 

@@ -45,7 +45,7 @@ REPORT = os.path.join(os.path.dirname(GOLD), "..", "gpurun_out")
 # of the cancellation dS = P (dP - rowsum(dO o O)) whose rowsum the HIP kernels take from the bf16 O they stored
 # (measured 3.4 % at d=512, 6.6 % at d=1024 -- the same against the fp32 oracle; every variable's gradient NORM is
 # within 1 %, i.e. the difference is direction noise, not a missing term)
-SLICE_TOL = (1e-1, 2e-2, 2e-2)
+SLICE_TOL = (1e-1, 2e-2, 2e-2, 3e-2, 3e-2)
 
 
 def _report(name, obj):
