@@ -84,10 +84,10 @@ class GemmProfiler(object):
 
     def _name(self, M, N, K, ta, tb, out_f32, plain):
         code = self.eng.lib.raw("zk_gemm_plan")(M, N, K, out_f32, plain)
-        gen, bm, bn = code & 255, (code >> 8) & 255, (code >> 16) & 255   # [27:24] split-K, [30:28] producer waves
+        gen, bm, bn = code & 255, ((code >> 8) & 255) * 8, ((code >> 16) & 255) * 8   # [27:24] split-K, [30:28] producer waves
         tf = lambda v: "true" if v else "false"
         if gen == 2:
-            ns = 4 if (bm, bn) == (64, 64) else 2
+            ns = 4 if (bm, bn) == (64, 64) else 3 if max(bm, bn) == 256 else 2
             # ..., 4 compute waves, producer waves per workgroup
             return "k_gemm_dlds<%d, %d, %d, %s, %s, 4, %d>" % (bm, bn, ns, tf(ta), tf(tb), (code >> 28) & 7)
         return "k_gemm_mfma<%d, %d, %s, %s>" % (bm, bn, tf(ta), tf(tb))
@@ -105,7 +105,9 @@ class GemmProfiler(object):
 
         def timed_grouped(problems, ta, tb, tile=128):
             tf = lambda v: "true" if v else "false"
-            name = "k_gemm_grouped<%d, %d, %d, %s, %s, 0>" % (tile, tile, 2 if tile == 128 else 4, tf(ta), tf(tb))
+            bm_, bn_ = (tile, tile) if isinstance(tile, int) else tile
+            name = "k_gemm_grouped<%d, %d, %d, %s, %s, %d>" % (bm_, bn_, 4 if bm_ == 64 else 3 if max(bm_, bn_) == 256 else 2,
+                                                              tf(ta), tf(tb), 4 if max(bm_, bn_) == 256 else 0)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             self._grouped(problems, ta, tb, tile=tile)

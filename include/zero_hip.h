@@ -45,7 +45,7 @@ const char* zk_last_error_string(void);
  *   (aux>0)*aux_scale (ReLU+dropout backward through the saved activation).          */
 size_t zk_gemm_workspace(int M, int N, int K);
 size_t zk_gemm_workspace_split(int M, int N, int splits);
-int zk_gemm_plan(int M, int N, int K, int out_f32, int plain);  /* gen | bm<<8 | bn<<16 | splits<<24 | producer waves<<28 chosen by impl=0 */
+int zk_gemm_plan(int M, int N, int K, int out_f32, int plain);  /* gen | (bm/8)<<8 | (bn/8)<<16 | splits<<24 | producer waves<<28 chosen by impl=0 */
 int zk_gemm_set_generation(int gen);   /* 1 = register-staged kernel, 2 = LDS-DMA ring kernel (default) */
 /* K-segmented GEMM: C bf16 [M, ldc] = sum_s A_s [M, kseg] x B_s (+ bf16 residual, may alias C) in ONE launch --
    gradient contributions that the reference accumulates with add_n over the users of a tensor (the encoder
@@ -221,6 +221,14 @@ size_t zk_adam_step_workspace(void);
 int zk_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n, float* hyper,
                  float* pnorm_out, uint64_t* seed, int norm_free, void* workspace, size_t ws_bytes,
                  zk_stream_t stream);
+/* the norm-free update in pieces: TF1 Adam on n elements writing its partial sums of squares into workspace slot
+ * `slot` (< 16); zk_adam_finish sums nslots slots -> hyper[6] (+ flags), pnorm_out, seed += 1.  Lets the update of
+ * the parameters whose gradients are final run beside the rest of the backward (and behind per-bucket all-reduces). */
+size_t zk_adam_range_workspace(void);
+int zk_adam_range(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n, float* hyper, int slot,
+                  void* workspace, size_t ws_bytes, zk_stream_t stream);
+int zk_adam_finish(float* hyper, float* pnorm_out, uint64_t* seed, int nslots, const void* workspace, size_t ws_bytes,
+                   zk_stream_t stream);
 int zk_norm_flag(float* hyper, zk_stream_t stream);
 int zk_cast_f32_bf16(const float* x, void* y, size_t n, zk_stream_t stream);
 int zk_cast_bf16_f32(const void* x, float* y, size_t n, zk_stream_t stream);
@@ -252,6 +260,26 @@ int zk_comm_allreduce_multi(void* comm, void* const* bufs, const size_t* counts,
                             zk_stream_t stream);
 /* recv[r*count .. (r+1)*count) <- send of rank r (row-sparse source-embedding gradient, parallel.py:142-181) */
 int zk_comm_allgather(void* comm, const void* send, void* recv, size_t count, int dtype, zk_stream_t stream);
+
+/* ---- Layer program (zk_layer.hip): a run of dependent, sentence-local ops -- the linear / attention / residual +
+ * LayerNorm chain of the encoder and decoder stacks (transformer.py:35-69, 121-181; func.py:194-338) -- executed by ONE
+ * persistent launch instead of one launch per op.  The B sentences are dealt to the 8 XCDs; every XCD walks the op list
+ * on its own sentences with a barrier among ITS workgroups between ops, activations staying in its L2.  The ops run
+ * the same tile functions as the launch-per-op kernels: bit-identical results.
+ * Recording: between zk_prog_begin(B) and zk_prog_end on one host thread, zk_gemm (untransposed A), zk_attn_fwd,
+ * zk_attn_bwd (one 64x64 tile per sentence and head) and zk_add_ln_fwd append an op instead of launching; any other
+ * variant makes the recording fail (zk_prog_end returns -2 and the caller issues ordinary launches).  Entry points
+ * that are not listed here must not be called while recording.  A program is either a forward chain (gemm, attention
+ * forward, residual + LayerNorm) or a backward chain (gemm, attention backward): zk_prog_end reports which in
+ * *is_backward, to be passed to zk_prog_launch.  zk_prog_end copies the ops to a HOST buffer; the
+ * caller uploads them and owns the device copy and the state buffer (zk_prog_state_bytes(), any content).
+ * state after a launch (ints): [576] workgroups found on another XCD than their group's (handled: that group runs
+ * placement-independent barriers), [577] != 0: a barrier timed out and the launch drained (results invalid). */
+size_t zk_prog_op_bytes(void);
+size_t zk_prog_state_bytes(void);
+int zk_prog_begin(int sentences);
+int zk_prog_end(void* ops_out, size_t cap_bytes, int* nops, int* is_backward);
+int zk_prog_launch(const void* ops_dev, int nops, int sentences, int backward, void* state_dev, zk_stream_t stream);
 
 /* dropout plumbing */
 int zk_dropout_mask(float* out, size_t n, float drop_p, const uint64_t* seed, uint32_t sid, zk_stream_t stream);

@@ -786,6 +786,29 @@ def test_gemm_k_segmented(tb, shape):
         e.gemm_kseg([(mat(A[0]), mat(Bm[0]))] * 17, mat(C), M, N, kseg, tb)
 
 
+@pytest.mark.parametrize("tile", [6, 7])
+@pytest.mark.parametrize("tt", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("ns", [0, 2])
+def test_gemm_wide_register_tiles(tile, tt, ns):
+    """256x128 / 128x256 workgroup tiles with a 128x64 register tile per compute wave + four producer waves (ring depth
+    3 or 2): every transposition, ragged M / N / K, epilogues, fp32 and bf16 outputs, split-K -- against fp32 torch."""
+    e = eng()
+    ta, tb = tt
+    for (M, N, K, f32, split) in [(512, 512, 256, 0, 0), (304, 520, 200, 1, 0), (776, 264, 4096, 1, 3), (256, 768, 72, 0, 0)]:
+        A = rand_bf(K, M, seed=1) if ta else rand_bf(M, K, seed=1)
+        Bm = rand_bf(N, K, seed=2) if tb else rand_bf(K, N, seed=2)
+        bias = torch.randn(N, device="cuda") if not split else None
+        res = rand_bf(M, N, seed=3) if not split else None
+        C = torch.zeros(M, N, device="cuda", dtype=torch.float32 if f32 else torch.bfloat16)
+        e.gemm(mat(A), mat(Bm), mat(C), M, N, K, ta, tb, bias=bias, residual=mat(res) if res is not None else None,
+               act=1 if not split else 0, impl=2 | (tile << 8) | (split << 16) | (ns << 24))
+        torch.cuda.synchronize()
+        ref = (A.float().t() if ta else A.float()) @ (Bm.float().t() if tb else Bm.float())
+        if bias is not None:
+            ref = torch.relu(ref + bias + res.float())
+        assert rel_err(C, ref) < (1e-5 if f32 else 8e-3), (tile, tt, ns, M, N, K, rel_err(C, ref))
+
+
 def test_gemm_plan_reports_producer_waves():
     """zk_gemm_plan labels the instance that runs: bits [30:28] carry the producer waves of the tile class."""
     e = eng()
@@ -793,7 +816,9 @@ def test_gemm_plan_reports_producer_waves():
     old = e.lib.raw("zk_tune")(6, 0x44)
     try:
         code = plan(4096, 512, 512, 0, 1)
-        assert (code & 255, (code >> 8) & 255, (code >> 16) & 255, (code >> 28) & 7) == (2, 64, 64, 4)
+        assert (code & 255, ((code >> 8) & 255) * 8, ((code >> 16) & 255) * 8, (code >> 28) & 7) == (2, 64, 64, 4)
+        wide = plan(4096, 512, 32000, 0, 1)          # dlogits x E: 128x256 tiles of 128x64 register tiles, split 4
+        assert (((wide >> 8) & 255) * 8, ((wide >> 16) & 255) * 8, (wide >> 24) & 15, (wide >> 28) & 7) == (128, 256, 4, 4)
         e.lib.raw("zk_tune")(6, 0)
         assert (plan(4096, 512, 512, 0, 1) >> 28) & 7 == 0
     finally:

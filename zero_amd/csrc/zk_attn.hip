@@ -16,122 +16,8 @@
 //     16-lane shuffle reductions.  Backward = flash-style recompute from the saved
 //     log-sum-exp: kernel A (per query tile) -> dQ and D=rowsum(dO*O); kernel B (per key
 //     tile) -> dK, dV.
-#include "zk_common.h"
-
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-
-struct AttnArgs {
-  const bf16_t* q; const bf16_t* k; const bf16_t* v;
-  int ldq, ldk, ldv;
-  long bsq, bsk, bsv;      // batch strides (elements) of q / k / v
-  int kv_group;            // key/value (and kmask) batch index = b / kv_group (beam-tiled queries)
-  int B, nh, Lq, Lk, d;
-  const float* kmask;      // [B, Lk] 1 = valid key, 0 = pad; may be null
-  int causal; int q_pos0;  // absolute position of query row 0 (decode: the time step)
-  float scale; float mask_inf;
-  const bf16_t* rpr_k; const bf16_t* rpr_v; int max_rel;   // [2*max_rel+1, d] tables or null
-  uint32_t thr; float inv_keep; const uint64_t* seed; uint32_t sid;
-  int ldmask;              // row stride of kmask (= the host-side Lk)
-  // decode step replayed from a hipGraph: the time step lives in device memory.  pos_flags bit 0:
-  // q_pos0 = *pos_dev; bit 1: only keys 0 .. *pos_dev are valid (self-attention over the cache)
-  const int* pos_dev; int pos_flags;
-  // Relative-position terms on the MFMA path (modules/rpr.py:10-75), decomposed so that the table
-  // products are plain GEMMs done by the caller.  All four are [B*Lq, ldg] (gq, gd fp32; pb, dsb bf16) with the entry of
-  // (token t, head h, relative index r) at t*ldg + h*nrp + r:
-  //   gq  in : Q_h . Rk^T   -> gathered into the scores      gd  in : dO_h . Rv^T -> gathered into dP
-  //   pb  out: sum over keys with relative index r of P (after dropout)   -> O += pb . Rv, dRv = pb^T dO
-  //   dsb out: the same bucket sums of dS                                  -> dQ += dsb . Rk, dRk = dsb^T Q
-  const float* gq; const float* gd; bf16_t* pb; bf16_t* dsb; int ldg; int nrp;
-};
-
-__device__ __forceinline__ void attn_apply_pos(AttnArgs& a) {
-  if (a.pos_dev != nullptr) {
-    const int t = *a.pos_dev;
-    if (a.pos_flags & 1) a.q_pos0 = t;
-    if (a.pos_flags & 2) a.Lk = min(a.Lk, t + 1);
-  }
-}
-
-__device__ __forceinline__ int rel_index(int i_abs, int j, int max_rel) {
-  int dlt = i_abs - j;                         // modules/rpr.py:66-75
-  dlt = dlt < -max_rel ? -max_rel : (dlt > max_rel ? max_rel : dlt);
-  return dlt + max_rel;
-}
-
-// additive mask of key j for query i (absolute position), reference semantics
-__device__ __forceinline__ float mask_bias(const AttnArgs& a, int b, int i_abs, int j) {
-  float bias = 0.f;
-  if (a.kmask != nullptr && a.kmask[(size_t)(b / a.kv_group) * a.ldmask + j] == 0.f) bias -= a.mask_inf;
-  if (a.causal && j > i_abs) bias -= a.mask_inf;
-  return bias;
-}
-
-// Bucket sums over the relative index for the 16 query rows a wave owns.  `val(row, j)` reads entry
-// (local row, key j) of a [64 x Lk] LDS tile; keys j in [0, Lk).  Interior indices 0 < r < 2m pick the
-// single key j = i_abs - (r - m); r = 0 collects j >= i_abs + m, r = 2m collects j <= i_abs - m
-// (the clipped tails of modules/rpr.py:66-75); r > 2m is padding (0).
-template <typename F>
-__device__ __forceinline__ void rpr_bucket_rows(const AttnArgs& a, bf16_t* __restrict__ dst, int b, int h, int i0,
-                                                int w, int lane, F val) {
-  const int m = a.max_rel;
-  for (int e = lane; e < 16 * a.nrp; e += 64) {
-    const int row = w * 16 + e / a.nrp, r = e % a.nrp;
-    const int i = i0 + row;
-    if (i >= a.Lq) continue;
-    const int ia = a.q_pos0 + i;
-    float acc = 0.f;
-    if (r > 0 && r < 2 * m) {
-      const int j = ia - (r - m);
-      if (j >= 0 && j < a.Lk) acc = val(row, j);
-    } else if (r == 0) {
-      for (int j = max(ia + m, 0); j < a.Lk; ++j) acc += val(row, j);
-    } else if (r == 2 * m) {
-      for (int j = min(ia - m, a.Lk - 1); j >= 0; --j) acc += val(row, j);
-    }
-    dst[((size_t)b * a.Lq + i) * a.ldg + h * a.nrp + r] = f2bf(acc);
-  }
-}
-// Multi-tile form: entry u of this lane (e = lane + 64 u) accumulates the keys [j0, j0 + 64) of the tile
-// currently in LDS; `val(row, jl)` reads local key jl.  MAXU * 64 >= 16 * nrp entries per wave.
-#define RPR_MAXU 16
-template <typename F>
-__device__ __forceinline__ void rpr_bucket_accum(const AttnArgs& a, float (&acc)[RPR_MAXU], int i0, int j0, int w,
-                                                 int lane, F val) {
-  const int m = a.max_rel;
-#pragma unroll
-  for (int u = 0; u < RPR_MAXU; ++u) {
-    const int e = lane + 64 * u;
-    if (e >= 16 * a.nrp) break;
-    const int row = w * 16 + e / a.nrp, r = e % a.nrp;
-    const int i = i0 + row;
-    if (i >= a.Lq) continue;
-    const int ia = a.q_pos0 + i;
-    const int jend = min(j0 + 64, a.Lk);
-    if (r > 0 && r < 2 * m) {
-      const int j = ia - (r - m);
-      if (j >= j0 && j < jend) acc[u] += val(row, j - j0);
-    } else if (r == 0) {
-      for (int j = max(ia + m, j0); j < jend; ++j) acc[u] += val(row, j - j0);
-    } else if (r == 2 * m) {
-      for (int j = min(ia - m, jend - 1); j >= j0; --j) acc[u] += val(row, j - j0);
-    }
-  }
-}
-__device__ __forceinline__ void rpr_bucket_store(const AttnArgs& a, const float (&acc)[RPR_MAXU], bf16_t* __restrict__ dst,
-                                                 int b, int h, int i0, int w, int lane) {
-#pragma unroll
-  for (int u = 0; u < RPR_MAXU; ++u) {
-    const int e = lane + 64 * u;
-    if (e >= 16 * a.nrp) break;
-    const int i = i0 + w * 16 + e / a.nrp;
-    if (i < a.Lq) dst[((size_t)b * a.Lq + i) * a.ldg + h * a.nrp + e % a.nrp] = f2bf(acc[u]);
-  }
-}
-__device__ __forceinline__ float rpr_gather(const AttnArgs& a, const float* __restrict__ tab, int b, int h, int i,
-                                            int j) {
-  return tab[((size_t)b * a.Lq + i) * a.ldg + h * a.nrp + rel_index(a.q_pos0 + i, j, a.max_rel)];
-}
+#include "zk_attn_dev.h"
+#include "zk_prog.h"
 
 // =====================================================================================
 // reference kernels
@@ -344,250 +230,15 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv_naive(AttnArgs a, const bf
 }
 
 // =====================================================================================
-// MFMA kernels (d = 64)
+// MFMA kernels (d = 64): tile functions in zk_attn_dev.h
 // =====================================================================================
-#define AD 64            // head dim
-#define ALD 72           // LDS row stride (bf16): 144 B rows -> conflict-free b128 fragment reads
-#define TQ 64            // query / key tile
-
-__device__ __forceinline__ f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
-                                                 __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-// fragment of a [rows][ALD] LDS tile: row r0+(lane&15), 8 consecutive k at kk*32+8*(lane>>4)
-__device__ __forceinline__ uint4 frag(const bf16_t* t, int r0, int kk, int lane) {
-  return *reinterpret_cast<const uint4*>(t + (r0 + (lane & 15)) * ALD + kk * 32 + (lane >> 4) * 8);
-}
-// stage rows [row0, row0+64) x 64 channels (channel-contiguous in HBM) -> dst[64][ALD]; rows >= nrows -> 0
-__device__ __forceinline__ void stage_direct(bf16_t* dst, const bf16_t* src, int ld, int row0, int nrows, int tid) {
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int t = tid + it * 256;
-    const int r = t >> 3, c = (t & 7) * 8;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (row0 + r < nrows) v = *reinterpret_cast<const uint4*>(src + (size_t)(row0 + r) * ld + c);
-    *reinterpret_cast<uint4*>(dst + r * ALD + c) = v;
-  }
-}
-__device__ __forceinline__ uint32_t half_of4(const uint4& v, int i) {
-  const uint32_t w = (i >> 1) == 0 ? v.x : ((i >> 1) == 1 ? v.y : ((i >> 1) == 2 ? v.z : v.w));
-  return (i & 1) ? (w >> 16) : (w & 0xffffu);
-}
-// transposed staging: dst[phys(c)][r] = src[row0+r][c]; channel rows stored in permuted order
-// phys(c) = (c%8)*8 + c/8 so that the 8-byte LDS writes of neighbouring lanes hit different banks.
-__device__ __forceinline__ void stage_trans(bf16_t* dst, const bf16_t* src, int ld, int row0, int nrows, int tid) {
-  if (tid < 128) {
-    const int dc = tid & 7, rq = tid >> 3;   // channel chunk (8 channels), row quad (4 rows)
-    uint4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int r = row0 + rq * 4 + u;
-      v[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (r < nrows) v[u] = *reinterpret_cast<const uint4*>(src + (size_t)r * ld + dc * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      uint2 o;
-      o.x = half_of4(v[0], i) | (half_of4(v[1], i) << 16);
-      o.y = half_of4(v[2], i) | (half_of4(v[3], i) << 16);
-      *reinterpret_cast<uint2*>(dst + (i * 8 + dc) * ALD + rq * 4) = o;
-    }
-  }
-}
-__device__ __forceinline__ int chan_of_phys(int q) { return (q & 7) * 8 + (q >> 3); }
-// The same staging in two halves -- all global loads of a prologue are issued before the first LDS store, so
-// their latencies overlap instead of adding up (one stage_* call after another measured ~1500 cycles each).
-// Branch-free: rows past the end are clamped for the address and zeroed by a select.
-struct DirectRegs { uint4 v[2]; };
-__device__ __forceinline__ void load_direct(DirectRegs& R, const bf16_t* src, int ld, int row0, int nrows, int tid) {
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int t = tid + it * 256;
-    const int r = row0 + (t >> 3), c = (t & 7) * 8;
-    const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)min(r, nrows - 1) * ld + c);
-    R.v[it] = r < nrows ? v : make_uint4(0u, 0u, 0u, 0u);
-  }
-}
-__device__ __forceinline__ void store_direct(bf16_t* dst, const DirectRegs& R, int tid) {
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int t = tid + it * 256;
-    *reinterpret_cast<uint4*>(dst + (t >> 3) * ALD + (t & 7) * 8) = R.v[it];
-  }
-}
-struct TransRegs { uint4 v[4]; };
-__device__ __forceinline__ void load_trans(TransRegs& R, const bf16_t* src, int ld, int row0, int nrows, int t128) {
-  const int dc = t128 & 7, rq = t128 >> 3;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int r = row0 + rq * 4 + u;
-    const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)min(r, nrows - 1) * ld + dc * 8);
-    R.v[u] = r < nrows ? v : make_uint4(0u, 0u, 0u, 0u);
-  }
-}
-__device__ __forceinline__ void store_trans(bf16_t* dst, const TransRegs& R, int t128) {
-  const int dc = t128 & 7, rq = t128 >> 3;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    uint2 o;
-    o.x = half_of4(R.v[0], i) | (half_of4(R.v[1], i) << 16);
-    o.y = half_of4(R.v[2], i) | (half_of4(R.v[3], i) << 16);
-    *reinterpret_cast<uint2*>(dst + (i * 8 + dc) * ALD + rq * 4) = o;
-  }
-}
-// [64 rows][64 channels] bf16 tile in LDS (row stride ALD) -> global rows [0, nrows), 16 bytes per thread and store
-__device__ __forceinline__ void store_tile_rows(const bf16_t* tile, bf16_t* dst, size_t ld, int nrows, int tid) {
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int t = tid + it * 256;
-    const int r = t >> 3, c = (t & 7) * 8;
-    if (r < nrows) *reinterpret_cast<uint4*>(dst + (size_t)r * ld + c) = *reinterpret_cast<const uint4*>(tile + r * ALD + c);
-  }
-}
-
-__device__ __forceinline__ float quad16_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
-  v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
-  return v;
-}
-__device__ __forceinline__ float quad16_sum(float v) {
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-  return v;
-}
-
 // ---- forward: grid (ceil(Lq/64), nh, B); NKT = ceil(Lk/64) <= 4
 template <int NKT>
 __global__ void __launch_bounds__(256) k_attn_fwd_mfma(AttnArgs a, bf16_t* __restrict__ out, int ldo,
                                                        float* __restrict__ lse) {
-  __shared__ __attribute__((aligned(16))) bf16_t sQ[TQ * ALD];
-  __shared__ __attribute__((aligned(16))) bf16_t sK[TQ * ALD];    // K tile, later V^T tile
-  __shared__ __attribute__((aligned(16))) bf16_t sP[TQ * (NKT * 64 + 8)];
-  constexpr int PLD = NKT * 64 + 8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[AttnFwdLds<NKT>::BYTES];
   attn_apply_pos(a);
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int i0 = blockIdx.x * TQ, h = blockIdx.y, b = blockIdx.z;
-  const bf16_t* qb = a.q + (size_t)b * a.bsq + h * AD;
-  const bf16_t* kb = a.k + (size_t)(b / a.kv_group) * a.bsk + h * AD;
-  const bf16_t* vb = a.v + (size_t)(b / a.kv_group) * a.bsv + h * AD;
-  const uint64_t seed = a.thr ? *a.seed : 0;
-
-  // the loads that do not depend on anything computed here are issued together: Q, the first K tile, the first
-  // V tile (kept in registers until P is ready) and the key mask -- one memory round trip instead of four
-  DirectRegs rQ, rK;
-  TransRegs rVt;
-  load_direct(rQ, qb, a.ldq, i0, a.Lq, tid);
-  load_direct(rK, kb, a.ldk, 0, a.Lk, tid);
-  if (tid < 128) load_trans(rVt, vb, a.ldv, 0, a.Lk, tid);
-  float kbias[NKT * 4];
-#pragma unroll
-  for (int t = 0; t < NKT * 4; ++t) {
-    const int j = t * 16 + (lane & 15);
-    kbias[t] = (a.kmask != nullptr && a.kmask[(size_t)(b / a.kv_group) * a.ldmask + min(j, a.Lk - 1)] == 0.f) ? -a.mask_inf : 0.f;
-  }
-  store_direct(sQ, rQ, tid);
-  store_direct(sK, rK, tid);
-  f32x4_t S[NKT * 4];
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-    if (kt > 0) {
-      __syncthreads();   // previous tile's readers are done with sK
-      stage_direct(sK, kb, a.ldk, kt * 64, a.Lk, tid);
-    }
-    __syncthreads();
-    const uint4 q0 = frag(sQ, w * 16, 0, lane), q1 = frag(sQ, w * 16, 1, lane);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-      acc = mfma16(q0, frag(sK, nt * 16, 0, lane), acc);
-      acc = mfma16(q1, frag(sK, nt * 16, 1, lane), acc);
-      S[kt * 4 + nt] = acc;
-    }
-  }
-  // scale + mask; C layout: col (key) = lane&15, row (query) = (lane>>4)*4 + reg
-  const int rbase = i0 + w * 16 + (lane >> 4) * 4;
-  float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-  for (int t = 0; t < NKT * 4; ++t) {
-    const int j = t * 16 + (lane & 15);
-    const bool kvalid = j < a.Lk;
-    const float kb_ = kvalid ? kbias[t] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float raw = S[t][r];
-      if (a.gq != nullptr && kvalid && rbase + r < a.Lq) raw += rpr_gather(a, a.gq, b, h, rbase + r, j);
-      float s = raw * a.scale + kb_;
-      if (a.causal && j > a.q_pos0 + rbase + r) s -= a.mask_inf;
-      s = kvalid ? s : -INFINITY;
-      S[t][r] = s;
-      mx[r] = fmaxf(mx[r], s);
-    }
-  }
-  float sum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int r = 0; r < 4; ++r) mx[r] = quad16_max(mx[r]);
-#pragma unroll
-  for (int t = 0; t < NKT * 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float e = __expf(S[t][r] - mx[r]);
-      S[t][r] = e;
-      sum[r] += e;
-    }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    sum[r] = quad16_sum(sum[r]);
-    const int i = rbase + r;
-    if ((lane & 15) == 0 && i < a.Lq && lse != nullptr)
-      lse[((size_t)b * a.nh + h) * a.Lq + i] = mx[r] + __logf(sum[r]);
-    sum[r] = 1.f / sum[r];
-  }
-  // P (bf16, after dropout) -> sP rows owned by this wave
-#pragma unroll
-  for (int t = 0; t < NKT * 4; ++t) {
-    const int j = t * 16 + (lane & 15);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float p = S[t][r] * sum[r];
-      if (a.thr) {
-        const uint64_t idx = (((uint64_t)b * a.nh + h) * a.Lq + (rbase + r)) * a.Lk + j;
-        p *= zk_drop_scale(seed, a.sid, idx, a.thr, a.inv_keep);
-      }
-      sP[(w * 16 + (lane >> 4) * 4 + r) * PLD + j] = f2bf(p);
-    }
-  }
-  if (a.pb != nullptr) {   // relative-position value term: bucket sums of this wave's own rows of P
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    rpr_bucket_rows(a, a.pb, b, h, i0, w, lane, [&](int row, int j) { return bf2f(sP[row * PLD + j]); });
-  }
-  // O = P V, V^T staged per key tile into sK
-  f32x4_t O[4];
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb) O[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-    __syncthreads();   // sK readers done / sP complete
-    if (kt == 0) { if (tid < 128) store_trans(sK, rVt, tid); }
-    else stage_trans(sK, vb, a.ldv, kt * 64, a.Lk, tid);
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const uint4 pa = *reinterpret_cast<const uint4*>(sP + (w * 16 + (lane & 15)) * PLD + kt * 64 + kk * 32 +
-                                                       (lane >> 4) * 8);
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) O[nb] = mfma16(pa, frag(sK, nb * 16, kk, lane), O[nb]);
-    }
-  }
-  // O through LDS (sQ is dead) so that every thread stores 16 bytes of a row
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb) {
-    const int c = chan_of_phys(nb * 16 + (lane & 15));
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sQ[(w * 16 + (lane >> 4) * 4 + r) * ALD + c] = f2bf(O[nb][r]);
-  }
-  __syncthreads();
-  store_tile_rows(sQ, out + ((size_t)b * a.Lq + i0) * ldo + h * AD, ldo, a.Lq - i0, tid);
+  attn_fwd_tile<NKT>(smem, a, out, ldo, lse, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ---- backward A: grid (ceil(Lq/64), nh, B) -> dQ, Dbuf
@@ -819,184 +470,15 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv_mfma(AttnArgs a, const bf1
   }
 }
 
-// ---- backward, single tile (Lq <= 64 and Lk <= 64): grid (1, nh, B) -> dQ, dK, dV in ONE pass.
-// The two-kernel form above reads Q, K, V, dO twice and recomputes S and dP; at the training
-// shapes of the north star (L = 64) a whole (batch, head) problem is one 64x64 tile, so one
-// workgroup computes P and dS once (wave w owns query rows 16w..16w+15) and all three gradients
-// follow from LDS: dQ = dS K, dK = dS^T Q, dV = P^T dO.  The operand tiles of the first phase are
-// dead by then and their LDS is reused for dS, P^T and dS^T (7 tiles = 64.5 KB -> 2 workgroups/CU).
+// ---- backward, single tile (Lq <= 64 and Lk <= 64): grid (1, nh, B) -> dQ, dK, dV in ONE pass (attn_bwd_fused64_tile)
 __global__ void __launch_bounds__(256) k_attn_bwd_fused64(AttnArgs a, const bf16_t* __restrict__ o, int ldo,
                                                           const bf16_t* __restrict__ dout, int lddo,
                                                           const float* __restrict__ lse,
                                                           bf16_t* __restrict__ dq, int lddq,
                                                           bf16_t* __restrict__ dk, int lddk,
                                                           bf16_t* __restrict__ dv, int lddv) {
-  __shared__ __attribute__((aligned(16))) bf16_t sQ[TQ * ALD];    // phase 2: dS   [query][key]
-  __shared__ __attribute__((aligned(16))) bf16_t sK[TQ * ALD];    // phase 2: P^T  [key][query]
-  __shared__ __attribute__((aligned(16))) bf16_t sV[TQ * ALD];    // phase 2: dS^T [key][query]
-  __shared__ __attribute__((aligned(16))) bf16_t sdO[TQ * ALD];
-  __shared__ __attribute__((aligned(16))) bf16_t sKt[TQ * ALD];
-  __shared__ __attribute__((aligned(16))) bf16_t sQt[TQ * ALD];
-  __shared__ __attribute__((aligned(16))) bf16_t sdOt[TQ * ALD];
-  __shared__ float sL[TQ];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const bf16_t* qb = a.q + (size_t)b * a.bsq + h * AD;
-  const bf16_t* kb = a.k + (size_t)b * a.bsk + h * AD;
-  const bf16_t* vb = a.v + (size_t)b * a.bsv + h * AD;
-  (void)o; (void)ldo;
-  const bf16_t* dob = dout + (size_t)b * a.Lq * lddo + h * AD;
-  const uint64_t seed = a.thr ? *a.seed : 0;
-
-  // every global load of the prologue first (tiles, the O / dO rows of D_i, lse, the key mask), then the LDS stores
-  DirectRegs rQ, rdO, rK, rV;
-  TransRegs t0, t1;
-  load_direct(rQ, qb, a.ldq, 0, a.Lq, tid);
-  load_direct(rdO, dob, lddo, 0, a.Lq, tid);
-  load_direct(rK, kb, a.ldk, 0, a.Lk, tid);
-  load_direct(rV, vb, a.ldv, 0, a.Lk, tid);
-  if (tid < 128) {
-    load_trans(t0, kb, a.ldk, 0, a.Lk, tid);
-  } else {
-    load_trans(t0, qb, a.ldq, 0, a.Lq, tid - 128);
-    load_trans(t1, dob, lddo, 0, a.Lq, tid - 128);
-  }
-  // D_i = sum_j P_ij dP_ij is taken from the P and dP this workgroup computes anyway (whole rows live in one tile),
-  // not from rowsum(dO o O) over the stored bf16 O: no O / dO row loads, and sum_j dS_ij = 0 holds to fp32 rounding
-  // (with the bf16 O the rows of dS kept a common offset ~2^-9 |dO.O| that leaked mean(K) into dQ -- 30 % of the
-  // tiny q_map / k_map gradients of the 12-layer-encoder configuration, tests/test_gpu_fullsize.py)
-  const int dr = tid >> 2, dpart = tid & 3;
-  const int drc = min(dr, a.Lq - 1);
-  const float lse_r = lse[((size_t)b * a.nh + h) * a.Lq + drc];
-  float kbias4[4];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const int j = nt * 16 + (lane & 15);
-    kbias4[nt] = (a.kmask != nullptr && a.kmask[(size_t)b * a.ldmask + min(j, a.Lk - 1)] == 0.f) ? -a.mask_inf : 0.f;
-  }
-  store_direct(sQ, rQ, tid);
-  store_direct(sdO, rdO, tid);
-  store_direct(sK, rK, tid);
-  store_direct(sV, rV, tid);
-  if (tid < 128) {
-    store_trans(sKt, t0, tid);
-  } else {
-    store_trans(sQt, t0, tid - 128);
-    store_trans(sdOt, t1, tid - 128);
-  }
-  if (dpart == 0) sL[dr] = (dr < a.Lq) ? lse_r : 0.f;
-  __syncthreads();
-  // ---- phase 1: P and dS of query rows 16w .. 16w+15 against all 64 keys, kept in registers
-  const int rloc = w * 16 + (lane >> 4) * 4;
-  float pv[4][4], dsv[4][4];
-  {
-    float pu[4][4], dpv[4][4], Di[4] = {0.f, 0.f, 0.f, 0.f};
-    const uint4 q0 = frag(sQ, w * 16, 0, lane), q1 = frag(sQ, w * 16, 1, lane);
-    const uint4 g0 = frag(sdO, w * 16, 0, lane), g1 = frag(sdO, w * 16, 1, lane);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      f32x4_t sc4 = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-      sc4 = mfma16(q0, frag(sK, nt * 16, 0, lane), sc4);
-      sc4 = mfma16(q1, frag(sK, nt * 16, 1, lane), sc4);
-      dp = mfma16(g0, frag(sV, nt * 16, 0, lane), dp);
-      dp = mfma16(g1, frag(sV, nt * 16, 1, lane), dp);
-      const int j = nt * 16 + (lane & 15);
-      const bool kvalid = j < a.Lk;
-      const float kbias = kvalid ? kbias4[nt] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = rloc + r;
-        const bool live = kvalid && i < a.Lq;
-        float raw = sc4[r], dpr = dp[r];
-        if (a.gq != nullptr && live) { raw += rpr_gather(a, a.gq, b, h, i, j); dpr += rpr_gather(a, a.gd, b, h, i, j); }
-        float sc = raw * a.scale + kbias;
-        if (a.causal && j > a.q_pos0 + i) sc -= a.mask_inf;
-        const float p = live ? __expf(sc - sL[i]) : 0.f;
-        float ms = 1.f;
-        if (a.thr) {
-          const uint64_t idx = (((uint64_t)b * a.nh + h) * a.Lq + i) * a.Lk + j;
-          ms = zk_drop_scale(seed, a.sid, idx, a.thr, a.inv_keep);
-        }
-        pv[nt][r] = p * ms;
-        pu[nt][r] = p;
-        dpv[nt][r] = dpr * ms;
-        Di[r] += p * dpr * ms;
-      }
-    }
-    // a query row's 64 keys sit in the 16 lanes of its group x 4 key tiles
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      Di[r] += __shfl_xor(Di[r], 1, 64);
-      Di[r] += __shfl_xor(Di[r], 2, 64);
-      Di[r] += __shfl_xor(Di[r], 4, 64);
-      Di[r] += __shfl_xor(Di[r], 8, 64);
-    }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dsv[nt][r] = pu[nt][r] * (dpv[nt][r] - Di[r]) * a.scale;
-  }
-  __syncthreads();                     // every wave is done reading sQ / sK / sV / sdO
-  bf16_t* sdS = sQ;
-  bf16_t* sPt = sK;
-  bf16_t* sdSt = sV;
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const int j = nt * 16 + (lane & 15);
-    uint2 pp, dd;
-    pp.x = (uint32_t)f2bf(pv[nt][0]) | ((uint32_t)f2bf(pv[nt][1]) << 16);
-    pp.y = (uint32_t)f2bf(pv[nt][2]) | ((uint32_t)f2bf(pv[nt][3]) << 16);
-    dd.x = (uint32_t)f2bf(dsv[nt][0]) | ((uint32_t)f2bf(dsv[nt][1]) << 16);
-    dd.y = (uint32_t)f2bf(dsv[nt][2]) | ((uint32_t)f2bf(dsv[nt][3]) << 16);
-    *reinterpret_cast<uint2*>(sPt + j * ALD + rloc) = pp;       // 4 consecutive queries of key row j
-    *reinterpret_cast<uint2*>(sdSt + j * ALD + rloc) = dd;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sdS[(rloc + r) * ALD + j] = f2bf(dsv[nt][r]);
-  }
-  __syncthreads();
-  if (a.dsb != nullptr) {   // bucket sums for the relative-position table products (see AttnArgs)
-    rpr_bucket_rows(a, a.dsb, b, h, 0, w, lane, [&](int row, int j) { return bf2f(sdS[row * ALD + j]); });
-    rpr_bucket_rows(a, a.pb, b, h, 0, w, lane, [&](int row, int j) { return bf2f(sPt[j * ALD + row]); });
-  }
-  // ---- phase 2: wave w -> dQ rows 16w.. (queries) and dK / dV rows 16w.. (keys)
-  f32x4_t dQ[4], dK[4], dV[4];
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb) {
-    dQ[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    dK[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    dV[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  }
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    const uint4 da = frag(sdS, w * 16, kk, lane);
-    const uint4 pa = frag(sPt, w * 16, kk, lane);
-    const uint4 dt = frag(sdSt, w * 16, kk, lane);
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      dQ[nb] = mfma16(da, frag(sKt, nb * 16, kk, lane), dQ[nb]);
-      dV[nb] = mfma16(pa, frag(sdOt, nb * 16, kk, lane), dV[nb]);
-      dK[nb] = mfma16(dt, frag(sQt, nb * 16, kk, lane), dK[nb]);
-    }
-  }
-  // results through LDS ([row][channel] tiles over the transposed operands, which are dead now) so that every
-  // thread stores 16 bytes instead of 48 scattered 2-byte elements
-  __syncthreads();
-  bf16_t* oQ = sKt; bf16_t* oK = sQt; bf16_t* oV = sdOt;
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb) {
-    const int c = chan_of_phys(nb * 16 + (lane & 15));
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = rloc + r;     // query row for dQ, key row for dK / dV
-      oQ[i * ALD + c] = f2bf(dQ[nb][r]);
-      oK[i * ALD + c] = f2bf(dK[nb][r]);
-      oV[i * ALD + c] = f2bf(dV[nb][r]);
-    }
-  }
-  __syncthreads();
-  store_tile_rows(oQ, dq + (size_t)b * a.Lq * lddq + h * AD, lddq, a.Lq, tid);
-  store_tile_rows(oK, dk + (size_t)b * a.Lk * lddk + h * AD, lddk, a.Lk, tid);
-  store_tile_rows(oV, dv + (size_t)b * a.Lk * lddv + h * AD, lddv, a.Lk, tid);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[ATTN_BWD64_LDS_BYTES];
+  attn_bwd_fused64_tile(smem, a, o, ldo, dout, lddo, lse, dq, lddq, dk, lddk, dv, lddv, blockIdx.y, blockIdx.z);
 }
 
 // =====================================================================================
@@ -1058,6 +540,7 @@ int zk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* l
   if (impl == 2 || (impl == 0 && ok)) {
     dim3 grid((Lq + TQ - 1) / TQ, nh, B);
     const int nkt = (Lk + 63) / 64;
+    if (zk_prog_active()) return zk_prog_record_attn_fwd(a, (bf16_t*)out, ldo, lse, nkt);
     if (nkt == 1) hipLaunchKernelGGL(k_attn_fwd_mfma<1>, grid, dim3(256), 0, stream, a, (bf16_t*)out, ldo, lse);
     else if (nkt == 2) hipLaunchKernelGGL(k_attn_fwd_mfma<2>, grid, dim3(256), 0, stream, a, (bf16_t*)out, ldo, lse);
     else if (nkt == 3) hipLaunchKernelGGL(k_attn_fwd_mfma<3>, grid, dim3(256), 0, stream, a, (bf16_t*)out, ldo, lse);
@@ -1068,6 +551,7 @@ int zk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* l
   ZK_CHECK_ARG(Lk <= NAIVE_MAXK * 64, "zk_attn_fwd: Lk=%d exceeds the reference kernel limit %d", Lk,
                NAIVE_MAXK * 64);
   ZK_CHECK_ARG(d <= 256, "zk_attn_fwd: d=%d > 256", d);
+  if (zk_prog_active()) return zk_prog_reject("attention forward on the reference kernel");
   const long rows = (long)B * nh * Lq;
   hipLaunchKernelGGL(k_attn_fwd_naive, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a, (bf16_t*)out, ldo,
                      lse);
@@ -1106,6 +590,12 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
   ZK_CHECK_ARG(rpr_gq == nullptr || (ok && impl != 1), "zk_attn_bwd: decomposed rpr runs on the MFMA kernels only");
   ZK_CHECK_ARG(impl != 2 || ok, "zk_attn_bwd: MFMA kernel needs d=64, no rpr, ld%%8==0");
   ZK_CHECK_ARG(impl != 3 || ok, "zk_attn_bwd: MFMA kernels need d=64, no rpr, ld%%8==0");
+  if (zk_prog_active()) {
+    if (!((impl == 0 || impl == 2) && ok && Lq <= TQ && Lk <= TQ && rpr_gq == nullptr))
+      return zk_prog_reject("attention backward that is not one 64x64 MFMA tile per (sentence, head)");
+    return zk_prog_record_attn_bwd64(a, (const bf16_t*)out, ldo, (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq,
+                                     (bf16_t*)dk, lddk, (bf16_t*)dv, lddv);
+  }
   if ((impl == 0 || impl == 2) && ok && Lq <= TQ && Lk <= TQ) {      // impl 3 forces the two-kernel form
     hipLaunchKernelGGL(k_attn_bwd_fused64, dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
                        (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv);
@@ -1124,6 +614,7 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
   ZK_CHECK_ARG(Lk <= NAIVE_MAXK * 64, "zk_attn_bwd: Lk=%d exceeds the reference kernel limit %d", Lk,
                NAIVE_MAXK * 64);
   ZK_CHECK_ARG(d <= 256, "zk_attn_bwd: d=%d > 256", d);
+  if (zk_prog_active()) return zk_prog_reject("attention backward on the reference kernels");
   const long qrows = (long)B * nh * Lq, krows = (long)B * nh * Lk;
   hipLaunchKernelGGL(k_attn_bwd_dq_naive, dim3((unsigned)((qrows + 3) / 4)), dim3(256), 0, stream, a,
                      (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, Dbuf, drpr_k, drpr_v);

@@ -56,6 +56,25 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
   return v;
 }
 
+// ---------------------------------------------------------------- loads of data another CU wrote during THIS launch
+// A CU's vector L1 is never refreshed by another CU's stores (MI355X_MICROARCH.md, inter-workgroup visibility).  Inside
+// the persistent layer program (zk_layer.hip) an op reads what other workgroups of its XCD stored one barrier earlier:
+// FRESH = true issues the load with the nt policy, which bypasses the L1 and is served by the XCD's (coherent) L2, so
+// the barrier needs no L1 invalidate (~5 us per barrier at two workgroups per CU).  FRESH = false: ordinary load.
+typedef unsigned int zk_u32x4 __attribute__((ext_vector_type(4)));
+template <bool FRESH>
+__device__ __forceinline__ uint4 zk_ld16(const void* p) {
+  if (FRESH) {
+    const zk_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const zk_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  }
+  return *reinterpret_cast<const uint4*>(p);
+}
+template <bool FRESH>
+__device__ __forceinline__ float zk_ld_f32(const float* p) {
+  return FRESH ? __builtin_nontemporal_load(p) : *p;
+}
+
 // ---------------------------------------------------------------- wave / block reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

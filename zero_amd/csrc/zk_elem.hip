@@ -4,6 +4,8 @@
 // token row with shuffle reductions, fp32 math on bf16 storage.  Reference
 // semantics are cited per kernel (paths relative to bzhangGo/zero).
 #include "zk_common.h"
+#include "zk_ln_dev.h"
+#include "zk_prog.h"
 #include <cstring>
 #include <stdarg.h>
 #include <stdio.h>
@@ -120,56 +122,8 @@ __global__ void __launch_bounds__(256) k_add_ln_fwd(
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const uint64_t seed = (thr != 0) ? *seedp : 0;
   const float invH = 1.f / (float)H;
-  for (int r = wave; r < rows; r += nwaves) {
-    float v[MAXC][8];
-    float s1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-      const int c = (i * 64 + lane) * 8;
-      if (c < H) {
-        float a[8], b[8];
-        unpack8(*reinterpret_cast<const uint4*>(x + (size_t)r * H + c), a);
-        if (y != nullptr) {
-          unpack8(*reinterpret_cast<const uint4*>(y + (size_t)r * H + c), b);
-          if (thr != 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              b[j] *= zk_drop_scale(seed, sid, (uint64_t)r * H + c + j, thr, inv_keep);
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) a[j] += b[j];
-        }
-        uint4 p = pack8(a);
-        if (sum_out != nullptr) *reinterpret_cast<uint4*>(sum_out + (size_t)r * H + c) = p;
-        unpack8(p, v[i]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s1 += v[i][j];
-      }
-    }
-    const float mean = wave_sum(s1) * invH;
-    float s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-      const int c = (i * 64 + lane) * 8;
-      if (c < H) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; s2 += d * d; }
-      }
-    }
-    const float var = wave_sum(s2) * invH;
-    const float rstd = rsqrtf(var + eps);
-    if (lane == 0 && mean_out != nullptr) { mean_out[r] = mean; rstd_out[r] = rstd; }
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-      const int c = (i * 64 + lane) * 8;
-      if (c < H) {
-        float o[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = gamma[c + j] * (v[i][j] - mean) * rstd + beta[c + j];
-        *reinterpret_cast<uint4*>(out + (size_t)r * H + c) = pack8(o);
-      }
-    }
-  }
+  for (int r = wave; r < rows; r += nwaves)
+    add_ln_fwd_row<MAXC>(x, y, gamma, beta, out, sum_out, mean_out, rstd_out, r, H, invH, eps, thr, inv_keep, seed, sid, lane);
 }
 
 // backward of the above.  Per row: xhat=(s-mean)*rstd, g=dout*gamma,
@@ -1240,6 +1194,9 @@ int zk_add_ln_fwd(const void* x, const void* y, const float* gamma, const float*
   if (rows == 0) return 0;
   const uint32_t thr = (drop_p > 0.f && y != nullptr) ? zk_drop_threshold(drop_p) : 0;
   const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  if (zk_prog_active())
+    return zk_prog_record_add_ln_fwd((const bf16_t*)x, (const bf16_t*)y, gamma, beta, (bf16_t*)out, (bf16_t*)sum_out, mean,
+                                     rstd, rows, H, eps, thr, ik, seed, sid);
 #define ZK_LN_FWD(NC)                                                                                   \
   hipLaunchKernelGGL(k_add_ln_fwd<NC>, dim3(row_grid(rows)), dim3(256), 0, stream, (const bf16_t*)x,    \
                      (const bf16_t*)y, gamma, beta, (bf16_t*)out, (bf16_t*)sum_out, mean, rstd, rows, H, \
@@ -1590,6 +1547,50 @@ int zk_adam_step(float* p, const float* g, float* m, float* v, void* shadow, siz
     ZK_LAUNCH_CHECK();
     if (pnorm_out) hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, stream, (const float*)psq, grid, 1.f, pnorm_out);
   }
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+// The norm-free update in pieces (utils/parallel.py buckets; with ONE rank: the decoder-side parameters are updated
+// on a side stream while the encoder backward is still running).  zk_adam_range: TF1 Adam + shadow refresh on n
+// elements, per-block sums of squares of the scaled gradient and of the parameters into slot `slot` (< 16) of the
+// workspace (always 2048 blocks, so every entry of the slot is written); zk_adam_finish: one block sums nslots slots
+// -> hyper[6] gradient norm (+ flag hyper[7], sticky count hyper[10]), pnorm_out, seed += 1.
+size_t zk_adam_range_workspace(void) { return 16 * 4096 * sizeof(float); }
+int zk_adam_range(float* p, const float* g, float* m, float* v, void* shadow, size_t n, float* hyper, int slot,
+                  void* workspace, size_t ws_bytes, hipStream_t stream) {
+  ZK_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+               "zk_adam_range: buffers must be 16-byte aligned");
+  ZK_CHECK_ARG(slot >= 0 && slot < 16 && ws_bytes >= zk_adam_range_workspace() && hyper != nullptr,
+               "zk_adam_range: slot %d / workspace", slot);
+  float* psq = (float*)workspace + (size_t)slot * 4096;
+  hipLaunchKernelGGL(k_adam<true>, dim3(2048), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n, hyper, psq,
+                     psq + 2048, (uint64_t*)nullptr);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+__global__ void __launch_bounds__(256) k_adam_finish(const float* __restrict__ ws, int nslots, float* __restrict__ hyper,
+                                                     float* __restrict__ pnorm_out, uint64_t* __restrict__ seed) {
+  __shared__ float sm[8];
+  float a = 0.f, b = 0.f;
+  for (int s = 0; s < nslots; ++s)
+    for (int i = threadIdx.x; i < 2048; i += 256) { b += ws[s * 4096 + i]; a += ws[s * 4096 + 2048 + i]; }
+  a = block_sum<4>(a, sm);
+  b = block_sum<4>(b, sm);
+  if (threadIdx.x == 0) {
+    const float gn = sqrtf(a);
+    hyper[6] = gn;
+    const bool bad = !(gn == gn) || fabsf(gn) == INFINITY;
+    hyper[7] = bad ? 1.f : 0.f;
+    if (bad) hyper[10] += 1.f;
+    if (pnorm_out != nullptr) pnorm_out[0] = sqrtf(b);
+    if (seed != nullptr) *seed += 1;
+  }
+}
+int zk_adam_finish(float* hyper, float* pnorm_out, uint64_t* seed, int nslots, const void* workspace, size_t ws_bytes,
+                   hipStream_t stream) {
+  ZK_CHECK_ARG(hyper != nullptr && nslots >= 1 && nslots <= 16 && ws_bytes >= zk_adam_range_workspace(),
+               "zk_adam_finish: nslots %d / workspace", nslots);
+  hipLaunchKernelGGL(k_adam_finish, dim3(1), dim3(256), 0, stream, (const float*)workspace, nslots, hyper, pnorm_out, seed);
   ZK_LAUNCH_CHECK();
   return 0;
 }

@@ -21,6 +21,7 @@
 #include "zk_common.h"
 
 #include "zk_gemm.h"
+#include "zk_prog.h"
 
 // ------------------------------------------------------------------ reference kernel
 // one thread per output element; any shape / alignment.  Used for parity checks of the
@@ -248,7 +249,8 @@ static bool mfma_ok(const void* A, const void* B, int M, int N, int K, int lda, 
 // before tile area (arithmetic intensity) is considered.  Large outputs use 128x128; mid-size
 // ones 64x128 / 128x64; small ones 64x64 plus split-K when the epilogue allows it.
 extern int g_tune[8];
-static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, int* splits) {
+static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, int* splits, int* wide = nullptr) {
+  if (wide) *wide = 0;
   // Measured on MI355X (scripts/gemm_bench.py at base and big widths, profiles/r01_gemm_microbench*.txt):
   //  * >= 8 M outputs (or a very long K): 128x128 -- most MFMAs per LDS byte, still >= 512 workgroups;
   //  * 3 M .. 8 M outputs (4096x1024, 4096x1536): 128x64 / 64x128 -- 64x64 leaves 20-35 % on the table
@@ -259,6 +261,11 @@ static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, 
   //    long K of dlogits x E (K = 32000: 2-way split to 1024 workgroups is worth 0.15 ms per step).
   const long out = (long)M * N;
   if (g_tune[5] && out >= (long)g_tune[5] * 1024 * 1024 && M >= 256) { *bm = 256; *bn = 128; }   // A/B: 256x128 macro tile
+  else if (wide && !g_tune[5] && K >= 8192 && M >= 128 && N >= 256 && allow_split) {
+    // dlogits x E (K = 32000): 128x256 tiles of four 128x64 register tiles + producer waves, ring depth 3
+    // (scripts/gemm_big_bench.py: 245 -> 203 us)
+    *bm = 128; *bn = 256; *wide = 1;
+  }
   else if (out >= 8L * 1024 * 1024 || (K >= 8192 && M >= 128 && N >= 128)) { *bm = 128; *bn = 128; }
   else if (out >= 3L * 1024 * 1024) { if (N >= M) { *bm = 64; *bn = 128; } else { *bm = 128; *bn = 64; } }
   else if (g_tune[2] == 1) { if (N >= M) { *bm = 64; *bn = 128; } else { *bm = 128; *bn = 64; } }   // A/B switches
@@ -266,14 +273,15 @@ static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, 
   else { *bm = 64; *bn = 64; }
   const long tiles = (long)((M + *bm - 1) / *bm) * ((N + *bn - 1) / *bn);
   int s = 1;
-  if (g_tune[1] && allow_split && tiles < 1024 && K >= 1024) s = (int)((1024 + tiles - 1) / tiles);   // A/B: round-1 rule
+  if (wide && *wide && allow_split && tiles < 256) s = (int)((256 + tiles - 1) / tiles);   // one 144-KiB workgroup per CU
+  else if (g_tune[1] && allow_split && tiles < 1024 && K >= 1024) s = (int)((1024 + tiles - 1) / tiles);   // A/B: round-1 rule
   else if (allow_split && tiles < 1024 && K >= 8192) s = (int)((1024 + tiles - 1) / tiles);   // dlogits x E: K = 32000
   else if (allow_split && tiles <= 96 && K >= 1024) s = (int)((256 + tiles - 1) / tiles);
   if (s > 1) {
     const int maxs = K / (4 * BK);            // keep >= 4 K-tiles per split
     if (s > maxs) s = maxs;
     if (s > 8) s = 8;
-    const long slab_cap = (16L << 20) / ((long)M * N * 4);   // keep the fp32 slab traffic <= 16 MiB
+    const long slab_cap = ((K >= 8192 ? 64L : 16L) << 20) / ((long)M * N * 4);   // keep the fp32 slab traffic <= 16 MiB (64 MiB behind a very long K)
     if (s > slab_cap) s = (int)slab_cap;
     if (s < 1) s = 1;
   }
@@ -297,19 +305,20 @@ int zk_gemm_set_generation(int gen) {
 
 // workspace bytes zk_gemm may need for (M,N,K) (split-K slabs), upper bound
 size_t zk_gemm_workspace(int M, int N, int K) {
-  int bm, bn, s;
-  pick_config(M, N, K, 1, &bm, &bn, &s);
+  int bm, bn, s, wide;
+  pick_config(M, N, K, 1, &bm, &bn, &s, &wide);
   if (s < 2 && K >= 1024) s = 2;
   return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
-// Which kernel would impl=0 pick?  Returns gen | bm<<8 | bn<<16 | splits<<24 | producer waves<<28 (for
+// Which kernel would impl=0 pick?  Returns gen | (bm/8)<<8 | (bn/8)<<16 | splits<<24 | producer waves<<28 (for
 // labelling measurements with the kernel instance that actually runs).
 int zk_gemm_plan(int M, int N, int K, int out_f32, int plain) {
-  int bm, bn, s;
-  pick_config(M, N, K, plain ? 1 : 0, &bm, &bn, &s);
+  int bm, bn, s, wide;
+  pick_config(M, N, K, plain ? 1 : 0, &bm, &bn, &s, &wide);
   int gen = g_default_gen;
   if (!g_tune[7] && gen == 2 && out_f32 && K <= 512 && (long)M * N >= 64L * 1024 * 1024) gen = 1;
-  return gen | (bm << 8) | (bn << 16) | (s << 24) | ((gen == 2 ? zk_gemm_dlds_pw(bm, bn) : 0) << 28);
+  // tile sizes in units of 8 (256 does not fit a byte); wide register tiles always carry four producer waves
+  return gen | ((bm / 8) << 8) | ((bn / 8) << 16) | ((s & 15) << 24) | ((gen == 2 ? (wide ? 4 : zk_gemm_dlds_pw(bm, bn)) : 0) << 28);
 }
 
 // workspace for an explicit split-K override (tuning)
@@ -346,6 +355,8 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
   const bool ok = mfma_ok(A, B, M, N, K, lda, ldb, ta, tb);
   ZK_CHECK_ARG(impl != 2 || ok, "zk_gemm: shape/alignment not supported by the MFMA kernel "
                "(M=%d N=%d K=%d lda=%d ldb=%d ta=%d tb=%d)", M, N, K, lda, ldb, ta, tb);
+  if (zk_prog_active() && (impl == 1 || (impl == 0 && !ok)))
+    return zk_prog_reject("gemm on the reference kernel");
   if (impl == 1 || (impl == 0 && !ok)) {
     const size_t n = (size_t)M * N;
     hipLaunchKernelGGL(k_gemm_naive, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)A,
@@ -355,11 +366,19 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
   }
   int bm, bn, splits;
   const bool plain = (bias == nullptr && residual == nullptr && act == 0 && drop_p == 0.f);
-  pick_config(M, N, K, plain ? 1 : 0, &bm, &bn, &splits);
-
-  if (tile_ovr && tile_ovr <= 5) { const int tb_[6][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}}; bm = tb_[tile_ovr][0]; bn = tb_[tile_ovr][1]; }
+  int wide = 0;
+  pick_config(M, N, K, plain ? 1 : 0, &bm, &bn, &splits, &wide);
+     // tile overrides 6 / 7: 256x128 / 128x256 with 128x64 register tiles per wave
+  if (tile_ovr && tile_ovr <= 7) {
+    const int tb_[8][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}, {256, 128}, {128, 256}};
+    bm = tb_[tile_ovr][0]; bn = tb_[tile_ovr][1]; wide = tile_ovr >= 6;
+  }
   if (split_ovr && plain) splits = split_ovr;
   if (splits > 1 && ws_bytes < (size_t)splits * M * N * sizeof(float)) splits = 1;
+  if (zk_prog_active()) {
+    if (gen != 2 || splits > 1 || wide) return zk_prog_reject("gemm variant (generation / split-K / wide tile) not available in the layer program");
+    return zk_prog_record_gemm((const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, ta, tb, bm, bn, e);
+  }
   int kchunk = K;
   float* slabs = nullptr;
   if (splits > 1) {
@@ -371,7 +390,7 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
   if (kchunk < 1) kchunk = 1;
   int rc;
   const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
-  if (gen == 2) rc = zk_gemm_dlds_dispatch(a, b, M, N, K, lda, ldb, ta, tb, bm, bn, splits, kchunk, slabs, e, sched_flags, stream);
+  if (gen == 2) rc = zk_gemm_dlds_dispatch(a, b, M, N, K, lda, ldb, ta, tb, bm, bn, splits, kchunk, slabs, e, sched_flags | (wide ? 0x100 : 0), stream);
   else if (bm == 128 && bn == 128) rc = launch_mfma<128, 128>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
   else if (bm == 128 && bn == 64) rc = launch_mfma<128, 64>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
   else if (bm == 64 && bn == 128) rc = launch_mfma<64, 128>(a, b, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);

@@ -14,463 +14,7 @@
 //     register transposes, no row permutation;
 //   * the epilogue goes through LDS: every thread finishes 8 contiguous outputs with 16-byte
 //     loads/stores (bias, residual, ReLU, ReLU-backward mask, dropout fused as before).
-#include "zk_gemm.h"
-
-typedef short v4s_t __attribute__((ext_vector_type(4)));
-
-__device__ __attribute__((aligned(16))) uint4 zk_zero_page[4];   // source of out-of-range pieces
-// In-kernel timeline (diagnostic build only: make TRACE=1, scripts/trace_gemm.py): wave 0 of workgroup 301
-// stamps s_memtime at the phase boundaries of the K loop (ZK_T, one row per K step) and of the kernel (ZK_E).
-#ifdef ZK_GEMM_TRACE
-__device__ unsigned long long zk_trace_buf[8192];
-#define ZK_E(slot) do { if (blockIdx.x == 301 && threadIdx.x == 0) zk_trace_buf[4096 + (slot)] = __builtin_readcyclecounter(); } while (0)
-#define ZK_T(slot) do { if (tr_on) zk_trace_buf[tr_i * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define ZK_E(slot) do { } while (0)
-#define ZK_T(slot) do { } while (0)
-#endif
-
-// LDS-DMA issued from inline asm: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every
-// ds_read that may alias an LDS-DMA it knows about, which would drain the ring each K step.  The
-// asm form is invisible to that pass; completion is tracked by the counted vmcnt waits below.
-// LDS destination = M0 (wave-uniform byte address) + lane*16.  Nothing else in these kernels reads
-// M0 (gfx9+ DS instructions do not), so it is written and left.
-__device__ __forceinline__ void glds16(const bf16_t* gsrc, uint32_t lds_byte_addr) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-               :
-               : "v"(gsrc), "s"(lds_byte_addr)
-               : "memory");
-}
-__device__ __forceinline__ uint32_t lds_addr(const void* p) {
-  return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) unsigned char*)p);
-}
-
-// chunk-position swizzles (16-byte chunks)
-__device__ __forceinline__ int swz_direct(int row) { return (row >> 1) & 7; }            // 128-B rows
-template <int R>
-__device__ __forceinline__ int swz_trans(int k) { return R == 128 ? ((k & 3) << 2) : (((k >> 1) & 1) << 2); }
-
-// Per-lane LDS-DMA plan of one operand: for each of the wave's NINSTR pieces the running source
-// pointer (advanced by one K tile after every issue) and the k index inside the tile that decides
-// the K-tail predicate.  Tile rows / column chunks outside the matrix are CLAMPED to a valid
-// row / chunk 0: what they bring in only feeds output rows / columns the epilogue never stores.
-// Only a K tile that crosses kend needs zero fill (both operands), done by the TAIL variant.
-template <int R, int NW = 4>
-struct DmaPlan {
-  static constexpr int PER_WAVE = R * 8 / NW;     // 16-byte chunks per wave
-  static constexpr int NINSTR = PER_WAVE / 64;
-  const bf16_t* cur[NINSTR];
-  int kofs[NINSTR];
-};
-
-template <int R, bool TRANS, int NW>
-__device__ __forceinline__ void dma_plan(DmaPlan<R, NW>& pl, const bf16_t* __restrict__ src, int ld, int row0,
-                                         int rows_total, int kbeg, int wave, int lane) {
-#pragma unroll
-  for (int j = 0; j < DmaPlan<R, NW>::NINSTR; ++j) {
-    const int P = wave * DmaPlan<R, NW>::PER_WAVE + j * 64 + lane;
-    if (!TRANS) {
-      const int row = P >> 3, pos = P & 7;
-      const int c = pos ^ swz_direct(row);
-      const int grow = min(row0 + row, rows_total - 1);
-      pl.kofs[j] = c * 8;
-      pl.cur[j] = src + (size_t)grow * ld + kbeg + c * 8;
-    } else {
-      constexpr int CPR = R / 8;             // chunks per k row
-      const int k = P / CPR, pos = P % CPR;
-      const int c = pos ^ swz_trans<R>(k);
-      int grow = row0 + c * 8;
-      grow = grow < rows_total ? grow : 0;
-      pl.kofs[j] = k;
-      pl.cur[j] = src + (size_t)(kbeg + k) * ld + grow;
-    }
-  }
-}
-
-// issue the LDS-DMA of the next K tile `t` (k range [kbeg + 64 t, ...)) of one operand into `stage`
-// and advance the plan.  TAIL: the tile crosses (or lies past) kend.
-template <int R, bool TRANS, bool TAIL, int NW>
-__device__ __forceinline__ void dma_tile(DmaPlan<R, NW>& pl, size_t step, int t, int klen, uint32_t stage_addr, int wave) {
-#pragma unroll
-  for (int j = 0; j < DmaPlan<R, NW>::NINSTR; ++j) {
-    const bf16_t* g = pl.cur[j];
-    if (TAIL) g = (t * 64 + pl.kofs[j] < klen) ? g : reinterpret_cast<const bf16_t*>(zk_zero_page);
-    glds16(g, stage_addr + (uint32_t)(wave * DmaPlan<R, NW>::PER_WAVE + j * 64) * 16u);
-    pl.cur[j] += step;
-  }
-}
-
-// MFMA 32x32x16 operand fragment of rows r0 + (lane&31), k = kk*16 + (lane>>5)*8 .. +7
-template <int R, bool TRANS>
-__device__ __forceinline__ bf16x8_t load_frag(const bf16_t* stage, int r0, int kk, int lane) {
-  if (!TRANS) {
-    const int row = r0 + (lane & 31);
-    const int c = kk * 2 + (lane >> 5);
-    const uint4 v = *reinterpret_cast<const uint4*>(stage + row * 64 + ((c ^ swz_direct(row)) << 3));
-    return __builtin_bit_cast(bf16x8_t, v);
-  } else {
-    // ds_read_b64_tr_b16: in each 16-lane group, lane p supplies 4 contiguous elements of k-row p/4
-    // at column (p%4)*4 and receives column p of the 4(k) x 16 block
-    const int p = lane & 15;
-    const int rr = r0 + ((lane >> 4) & 1) * 16 + (p & 3) * 4;
-    const int kb = kk * 16 + (lane >> 5) * 8 + (p >> 2);
-    const int chunk = rr >> 3, within = rr & 7;
-    v4s_t lo, hi;
-    {
-      const int k = kb;
-      const bf16_t* a = stage + k * R + ((chunk ^ swz_trans<R>(k)) << 3) + within;
-      lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)a);
-    }
-    {
-      const int k = kb + 4;
-      const bf16_t* a = stage + k * R + ((chunk ^ swz_trans<R>(k)) << 3) + within;
-      hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)a);
-    }
-    typedef short v8s_t __attribute__((ext_vector_type(8)));
-    const v8s_t both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8_t, both);
-  }
-}
-
-extern int g_tune[8];   // A/B switches (zk_tune, zk_elem.hip)
-
-struct EpiVec {
-  int vec_ok;   // 16-byte vector epilogue allowed (alignment checked on the host)
-};
-
-template <int BM, int BN, int NS>
-struct DldsCfg {
-  static constexpr int STAGE = (BM + BN) * 64;                     // bf16 elements per ring stage
-  static constexpr int CLD = BN + 4;                               // fp32 epilogue tile row stride
-  static constexpr int RING_BYTES = NS * STAGE * 2, EPI_BYTES = BM * CLD * 4;
-  static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
-};
-
-// K-segmented GEMM: C = sum_s A_s B_s with every A_s / B_s its own matrix (same shape and leading dimension), e.g.
-// the gradient of the encoder output, which every decoder layer's cross-attention K and V projection feeds
-// (12 segments of K = 512 in one launch instead of 12 dependent GEMMs accumulating in place).
-#define ZK_KSEG_MAX 16
-struct KSegDesc {
-  const bf16_t* A[ZK_KSEG_MAX];
-  const bf16_t* B[ZK_KSEG_MAX];
-  int nseg, tps;               // segments, 64-deep K tiles per segment
-};
-
-// NW compute waves per workgroup: 4 (2 x 2 over the tile), 2 (2 x 1: each wave a BM/2 x BN slab) or 8 (4 x 2: the
-// 256x128 macro tile -- 25 % fewer L1->LDS bytes and DMA issues per MFMA than two 128x128 tiles).
-// PW > 0: PW extra PRODUCER waves (wave index >= NW) issue every LDS-DMA of the workgroup and the NW compute
-// waves issue none.  Reason (profiles/r01_gemm_kloop_trace.txt): a global_load_lds stalls its wave ~100 cycles
-// while the CU's texture-address path is busy, and a stalled wave cannot issue its MFMAs, so with PW = 0 the
-// DMA-issue time and the MFMA time of a K step add up inside a workgroup; with producer waves they overlap.
-// K loop of one BMxBN tile over k in [kbeg, kend); leaves the fp32 tile in LDS (sC[BM][CLD], smem reused)
-// behind a workgroup barrier, ready for a row-wise epilogue.
-template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0, bool KSEG = false>
-__device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16_t* __restrict__ A,
-                                                 const bf16_t* __restrict__ B, int M, int N, int lda, int ldb,
-                                                 int kbeg, int kend, int m0, int n0, const KSegDesc* ks = nullptr) {
-  constexpr int NWM = NW == 8 ? 4 : 2, NWN = NW / NWM;       // wave grid over the tile: 2x2, 2x1 or 4x2
-  constexpr int WTM = BM / NWM, WTN = BN / NWN, TM = WTM / 32, TN = WTN / 32;
-  constexpr int STAGE = DldsCfg<BM, BN, NS>::STAGE;
-  constexpr int NDW = PW ? PW : NW;                          // waves that issue the DMA
-  constexpr int PER_STAGE = (BM * 8 / NDW + BN * 8 / NDW) / 64;  // DMA instructions per issuing wave per stage
-  constexpr int CLD = DldsCfg<BM, BN, NS>::CLD;
-  bf16_t* ring = reinterpret_cast<bf16_t*>(smem);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = PW > 0 && wave >= NW;
-  const int dwave = PW ? wave - NW : wave;                   // index among the issuing waves
-  const int wm = wave / NWN, wn = wave % NWN;
-  const int nk = (kend - kbeg + 63) >> 6;
-
-  ZK_E(0);
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  DmaPlan<BM, NDW> planA;
-  DmaPlan<BN, NDW> planB;
-  if (!KSEG && (PW == 0 || producer)) {
-    dma_plan<BM, TA, NDW>(planA, A, lda, m0, M, kbeg, dwave, lane);
-    dma_plan<BN, !TB, NDW>(planB, B, ldb, n0, N, kbeg, dwave, lane);
-  }
-  [[maybe_unused]] int seg_left = 0, seg_id = 0;   // KSEG: K tiles left in the current segment, next segment
-  const int klen = kend - kbeg;
-  const size_t stepA = TA ? (size_t)64 * lda : (size_t)64;
-  const size_t stepB = !TB ? (size_t)64 * ldb : (size_t)64;
-  const uint32_t ring_addr = lds_addr(ring);
-  auto issue = [&](int t) {
-    if (KSEG) {                                   // tiles are issued in order: re-plan at every segment start
-      if (seg_left == 0) {
-        if (seg_id < ks->nseg) {
-          dma_plan<BM, TA, NDW>(planA, ks->A[seg_id], lda, m0, M, 0, dwave, lane);
-          dma_plan<BN, !TB, NDW>(planB, ks->B[seg_id], ldb, n0, N, 0, dwave, lane);
-          ++seg_id;
-          seg_left = ks->tps;
-        } else {
-          seg_left = 0x40000000;                  // past the last segment: only all-zero tail pieces follow
-        }
-      }
-      --seg_left;
-    }
-    const uint32_t st = ring_addr + (uint32_t)((t % NS) * STAGE * 2);
-    if (t * 64 + 64 <= klen) {
-      dma_tile<BM, TA, false, NDW>(planA, stepA, t, klen, st, dwave);
-      dma_tile<BN, !TB, false, NDW>(planB, stepB, t, klen, st + BM * 128, dwave);
-    } else {
-      dma_tile<BM, TA, true, NDW>(planA, stepA, t, klen, st, dwave);
-      dma_tile<BN, !TB, true, NDW>(planB, stepB, t, klen, st + BM * 128, dwave);
-    }
-  };
-  // MFMAs of K tile kt out of its ring stage
-  auto compute = [&](int kt) {
-    const bf16_t* sA = ring + (kt % NS) * STAGE;
-    const bf16_t* sB = sA + BM * 64;
-    // fragments of k-slice kk+1 are read while the MFMAs of slice kk run (two register sets)
-    bf16x8_t af[2][TM], bfr[2][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) af[0][i] = load_frag<BM, TA>(sA, wm * WTM + i * 32, 0, lane);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bfr[0][j] = load_frag<BN, !TB>(sB, wn * WTN + j * 32, 0, lane);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      if (kk < 3) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[(kk + 1) & 1][i] = load_frag<BM, TA>(sA, wm * WTM + i * 32, kk + 1, lane);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[(kk + 1) & 1][j] = load_frag<BN, !TB>(sB, wn * WTN + j * 32, kk + 1, lane);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
-    }
-  };
-  [[maybe_unused]] const bool tr_on = (blockIdx.x == 301) && (tid == 0);
-  if (PW > 0) {
-    // invariant at the barrier of step kt: tile kt has landed (the producers waited for it) and every compute
-    // wave is done with tile kt-1, whose stage the producers refill next.  Both roles pass nk barriers.
-    if (producer) {
-#pragma unroll
-      for (int s = 0; s < NS - 1; ++s) issue(s);
-      for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PER_STAGE) : "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        issue(kt + NS - 1);
-      }
-    } else {
-      ZK_E(1);
-      for (int kt = 0; kt < nk; ++kt) {
-        [[maybe_unused]] const int tr_i = kt;
-        ZK_T(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        ZK_T(2);
-        compute(kt);
-        __builtin_amdgcn_sched_barrier(0);
-        ZK_T(4);
-      }
-    }
-  } else {
-    // prologue: tiles 0 .. NS-2 (tiles past the end are all-zero pieces: keeps the DMA count uniform)
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue(s);
-    __builtin_amdgcn_sched_barrier(0);
-    ZK_E(1);
-    for (int kt = 0; kt < nk; ++kt) {
-      [[maybe_unused]] const int tr_i = kt;
-      ZK_T(0);
-      // tile kt has landed once at most NS-2 later tiles of this wave are still in flight
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PER_STAGE) : "memory");
-      ZK_T(1);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      ZK_T(2);
-      issue(kt + NS - 1);                         // refill the stage everybody finished reading
-      __builtin_amdgcn_sched_barrier(0);
-      ZK_T(3);
-      compute(kt);
-      __builtin_amdgcn_sched_barrier(0);
-      ZK_T(4);
-    }
-  }
-  // ---- epilogue through LDS
-  ZK_E(2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (all-zero) pieces have landed
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  float* sC = reinterpret_cast<float*>(smem);
-  if (!producer) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = wn * WTN + j * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          sC[row * CLD + col] = acc[i][j][r];
-        }
-      }
-  }
-  __syncthreads();
-  ZK_E(3);
-}
-
-// one BMxBN output tile over k in [kbeg, kend); slab != null: write the fp32 partial tile there
-template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0, bool KSEG = false>
-__device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __restrict__ A,
-                                          const bf16_t* __restrict__ B, int M, int N, int lda, int ldb, int kbeg,
-                                          int kend, int m0, int n0, float* __restrict__ slab, const GemmEpi& e,
-                                          int vec_ok, const KSegDesc* ks = nullptr) {
-  gemm_tile_to_lds<BM, BN, NS, TA, TB, NW, PW, KSEG>(smem, A, B, M, N, lda, ldb, kbeg, kend, m0, n0, ks);
-  constexpr int CLD = DldsCfg<BM, BN, NS>::CLD;
-  constexpr int NT = (NW + PW) * 64;
-  const int tid = threadIdx.x;
-  const float* sC = reinterpret_cast<const float*>(smem);
-  const uint64_t seed = e.thr ? *e.seed : 0;
-  constexpr int CPRW = BN / 8;
-  // Fast path (interior tile, 16-byte epilogue, no split-K slab): every thread's chunks sit in the same 8
-  // columns (NT is a multiple of CPRW), so the loop is fully unrolled with all LDS reads first, then all
-  // residual / mask loads, then the arithmetic and the stores -- the latencies overlap instead of adding up
-  // once per chunk (the rolled loop below cost ~1200 cycles per chunk, profiles/r01_gemm_kloop_trace.txt).
-  if (slab == nullptr && vec_ok && m0 + BM <= M && n0 + BN <= N) {
-    static_assert(NT % CPRW == 0, "a thread's chunks must share their columns");
-    constexpr int CH = BM * CPRW, ITER = (CH + NT - 1) / NT;
-    const int cc = (tid % CPRW) * 8, gn = n0 + cc, row0 = tid / CPRW;
-    constexpr int RSTEP = NT / CPRW;
-    float v[ITER][8];
-    uint4 rres[ITER], raux[ITER];
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int row = min(row0 + it * RSTEP, BM - 1);
-      const float4 a = *reinterpret_cast<const float4*>(sC + row * CLD + cc);
-      const float4 b = *reinterpret_cast<const float4*>(sC + row * CLD + cc + 4);
-      v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
-      v[it][4] = b.x; v[it][5] = b.y; v[it][6] = b.z; v[it][7] = b.w;
-    }
-    if (e.res) {
-#pragma unroll
-      for (int it = 0; it < ITER; ++it) {
-        const int gm = m0 + min(row0 + it * RSTEP, BM - 1);
-        rres[it] = *reinterpret_cast<const uint4*>(e.res + (size_t)gm * e.ldr + gn);
-      }
-    }
-    if (e.act == 2) {
-#pragma unroll
-      for (int it = 0; it < ITER; ++it) {
-        const int gm = m0 + min(row0 + it * RSTEP, BM - 1);
-        raux[it] = *reinterpret_cast<const uint4*>(e.aux + (size_t)gm * e.ldaux + gn);
-      }
-    }
-    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (e.bias) {
-      const float4 a = *reinterpret_cast<const float4*>(e.bias + gn);
-      const float4 b = *reinterpret_cast<const float4*>(e.bias + gn + 4);
-      bv[0] = a.x; bv[1] = a.y; bv[2] = a.z; bv[3] = a.w; bv[4] = b.x; bv[5] = b.y; bv[6] = b.z; bv[7] = b.w;
-    }
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int row = row0 + it * RSTEP;
-      if (CH % NT != 0 && row >= BM) break;
-      const int gm = m0 + row;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[it][j] = v[it][j] * e.alpha + bv[j];
-      if (e.res) {
-        float rv[8];
-        unpack8(rres[it], rv);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[it][j] += rv[j];
-      }
-      if (e.act == 1) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[it][j] = fmaxf(v[it][j], 0.f);
-      } else if (e.act == 2) {
-        float av[8];
-        unpack8(raux[it], av);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[it][j] = av[j] > 0.f ? v[it][j] * e.aux_scale : 0.f;
-      }
-      if (e.thr) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          v[it][j] *= zk_drop_scale(seed, e.sid, (uint64_t)gm * N + gn + j, e.thr, e.inv_keep);
-      }
-      if (e.out_f32) {
-        float* d = reinterpret_cast<float*>(e.C) + (size_t)gm * e.ldc + gn;
-        reinterpret_cast<float4*>(d)[0] = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
-        reinterpret_cast<float4*>(d)[1] = make_float4(v[it][4], v[it][5], v[it][6], v[it][7]);
-      } else {
-        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)gm * e.ldc + gn) = pack8(v[it]);
-      }
-    }
-    return;
-  }
-  for (int c = tid; c < BM * CPRW; c += NT) {
-    const int row = c / CPRW, cc = (c % CPRW) * 8;
-    const int gm = m0 + row, gn = n0 + cc;
-    if (gm >= M || gn >= N) continue;
-    float v[8];
-    {
-      const float4 a = *reinterpret_cast<const float4*>(sC + row * CLD + cc);
-      const float4 b = *reinterpret_cast<const float4*>(sC + row * CLD + cc + 4);
-      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    }
-    if (slab != nullptr) {
-      float* d = slab + (size_t)gm * N + gn;
-      if (gn + 8 <= N && (N & 3) == 0) {
-        reinterpret_cast<float4*>(d)[0] = make_float4(v[0], v[1], v[2], v[3]);
-        reinterpret_cast<float4*>(d)[1] = make_float4(v[4], v[5], v[6], v[7]);
-      } else {
-        for (int j = 0; j < 8 && gn + j < N; ++j) d[j] = v[j];
-      }
-      continue;
-    }
-    if (vec_ok && gn + 8 <= N) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] *= e.alpha;
-      if (e.bias) {
-        const float4 a = *reinterpret_cast<const float4*>(e.bias + gn);
-        const float4 b = *reinterpret_cast<const float4*>(e.bias + gn + 4);
-        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-      }
-      if (e.res) {
-        float rv[8];
-        unpack8(*reinterpret_cast<const uint4*>(e.res + (size_t)gm * e.ldr + gn), rv);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += rv[j];
-      }
-      if (e.act == 1) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-      } else if (e.act == 2) {
-        float av[8];
-        unpack8(*reinterpret_cast<const uint4*>(e.aux + (size_t)gm * e.ldaux + gn), av);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = av[j] > 0.f ? v[j] * e.aux_scale : 0.f;
-      }
-      if (e.thr) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= zk_drop_scale(seed, e.sid, (uint64_t)gm * N + gn + j, e.thr, e.inv_keep);
-      }
-      if (e.out_f32) {
-        float* d = reinterpret_cast<float*>(e.C) + (size_t)gm * e.ldc + gn;
-        reinterpret_cast<float4*>(d)[0] = make_float4(v[0], v[1], v[2], v[3]);
-        reinterpret_cast<float4*>(d)[1] = make_float4(v[4], v[5], v[6], v[7]);
-      } else {
-        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)gm * e.ldc + gn) = pack8(v);
-      }
-    } else {
-      for (int j = 0; j < 8 && gn + j < N; ++j) epi_store(e, v[j], gm, gn + j, N, seed);
-    }
-  }
-}
+#include "zk_gemm2_dev.h"
 
 template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0>
 __global__ void __launch_bounds__((NW + PW) * 64) k_gemm_dlds(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M,
@@ -656,7 +200,8 @@ extern "C" {
 // fields are the running sum of ceil(M/bm)*ceil(N/bn); total_tiles = that sum.
 int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int tb, int tile, hipStream_t stream) {
   ZK_CHECK_ARG(nprob >= 1 && total_tiles >= 1, "zk_gemm_grouped: empty group");
-  ZK_CHECK_ARG(tile == 1 || tile == 4, "zk_gemm_grouped: tile must be 1 (128x128) or 4 (64x64)");
+  ZK_CHECK_ARG(tile == 1 || tile == 4 || tile == 5 || tile == 6,
+               "zk_gemm_grouped: tile must be 1 (128x128), 4 (64x64), 5 (256x128) or 6 (128x256)");
   const GroupDesc* d = (const GroupDesc*)descs;
   dim3 grid((unsigned)total_tiles);
 #define ZK_GROUP_LAUNCH(BM_, BN_, NS_, PW_)                                                                     \
@@ -669,6 +214,11 @@ int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int t
   } while (0)
   const bool pw = (g_tune[6] >> 16) & 1;          // producer-wave workgroups (see gemm_tile_to_lds)
   if (tile == 1) { if (pw) ZK_GROUP_LAUNCH(128, 128, 2, 4); else ZK_GROUP_LAUNCH(128, 128, 2, 0); }
+  // 256x128 / 128x256: four compute waves with a 128x64 register tile each (half the LDS fragment bytes and 3/4
+  // of the L1->LDS bytes per MFMA of the 128x128 tile) + four producer waves, three-stage ring (144 KiB: one
+  // workgroup per CU)
+  else if (tile == 5) { if (g_tune[6] & (1 << 17)) ZK_GROUP_LAUNCH(256, 128, 2, 4); else ZK_GROUP_LAUNCH(256, 128, 3, 4); }
+  else if (tile == 6) { if (g_tune[6] & (1 << 17)) ZK_GROUP_LAUNCH(128, 256, 2, 4); else ZK_GROUP_LAUNCH(128, 256, 3, 4); }
   else { if (pw) ZK_GROUP_LAUNCH(64, 64, 4, 4); else ZK_GROUP_LAUNCH(64, 64, 4, 0); }
 #undef ZK_GROUP_LAUNCH
   ZK_LAUNCH_CHECK();
@@ -797,6 +347,17 @@ int zk_gemm_dlds_pw(int bm, int bn) {
 int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
                           int bm, int bn, int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags,
                           hipStream_t stream) {
+  if (sched_flags & 0x100) {          // wide register tiles (tile overrides 6 / 7): 4 compute waves of 128x64 + 4 producers
+    const int ns_w = (sched_flags >> 4) & 15;
+    if (bm == 256 && bn == 128) {
+      if (ns_w == 2) return launch_dlds<256, 128, 2, 4, 4>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+      return launch_dlds<256, 128, 3, 4, 4>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+    }
+    if (bm == 128 && bn == 256) {
+      if (ns_w == 2) return launch_dlds<128, 256, 2, 4, 4>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+      return launch_dlds<128, 256, 3, 4, 4>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+    }
+  }
   int ns = (sched_flags >> 4) & 15;   // ring-depth override (tuning)
   if (!ns && bm == 64 && bn == 64 && g_tune[3]) ns = g_tune[3];     // A/B: ring depth of the 64x64 tile in-step
   if (bm == 64 && bn == 64 && g_tune[4] == 2)                       // A/B: two-wave workgroups, ring depth 2

@@ -98,6 +98,9 @@ class Engine(object):
         self.seed = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.realloc_gen = 0
         self._timing = None
+        # layer programs (run_program): one persistent launch per sentence-local chain instead of one launch per op
+        self.programs_enabled = os.environ.get("ZERO_HIP_PROGRAM", "0") != "0"
+        self._prog_host = None
 
     # ---- plumbing -----------------------------------------------------------
     @property
@@ -177,7 +180,9 @@ class Engine(object):
         The device descriptor table is cached per problem list (buffers are static, so it is built
         once)."""
         problems = [tuple(p) + (None,) * (8 - len(p)) for p in problems]
-        key = (ta, tb, tile) + tuple((a.ptr, b.ptr, c.ptr, M, N, K, hip.ptr(bias) or 0, r.ptr if r is not None else 0)
+        bm, bn = (tile, tile) if isinstance(tile, int) else tile      # 128, 64, (256, 128) or (128, 256)
+        code = {(128, 128): 1, (64, 64): 4, (256, 128): 5, (128, 256): 6}[(bm, bn)]
+        key = (ta, tb, bm, bn) + tuple((a.ptr, b.ptr, c.ptr, M, N, K, hip.ptr(bias) or 0, r.ptr if r is not None else 0)
                                      for a, b, c, M, N, K, bias, r in problems)
         cache = self.__dict__.setdefault("_group_cache", {})
         ent = cache.get(key)
@@ -185,19 +190,19 @@ class Engine(object):
             arr = (_GroupDesc * len(problems))()
             start = 0
             for i, (a, b, c, M, N, K, bias, res) in enumerate(problems):
-                tn = (N + tile - 1) // tile
+                tn = (N + bn - 1) // bn
                 d = arr[i]
                 d.A, d.B, d.C, d.bias = a.ptr, b.ptr, c.ptr, hip.ptr(bias) or 0
                 d.res, d.ldr = (res.ptr, res.ld) if res is not None else (0, 0)
                 d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, a.ld, b.ld, c.ld
                 d.out_f32 = 1 if c.t.dtype == torch.float32 else 0
                 d.tile_start, d.tiles_n = start, tn
-                start += ((M + tile - 1) // tile) * tn
+                start += ((M + bm - 1) // bm) * tn
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             ent = (host.to(self.device), len(problems), start)
             cache[key] = ent
         dev, n, total = ent
-        self.lib.call("zk_gemm_grouped", dev.data_ptr(), n, total, ta, tb, 1 if tile == 128 else 4, self.stream)
+        self.lib.call("zk_gemm_grouped", dev.data_ptr(), n, total, ta, tb, code, self.stream)
 
     def reductions_grouped(self, colsums, ln_parts):
         """colsums: [(Mat dY, out fp32 view, private fp32 partial buffer)];
@@ -435,6 +440,54 @@ class Engine(object):
 
     def aan_gate_bwd(self, dg, z, cat, dz, dxg, dyg, rows, H):
         self.lib.call("zk_aan_gate_bwd", dg.ptr, z.ptr, cat.ptr, dz.ptr, dxg.ptr, dyg.ptr, rows, H, self.stream)
+
+    # ---- layer programs: a run of sentence-local ops as ONE persistent launch (zk_layer.hip) --------------
+    def run_program(self, sentences, fn):
+        """Issue the launches of ``fn()`` as one layer program when every one of them can be an op of it
+        (zk_gemm with an untransposed A, zk_attn_fwd / zk_attn_bwd on the MFMA tiles, zk_add_ln_fwd), else as
+        ordinary launches.  ``fn`` is run in recording mode first -- the entry points append ops instead of
+        launching -- so the host-side schedule is written once (zero_amd/models/_core.py) for both forms.
+        The device copy of the op table is cached by content: replays and hipGraph captures only launch."""
+        if not self.programs_enabled:
+            return fn()
+        lib = self.lib
+        op_bytes = lib.query("zk_prog_op_bytes")
+        cap = 512
+        if getattr(self, "_prog_host", None) is None:
+            self._prog_host = ctypes.create_string_buffer(cap * op_bytes)
+            self._prog_cache = {}
+        lib.call("zk_prog_begin", int(sentences))
+        lib.recording = True
+        n, bwd = ctypes.c_int(0), ctypes.c_int(0)
+        try:
+            out = fn()
+            ok = True
+        except hip.ZeroHipError:
+            ok = False
+        finally:
+            lib.recording = False
+            rc = lib.raw("zk_prog_end")(self._prog_host, cap * op_bytes, ctypes.byref(n), ctypes.byref(bwd))
+        if not ok or rc != 0 or n.value == 0:
+            return fn()                      # nothing was launched while recording: issue it all normally
+        key = (self._prog_host.raw[:n.value * op_bytes], int(sentences))
+        ent = self._prog_cache.get(key)
+        if ent is None:
+            dev = torch.frombuffer(bytearray(key[0]), dtype=torch.uint8).to(self.device)
+            state = torch.zeros(lib.query("zk_prog_state_bytes") // 4, dtype=torch.int32, device=self.device)
+            torch.cuda.current_stream(self.device).synchronize()      # the upload is complete before any capture
+            ent = (dev, state)
+            self._prog_cache[key] = ent
+        lib.call("zk_prog_launch", ent[0].data_ptr(), n.value, int(sentences), bwd.value, ent[1].data_ptr(), self.stream)
+        self.last_program_state = ent[1]
+        return out
+
+    def program_status(self):
+        """(workgroups found off their XCD, aborted) of the last program launch -- forces a sync (tests)."""
+        st = getattr(self, "last_program_state", None)
+        if st is None:
+            return None
+        h = st.cpu()
+        return int(h[576]), bool(h[577] != 0)
 
     # ---- hipGraph capture of a launch sequence ----------------------------------------
     @property

@@ -74,6 +74,7 @@ class _Lib(object):
                 "or `make -C zero_amd/csrc`). There is no CPU fallback." % LIB_PATH)
         self._dll = ctypes.CDLL(LIB_PATH)
         self.ncalls = 0
+        self.recording = False        # a layer program is being recorded (func.Engine.run_program)
         self.protos = parse_header()
         for name, (restype, argtypes, _) in self.protos.items():
             try:
@@ -88,8 +89,14 @@ class _Lib(object):
     def raw(self, name):
         return getattr(self._dll, name)
 
+    # entry points that append an op while a layer program is being recorded (include/zero_hip.h, zk_prog_*)
+    RECORDABLE = frozenset(["zk_gemm", "zk_attn_fwd", "zk_attn_bwd", "zk_add_ln_fwd", "zk_prog_begin", "zk_prog_end"])
+
     def call(self, name, *args):
         """Call an int-returning entry point; raise on a non-zero status."""
+        if self.recording and name not in self.RECORDABLE:
+            # it would launch immediately, ahead of the ops recorded before it
+            raise ZeroHipError("%s cannot be part of a layer program" % name)
         self.ncalls += 1          # lets callers tell whether anything was enqueued between two points
         rc = getattr(self._dll, name)(*args)
         if rc != 0:

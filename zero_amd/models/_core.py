@@ -74,6 +74,10 @@ class TransformerCore(object):
         # weight-gradient GEMMs are deferred and launched as ONE grouped grid per `group_layers`
         # layers (each is far too small to fill 256 CUs on its own)
         self.group_wgrad = os.environ.get("ZERO_HIP_GROUP_WGRAD", "1") != "0"
+        # tile of the grouped weight-gradient launch: 128x256 (four waves with a 128x64 register tile each + four
+        # producer waves, scripts/gemm_big_bench.py: 780 -> 856 TF on the decoder side incl. the logits problem)
+        wt = os.environ.get("ZERO_HIP_WGRAD_TILE", "128x256").lower()
+        self.wgrad_tile = {"128": 128, "128x128": 128, "256x128": (256, 128), "128x256": (128, 256)}[wt]
         # one group per side of the model with a single rank (fewest launches); smaller groups with
         # data parallelism so that the gradient all-reduce of finished layers starts early
         import torch.distributed as _dist
@@ -111,7 +115,7 @@ class TransformerCore(object):
         if self._pending_wgrads:
             probs = self._pending_wgrads
             self._pending_wgrads = []
-            self._side(lambda: self.eng.gemm_grouped(probs, 1, 0))
+            self._side(lambda: self.eng.gemm_grouped(probs, 1, 0, tile=self.wgrad_tile))
         if self._pending_colsums or self._pending_lnred:
             cs, ln = self._pending_colsums, self._pending_lnred
             self._pending_colsums, self._pending_lnred = [], []
@@ -496,11 +500,16 @@ class TransformerCore(object):
         x = e.mat("enc.x0", Ts, H)
         e.embed_fwd(batch["src"], self.store.s(self.src_emb), self.b("bias"), x, B, Ls, H,
                     drop_p=hp.dropout if train else 0.0, sid=9001)
-        for l in range(hp.num_encoder_layer):
-            pre = "encoder/layer_%d" % l
-            x = self._self_attn_fwd(x, B, Ls, pre + "/self_attention", "e%d.sa" % l, smask, False, save,
-                                    100 * l + 1, train)
-            x = self._ffn_fwd(x, pre + "/feed_forward", "e%d.ff" % l, save, 100 * l + 11, train)
+        def layers(x=x):
+            for l in range(hp.num_encoder_layer):
+                pre = "encoder/layer_%d" % l
+                x = self._self_attn_fwd(x, B, Ls, pre + "/self_attention", "e%d.sa" % l, smask, False, save,
+                                        100 * l + 1, train)
+                x = self._ffn_fwd(x, pre + "/feed_forward", "e%d.ff" % l, save, 100 * l + 11, train)
+            return x
+        # the layer stack is sentence-local all the way down: one persistent launch (zk_layer.hip) when every op of
+        # it can be recorded (plain dot-product attention on the MFMA tiles), ordinary launches otherwise
+        x = e.run_program(B, layers) if (not self.rpr and not self.use_side) else layers()
         return x, smask
 
     def decode_train(self, batch, enc, smask, train, save):

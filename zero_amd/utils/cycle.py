@@ -42,8 +42,8 @@ class TrainOp(object):
             self.ema = store.master.clone()      # shadows start at the variables' initial values
         self.pnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.count = 0
-        self._ws = torch.empty(max(hip.lib().query("zk_norm_workspace") * 2, hip.lib().query("zk_adam_step_workspace")),
-                               dtype=torch.uint8, device=dev)
+        self._ws = torch.empty(max(hip.lib().query("zk_norm_workspace") * 2, hip.lib().query("zk_adam_step_workspace"),
+                                   hip.lib().query("zk_adam_range_workspace")), dtype=torch.uint8, device=dev)
 
     # cycle.py:58-71
     def zero(self):
@@ -116,6 +116,22 @@ class TrainOp(object):
         hp = self.hp
         clip = hp.clip_grad_norm or None
         return not isinstance(clip, float) and not getattr(hp, "safe_nan", False)
+
+    # -- the norm-free update in pieces, norms included (single rank: parts of it overlap the backward) -----------
+    def launch_update_slot(self, lo, hi, slot):
+        """TF1 Adam on elements [lo, hi) (64-element aligned) + its partial sums of squares into workspace slot."""
+        st, lib, s = self.store, self.eng.lib, self.eng.stream
+        lib.call("zk_adam_range", st.master.data_ptr() + lo * 4, st.grad.data_ptr() + lo * 4, st.m.data_ptr() + lo * 4,
+                 st.v.data_ptr() + lo * 4, st.shadow.data_ptr() + lo * 2, hi - lo, self.hyper.data_ptr(), slot,
+                 self._ws.data_ptr(), self._ws.numel(), s)
+
+    def finish_update_slots(self, nslots):
+        """Gradient / parameter norms from the slots, flags, seed advance, EMA."""
+        st, lib, s = self.store, self.eng.lib, self.eng.stream
+        lib.call("zk_adam_finish", self.hyper.data_ptr(), self.pnorm.data_ptr(), self.eng.seed.data_ptr(), nslots,
+                 self._ws.data_ptr(), self._ws.numel(), s)
+        if self.ema is not None:
+            lib.call("zk_ema", self.ema.data_ptr(), st.master.data_ptr(), self.hyper.data_ptr(), st.numel, s)
 
     def begin_update_by_range(self):
         """hyper[6] (the norm the Adam kernel guards on) is only known after the last bucket: a finite
