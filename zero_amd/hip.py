@@ -14,7 +14,8 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "csrc", "libzero_hip.so")
+# ZERO_HIP_LIB: an alternative build of the same library (the AddressSanitizer build of scripts/asan_host.sh)
+LIB_PATH = os.environ.get("ZERO_HIP_LIB") or os.path.join(_HERE, "csrc", "libzero_hip.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "zero_hip.h")
 
 
