@@ -63,7 +63,7 @@ def grouped():
     flops += 2.0 * V * H * T
     ref = X[:, :H].float().t() @ dY[:, :F].float()
     res = []
-    for tile in (128, (256, 128), (128, 256)):
+    for tile in (128, (128, 256), (256, 256), (256, 256, 0)):
         for g_ in outs:
             g_.zero_()
         e.gemm_grouped(probs, 1, 0, tile=tile)
@@ -76,15 +76,31 @@ def grouped():
     print("grouped wgrad (decoder side + logits, %.0f GFLOP): %s" % (flops / 1e9, " | ".join(res)), flush=True)
 
 
-single("logits fwd", T, V, H, 0, 1, 1)
-single("logits bf16", T, V, H, 0, 1, 0)
-single("wgrad lgt", V, H, T, 1, 0, 1)
-single("dgrad lgt", T, H, V, 0, 0, 0)
-single("fwd ffn1", T, F, H, 0, 0, 0)
-single("dgrad ffn1", T, H, F, 0, 1, 0)
+def grouped_one(name, M, N, K, ta, tb):
+    """one plain fp32-output GEMM through the grouped launch, all tiles"""
+    A = torch.randn((K, M) if ta else (M, K), device="cuda").bfloat16()
+    B = torch.randn((N, K) if tb else (K, N), device="cuda").bfloat16()
+    C = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ref = ((A.float().t() if ta else A.float())[:256] @ (B.float().t() if tb else B.float()))
+    res = []
+    for tile in (128, (128, 256), (256, 256), (256, 256, 0)):
+        C.zero_()
+        probs = [(Mat(A, *A.shape), Mat(B, *B.shape), Mat(C, M, N), M, N, K, None)]
+        e.gemm_grouped(probs, ta, tb, tile=tile)
+        torch.cuda.synchronize()
+        err = float((C[:256] - ref).norm() / ref.norm())
+        us = timed(lambda: e.gemm_grouped(probs, ta, tb, tile=tile), reps=4)
+        res.append("%s %7.1f us %5.0f TF err %.1e" % (tile, us, 2.0 * M * N * K / us / 1e6, err))
+    print("%-12s %s" % (name, " | ".join(res)), flush=True)
+
+
+if "--quick" not in sys.argv:
+    single("logits fwd", T, V, H, 0, 1, 1)
+    single("wgrad lgt", V, H, T, 1, 0, 1)
+    single("dgrad lgt", T, H, V, 0, 0, 0)
+grouped_one("logits fwd", T, V, H, 0, 1)
+grouped_one("wgrad lgt", V, H, T, 1, 0)
+grouped_one("4096^3 NT", 4096, 4096, 4096, 0, 1)
+grouped_one("4096^3 TN", 4096, 4096, 4096, 1, 0)
+grouped_one("ragged TN", 1000, 520, 777 * 8, 1, 0)
 grouped()
-for ns2 in (0, 1):
-    e.lib.raw("zk_tune")(6, 0x44 | (ns2 << 17))
-    if ns2:
-        print("ring depth 2 for the wide grouped tiles:")
-        grouped()

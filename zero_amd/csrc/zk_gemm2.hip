@@ -73,6 +73,116 @@ __global__ void __launch_bounds__((4 + PW) * 64) k_gemm_grouped(const GroupDesc*
 }
 
 // =====================================================================================
+// 256x256 tiles for the large fp32-output GEMMs (grouped weight gradients incl. the logits problem: 40 % of the
+// step's FLOPs).  scripts/gemm_big_bench.py + the K-step arithmetic: these GEMMs are bound by the L2 -> LDS path at
+// ~10-13 TB/s chip-wide (the same rate the best published gfx950 kernels sustain), so the lever is bytes per FLOP:
+// 256x256x64 moves 64 KB for 8.4 MFLOP (7.8 KB/MFLOP; 128x256: 11.7, 128x128: 15.6).
+// Eight waves as 2 x 4, each a 128x64 register tile (TM = 4, TN = 2: 128 accumulator registers), all of them issue
+// LDS-DMA (two pieces after every 16-deep K slice's MFMAs, so the issue stalls sit behind matrix work), two ring
+// stages of 64 KiB.  The tile leaves straight from the accumulators (a 32x32 MFMA tile stores two full 128-byte
+// lines per instruction for fp32) -- the fp32 tile would not fit in LDS.  fp32 output only, no epilogue options.
+// =====================================================================================
+template <bool TA, bool TB, bool SPREAD>
+__global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __restrict__ descs, int nprob) {
+  constexpr int BM = 256, BN = 256, NS = 2, NW = 8, NWN = 4, WTM = 128, WTN = 64, TM = 4, TN = 2;
+  constexpr int STAGE = (BM + BN) * 64;
+  constexpr int PER_STAGE = (BM * 8 / NW + BN * 8 / NW) / 64;   // 8 LDS-DMA instructions per wave per stage
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE * 2];   // the ONLY LDS object (128 KiB)
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  int p = 0;
+  while (p + 1 < nprob && descs[p + 1].tile_start <= t) ++p;
+  const GroupDesc d = descs[p];
+  const int local = t - d.tile_start;
+  const int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN, M = d.M, N = d.N, K = d.K;
+  bf16_t* ring = reinterpret_cast<bf16_t*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int nk = (K + 63) >> 6;
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  DmaPlan<BM, NW> planA;
+  DmaPlan<BN, NW> planB;
+  dma_plan<BM, TA, NW>(planA, d.A, d.lda, m0, M, 0, wave, lane);
+  dma_plan<BN, !TB, NW>(planB, d.B, d.ldb, n0, N, 0, wave, lane);
+  const size_t stepA = TA ? (size_t)64 * d.lda : (size_t)64;
+  const size_t stepB = !TB ? (size_t)64 * d.ldb : (size_t)64;
+  const uint32_t ring_addr = lds_addr(ring);
+  // LDS-DMA of K tile t, pieces [j0, j1) of this wave's 4 + 4
+  auto issue_part = [&](int tt, int j0, int j1) {
+    const uint32_t st = ring_addr + (uint32_t)((tt % NS) * STAGE * 2);
+    const bool tail = tt * 64 + 64 > K;
+#pragma unroll
+    for (int j = j0; j < j1; ++j) {
+      if (j < 4) {
+        const bf16_t* g = planA.cur[j];
+        if (tail) g = (tt * 64 + planA.kofs[j] < K) ? g : reinterpret_cast<const bf16_t*>(zk_zero_page);
+        glds16(g, st + (uint32_t)(wave * DmaPlan<BM, NW>::PER_WAVE + j * 64) * 16u);
+        planA.cur[j] += stepA;
+      } else {
+        const int jb = j - 4;
+        const bf16_t* g = planB.cur[jb];
+        if (tail) g = (tt * 64 + planB.kofs[jb] < K) ? g : reinterpret_cast<const bf16_t*>(zk_zero_page);
+        glds16(g, st + BM * 128 + (uint32_t)(wave * DmaPlan<BN, NW>::PER_WAVE + jb * 64) * 16u);
+        planB.cur[jb] += stepB;
+      }
+    }
+  };
+  issue_part(0, 0, 8);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt has landed (it was issued one compute phase ago)
+    __builtin_amdgcn_s_barrier();                          // ... for every wave, and everybody is done with tile kt-1
+    __builtin_amdgcn_sched_barrier(0);
+    if (!SPREAD) { issue_part(kt + 1, 0, 8); __builtin_amdgcn_sched_barrier(0); }
+    const bf16_t* sA = ring + (kt % NS) * STAGE;
+    const bf16_t* sB = sA + BM * 64;
+    bf16x8_t af[2][TM], bfr[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = load_frag<BM, TA>(sA, wm * WTM + i * 32, 0, lane);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bfr[0][j] = load_frag<BN, !TB>(sB, wn * WTN + j * 32, 0, lane);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk < 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[(kk + 1) & 1][i] = load_frag<BM, TA>(sA, wm * WTM + i * 32, kk + 1, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[(kk + 1) & 1][j] = load_frag<BN, !TB>(sB, wn * WTN + j * 32, kk + 1, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
+      if (SPREAD) issue_part(kt + 1, kk * 2, kk * 2 + 2);   // the other stage is free since this step's barrier
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (all-zero) pieces
+  float* C = reinterpret_cast<float*>(d.C);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * WTN + j * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) C[(size_t)row * d.ldc + col] = acc[i][j][e];
+      }
+    }
+}
+
+// =====================================================================================
 // Fused logits + label-smoothed cross entropy (transformer.py:182-216, util.py:88-103) for the training
 // path: the [T, V] fp32 logits (524 MB at the bench shapes) are never written.
 //   forward : every 128x128 logits tile is reduced in its epilogue to one float4 per row
@@ -200,10 +310,24 @@ extern "C" {
 // fields are the running sum of ceil(M/bm)*ceil(N/bn); total_tiles = that sum.
 int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int tb, int tile, hipStream_t stream) {
   ZK_CHECK_ARG(nprob >= 1 && total_tiles >= 1, "zk_gemm_grouped: empty group");
-  ZK_CHECK_ARG(tile == 1 || tile == 4 || tile == 5 || tile == 6,
-               "zk_gemm_grouped: tile must be 1 (128x128), 4 (64x64), 5 (256x128) or 6 (128x256)");
+  ZK_CHECK_ARG(tile == 1 || tile == 4 || tile == 5 || tile == 6 || tile == 7 || tile == 8,
+               "zk_gemm_grouped: tile must be 1 (128x128), 4 (64x64), 5 (256x128), 6 (128x256) or 7 / 8 (256x256)");
   const GroupDesc* d = (const GroupDesc*)descs;
   dim3 grid((unsigned)total_tiles);
+  if (tile == 7 || tile == 8) {     // fp32 outputs without epilogue options only (checked on the host copy by the caller)
+    const dim3 blk(512);
+#define ZK_G256(SP_)                                                                                         \
+    do {                                                                                                     \
+      if (!ta && !tb) hipLaunchKernelGGL((k_gemm_grouped256<false, false, SP_>), grid, blk, 0, stream, d, nprob);   \
+      else if (!ta && tb) hipLaunchKernelGGL((k_gemm_grouped256<false, true, SP_>), grid, blk, 0, stream, d, nprob); \
+      else if (ta && !tb) hipLaunchKernelGGL((k_gemm_grouped256<true, false, SP_>), grid, blk, 0, stream, d, nprob); \
+      else hipLaunchKernelGGL((k_gemm_grouped256<true, true, SP_>), grid, blk, 0, stream, d, nprob);               \
+    } while (0)
+    if (tile == 7) ZK_G256(true); else ZK_G256(false);
+#undef ZK_G256
+    ZK_LAUNCH_CHECK();
+    return 0;
+  }
 #define ZK_GROUP_LAUNCH(BM_, BN_, NS_, PW_)                                                                     \
   do {                                                                                                         \
     const dim3 blk((4 + PW_) * 64);                                                                            \

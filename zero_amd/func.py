@@ -180,9 +180,14 @@ class Engine(object):
         The device descriptor table is cached per problem list (buffers are static, so it is built
         once)."""
         problems = [tuple(p) + (None,) * (8 - len(p)) for p in problems]
-        bm, bn = (tile, tile) if isinstance(tile, int) else tile      # 128, 64, (256, 128) or (128, 256)
-        code = {(128, 128): 1, (64, 64): 4, (256, 128): 5, (128, 256): 6}[(bm, bn)]
-        key = (ta, tb, bm, bn) + tuple((a.ptr, b.ptr, c.ptr, M, N, K, hip.ptr(bias) or 0, r.ptr if r is not None else 0)
+        # 128, 64, (256, 128), (128, 256), (256, 256) [fp32 outputs only] or (256, 256, 0) = the same without spreading
+        # the LDS-DMA issue between the MFMA groups
+        spread = not (isinstance(tile, tuple) and len(tile) == 3 and not tile[2])
+        bm, bn = (tile, tile) if isinstance(tile, int) else tile[:2]
+        code = {(128, 128): 1, (64, 64): 4, (256, 128): 5, (128, 256): 6, (256, 256): 7 if spread else 8}[(bm, bn)]
+        if (bm, bn) == (256, 256):
+            assert all(c.t.dtype == torch.float32 and bias is None and r is None for _, _, c, _, _, _, bias, r in problems)
+        key = (ta, tb, bm, bn, spread) + tuple((a.ptr, b.ptr, c.ptr, M, N, K, hip.ptr(bias) or 0, r.ptr if r is not None else 0)
                                      for a, b, c, M, N, K, bias, r in problems)
         cache = self.__dict__.setdefault("_group_cache", {})
         ent = cache.get(key)

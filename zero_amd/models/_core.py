@@ -77,7 +77,8 @@ class TransformerCore(object):
         # tile of the grouped weight-gradient launch: 128x256 (four waves with a 128x64 register tile each + four
         # producer waves, scripts/gemm_big_bench.py: 780 -> 856 TF on the decoder side incl. the logits problem)
         wt = os.environ.get("ZERO_HIP_WGRAD_TILE", "128x256").lower()
-        self.wgrad_tile = {"128": 128, "128x128": 128, "256x128": (256, 128), "128x256": (128, 256)}[wt]
+        self.wgrad_tile = {"128": 128, "128x128": 128, "256x128": (256, 128), "128x256": (128, 256),
+                           "256x256": (256, 256), "256x256n": (256, 256, 0)}[wt]
         # one group per side of the model with a single rank (fewest launches); smaller groups with
         # data parallelism so that the gradient all-reduce of finished layers starts early
         import torch.distributed as _dist
@@ -95,6 +96,7 @@ class TransformerCore(object):
         # pass over the 137-GFLOP GEMM costs what the saved 1 GB of traffic buys, so it is opt-in (it frees
         # T*V*4 bytes, which matters for larger batches / vocabularies)
         self.fused_ce = os.environ.get("ZERO_HIP_FUSED_CE", "0") != "0"
+        self.logits_tile256 = os.environ.get("ZERO_HIP_LOGITS_256", "1") != "0"
         self._red_id = 0
         self.side = torch.cuda.Stream(self.eng.device) if self.eng.device.type == "cuda" else None
 
@@ -558,7 +560,12 @@ class TransformerCore(object):
             self._ce_ctx = (lse, w, label_smooth) if need_grad else None
         else:
             logits = e.mat("logits", Tt, self.Vpad, F32)
-            e.gemm(feat, E, logits, Tt, self.V, self.H, 0, 1)
+            if self.logits_tile256 and e.gemm_impl == 0 and self.H % 8 == 0:
+                # 256x256 tiles, fp32 tile stored straight from the accumulators (scripts/gemm_big_bench.py:
+                # 223 us against 274-291 us for the 128x128 kernels on the 4096 x 32000 x 512 problem)
+                e.gemm_grouped([(feat, E, logits, Tt, self.V, self.H, None)], 0, 1, tile=(256, 256))
+            else:
+                e.gemm(feat, E, logits, Tt, self.V, self.H, 0, 1)
             dlogits = e.mat("dlogits", Tt, self.Vpad) if need_grad else None
             e.ce_fused(logits, batch["tgt"], w if need_grad else None, ce, dlogits, Tt, self.V, label_smooth)
         per_sample = e.buf("per_sample", (B,), F32)
