@@ -105,9 +105,12 @@ class GemmProfiler(object):
 
         def timed_grouped(problems, ta, tb, tile=128):
             tf = lambda v: "true" if v else "false"
-            bm_, bn_ = (tile, tile) if isinstance(tile, int) else tile
-            name = "k_gemm_grouped<%d, %d, %d, %s, %s, %d>" % (bm_, bn_, 4 if bm_ == 64 else 3 if max(bm_, bn_) == 256 else 2,
-                                                              tf(ta), tf(tb), 4 if max(bm_, bn_) == 256 else 0)
+            bm_, bn_ = (tile, tile) if isinstance(tile, int) else tile[:2]
+            if (bm_, bn_) == (256, 256):
+                name = "k_gemm_grouped256<%s, %s, %s>" % (tf(ta), tf(tb), tf(not (len(tile) == 3 and not tile[2])))
+            else:
+                name = "k_gemm_grouped<%d, %d, %d, %s, %s, %d>" % (bm_, bn_, 4 if bm_ == 64 else 3 if max(bm_, bn_) == 256 else 2,
+                                                                  tf(ta), tf(tb), 4 if max(bm_, bn_) == 256 else 0)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             self._grouped(problems, ta, tb, tile=tile)

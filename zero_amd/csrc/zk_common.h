@@ -62,6 +62,8 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
 // FRESH = true issues the load with the nt policy, which bypasses the L1 and is served by the XCD's (coherent) L2, so
 // the barrier needs no L1 invalidate (~5 us per barrier at two workgroups per CU).  FRESH = false: ordinary load.
 typedef unsigned int zk_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int zk_u32x2 __attribute__((ext_vector_type(2)));
+typedef float zk_f32x4 __attribute__((ext_vector_type(4)));
 template <bool FRESH>
 __device__ __forceinline__ uint4 zk_ld16(const void* p) {
   if (FRESH) {

@@ -544,7 +544,9 @@ __global__ void __launch_bounds__(256) k_ce_fused(
         o[j] = wr * (__expf(z[cc] - lse) - sl);
       } else o[j] = 0.f;
     }
-    *reinterpret_cast<uint2*>(d + c) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+    // streaming store: with an ordinary one the L2 fetches each line it is about to overwrite
+    zk_u32x2 pk; pk.x = pack2bf(o[0], o[1]); pk.y = pack2bf(o[2], o[3]);
+    __builtin_nontemporal_store(pk, reinterpret_cast<zk_u32x2*>(d + c));
   }
 }
 
@@ -567,7 +569,9 @@ __global__ void __launch_bounds__(1024) k_ce_fused_reg(
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 1024 + tid) * 4;
     if (c + 3 < V) {
-      v[i] = *reinterpret_cast<const float4*>(z + c);
+      // read once, never again: streaming load (no L2 allocation worth keeping)
+      const zk_f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const zk_f32x4*>(z + c));
+      v[i] = make_float4(t4.x, t4.y, t4.z, t4.w);
     } else {
       v[i].x = c < V ? z[c] : -INFINITY;
       v[i].y = c + 1 < V ? z[c + 1] : -INFINITY;

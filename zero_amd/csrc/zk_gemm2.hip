@@ -177,7 +177,9 @@ __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __rest
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (row < M && col < N) C[(size_t)row * d.ldc + col] = acc[i][j][e];
+        // streaming store: the tile is written once and read by a later kernel -- with an ordinary store the L2
+        // fetches every line it is about to overwrite (FETCH_SIZE == output size, profiles/r02_pmc_traffic.json)
+        if (row < M && col < N) __builtin_nontemporal_store(acc[i][j][e], &C[(size_t)row * d.ldc + col]);
       }
     }
 }

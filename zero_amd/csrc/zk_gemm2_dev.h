@@ -402,9 +402,14 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
           v[it][j] *= zk_drop_scale(seed, e.sid, (uint64_t)gm * N + gn + j, e.thr, e.inv_keep);
       }
       if (e.out_f32) {
+        // fp32 outputs are the large write-once tensors (weight gradients, logits): streaming stores, so that the
+        // L2 does not fetch the lines it is about to overwrite (FETCH_SIZE == output size with ordinary stores)
         float* d = reinterpret_cast<float*>(e.C) + (size_t)gm * e.ldc + gn;
-        reinterpret_cast<float4*>(d)[0] = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
-        reinterpret_cast<float4*>(d)[1] = make_float4(v[it][4], v[it][5], v[it][6], v[it][7]);
+        zk_f32x4 lo, hi;
+        lo.x = v[it][0]; lo.y = v[it][1]; lo.z = v[it][2]; lo.w = v[it][3];
+        hi.x = v[it][4]; hi.y = v[it][5]; hi.z = v[it][6]; hi.w = v[it][7];
+        __builtin_nontemporal_store(lo, reinterpret_cast<zk_f32x4*>(d));
+        __builtin_nontemporal_store(hi, reinterpret_cast<zk_f32x4*>(d) + 1);
       } else {
         *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)gm * e.ldc + gn) = pack8(v[it]);
       }
