@@ -344,6 +344,13 @@ int zk_add_gumbel(float* logits, int rows, int V, int ld, float eps, const uint6
 int zk_cache_rows(const void* src, size_t src_stride, const int* index, void* dst, size_t dst_stride, int rows,
                   size_t unit_bytes, int max_units, const int* time_dev, int mode, int period, zk_stream_t stream);
 /* transformer_aan.py:110-112: cache += x; cat = [x | cache/(t+1)] */
+/* Decode-step form of the residual + LayerNorm of the AAN decoder with its row-local neighbours in the same launch
+ * (transformer_aan.py:165-192): z/cat_in != NULL: the gate sigma(z_i) x + sigma(z_f) y is computed first (into ybuf);
+ * cache/cat_out != NULL: the next layer's running sum and [x | average] follow (zk_aan_decode).  Same arithmetic as
+ * zk_aan_gate_fwd + zk_add_ln_fwd + zk_aan_decode. */
+int zk_ln_decode(const void* x, void* ybuf, const float* gamma, const float* beta, void* out, int rows, int H, float eps,
+                 const void* z, const void* cat_in, float* cache, void* cat_out, float inv_count, const int* time_dev,
+                 zk_stream_t stream);
 int zk_aan_decode(const void* x, float* cache, void* cat, int rows, int H, float inv_count, const int* time_dev,
                   zk_stream_t stream);
 

@@ -614,3 +614,22 @@ def test_many_shapes_many_replays_match_eager():
         traces[mode] = out
     assert traces[False] == traces[True]
     assert not any(b for _, _, b in traces[True])
+
+
+@pytest.mark.parametrize("K", [1, 4])
+def test_aan_decode_ln_fusions_are_bit_identical(K, monkeypatch):
+    """zk_ln_decode (gate + residual + LayerNorm, and LayerNorm + the next layer's average-attention update, in one
+    launch each) against the separate launches: identical hypotheses AND identical scores, replayed graph and eager."""
+    from zero_amd import search
+    hp, Pn, src, tgt = _setup("transformer_aan", seed=8, beam_size=K)
+    hp = copy.copy(hp); hp.beam_size = K; hp.search_mode = "cache"
+    outs = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("ZERO_HIP_DECODE_FUSE_LN", fuse)
+        reset_cores()
+        get_core(hp, "transformer_aan", Pn)
+        enc, dec = registry.get_model("transformer_aan").infer_fn(hp)
+        outs[fuse] = search.beam_search({"source": src}, enc, dec, hp)
+    assert outs["0"]["steps"] == outs["1"]["steps"] > 2
+    assert np.array_equal(outs["0"]["seq"], outs["1"]["seq"])
+    assert np.array_equal(outs["0"]["score"], outs["1"]["score"])

@@ -219,6 +219,8 @@ def make_infer_fns(params, model_name):
             raise RuntimeError("decode step %d exceeds the allocated cache length %d" % (time, Tmax))
         zf = state["zero_flag"]
         e.lib.call("zk_all_equal", target.data_ptr(), BK, hp.tgt_vocab.pad(), zf.data_ptr(), e.stream)
+        import os as _os
+        fuse_ln = core.aan and _os.environ.get("ZERO_HIP_DECODE_FUSE_LN", "1") != "0"
         x = e.mat("dc.x", BK, H)
         e.embed_fwd(target, core.store.s(core.tgt_emb), core.b("bias"), x, BK, 1, H,
                     pos0=0 if time_dev is not None else time, zero_flag=zf, pos0_dev=time_dev, max_pos=Tmax)
@@ -228,9 +230,10 @@ def make_infer_fns(params, model_name):
             if core.aan:
                 a = pre + "/average_attention"
                 cat = e.mat("dc.cat", BK, 2 * H)
-                e.lib.call("zk_aan_decode", x.ptr, lay["aan"].data_ptr(), cat.ptr, BK, H,
-                           1.0 if time_dev is not None else 1.0 / float(time + 1),
-                           time_dev.data_ptr() if time_dev is not None else None, e.stream)
+                inv = 1.0 if time_dev is not None else 1.0 / float(time + 1)
+                tdev = time_dev.data_ptr() if time_dev is not None else None
+                if not (fuse_ln and l > 0 and not hp.use_ffn):      # else the previous layer's last LayerNorm did it
+                    e.lib.call("zk_aan_decode", x.ptr, lay["aan"].data_ptr(), cat.ptr, BK, H, inv, tdev, e.stream)
                 if hp.use_ffn:           # transformer_aan.py:176-183
                     ya = e.mat("dc.ya", BK, H)
                     e.lib.call("zk_gather_rows", cat.ptr + H * 2, 2 * H * 2, None, ya.ptr, H * 2, BK, H * 2, e.stream)
@@ -240,8 +243,16 @@ def make_infer_fns(params, model_name):
                 z = e.mat("dc.z", BK, 2 * H)
                 core._linear(cat, a + "/z_project", z)
                 g = e.mat("dc.y", BK, H)
-                e.aan_gate_fwd(z, cat, g, BK, H)
-                x = core._ln_fwd(x, g, a, "dc%d.aa" % l, False, 0.0, 0)
+                if fuse_ln:
+                    # gate + residual + LayerNorm in one launch (zk_ln_decode)
+                    xo = e.mat("dc%d.aa.o" % l, BK, H)
+                    e.lib.call("zk_ln_decode", x.ptr, g.ptr, core.b(a + "/layer_norm/scale").data_ptr(),
+                               core.b(a + "/layer_norm/offset").data_ptr(), xo.ptr, BK, H, zdtype.epsilon(),
+                               z.ptr, cat.ptr, None, None, 1.0, None, e.stream)
+                    x = xo
+                else:
+                    e.aan_gate_fwd(z, cat, g, BK, H)
+                    x = core._ln_fwd(x, g, a, "dc%d.aa" % l, False, 0.0, 0)
             elif not core.fuse:
                 p = pre + "/self_attention/dot_attention/"
                 qkv = e.mat("dc.qkv", BK, 3 * H)
@@ -283,7 +294,24 @@ def make_infer_fns(params, model_name):
             y = e.mat("dc.y", BK, H)
             core._linear(att, p + "o_map", y)
             x = core._ln_fwd(x, y, pre + "/" + core.cross, "dc%d.ca" % l, False, 0.0, 0)
-            x = core._ffn_fwd(x, pre + "/feed_forward", "dc%d.ff" % l, False, 0, False)
+            nxt = state["decoder"]["state"].get("layer_%d" % (l + 1))
+            if fuse_ln and core.aan and nxt is not None and not hp.use_ffn:
+                # feed-forward sub-layer whose LayerNorm also prepares the next layer's average attention
+                # (cache += x; cat = [x | cache / (time + 1)]) in the same launch
+                f = pre + "/feed_forward"
+                hh = e.mat("dc%d.ff.h" % l, BK, core.F)
+                core._linear(x, f + "/ffn_layer/enlarge", hh, act=1)
+                y = e.mat("dc.y", BK, H)
+                core._linear(hh, f + "/ffn_layer/output", y)
+                xo = e.mat("dc%d.ff.o" % l, BK, H)
+                e.lib.call("zk_ln_decode", x.ptr, y.ptr, core.b(f + "/layer_norm/scale").data_ptr(),
+                           core.b(f + "/layer_norm/offset").data_ptr(), xo.ptr, BK, H, zdtype.epsilon(), None, None,
+                           nxt["aan"].data_ptr(), e.mat("dc.cat", BK, 2 * H).ptr,
+                           1.0 if time_dev is not None else 1.0 / float(time + 1),
+                           time_dev.data_ptr() if time_dev is not None else None, e.stream)
+                x = xo
+            else:
+                x = core._ffn_fwd(x, pre + "/feed_forward", "dc%d.ff" % l, False, 0, False)
         logits = e.mat("dc.logits", BK, core.Vpad, F32)
         e.gemm(x, core.W(core.soft_emb), logits, BK, core.V, H, 0, 1)
         if time_dev is None:
