@@ -63,7 +63,9 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
  * gradients of several layers; the cross-attention k_map / v_map projections of every decoder
  * layer, func.py:206-216).  descs: DEVICE array of nprob records
  *   { const void* A, B; void* C; const float* bias; const void* res /* bf16 residual or NULL,
- *     may alias C */; int M, N, K, lda, ldb, ldc, out_f32, tile_start, tiles_n, ldr; }   (80 bytes)
+ *     may alias C */; int M, N, K, lda, ldb, ldc, out_f32, tile_start, tiles_n, ldr;
+ *     float* colsum /* NULL, or fp32 [N]: receives sum_k B[k][n] (tb = 0, tiles 5 / 6: the bias gradient beside a
+ *     weight gradient, func.py:16,58-60) */; long pad; }   (96 bytes)
  * tile_start = running sum of ceil(M/T)*ceil(N/T) with T = 128 (tile=1) or 64 (tile=4). */
 int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int tb, int tile,
                     zk_stream_t stream);

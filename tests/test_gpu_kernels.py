@@ -873,3 +873,25 @@ def test_logits_ce_fused_matches_gemm_plus_ce(T, V, H, ls):
     ref_d = w[:, None] * (torch.softmax(z, -1) - soft)
     assert rel_err(dl[:, :V], ref_d) < 8e-3
     assert float(dl[:, V:].float().abs().max()) == 0.0 if Vpad > V else True
+
+
+@pytest.mark.parametrize("tile", [(128, 256), (256, 128)])
+def test_grouped_wgrad_with_folded_bias_column_sums(tile):
+    """zk_gemm_grouped on the wide tiles: the producer waves of the tm = 0 tiles also write sum_k dY[k][n] (the bias
+    gradient of func.py:14-65 linear) -- several problems in one grid, ragged K / N, against fp32 torch."""
+    e = eng()
+    probs, refs = [], []
+    for i, (K, Min, Nout) in enumerate([(4096, 512, 1536), (1000, 512, 520), (72, 128, 64), (4096, 2048, 512)]):
+        X, dY = rand_bf(K, Min, seed=10 + i), rand_bf(K, Nout, seed=20 + i)
+        G = torch.zeros(Min, Nout, device="cuda")
+        cs = torch.full((Nout,), 7.0, device="cuda")
+        probs.append((mat(X), mat(dY), mat(G), Min, Nout, K, None, None, cs if i != 2 else None))
+        refs.append((G, X.float().t() @ dY.float(), cs, dY.float().sum(0)))
+    e.gemm_grouped(probs, 1, 0, tile=tile)
+    torch.cuda.synchronize()
+    for i, (G, gref, cs, cref) in enumerate(refs):
+        assert rel_err(G, gref) < 1e-5, i
+        if i != 2:
+            assert rel_err(cs, cref) < 1e-5, (i, rel_err(cs, cref))
+        else:
+            assert float(cs.min()) == 7.0                 # no output requested: untouched

@@ -49,7 +49,9 @@ struct GroupDesc {
   const bf16_t* A; const bf16_t* B; void* C; const float* bias;
   const bf16_t* res;          // optional bf16 residual added in the epilogue (may alias C), row stride ldr
   int M, N, K, lda, ldb, ldc, out_f32, tile_start, tiles_n, ldr;
-};                            // 80 bytes; mirrored by zero_amd/func.py:_GroupDesc
+  float* colsum;              // optional fp32 [N]: column sums of B (tb = 0) over K, written by the producer waves of the
+  long pad_;                  // tm = 0 tiles (bias gradient beside a weight gradient); needs a producer-wave tile
+};                            // 96 bytes; mirrored by zero_amd/func.py:_GroupDesc
 
 template <int BM, int BN, int NS, bool TA, bool TB, int PW = 0>
 __global__ void __launch_bounds__((4 + PW) * 64) k_gemm_grouped(const GroupDesc* __restrict__ descs, int nprob) {
@@ -69,7 +71,7 @@ __global__ void __launch_bounds__((4 + PW) * 64) k_gemm_grouped(const GroupDesc*
   const uintptr_t al = (uintptr_t)d.C | (uintptr_t)d.bias | (uintptr_t)d.res;
   const int vec_ok = ((al & 15) == 0) && (d.ldc % 8 == 0) && (d.res == nullptr || d.ldr % 8 == 0);
   gemm_tile<BM, BN, NS, TA, TB, 4, PW>(smem, d.A, d.B, d.M, d.N, d.lda, d.ldb, 0, d.K, tm * BM, tn * BN, nullptr, e,
-                                       vec_ok);
+                                       vec_ok, nullptr, (PW > 0 && tm == 0) ? d.colsum : nullptr);
 }
 
 // =====================================================================================
@@ -308,7 +310,7 @@ static int launch_dlds(const bf16_t* A, const bf16_t* B, int M, int N, int K, in
 }
 
 extern "C" {
-// descs: device array of `nprob` GroupDesc (80 bytes each, see zk_gemm2.hip) whose tile_start
+// descs: device array of `nprob` GroupDesc (96 bytes each, see zk_gemm2.hip) whose tile_start
 // fields are the running sum of ceil(M/bm)*ceil(N/bn); total_tiles = that sum.
 int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int tb, int tile, hipStream_t stream) {
   ZK_CHECK_ARG(nprob >= 1 && total_tiles >= 1, "zk_gemm_grouped: empty group");

@@ -166,7 +166,8 @@ struct KSegDesc {
 template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0, bool KSEG = false, bool FRESH = false>
 __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16_t* __restrict__ A,
                                                  const bf16_t* __restrict__ B, int M, int N, int lda, int ldb,
-                                                 int kbeg, int kend, int m0, int n0, const KSegDesc* ks = nullptr) {
+                                                 int kbeg, int kend, int m0, int n0, const KSegDesc* ks = nullptr,
+                                                 float* __restrict__ colsum = nullptr) {
   constexpr int NWM = NW == 8 ? 4 : 2, NWN = NW / NWM;       // wave grid over the tile: 2x2, 2x1 or 4x2
   constexpr int WTM = BM / NWM, WTN = BN / NWN, TM = WTM / 32, TN = WTN / 32;
   constexpr int STAGE = DldsCfg<BM, BN, NS>::STAGE;
@@ -255,6 +256,13 @@ __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16
     // invariant at the barrier of step kt: tile kt has landed (the producers waited for it) and every compute
     // wave is done with tile kt-1, whose stage the producers refill next.  Both roles pass nk barriers.
     if (producer) {
+      // colsum != nullptr (B stored [k][n], i.e. !TB: the dY operand of a weight gradient): the producer waves, idle
+      // between two DMA issues, also sum the columns of every B tile they brought in -- the bias gradient
+      // sum_k dY[k][n] (func.py:16, 58-60) -- so that no separate pass re-reads dY (k_colsum_grouped: 430 MB per step).
+      // Thread p of the producers owns column n0 + p; tile kt has landed for everybody at barrier kt and its stage is
+      // refilled by this wave itself only after these reads.
+      float cs = 0.f;
+      const int pcol = dwave * 64 + lane;
 #pragma unroll
       for (int s = 0; s < NS - 1; ++s) issue(s);
       for (int kt = 0; kt < nk; ++kt) {
@@ -262,7 +270,14 @@ __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         issue(kt + NS - 1);
+        if (!TB && colsum != nullptr && pcol < BN) {
+          const bf16_t* sBk = ring + (kt % NS) * STAGE + BM * 64;
+          const int chunk = pcol >> 3, within = pcol & 7;
+#pragma unroll 8
+          for (int k = 0; k < 64; ++k) cs += bf2f(sBk[k * BN + ((chunk ^ swz_trans<BN>(k)) << 3) + within]);
+        }
       }
+      if (!TB && colsum != nullptr && pcol < BN && n0 + pcol < N) colsum[n0 + pcol] = cs;
     } else {
       ZK_E(1);
       for (int kt = 0; kt < nk; ++kt) {
@@ -327,8 +342,8 @@ template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0, bool
 __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __restrict__ A,
                                           const bf16_t* __restrict__ B, int M, int N, int lda, int ldb, int kbeg,
                                           int kend, int m0, int n0, float* __restrict__ slab, const GemmEpi& e,
-                                          int vec_ok, const KSegDesc* ks = nullptr) {
-  gemm_tile_to_lds<BM, BN, NS, TA, TB, NW, PW, KSEG, FRESH>(smem, A, B, M, N, lda, ldb, kbeg, kend, m0, n0, ks);
+                                          int vec_ok, const KSegDesc* ks = nullptr, float* __restrict__ colsum = nullptr) {
+  gemm_tile_to_lds<BM, BN, NS, TA, TB, NW, PW, KSEG, FRESH>(smem, A, B, M, N, lda, ldb, kbeg, kend, m0, n0, ks, colsum);
   constexpr int CLD = DldsCfg<BM, BN, NS>::CLD;
   constexpr int NT = (NW + PW) * 64;
   const int tid = threadIdx.x;

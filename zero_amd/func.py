@@ -29,7 +29,7 @@ class _GroupDesc(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p),
                 ("bias", ctypes.c_void_p), ("res", ctypes.c_void_p)] + \
                [(n, ctypes.c_int) for n in ("M", "N", "K", "lda", "ldb", "ldc", "out_f32", "tile_start",
-                                            "tiles_n", "ldr")]
+                                            "tiles_n", "ldr")] + [("colsum", ctypes.c_void_p), ("pad", ctypes.c_long)]
 
 
 class _ColsumDesc(ctypes.Structure):
@@ -179,26 +179,30 @@ class Engine(object):
         problems: list of (A, B, C, M, N, K, bias-or-None[, residual Mat-or-None]) with Mat operands.
         The device descriptor table is cached per problem list (buffers are static, so it is built
         once)."""
-        problems = [tuple(p) + (None,) * (8 - len(p)) for p in problems]
+        problems = [tuple(p) + (None,) * (9 - len(p)) for p in problems]     # ..., residual, column-sum output
         # 128, 64, (256, 128), (128, 256), (256, 256) [fp32 outputs only] or (256, 256, 0) = the same without spreading
         # the LDS-DMA issue between the MFMA groups
         spread = not (isinstance(tile, tuple) and len(tile) == 3 and not tile[2])
         bm, bn = (tile, tile) if isinstance(tile, int) else tile[:2]
         code = {(128, 128): 1, (64, 64): 4, (256, 128): 5, (128, 256): 6, (256, 256): 7 if spread else 8}[(bm, bn)]
         if (bm, bn) == (256, 256):
-            assert all(c.t.dtype == torch.float32 and bias is None and r is None for _, _, c, _, _, _, bias, r in problems)
-        key = (ta, tb, bm, bn, spread) + tuple((a.ptr, b.ptr, c.ptr, M, N, K, hip.ptr(bias) or 0, r.ptr if r is not None else 0)
-                                     for a, b, c, M, N, K, bias, r in problems)
+            assert all(c.t.dtype == torch.float32 and bias is None and r is None and cs is None
+                       for _, _, c, _, _, _, bias, r, cs in problems)
+        if any(p[8] is not None for p in problems):
+            assert code in (5, 6) and not tb, "column sums ride on the producer waves of the wide tiles (tb = 0)"
+        key = (ta, tb, bm, bn, spread) + tuple((a.ptr, b.ptr, c.ptr, M, N, K, hip.ptr(bias) or 0, r.ptr if r is not None else 0,
+                                                hip.ptr(cs) or 0) for a, b, c, M, N, K, bias, r, cs in problems)
         cache = self.__dict__.setdefault("_group_cache", {})
         ent = cache.get(key)
         if ent is None:
             arr = (_GroupDesc * len(problems))()
             start = 0
-            for i, (a, b, c, M, N, K, bias, res) in enumerate(problems):
+            for i, (a, b, c, M, N, K, bias, res, cs) in enumerate(problems):
                 tn = (N + bn - 1) // bn
                 d = arr[i]
                 d.A, d.B, d.C, d.bias = a.ptr, b.ptr, c.ptr, hip.ptr(bias) or 0
                 d.res, d.ldr = (res.ptr, res.ld) if res is not None else (0, 0)
+                d.colsum = hip.ptr(cs) or 0
                 d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, a.ld, b.ld, c.ld
                 d.out_f32 = 1 if c.t.dtype == torch.float32 else 0
                 d.tile_start, d.tiles_n = start, tn

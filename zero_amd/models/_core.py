@@ -185,9 +185,13 @@ class TransformerCore(object):
             adds = [(gW.t, tW)] + ([(gb, tb)] if bias_grad else [])
             gW, gb = Mat(tW, gW.rows, gW.cols), tb
 
+        # bias gradient = column sums of dY: on the wide (producer-wave) tiles the producers of the weight-gradient GEMM
+        # compute them from the dY tiles they stage anyway (no separate pass over dY)
+        fold_cs = bias_grad and isinstance(self.wgrad_tile, tuple) and self.wgrad_tile[:2] != (256, 256) and \
+            os.environ.get("ZERO_HIP_FOLD_COLSUM", "1") != "0"
         if self.group_wgrad and self.eng.gemm_impl == 0:
-            self._pending_wgrads.append((x, dy, gW, Wm.rows, Wm.cols, x.rows, None))
-            if bias_grad:
+            self._pending_wgrads.append((x, dy, gW, Wm.rows, Wm.cols, x.rows, None, None, gb if fold_cs else None))
+            if bias_grad and not fold_cs:
                 gy = self.eng.lib.raw("zk_colsum_rowchunks")(dy.rows)
                 pw = self.eng.buf("g.cs%d" % len(self._pending_colsums) + scope, (gy * dy.cols,), F32)
                 self._pending_colsums.append((dy, gb, pw))
