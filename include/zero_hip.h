@@ -100,7 +100,11 @@ int zk_logits_ce_bwd(const void* feat, const void* E, const int* ids, const floa
  * relative index (same layout, bf16); the caller finishes O += rpr_pb . rpr_v.  The backward takes
  * rpr_gq, rpr_gd = dO_h . rpr_v^T (fp32) and writes rpr_pb, rpr_dsb (bf16 bucket sums of P and dS): dQ += dsb . rpr_k,
  * d rpr_k = dsb^T Q, d rpr_v = pb^T dO are the caller's GEMMs.  Without rpr_gq the reference kernels
- * apply the tables directly (any head size). */
+ * apply the tables directly (any head size).
+ * zk_attn_fwd with impl | 256 and rpr_k / rpr_v but no rpr_gq: the relative-position terms are FOLDED into the MFMA tile
+ * (d = 64, 2*max_rel+1 <= 64): both tables are staged in LDS, G = Q_h . rpr_k^T is one MFMA pass, the scores gather from it,
+ * the bucket sums of P stay in LDS and O += PB . rpr_v follows the P.V product -- no table products through HBM, no extra
+ * launches, single-query decode steps included; shapes it does not cover fall back to the reference kernel (impl 0). */
 int zk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int nh, int Lq,
                 int Lk, int d, int ldq, int ldk, int ldv, int ldo, const float* kmask, int causal,
                 int q_pos0, float scale, float mask_inf, const void* rpr_k, const void* rpr_v, int max_rel,

@@ -233,12 +233,12 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv_naive(AttnArgs a, const bf
 // MFMA kernels (d = 64): tile functions in zk_attn_dev.h
 // =====================================================================================
 // ---- forward: grid (ceil(Lq/64), nh, B); NKT = ceil(Lk/64) <= 4
-template <int NKT>
+template <int NKT, bool RPR = false>
 __global__ void __launch_bounds__(256) k_attn_fwd_mfma(AttnArgs a, bf16_t* __restrict__ out, int ldo,
                                                        float* __restrict__ lse) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[AttnFwdLds<NKT>::BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[AttnFwdLds<NKT, RPR>::BYTES];
   attn_apply_pos(a);
-  attn_fwd_tile<NKT>(smem, a, out, ldo, lse, blockIdx.x, blockIdx.y, blockIdx.z);
+  attn_fwd_tile<NKT, false, RPR>(smem, a, out, ldo, lse, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ---- backward A: grid (ceil(Lq/64), nh, B) -> dQ, Dbuf
@@ -535,11 +535,28 @@ int zk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* l
   a.kv_group = kv_group;
   a.pos_dev = pos_dev; a.pos_flags = pos_dev ? pos_flags : 0;
   a.gq = (const float*)rpr_gq; a.pb = (bf16_t*)rpr_pb; a.ldg = rpr_ldg; a.nrp = rpr_nrp;
-  const bool ok = attn_mfma_ok(a, ldo) && Lk <= 256 && (a.bsq % 8 == 0) && (a.bsk % 8 == 0) && (a.bsv % 8 == 0) && (((uintptr_t)out & 15) == 0);
+  // relative positions folded into the MFMA tile (impl bit 8 = 256, set by the caller): tables in LDS, no products in HBM
+  const bool fold = (impl & 256) && rpr_k != nullptr && rpr_gq == nullptr && d == AD && 2 * max_rel + 1 <= 64 &&
+                    ((((uintptr_t)rpr_k | (uintptr_t)rpr_v) & 15) == 0);
+  impl &= 255;
+  if (fold) { a.rpr_k = nullptr; a.rpr_v = nullptr; }          // attn_mfma_ok() refuses undecomposed tables
+  bool ok = attn_mfma_ok(a, ldo) && Lk <= 256 && (a.bsq % 8 == 0) && (a.bsk % 8 == 0) && (a.bsv % 8 == 0) && (((uintptr_t)out & 15) == 0);
+  if (fold) { a.rpr_k = (const bf16_t*)rpr_k; a.rpr_v = (const bf16_t*)rpr_v; }
+  const bool folded = fold && ok && impl != 1;
+  if (fold && !folded) ok = false;
   ZK_CHECK_ARG(impl != 2 || ok, "zk_attn_fwd: MFMA kernel needs d=64, no rpr, Lk<=256, ld%%8==0");
   if (impl == 2 || (impl == 0 && ok)) {
     dim3 grid((Lq + TQ - 1) / TQ, nh, B);
     const int nkt = (Lk + 63) / 64;
+    if (folded) {
+      if (zk_prog_active()) return zk_prog_reject("attention with relative positions");
+      if (nkt == 1) hipLaunchKernelGGL((k_attn_fwd_mfma<1, true>), grid, dim3(256), 0, stream, a, (bf16_t*)out, ldo, lse);
+      else if (nkt == 2) hipLaunchKernelGGL((k_attn_fwd_mfma<2, true>), grid, dim3(256), 0, stream, a, (bf16_t*)out, ldo, lse);
+      else if (nkt == 3) hipLaunchKernelGGL((k_attn_fwd_mfma<3, true>), grid, dim3(256), 0, stream, a, (bf16_t*)out, ldo, lse);
+      else hipLaunchKernelGGL((k_attn_fwd_mfma<4, true>), grid, dim3(256), 0, stream, a, (bf16_t*)out, ldo, lse);
+      ZK_LAUNCH_CHECK();
+      return 0;
+    }
     if (zk_prog_active()) return zk_prog_record_attn_fwd(a, (bf16_t*)out, ldo, lse, nkt);
     if (nkt == 1) hipLaunchKernelGGL(k_attn_fwd_mfma<1>, grid, dim3(256), 0, stream, a, (bf16_t*)out, ldo, lse);
     else if (nkt == 2) hipLaunchKernelGGL(k_attn_fwd_mfma<2>, grid, dim3(256), 0, stream, a, (bf16_t*)out, ldo, lse);

@@ -239,18 +239,32 @@ __device__ __forceinline__ float quad16_sum(float v) {
 
 // ---- forward: grid (ceil(Lq/64), nh, B); NKT = ceil(Lk/64) <= 4
 // LDS bytes of one forward tile: sQ, sK (K tile, later V^T tile), sP
-template <int NKT>
-struct AttnFwdLds { static constexpr int BYTES = (2 * TQ * ALD + TQ * (NKT * 64 + 8)) * 2; };
+// (+ with relative positions folded in: the key table [r][channel], the value table transposed [channel][r], the
+//  bucket sums of P [query][r] -- bf16 tiles of 64 x ALD -- and G = Q.Rk^T as fp32 [query][GLD])
+#define GLD 68
+template <int NKT, bool RPR = false>
+struct AttnFwdLds {
+  static constexpr int BASE = (2 * TQ * ALD + TQ * (NKT * 64 + 8)) * 2;
+  static constexpr int BYTES = BASE + (RPR ? 3 * TQ * ALD * 2 + TQ * GLD * 4 : 0);
+};
 // one (64-query tile qt, head h, sentence b) problem by a 256-thread workgroup (the caller has applied attn_apply_pos); smem: AttnFwdLds<NKT>::BYTES, 16-byte
 // aligned, the workgroup's ONLY LDS object (shared with whatever ran before: the function starts with a barrier-free
 // overwrite, callers separate it from earlier readers of smem with a workgroup barrier)
-template <int NKT, bool FRESH = false>
+// RPR (modules/rpr.py:10-75 folded into the tile): with only 2*max_rel+1 <= 64 distinct table rows, q.R_k[idx(i,j)] is
+// a gather from G = Q_h.Rk^T (64 x 64, one MFMA pass over the LDS-resident table) and sum_j P[i,j] R_v[idx(i,j)] is
+// PB.Rv with PB[i,r] = the sum of P over the keys of relative index r -- no products through HBM, no extra launches.
+template <int NKT, bool FRESH = false, bool RPR = false>
 __device__ __forceinline__ void attn_fwd_tile(unsigned char* smem, const AttnArgs& a, bf16_t* __restrict__ out, int ldo,
                                               float* __restrict__ lse, int qt, int h, int b) {
   bf16_t* sQ = reinterpret_cast<bf16_t*>(smem);
   bf16_t* sK = sQ + TQ * ALD;     // K tile, later V^T tile
   bf16_t* sP = sK + TQ * ALD;
   constexpr int PLD = NKT * 64 + 8;
+  [[maybe_unused]] bf16_t* sRk = reinterpret_cast<bf16_t*>(smem + AttnFwdLds<NKT, false>::BASE);
+  [[maybe_unused]] bf16_t* sRvT = sRk + TQ * ALD;
+  [[maybe_unused]] bf16_t* sPB = sRvT + TQ * ALD;
+  [[maybe_unused]] float* sG = reinterpret_cast<float*>(sPB + TQ * ALD);
+  [[maybe_unused]] const int nrel = 2 * a.max_rel + 1;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i0 = qt * TQ;
   const bf16_t* qb = a.q + (size_t)b * a.bsq + h * AD;
@@ -273,6 +287,10 @@ __device__ __forceinline__ void attn_fwd_tile(unsigned char* smem, const AttnArg
   }
   store_direct(sQ, rQ, tid);
   store_direct(sK, rK, tid);
+  if (RPR) {
+    stage_direct(sRk, a.rpr_k, AD, 0, nrel, tid);        // [r][channel], rows >= nrel zero
+    stage_trans(sRvT, a.rpr_v, AD, 0, nrel, tid);        // [physical channel][r]
+  }
   f32x4_t S[NKT * 4];
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
@@ -290,6 +308,20 @@ __device__ __forceinline__ void attn_fwd_tile(unsigned char* smem, const AttnArg
       S[kt * 4 + nt] = acc;
     }
   }
+  if (RPR) {
+    // G rows of this wave's 16 queries (only this wave reads them back)
+    const uint4 q0 = frag(sQ, w * 16, 0, lane), q1 = frag(sQ, w * 16, 1, lane);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      acc = mfma16(q0, frag(sRk, nt * 16, 0, lane), acc);
+      acc = mfma16(q1, frag(sRk, nt * 16, 1, lane), acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sG[(w * 16 + (lane >> 4) * 4 + r) * GLD + nt * 16 + (lane & 15)] = acc[r];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
   // scale + mask; C layout: col (key) = lane&15, row (query) = (lane>>4)*4 + reg
   const int rbase = i0 + w * 16 + (lane >> 4) * 4;
   float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -302,6 +334,7 @@ __device__ __forceinline__ void attn_fwd_tile(unsigned char* smem, const AttnArg
     for (int r = 0; r < 4; ++r) {
       float raw = S[t][r];
       if (a.gq != nullptr && kvalid && rbase + r < a.Lq) raw += rpr_gather(a, a.gq, b, h, rbase + r, j);
+      if (RPR && kvalid) raw += sG[(w * 16 + (lane >> 4) * 4 + r) * GLD + rel_index(a.q_pos0 + rbase + r, j, a.max_rel)];
       float s = raw * a.scale + kb_;
       if (a.causal && j > a.q_pos0 + rbase + r) s -= a.mask_inf;
       s = kvalid ? s : -INFINITY;
@@ -347,6 +380,27 @@ __device__ __forceinline__ void attn_fwd_tile(unsigned char* smem, const AttnArg
     __builtin_amdgcn_wave_barrier();
     rpr_bucket_rows(a, a.pb, b, h, i0, w, lane, [&](int row, int j) { return bf2f(sP[row * PLD + j]); });
   }
+  if (RPR) {   // PB[i][r] for this wave's rows, r in [0, 64): interior indices pick one key, the two clipped tails sum
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const int m = a.max_rel;
+    for (int e = lane; e < 16 * 64; e += 64) {
+      const int row = w * 16 + (e >> 6), r = e & 63;
+      const int ia = a.q_pos0 + i0 + row;
+      float acc = 0.f;
+      if (i0 + row < a.Lq) {
+        if (r > 0 && r < 2 * m) {
+          const int j = ia - (r - m);
+          if (j >= 0 && j < a.Lk) acc = bf2f(sP[row * PLD + j]);
+        } else if (r == 0) {
+          for (int j = max(ia + m, 0); j < a.Lk; ++j) acc += bf2f(sP[row * PLD + j]);
+        } else if (r == 2 * m) {
+          for (int j = min(ia - m, a.Lk - 1); j >= 0; --j) acc += bf2f(sP[row * PLD + j]);
+        }
+      }
+      sPB[row * ALD + r] = f2bf(acc);
+    }
+  }
   // O = P V, V^T staged per key tile into sK
   f32x4_t O[4];
 #pragma unroll
@@ -363,6 +417,16 @@ __device__ __forceinline__ void attn_fwd_tile(unsigned char* smem, const AttnArg
                                                        (lane >> 4) * 8);
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) O[nb] = mfma16(pa, frag(sK, nb * 16, kk, lane), O[nb]);
+    }
+  }
+  if (RPR) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();             // this wave's sPB rows are complete (sRvT since the first barrier)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const uint4 pa = frag(sPB, w * 16, kk, lane);
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) O[nb] = mfma16(pa, frag(sRvT, nb * 16, kk, lane), O[nb]);
     }
   }
   // O through LDS (sQ is dead) so that every thread stores 16 bytes of a row

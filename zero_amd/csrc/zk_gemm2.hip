@@ -487,7 +487,7 @@ int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K,
     }
   }
   int ns = (sched_flags >> 4) & 15;   // ring-depth override (tuning)
-  if (!ns && bm == 64 && bn == 64 && g_tune[3]) ns = g_tune[3];     // A/B: ring depth of the 64x64 tile in-step
+  if (!ns && bm == 64 && bn == 64 && g_tune[3] && g_tune[3] != 5) ns = g_tune[3];     // A/B: ring depth of the 64x64 tile in-step
   if (bm == 64 && bn == 64 && g_tune[4] == 2)                       // A/B: two-wave workgroups, ring depth 2
     return launch_dlds<64, 64, 2, 2>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
   if (bm == 64 && bn == 64 && g_tune[4] == 4)                       // two-wave workgroups, ring depth 4
@@ -495,6 +495,8 @@ int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K,
   if (!ns) {                                                        // producer-wave workgroups (default for 64x64, 128x128)
     const int t = g_tune[6], pw = zk_gemm_dlds_pw(bm, bn), ns3 = (t >> 8) & 1;
 #define ZK_PW(BM_, BN_, NS_, PW_) return launch_dlds<BM_, BN_, NS_, 4, PW_>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream)
+    // tuning key 3 = 5: five ring stages (80 KiB: two workgroups fill the CU's 160 KiB of LDS, 128 KiB in flight)
+    if (bm == 64 && bn == 64 && g_tune[3] == 5 && pw == 4) ZK_PW(64, 64, 5, 4);
     if (bm == 64 && bn == 64) { if (pw == 2) ZK_PW(64, 64, 4, 2); if (pw == 4) ZK_PW(64, 64, 4, 4); if (pw == 8) ZK_PW(64, 64, 4, 8); }
     if (bm == 128 && bn == 128 && !ns3) { if (pw == 2) ZK_PW(128, 128, 2, 2); if (pw == 4) ZK_PW(128, 128, 2, 4); if (pw == 8) ZK_PW(128, 128, 2, 8); }
     if (bm == 128 && bn == 128 && ns3) { if (pw == 4) ZK_PW(128, 128, 3, 4); if (pw == 8) ZK_PW(128, 128, 3, 8); }

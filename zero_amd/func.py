@@ -100,6 +100,8 @@ class Engine(object):
         self._timing = None
         # layer programs (run_program): one persistent launch per sentence-local chain instead of one launch per op
         self.programs_enabled = os.environ.get("ZERO_HIP_PROGRAM", "0") != "0"
+        # relative positions folded into the attention forward tile (zk_attn_dev.h attn_fwd_tile<.., RPR>)
+        self.rpr_fold = os.environ.get("ZERO_HIP_RPR_FOLD", "1") != "0"
         self._prog_host = None
 
     # ---- plumbing -----------------------------------------------------------
@@ -269,6 +271,9 @@ class Engine(object):
         rounded up to 8) so that they can be GEMM operands with an 8-aligned contraction length."""
         nrel = 2 * max_rel + 1
         nrp = (nrel + 7) // 8 * 8
+        if rpr_k.shape[0] >= nrp and rpr_v.shape[0] >= nrp:
+            # views of the variable store: already padded with zero rows (zero_amd/variables.py)
+            return nrp, Mat(rpr_k, nrp, d), Mat(rpr_v, nrp, d)
         pads = []
         for tag, t in (("k", rpr_k), ("v", rpr_v)):
             name = "rpr.pad%s.%d" % (tag, t.data_ptr())
@@ -291,7 +296,14 @@ class Engine(object):
                  impl=None, pos_dev=None, pos_flags=0):
         gq = pb = None
         ldg = nrp = 0
-        if Lq > 1 and kv_group == 1 and not bsq and self._rpr_mfma(impl, d, Lk, rpr_k, (q.ld, k.ld, v.ld, out.ld), max_rel):
+        eff_impl = self.attn_impl if impl is None else impl
+        fold = self.rpr_fold and rpr_k is not None and eff_impl in (0, 2) and d == 64 and 2 * max_rel + 1 <= 64
+        if fold:
+            # relative positions inside the MFMA tile (tables in LDS): no table products through HBM, no extra
+            # launches; also serves single-query decode steps (falls back to the reference kernel when the shape is
+            # not covered)
+            eff_impl = (0 if eff_impl == 0 else 2) | 256
+        elif Lq > 1 and kv_group == 1 and not bsq and self._rpr_mfma(impl, d, Lk, rpr_k, (q.ld, k.ld, v.ld, out.ld), max_rel):
             # decomposed form: scores gather Q_h.Rk^T, the kernel returns the per-index sums of P and
             # O += pb.Rv finishes the value term -- three grouped GEMM launches around the MFMA kernel
             T = B * Lq
@@ -305,7 +317,7 @@ class Engine(object):
             "zk_attn_fwd", q.ptr, k.ptr, v.ptr, out.ptr, hip.ptr(lse), B, nh, Lq, Lk, d, q.ld, k.ld, v.ld,
             out.ld, hip.ptr(kmask), 1 if causal else 0, q_pos0, float(d) ** -0.5, zdtype.inf(),
             hip.ptr(rpr_k), hip.ptr(rpr_v), max_rel, float(drop_p), self.seed.data_ptr(), sid,
-            bsq, bsk, bsv, kv_group, self.attn_impl if impl is None else impl, hip.ptr(pos_dev), pos_flags,
+            bsq, bsk, bsv, kv_group, eff_impl, hip.ptr(pos_dev), pos_flags,
             gq.ptr if gq is not None else None, pb.ptr if pb is not None else None, ldg, nrp, self.stream)
         if gq is not None:
             self.gemm_grouped([(pb.cols_slice(h * nrp, (h + 1) * nrp), rv, out.cols_slice(h * d, (h + 1) * d), T, d, nrp,

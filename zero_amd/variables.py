@@ -149,7 +149,9 @@ class VariableStore(object):
         off = 0
         for name, shape, kind, _ in self.specs:
             pshape = tuple(shape)
-            if kind == "embed":
+            if kind == "embed" or name.endswith("/embeddings"):
+                # (relative-position tables too: their zero rows make them GEMM operands with an 8-aligned
+                # contraction length as they are -- no padded copy per attention call)
                 pshape = ((shape[0] + 7) // 8 * 8, shape[1])
             n = int(np.prod(pshape))
             self.offsets[name] = off
