@@ -330,6 +330,10 @@ class Engine(object):
         dec = self._rpr_mfma(impl, d, 0, rpr_k, (q.ld, k.ld, v.ld, out.ld, dout.ld, dq.ld, dk.ld, dv.ld), max_rel, bwd=True)
         tabs = (None, None, None, None)
         ldg = nrp = 0
+        if not dec and drpr_k is not None:
+            # the reference kernels ADD their table gradients with atomics
+            self.zero(drpr_k)
+            self.zero(drpr_v)
         if dec:
             T = B * Lq
             nrp, rk, rv = self._rpr_tables(rpr_k, rpr_v, max_rel, d)
@@ -359,8 +363,9 @@ class Engine(object):
                               [(sl(pb, h, nrp), sl(dout, h, d), rows(nh + h), nrp, d, T, None) for h in heads],
                               1, 0, tile=64)
             n = (2 * max_rel + 1) * d
-            self.lib.call("zk_sum_slices", drpr_k.data_ptr(), part.ptr, nh, n, nrp * d, 1, self.stream)
-            self.lib.call("zk_sum_slices", drpr_v.data_ptr(), part.ptr + nh * nrp * d * 4, nh, n, nrp * d, 1, self.stream)
+            # every table belongs to ONE attention scope: its gradient is overwritten, not accumulated (no zero fill)
+            self.lib.call("zk_sum_slices", drpr_k.data_ptr(), part.ptr, nh, n, nrp * d, 0, self.stream)
+            self.lib.call("zk_sum_slices", drpr_v.data_ptr(), part.ptr + nh * nrp * d * 4, nh, n, nrp * d, 0, self.stream)
 
     # ---- embedding + timing (transformer.py:16-33, 88-119; func.py:341-369) -------
     def embed_fwd(self, ids, table, bias, out, B, L, H, shift=False, pos0=0, zero_flag=None, drop_p=0.0,

@@ -607,10 +607,7 @@ class TransformerCore(object):
             e.zero(st.g(self.src_emb))
         if self.tgt_emb != self.soft_emb and self.tgt_emb != self.src_emb:
             e.zero(st.g(self.tgt_emb))
-        if self.rpr:
-            for name in st.names():
-                if name.endswith("/embeddings"):
-                    e.zero(st.g(name))
+        # (relative-position tables: zk_attn_bwd's callers overwrite or zero-then-accumulate them, func.Engine.attn_bwd)
         # logits / softmax embedding
         E = self.W(self.soft_emb)
         P = [e.mat("gd.p0", Tt, H), e.mat("gd.p1", Tt, H)]
