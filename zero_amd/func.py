@@ -357,15 +357,25 @@ class Engine(object):
             # dQ += dsb.Rk ; table gradients: per-head partials dsb_h^T Q_h and pb_h^T dO_h, summed over heads
             self.gemm_grouped([(sl(dsb, h, nrp), rk, sl(dq, h, d), T, d, nrp, None, sl(dq, h, d)) for h in heads],
                               0, 0, tile=64)
-            part = self.mat("rpr.part", 2 * nh * nrp, d, torch.float32)
+            # table gradients dsb_h^T Q_h and pb_h^T dO_h: [nrp x d] outputs over K = T rows.  One 64x64 tile per head would
+            # walk all T rows alone (64 K steps, 24 us on 16 workgroups); cutting the rows into KS slices (every (head,
+            # slice) its own tile, zk_sum_slices adds the nh * KS partials) was measured and is SLOWER in the step
+            # (same box: KS = 1 6.37 ms, 4 6.41, 8 6.64), so KS = 1 stays the default
+            KS = int(os.environ.get("ZERO_HIP_RPR_KSPLIT", "1"))
+            KS = KS if T % (KS * 64) == 0 else 1
+            Tk = T // KS
+            part = self.mat("rpr.part", 2 * nh * KS * nrp, d, torch.float32)
             rows = lambda i: Mat(part.t, nrp, d, d, i * nrp * d)
-            self.gemm_grouped([(sl(dsb, h, nrp), sl(q, h, d), rows(h), nrp, d, T, None) for h in heads] +
-                              [(sl(pb, h, nrp), sl(dout, h, d), rows(nh + h), nrp, d, T, None) for h in heads],
-                              1, 0, tile=64)
+            rsl = lambda m, h, w, s_: Mat(m.t, Tk, w, m.ld, m.off + s_ * Tk * m.ld + h * w)
+            self.gemm_grouped([(rsl(dsb, h, nrp, s_), rsl(q, h, d, s_), rows(h * KS + s_), nrp, d, Tk, None)
+                               for h in heads for s_ in range(KS)] +
+                              [(rsl(pb, h, nrp, s_), rsl(dout, h, d, s_), rows((nh + h) * KS + s_), nrp, d, Tk, None)
+                               for h in heads for s_ in range(KS)], 1, 0, tile=64)
             n = (2 * max_rel + 1) * d
             # every table belongs to ONE attention scope: its gradient is overwritten, not accumulated (no zero fill)
-            self.lib.call("zk_sum_slices", drpr_k.data_ptr(), part.ptr, nh, n, nrp * d, 0, self.stream)
-            self.lib.call("zk_sum_slices", drpr_v.data_ptr(), part.ptr + nh * nrp * d * 4, nh, n, nrp * d, 0, self.stream)
+            self.lib.call("zk_sum_slices", drpr_k.data_ptr(), part.ptr, nh * KS, n, nrp * d, 0, self.stream)
+            self.lib.call("zk_sum_slices", drpr_v.data_ptr(), part.ptr + nh * KS * nrp * d * 4, nh * KS, n, nrp * d, 0,
+                          self.stream)
 
     # ---- embedding + timing (transformer.py:16-33, 88-119; func.py:341-369) -------
     def embed_fwd(self, ids, table, bias, out, B, L, H, shift=False, pos0=0, zero_flag=None, drop_p=0.0,
