@@ -268,7 +268,7 @@ static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, 
   }
   else if (out >= 8L * 1024 * 1024 || (K >= 8192 && M >= 128 && N >= 128)) { *bm = 128; *bn = 128; }
   else if (out >= 3L * 1024 * 1024) { if (N >= M) { *bm = 64; *bn = 128; } else { *bm = 128; *bn = 64; } }
-  else if (g_tune[2] == 1) { if (N >= M) { *bm = 64; *bn = 128; } else { *bm = 128; *bn = 64; } }   // A/B switches
+  else if (g_tune[2] == 1 || g_tune[2] == 3) { if (N >= M) { *bm = 64; *bn = 128; } else { *bm = 128; *bn = 64; } }   // A/B switches (3: deep ring, see dispatch)
   else if (g_tune[2] == 2) { *bm = 128; *bn = 128; }
   else { *bm = 64; *bn = 64; }
   const long tiles = (long)((M + *bm - 1) / *bm) * ((N + *bn - 1) / *bn);

@@ -500,6 +500,13 @@ int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K,
       return launch_dlds<128, 256, 3, 4, 4>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
     }
   }
+  if (g_tune[2] == 3 && bm == 128 && bn == 64) {
+    // A/B: ONE 128x64 workgroup per CU with a deep ring (tuning key 3 = 4 / 5 / 6 stages of 24 KiB) + producer waves:
+    // 25 % fewer L2 -> LDS bytes than two 64x64 workgroups and more of them in flight
+    if (g_tune[3] == 6) return launch_dlds<128, 64, 6, 4, 4>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+    if (g_tune[3] == 5) return launch_dlds<128, 64, 5, 4, 4>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+    return launch_dlds<128, 64, 4, 4, 4>(A, B, M, N, K, lda, ldb, ta, tb, splits, kchunk, slabs, e, sched_flags, stream);
+  }
   int ns = (sched_flags >> 4) & 15;   // ring-depth override (tuning)
   if (!ns && bm == 64 && bn == 64 && g_tune[3] && g_tune[3] != 5) ns = g_tune[3];     // A/B: ring depth of the 64x64 tile in-step
   if (bm == 64 && bn == 64 && g_tune[4] == 2)                       // A/B: two-wave workgroups, ring depth 2
