@@ -112,6 +112,11 @@ int zk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* l
                 int impl, const int* pos_dev, int pos_flags, const void* rpr_gq, void* rpr_pb, int rpr_ldg,
                 int rpr_nrp, zk_stream_t stream);
 size_t zk_attn_bwd_workspace(int B, int nh, int Lq);
+/* zk_attn_bwd with impl | 256, rpr_k / rpr_v / drpr_k / drpr_v but no decomposed products, Lq, Lk <= 64, d = 64 and a
+ * workspace of zk_attn_bwd_rpr_workspace bytes: relative positions FOLDED into the single-tile backward kernel (tables,
+ * G = Q.Rk^T, Gd = dO.Rv^T, bucket sums of dS / P and dQ += dsb.Rk in LDS; per-(sentence, head) table-gradient partials
+ * in the workspace, summed into drpr_k / drpr_v -- which are OVERWRITTEN -- by one reduction launch). */
+size_t zk_attn_bwd_rpr_workspace(int B, int nh, int Lq);
 int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                 const float* lse, void* dq, void* dk, void* dv, float* drpr_k, float* drpr_v, int B, int nh,
                 int Lq, int Lk, int d, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk,

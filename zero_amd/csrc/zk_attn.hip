@@ -471,14 +471,37 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv_mfma(AttnArgs a, const bf1
 }
 
 // ---- backward, single tile (Lq <= 64 and Lk <= 64): grid (1, nh, B) -> dQ, dK, dV in ONE pass (attn_bwd_fused64_tile)
+template <bool RPR = false>
 __global__ void __launch_bounds__(256) k_attn_bwd_fused64(AttnArgs a, const bf16_t* __restrict__ o, int ldo,
                                                           const bf16_t* __restrict__ dout, int lddo,
                                                           const float* __restrict__ lse,
                                                           bf16_t* __restrict__ dq, int lddq,
                                                           bf16_t* __restrict__ dk, int lddk,
-                                                          bf16_t* __restrict__ dv, int lddv) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[ATTN_BWD64_LDS_BYTES];
-  attn_bwd_fused64_tile(smem, a, o, ldo, dout, lddo, lse, dq, lddq, dk, lddk, dv, lddv, blockIdx.y, blockIdx.z);
+                                                          bf16_t* __restrict__ dv, int lddv, float* __restrict__ rpr_part) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RPR ? ATTN_BWD64_RPR_LDS_BYTES : ATTN_BWD64_LDS_BYTES];
+  attn_bwd_fused64_tile<RPR>(smem, a, o, ldo, dout, lddo, lse, dq, lddq, dk, lddk, dv, lddv, blockIdx.y, blockIdx.z, rpr_part);
+}
+
+// sum of the per-(sentence, head) table-gradient partials of the folded relative-position backward:
+// part fp32 [nslices][2][64][64] -> dk / dv fp32 [n] (n = (2*max_rel+1)*64 leading elements of each table slab).
+// Block = 16 columns x 16 slice groups: every thread adds nslices/16 values with all its loads in flight.
+__global__ void __launch_bounds__(256) k_rpr_part_reduce(const float* __restrict__ part, int nslices, int n,
+                                                         float* __restrict__ dk, float* __restrict__ dv) {
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const float* src = part + (size_t)blockIdx.y * TQ * AD;
+  float t = 0.f;
+  if (c < n)
+    for (int s = g; s < nslices; s += 16) t += src[(size_t)s * 2 * TQ * AD + c];
+  red[g][cl] = t;
+  __syncthreads();
+  if (g == 0 && c < n) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v += red[i][cl];
+    (blockIdx.y == 0 ? dk : dv)[c] = v;
+  }
 }
 
 // =====================================================================================
@@ -511,6 +534,9 @@ static bool attn_mfma_ok(const AttnArgs& a, int extra_ld_or) {
 }
 
 extern "C" {
+size_t zk_attn_bwd_rpr_workspace(int B, int nh, int Lq) {
+  return (size_t)B * nh * Lq * sizeof(float) + (size_t)B * nh * 2 * TQ * AD * sizeof(float);
+}
 
 int zk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int nh, int Lq, int Lk,
                 int d, int ldq, int ldk, int ldv, int ldo, const float* kmask, int causal, int q_pos0,
@@ -602,11 +628,33 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
   float* Dbuf = (float*)workspace;
   a.gq = (const float*)rpr_gq; a.gd = (const float*)rpr_gd; a.pb = (bf16_t*)rpr_pb; a.dsb = (bf16_t*)rpr_dsb;
   a.ldg = rpr_ldg; a.nrp = rpr_nrp;
-  const bool ok = attn_mfma_ok(a, ldo | lddo | lddq | lddk | lddv) &&
-                  ((((uintptr_t)out | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0);   // 16-byte row accesses
+  // impl | 256 with tables but no decomposed products: relative positions folded into the single-tile kernel
+  const bool fold = (impl & 256) && rpr_k != nullptr && rpr_gq == nullptr && d == AD && 2 * max_rel + 1 <= 64 &&
+                    drpr_k != nullptr && drpr_v != nullptr && ((((uintptr_t)rpr_k | (uintptr_t)rpr_v) & 15) == 0) &&
+                    ws_bytes >= zk_attn_bwd_workspace(B, nh, Lq) + (size_t)B * nh * 2 * TQ * AD * sizeof(float);
+  impl &= 255;
+  if (fold) { a.rpr_k = nullptr; a.rpr_v = nullptr; }
+  bool ok = attn_mfma_ok(a, ldo | lddo | lddq | lddk | lddv) &&
+            ((((uintptr_t)out | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0);   // 16-byte row accesses
+  if (fold) { a.rpr_k = (const bf16_t*)rpr_k; a.rpr_v = (const bf16_t*)rpr_v; }
+  const bool folded = fold && ok && (impl == 0 || impl == 2) && Lq <= TQ && Lk <= TQ;
+  if (fold && !folded) ok = false;
   ZK_CHECK_ARG(rpr_gq == nullptr || (ok && impl != 1), "zk_attn_bwd: decomposed rpr runs on the MFMA kernels only");
   ZK_CHECK_ARG(impl != 2 || ok, "zk_attn_bwd: MFMA kernel needs d=64, no rpr, ld%%8==0");
   ZK_CHECK_ARG(impl != 3 || ok, "zk_attn_bwd: MFMA kernels need d=64, no rpr, ld%%8==0");
+  if (folded && Lq <= TQ && Lk <= TQ) {
+    if (zk_prog_active()) return zk_prog_reject("attention backward with relative positions");
+    // table-gradient partials behind Dbuf in the workspace, summed over the B*nh (sentence, head) tiles afterwards
+    float* part = (float*)workspace + (size_t)B * nh * Lq;
+    hipLaunchKernelGGL(k_attn_bwd_fused64<true>, dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
+                       (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, part);
+    ZK_LAUNCH_CHECK();
+    const int n = (2 * max_rel + 1) * AD;
+    hipLaunchKernelGGL(k_rpr_part_reduce, dim3((n + 15) / 16, 2), dim3(256), 0, stream, (const float*)part, B * nh, n,
+                       drpr_k, drpr_v);
+    ZK_LAUNCH_CHECK();
+    return 0;
+  }
   if (zk_prog_active()) {
     if (!((impl == 0 || impl == 2) && ok && Lq <= TQ && Lk <= TQ && rpr_gq == nullptr))
       return zk_prog_reject("attention backward that is not one 64x64 MFMA tile per (sentence, head)");
@@ -614,8 +662,9 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
                                      (bf16_t*)dk, lddk, (bf16_t*)dv, lddv);
   }
   if ((impl == 0 || impl == 2) && ok && Lq <= TQ && Lk <= TQ) {      // impl 3 forces the two-kernel form
-    hipLaunchKernelGGL(k_attn_bwd_fused64, dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
-                       (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv);
+    hipLaunchKernelGGL(k_attn_bwd_fused64<false>, dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
+                       (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv,
+                       (float*)nullptr);
     ZK_LAUNCH_CHECK();
     return 0;
   }

@@ -468,12 +468,20 @@ __device__ __forceinline__ void attn_fwd_tile(unsigned char* smem, const AttnArg
 // follow from LDS: dQ = dS K, dK = dS^T Q, dV = P^T dO.  The operand tiles of the first phase are
 // dead by then and their LDS is reused for dS, P^T and dS^T (7 tiles = 64.5 KB -> 2 workgroups/CU).
 #define ATTN_BWD64_LDS_BYTES (7 * TQ * ALD * 2 + TQ * 4)
+// RPR: the relative-position terms of modules/rpr.py:10-75 inside the tile (tables in LDS): G = Q.Rk^T and Gd = dO.Rv^T
+// by MFMA, gathered into the scores / dP; the bucket sums of dS and P stay in LDS; dQ += dsb.Rk; and the table
+// gradients dRk = dsb^T Q, dRv = pb^T dO of this (sentence, head) go to `rpr_part` (fp32 [B*nh][2][64][64], summed by
+// the caller) -- instead of four grouped-GEMM launches and two reductions around the kernel.  Six more bf16 tiles and
+// two fp32 tiles: one workgroup per CU.
+#define ATTN_BWD64_RPR_LDS_BYTES (ATTN_BWD64_LDS_BYTES + 6 * TQ * ALD * 2 + 2 * TQ * GLD * 4)
+template <bool RPR = false>
 __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const AttnArgs& a, const bf16_t* __restrict__ o, int ldo,
                                                       const bf16_t* __restrict__ dout, int lddo,
                                                       const float* __restrict__ lse,
                                                       bf16_t* __restrict__ dq, int lddq,
                                                       bf16_t* __restrict__ dk, int lddk,
-                                                      bf16_t* __restrict__ dv, int lddv, int h, int b) {
+                                                      bf16_t* __restrict__ dv, int lddv, int h, int b,
+                                                      float* __restrict__ rpr_part = nullptr) {
   bf16_t* sQ = reinterpret_cast<bf16_t*>(smem);      // phase 2: dS   [query][key]
   bf16_t* sK = sQ + TQ * ALD;                          // phase 2: P^T  [key][query]
   bf16_t* sV = sK + TQ * ALD;                          // phase 2: dS^T [key][query]
@@ -482,6 +490,14 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
   bf16_t* sQt = sKt + TQ * ALD;
   bf16_t* sdOt = sQt + TQ * ALD;
   float* sL = reinterpret_cast<float*>(sdOt + TQ * ALD);
+  [[maybe_unused]] bf16_t* sRk = reinterpret_cast<bf16_t*>(smem + ATTN_BWD64_LDS_BYTES);   // key table   [r][channel]
+  [[maybe_unused]] bf16_t* sRv = sRk + TQ * ALD;                                            // value table [r][channel]
+  [[maybe_unused]] bf16_t* sRkT = sRv + TQ * ALD;                                           // key table   [phys channel][r]
+  [[maybe_unused]] bf16_t* sSB = sRkT + TQ * ALD;                                           // bucket sums of dS  [query][r]
+  [[maybe_unused]] bf16_t* sSBt = sSB + TQ * ALD;                                           //                    [r][query]
+  [[maybe_unused]] bf16_t* sPBt = sSBt + TQ * ALD;                                          // bucket sums of P   [r][query]
+  [[maybe_unused]] float* sG = reinterpret_cast<float*>(sPBt + TQ * ALD);                   // Q.Rk^T  [query][GLD]
+  [[maybe_unused]] float* sGd = sG + TQ * GLD;                                              // dO.Rv^T [query][GLD]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const bf16_t* qb = a.q + (size_t)b * a.bsq + h * AD;
   const bf16_t* kb = a.k + (size_t)b * a.bsk + h * AD;
@@ -527,7 +543,35 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
     store_trans(sdOt, t1, tid - 128);
   }
   if (dpart == 0) sL[dr] = (dr < a.Lq) ? lse_r : 0.f;
+  if (RPR) {
+    const int nrel = 2 * a.max_rel + 1;
+    stage_direct(sRk, a.rpr_k, AD, 0, nrel, tid);
+    stage_direct(sRv, a.rpr_v, AD, 0, nrel, tid);
+    stage_trans(sRkT, a.rpr_k, AD, 0, nrel, tid);
+    for (int e = tid; e < 3 * TQ * ALD / 8; e += 256)          // bucket tiles: rows / buckets that are never emitted
+      reinterpret_cast<uint4*>(sSB)[e] = make_uint4(0u, 0u, 0u, 0u);
+  }
   __syncthreads();
+  if (RPR) {
+    // G and Gd rows of this wave's 16 queries (read back by this wave only)
+    const uint4 q0 = frag(sQ, w * 16, 0, lane), q1 = frag(sQ, w * 16, 1, lane);
+    const uint4 g0 = frag(sdO, w * 16, 0, lane), g1 = frag(sdO, w * 16, 1, lane);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      f32x4_t ga = {0.f, 0.f, 0.f, 0.f}, gb = {0.f, 0.f, 0.f, 0.f};
+      ga = mfma16(q0, frag(sRk, nt * 16, 0, lane), ga);
+      ga = mfma16(q1, frag(sRk, nt * 16, 1, lane), ga);
+      gb = mfma16(g0, frag(sRv, nt * 16, 0, lane), gb);
+      gb = mfma16(g1, frag(sRv, nt * 16, 1, lane), gb);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sG[(w * 16 + (lane >> 4) * 4 + r) * GLD + nt * 16 + (lane & 15)] = ga[r];
+        sGd[(w * 16 + (lane >> 4) * 4 + r) * GLD + nt * 16 + (lane & 15)] = gb[r];
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
   // ---- phase 1: P and dS of query rows 16w .. 16w+15 against all 64 keys, kept in registers
   const int rloc = w * 16 + (lane >> 4) * 4;
   float pv[4][4], dsv[4][4];
@@ -551,6 +595,11 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
         const bool live = kvalid && i < a.Lq;
         float raw = sc4[r], dpr = dp[r];
         if (a.gq != nullptr && live) { raw += rpr_gather(a, a.gq, b, h, i, j); dpr += rpr_gather(a, a.gd, b, h, i, j); }
+        if (RPR && live) {
+          const int ri = rel_index(a.q_pos0 + i, j, a.max_rel);
+          raw += sG[i * GLD + ri];
+          dpr += sGd[i * GLD + ri];
+        }
         float sc = raw * a.scale + kbias;
         if (a.causal && j > a.q_pos0 + i) sc -= a.mask_inf;
         const float p = live ? __expf(sc - sL[i]) : 0.f;
@@ -596,6 +645,13 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
     for (int r = 0; r < 4; ++r) sdS[(rloc + r) * ALD + j] = f2bf(dsv[nt][r]);
   }
   __syncthreads();
+  if (RPR) {
+    rpr_bucket_wave(a, 2 * a.max_rel + 1, 0, w, lane, [&](int row, int j) { return bf2f(sdS[row * ALD + j]); },
+                    [&](int row, int r, float v) { const bf16_t x = f2bf(v); sSB[row * ALD + r] = x; sSBt[r * ALD + row] = x; });
+    rpr_bucket_wave(a, 2 * a.max_rel + 1, 0, w, lane, [&](int row, int j) { return bf2f(sPt[j * ALD + row]); },
+                    [&](int row, int r, float v) { sPBt[r * ALD + row] = f2bf(v); });
+    __syncthreads();                     // the transposed bucket tiles are read across waves
+  }
   if (a.dsb != nullptr) {   // bucket sums for the relative-position table products (see AttnArgs)
     rpr_bucket_rows(a, a.dsb, b, h, 0, w, lane, [&](int row, int j) { return bf2f(sdS[row * ALD + j]); });
     rpr_bucket_rows(a, a.pb, b, h, 0, w, lane, [&](int row, int j) { return bf2f(sPt[j * ALD + row]); });
@@ -618,6 +674,46 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
       dQ[nb] = mfma16(da, frag(sKt, nb * 16, kk, lane), dQ[nb]);
       dV[nb] = mfma16(pa, frag(sdOt, nb * 16, kk, lane), dV[nb]);
       dK[nb] = mfma16(dt, frag(sQt, nb * 16, kk, lane), dK[nb]);
+    }
+  }
+  if (RPR) {
+    f32x4_t tk[4], tv[4];                // rows r = 16w .. of dRk / dRv of this (sentence, head)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) { tk[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; tv[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const uint4 sb = frag(sSB, w * 16, kk, lane);       // dsb rows (queries) x r
+      const uint4 st = frag(sSBt, w * 16, kk, lane);      // dsb^T rows (r) x queries
+      const uint4 pt = frag(sPBt, w * 16, kk, lane);      // pb^T  rows (r) x queries
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        dQ[nb] = mfma16(sb, frag(sRkT, nb * 16, kk, lane), dQ[nb]);
+        tk[nb] = mfma16(st, frag(sQt, nb * 16, kk, lane), tk[nb]);
+        tv[nb] = mfma16(pt, frag(sdOt, nb * 16, kk, lane), tv[nb]);
+      }
+    }
+    // this wave's 16 rows of the two [r][channel] partials through LDS (sG / sGd are dead since phase 1; a wave only
+    // touches its own rows of them) so that they leave as 16-byte row pieces; rows >= 2*max_rel+1 are never read
+    float* pk = rpr_part + ((size_t)b * a.nh + h) * 2 * TQ * AD;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const int c = chan_of_phys(nb * 16 + (lane & 15));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sG[(rloc + r) * GLD + c] = tk[nb][r];
+        sGd[(rloc + r) * GLD + c] = tv[nb][r];
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const int nrel = 2 * a.max_rel + 1;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int e = it * 64 + lane, rr = w * 16 + (e >> 4), c4 = (e & 15) * 4;
+      if (rr < nrel) {
+        *reinterpret_cast<float4*>(pk + rr * AD + c4) = *reinterpret_cast<const float4*>(sG + rr * GLD + c4);
+        *reinterpret_cast<float4*>(pk + TQ * AD + rr * AD + c4) = *reinterpret_cast<const float4*>(sGd + rr * GLD + c4);
+      }
     }
   }
   // results through LDS ([row][channel] tiles over the transposed operands, which are dead now) so that every

@@ -325,6 +325,19 @@ class Engine(object):
 
     def attn_bwd(self, q, k, v, out, dout, lse, dq, dk, dv, B, nh, Lq, Lk, d, kmask=None, causal=False,
                  rpr_k=None, rpr_v=None, drpr_k=None, drpr_v=None, max_rel=0, drop_p=0.0, sid=0, impl=None):
+        eff = self.attn_impl if impl is None else impl
+        fold = self.rpr_fold and rpr_k is not None and drpr_k is not None and eff in (0, 2) and d == 64 and \
+            Lq <= 64 and Lk <= 64 and 2 * max_rel + 1 <= 64 and rpr_k.shape[0] >= 2 * max_rel + 1
+        if fold:
+            # relative positions inside the single-tile backward kernel; table gradients are overwritten
+            ws = self.workspace(self.lib.query("zk_attn_bwd_rpr_workspace", B, nh, Lq))
+            self.lib.call(
+                "zk_attn_bwd", q.ptr, k.ptr, v.ptr, out.ptr, dout.ptr, lse.data_ptr(), dq.ptr, dk.ptr, dv.ptr,
+                hip.ptr(drpr_k), hip.ptr(drpr_v), B, nh, Lq, Lk, d, q.ld, k.ld, v.ld, out.ld, dout.ld, dq.ld,
+                dk.ld, dv.ld, hip.ptr(kmask), 1 if causal else 0, 0, float(d) ** -0.5, zdtype.inf(),
+                hip.ptr(rpr_k), hip.ptr(rpr_v), max_rel, float(drop_p), self.seed.data_ptr(), sid,
+                (0 if eff == 0 else 2) | 256, ws.data_ptr(), ws.numel(), None, None, None, None, 0, 0, self.stream)
+            return
         ws_bytes = self.lib.query("zk_attn_bwd_workspace", B, nh, Lq)
         ws = self.workspace(ws_bytes)
         dec = self._rpr_mfma(impl, d, 0, rpr_k, (q.ld, k.ld, v.ld, out.ld, dout.ld, dq.ld, dk.ld, dv.ld), max_rel, bwd=True)
