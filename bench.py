@@ -263,7 +263,8 @@ def decode_main(args, rank, world):
     from zero_amd.models import model as registry, load_all
     from zero_amd.search import beam_search
     load_all()
-    model = args.model if args.model != "transformer" else "transformer_aan"
+    # BASELINE configs[3] decodes with the average-attention decoder; "transformer_sa" = the plain self-attention model
+    model = {"transformer": "transformer_aan", "transformer_sa": "transformer"}.get(args.model, args.model)
     hp = transformer_base_params(model_name=model, scope_name=model, beam_size=4, decode_alpha=0.6,
                                  decode_length=50, eval_batch_size=32)
     hp.src_vocab = SyntheticVocab(V)

@@ -355,13 +355,42 @@ int zk_add_gumbel(float* logits, int rows, int V, int ld, float eps, const uint6
 int zk_cache_rows(const void* src, size_t src_stride, const int* index, void* dst, size_t dst_stride, int rows,
                   size_t unit_bytes, int max_units, const int* time_dev, int mode, int period, zk_stream_t stream);
 /* transformer_aan.py:110-112: cache += x; cat = [x | cache/(t+1)] */
-/* Decode-step form of the residual + LayerNorm of the AAN decoder with its row-local neighbours in the same launch
- * (transformer_aan.py:165-192): z/cat_in != NULL: the gate sigma(z_i) x + sigma(z_f) y is computed first (into ybuf);
- * cache/cat_out != NULL: the next layer's running sum and [x | average] follow (zk_aan_decode).  Same arithmetic as
- * zk_aan_gate_fwd + zk_add_ln_fwd + zk_aan_decode. */
+/* Decode-step form of the residual + LayerNorm of the decoder with its row-local neighbours in the same launch
+ * (transformer_aan.py:165-192, func.py:289-303): the sub-layer output y is ybuf (bf16 [rows, H]), or
+ *   z/cat_in != NULL: the AAN gate sigma(z_i) x + sigma(z_f) y, computed first (into ybuf), or
+ *   parts != NULL   : bf16(sum_p parts[p*part_stride + r*H + :] + bias) -- the output projection left as nparts fp32
+ *                     partial products by zk_dec_cross / zk_dec_self (summed in the fixed order p = 0 .. nparts-1);
+ * out = LayerNorm(x + y); cache/cat_out != NULL: the next layer's running sum and [x | average] follow (zk_aan_decode).
+ * The row stays in registers from the loads to the output and is rounded to bf16 where the separate kernels stored bf16:
+ * the first two forms equal zk_aan_gate_fwd + zk_add_ln_fwd + zk_aan_decode bit for bit.  ybuf is only read (first form). */
 int zk_ln_decode(const void* x, void* ybuf, const float* gamma, const float* beta, void* out, int rows, int H, float eps,
-                 const void* z, const void* cat_in, float* cache, void* cat_out, float inv_count, const int* time_dev,
-                 zk_stream_t stream);
+                 const void* z, const void* cat_in, const float* parts, int nparts, long part_stride, const float* bias,
+                 float* cache, void* cat_out, float inv_count, const int* time_dev, zk_stream_t stream);
+/* One attention sub-layer of a cached decode step in ONE launch (transformer.py:120-175 at Lq = 1; func.py:124-287):
+ * grid B * nh, workgroup (sentence b, head h) owns the sentence's R <= 8 beam rows: [prologue: the previous sub-layer's
+ * residual + LayerNorm, arguments x .. time_dev as zk_ln_decode; gamma == NULL: none, x is the block input; otherwise
+ * xout receives the normalised rows] -> q_h = x Wq[:, h] + bq -> softmax(scale q_h K_h^T + mask) V_h -> the head's share
+ * ctx_h Wo[h rows, :] of the output projection as fp32 out_parts[h][B*R][H].  The caller finishes with
+ * zk_ln_decode(parts = out_parts, nparts = nh, part_stride = B*R*H, bias = o_map bias) or the next prologue.
+ * The projection weights are passed TRANSPOSED (wqt = q_map^T [H, H], wot = o_map^T [H, H]: row = output channel, input
+ * dimension contiguous, row strides ldwq / ldwo) so that a matrix-core fragment is one 16-byte load.
+ * d = 64 per head, H = nh * 64 a power of two in 128 .. 2048.  Cross: keys / values of sentence b at k + b*bsk + j*ldk
+ * (func.py:206-216 mk / mv), kmask [B, ldmask] (1 = valid) or NULL.  Values are rounded to bf16 where the launch-per-op
+ * path stores bf16. */
+int zk_dec_cross(const void* x, void* ybuf, const float* gamma, const float* beta, void* xout, int H, float eps,
+                 const void* z, const void* cat_in, const float* parts, int nparts, long part_stride, const float* bias,
+                 float* cache, void* cat_out, float inv_count, const int* time_dev, const void* wqt, int ldwq,
+                 const float* bq, const void* k, const void* v, int ldk, int ldv, long bsk, long bsv, const float* kmask,
+                 int ldmask, const void* wot, int ldwo, float* out_parts, int B, int R, int nh, int Lk, float scale,
+                 float mask_inf, zk_stream_t stream);
+/* Self-attention over per-beam caches (func.py:199-205): wqkvt = qkv_map^T [3H, H] (q | k | v rows), bias [3H];
+ * kcache / vcache bf16 [B*R, Tmax, H]: this step's key / value are written at slot time (*time_dev when given), keys
+ * 0 .. time attended. */
+int zk_dec_self(const void* x, void* ybuf, const float* gamma, const float* beta, void* xout, int H, float eps,
+                const void* z, const void* cat_in, const float* parts, int nparts, long part_stride, const float* bias,
+                float* cache, void* cat_out, float inv_count, const int* ln_time_dev, const void* wqkvt, int ldw,
+                const float* bqkv, void* kcache, void* vcache, int Tmax, int time, const int* time_dev, const void* wot,
+                int ldwo, float* out_parts, int B, int R, int nh, float scale, zk_stream_t stream);
 int zk_aan_decode(const void* x, float* cache, void* cat, int rows, int H, float inv_count, const int* time_dev,
                   zk_stream_t stream);
 

@@ -283,8 +283,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dq_mfma(AttnArgs a, const bf16
         for (int c = 0; c < 8; ++c) acc += x[c] * y[c];
       }
     }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
+    acc = quad_sum(acc);
     if (part == 0) {
       sD[r] = acc;
       const int i = i0 + r;

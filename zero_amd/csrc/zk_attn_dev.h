@@ -84,8 +84,8 @@ __device__ __forceinline__ void rpr_bucket_wave(const AttnArgs& a, int nr, int i
         }
       }
     }
-    t0 += __shfl_xor(t0, 1, 64); t0 += __shfl_xor(t0, 2, 64);
-    t1 += __shfl_xor(t1, 1, 64); t1 += __shfl_xor(t1, 2, 64);
+    t0 = quad_sum(t0);
+    t1 = quad_sum(t1);
     if (q == 0 && i < a.Lq) { emit(row, 0, t0); if (m > 0) emit(row, 2 * m, t1); }
   }
   // interior indices and padding
@@ -258,13 +258,11 @@ __device__ __forceinline__ void store_tile_rows(const bf16_t* tile, bf16_t* dst,
 }
 
 __device__ __forceinline__ float quad16_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
-  v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
+  v = row16_max(v);
   return v;
 }
 __device__ __forceinline__ float quad16_sum(float v) {
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  v = row16_sum(v);
   return v;
 }
 
@@ -617,10 +615,7 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
     // a query row's 64 keys sit in the 16 lanes of its group x 4 key tiles
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      Di[r] += __shfl_xor(Di[r], 1, 64);
-      Di[r] += __shfl_xor(Di[r], 2, 64);
-      Di[r] += __shfl_xor(Di[r], 4, 64);
-      Di[r] += __shfl_xor(Di[r], 8, 64);
+      Di[r] = row16_sum(Di[r]);
     }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)

@@ -78,16 +78,77 @@ __device__ __forceinline__ float zk_ld_f32(const float* p) {
 }
 
 // ---------------------------------------------------------------- wave / block reductions
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane steps are DPP moves (a VALU operand modifier, a few cycles each), not __shfl_xor: that compiles to
+// ds_bpermute_b32, one LDS round trip (~100+ cycles) per step, and a 64-lane reduction is six DEPENDENT steps -- ~0.3 us
+// of every row-wise kernel whose whole launch is a 5 us latency chain.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float zk_dpp(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+#define ZK_DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define ZK_DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define ZK_DPP_HALF_MIRROR 0x141  // lane i <- lane 7-i of its half row: the other quad
+#define ZK_DPP_MIRROR 0x140       // lane i <- lane 15-i of its row: the other half
+#define ZK_DPP_BCAST15 0x142      // lane 15 of every row -> the next row
+#define ZK_DPP_BCAST31 0x143      // lane 31 -> rows 2 and 3
+// sum / max over the 4 lanes of a quad (lane ^ 1, lane ^ 2) and over the 16 lanes of a DPP row (lane >> 4 fixed);
+// every lane of the group receives the result; the pairing tree is the xor-butterfly's (1, 2, 4, 8)
+__device__ __forceinline__ float quad_sum(float v) {
+  v += zk_dpp<ZK_DPP_XOR1, 0xf>(0.f, v);
+  v += zk_dpp<ZK_DPP_XOR2, 0xf>(0.f, v);
   return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = quad_sum(v);
+  v += zk_dpp<ZK_DPP_HALF_MIRROR, 0xf>(0.f, v);
+  v += zk_dpp<ZK_DPP_MIRROR, 0xf>(0.f, v);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, zk_dpp<ZK_DPP_XOR1, 0xf>(v, v));
+  v = fmaxf(v, zk_dpp<ZK_DPP_XOR2, 0xf>(v, v));
+  v = fmaxf(v, zk_dpp<ZK_DPP_HALF_MIRROR, 0xf>(v, v));
+  v = fmaxf(v, zk_dpp<ZK_DPP_MIRROR, 0xf>(v, v));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  v += zk_dpp<ZK_DPP_BCAST15, 0xa>(0.f, v);      // rows 1, 3 += rows 0, 2
+  v += zk_dpp<ZK_DPP_BCAST31, 0xc>(0.f, v);      // rows 2, 3 += row 1: lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = row16_max(v);
+  v = fmaxf(v, zk_dpp<ZK_DPP_BCAST15, 0xa>(v, v));
+  v = fmaxf(v, zk_dpp<ZK_DPP_BCAST31, 0xc>(v, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int zk_dpp_i(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false);
+}
+// arg-best over the 64 lanes for a strict total order `better(s2, i2, s, i)` ((s2, i2) beats (s, i)); extra payload t
+// travels with the winner.  Every lane receives the winner (same selection as the xor butterfly: exact, no rounding).
+template <typename B>
+__device__ __forceinline__ void wave_argbest(float& s, int& i, int& t, B better) {
+#define ZK_ARG_STEP(CTRL, MASK)                                                       \
+  {                                                                                   \
+    const float s2 = zk_dpp<CTRL, MASK>(s, s);                                        \
+    const int i2 = zk_dpp_i<CTRL, MASK>(i, i), t2 = zk_dpp_i<CTRL, MASK>(t, t);       \
+    if (better(s2, i2, s, i)) { s = s2; i = i2; t = t2; }                             \
+  }
+  ZK_ARG_STEP(ZK_DPP_XOR1, 0xf)
+  ZK_ARG_STEP(ZK_DPP_XOR2, 0xf)
+  ZK_ARG_STEP(ZK_DPP_HALF_MIRROR, 0xf)
+  ZK_ARG_STEP(ZK_DPP_MIRROR, 0xf)
+  ZK_ARG_STEP(ZK_DPP_BCAST15, 0xa)
+  ZK_ARG_STEP(ZK_DPP_BCAST31, 0xc)
+#undef ZK_ARG_STEP
+  s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
+  i = __builtin_amdgcn_readlane(i, 63);
+  t = __builtin_amdgcn_readlane(t, 63);
+}
+
 // sum over a block of NW waves; every thread gets the result. sm: >= NW floats.
 template <int NW>
 __device__ __forceinline__ float block_sum(float v, float* sm) {

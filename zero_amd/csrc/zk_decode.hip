@@ -7,7 +7,7 @@
 // search.py:198-210: beam reordering of the per-beam caches = row gather.
 // transformer_aan.py:110-112: decode-time cumulative average, cache in HBM (fp32).
 #include "zk_common.h"
-#include "zk_ln_dev.h"
+#include "zk_lndec_dev.h"
 #include <alloca.h>
 
 #define TOPK_MAX 16
@@ -26,13 +26,7 @@ __device__ __forceinline__ void block_select(float (*ls)[TOPK_MAX + 1], int (*li
     float s = (head < cnt) ? ls[tid][head] : -INFINITY;
     int i = (head < cnt) ? li[tid][head] : 0x7fffffff;
     int t = tid;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float s2 = __shfl_xor(s, o, 64);
-      const int i2 = __shfl_xor(i, o, 64);
-      const int t2 = __shfl_xor(t, o, 64);
-      if (better(s2, i2, s, i)) { s = s2; i = i2; t = t2; }
-    }
+    wave_argbest(s, i, t, [](float s2, int i2, float s1, int i1) { return better(s2, i2, s1, i1); });
     __syncthreads();
     if ((tid & 63) == 0) { ws[tid >> 6] = s; wi[tid >> 6] = i; wt[tid >> 6] = t; }
     __syncthreads();
@@ -169,11 +163,9 @@ __global__ void __launch_bounds__(256) k_beam_topk_chunks(const float* __restric
   for (int r = 0; r < k2; ++r) {
     float bs = my_bs;
     int bi = my_bi;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float s2 = __shfl_xor(bs, o, 64);
-      const int i2 = __shfl_xor(bi, o, 64);
-      if (better(s2, i2, bs, bi)) { bs = s2; bi = i2; }
+    {
+      int unused = 0;
+      wave_argbest(bs, bi, unused, [](float s2, int i2, float s1, int i1) { return better(s2, i2, s1, i1); });
     }
     float* wsr = ws + (r & 1) * 4;                    // double-buffered: one barrier per round
     int* wir = wi + (r & 1) * 4;
@@ -342,59 +334,16 @@ __global__ void __launch_bounds__(256) k_fuse_decode(const bf16_t* __restrict__ 
   *reinterpret_cast<uint4*>(att + r * H + c) = pack8(o);
 }
 
-// Decode-step fusions around the residual + LayerNorm of the AAN decoder (transformer_aan.py:165-192, 92-117): a
+// Decode-step fusions around the residual + LayerNorm of the decoder (transformer_aan.py:165-192, 92-117): a
 // decode step runs on 128 rows, every launch costs its latency chain (~4.6 us for k_add_ln_fwd, k_aan_gate_fwd,
-// k_aan_decode alike), so the row-local neighbours of a LayerNorm ride in its launch:
-//   z != NULL     : first y = sigmoid(z_i) x_cat + sigmoid(z_f) y_cat (the gate, k_aan_gate_fwd) -> ybuf
-//   cache != NULL : afterwards the NEXT layer's average-attention input from the normalised row
-//                   (k_aan_decode: cache += out; cat_out = [out | cache / (time + 1)])
-// One wave per row; each lane re-reads only bytes it wrote itself, so the arithmetic is literally that of the
-// separate kernels (bit-identical results).
+// k_aan_decode alike), so the row-local neighbours of a LayerNorm ride in its launch (zk_lndec_dev.h).  One wave per row.
 template <int MAXC>
-__global__ void __launch_bounds__(256) k_ln_decode(const bf16_t* __restrict__ x, bf16_t* __restrict__ ybuf,
-                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   bf16_t* __restrict__ out, int rows, int H, float eps,
-                                                   const bf16_t* __restrict__ z, const bf16_t* __restrict__ cat_in,
-                                                   float* __restrict__ cache, bf16_t* __restrict__ cat_out,
-                                                   float inv_count, const int* __restrict__ time_dev) {
+__global__ void __launch_bounds__(256) k_ln_decode(LnDecArgs a) {
   const int lane = threadIdx.x & 63;
   const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (r >= rows) return;
-  if (z != nullptr) {
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-      const int c = (i * 64 + lane) * 8;
-      if (c < H) {
-        float zi[8], zf[8], xv[8], yv[8], o[8];
-        unpack8(*reinterpret_cast<const uint4*>(z + (size_t)r * 2 * H + c), zi);
-        unpack8(*reinterpret_cast<const uint4*>(z + (size_t)r * 2 * H + H + c), zf);
-        unpack8(*reinterpret_cast<const uint4*>(cat_in + (size_t)r * 2 * H + c), xv);
-        unpack8(*reinterpret_cast<const uint4*>(cat_in + (size_t)r * 2 * H + H + c), yv);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          o[j] = xv[j] / (1.f + __expf(-zi[j])) + yv[j] / (1.f + __expf(-zf[j]));
-        *reinterpret_cast<uint4*>(ybuf + (size_t)r * H + c) = pack8(o);
-      }
-    }
-  }
-  add_ln_fwd_row<MAXC>(x, ybuf, gamma, beta, out, nullptr, nullptr, nullptr, r, H, 1.f / (float)H, eps, 0u, 1.f, 0, 0u, lane);
-  if (cache != nullptr) {
-    if (time_dev != nullptr) inv_count = 1.f / (float)(*time_dev + 1);
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-      const int c = (i * 64 + lane) * 8;
-      if (c < H) {
-        const uint4 xv = *reinterpret_cast<const uint4*>(out + (size_t)r * H + c);
-        float v[8], o[8];
-        unpack8(xv, v);
-        float* cp = cache + (size_t)r * H + c;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float s = cp[j] + v[j]; cp[j] = s; o[j] = s * inv_count; }
-        *reinterpret_cast<uint4*>(cat_out + (size_t)r * 2 * H + c) = xv;
-        *reinterpret_cast<uint4*>(cat_out + (size_t)r * 2 * H + H + c) = pack8(o);
-      }
-    }
-  }
+  if (r >= a.rows) return;
+  uint4 outp[MAXC];
+  ln_decode_row<MAXC>(a, r, lane, true, outp);
 }
 
 extern "C" {
@@ -503,24 +452,23 @@ int zk_cache_rows(const void* src, size_t src_stride, const int* index, void* ds
   return 0;
 }
 
-// out = LayerNorm(x + y) with the optional neighbours described above.  x / out dense [rows, H]; ybuf [rows, H] is the
-// sub-layer output (read), or with z != NULL a scratch row buffer the gate output is written to first.
+// out = LayerNorm(x + y) with the optional neighbours described in zk_lndec_dev.h.  x / out dense [rows, H]; ybuf
+// [rows, H] is the sub-layer output (read), or with z != NULL / parts != NULL a scratch row buffer y is written to first.
 int zk_ln_decode(const void* x, void* ybuf, const float* gamma, const float* beta, void* out, int rows, int H, float eps,
-                 const void* z, const void* cat_in, float* cache, void* cat_out, float inv_count, const int* time_dev,
-                 hipStream_t stream) {
+                 const void* z, const void* cat_in, const float* parts, int nparts, long part_stride, const float* bias,
+                 float* cache, void* cat_out, float inv_count, const int* time_dev, hipStream_t stream) {
   ZK_CHECK_ARG(H % 8 == 0 && H <= 2048, "zk_ln_decode: H=%d must be a multiple of 8 and <= 2048", H);
   ZK_CHECK_ARG((z == nullptr) == (cat_in == nullptr) && (cache == nullptr) == (cat_out == nullptr),
                "zk_ln_decode: z / cat_in and cache / cat_out go together");
+  ZK_CHECK_ARG(parts == nullptr || (z == nullptr && nparts >= 1 && part_stride >= (long)rows * H),
+               "zk_ln_decode: partial sums exclude the gate and need nparts >= 1, part_stride >= rows * H");
   if (rows == 0) return 0;
   const dim3 grid((unsigned)((rows + 3) / 4));
-#define ZK_LND(NC)                                                                                                  \
-  hipLaunchKernelGGL(k_ln_decode<NC>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)ybuf, gamma, beta,      \
-                     (bf16_t*)out, rows, H, eps, (const bf16_t*)z, (const bf16_t*)cat_in, cache, (bf16_t*)cat_out,   \
-                     inv_count, time_dev)
-  if (H <= 512) ZK_LND(1);
-  else if (H <= 1024) ZK_LND(2);
-  else ZK_LND(4);
-#undef ZK_LND
+  LnDecArgs a{(const bf16_t*)x, (bf16_t*)ybuf, gamma, beta, (bf16_t*)out, rows, H, eps, (const bf16_t*)z,
+              (const bf16_t*)cat_in, parts, nparts, part_stride, bias, cache, (bf16_t*)cat_out, inv_count, time_dev};
+  if (H <= 512) hipLaunchKernelGGL(k_ln_decode<1>, grid, dim3(256), 0, stream, a);
+  else if (H <= 1024) hipLaunchKernelGGL(k_ln_decode<2>, grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(k_ln_decode<4>, grid, dim3(256), 0, stream, a);
   ZK_LAUNCH_CHECK();
   return 0;
 }

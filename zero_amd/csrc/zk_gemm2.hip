@@ -243,13 +243,13 @@ __global__ void __launch_bounds__(256) k_logits_ce(const bf16_t* __restrict__ fe
     const int gold = gm < T ? c.ids[gm] : -1;
     if (gold >= cbeg && gold < cbeg + nval) zg = zr[gold - cbeg];
     // merge the two halves of the row
-    const float m2 = __shfl_xor(m, 1, 64), se2 = __shfl_xor(se, 1, 64);
+    const float m2 = zk_dpp<ZK_DPP_XOR1, 0xf>(m, m), se2 = zk_dpp<ZK_DPP_XOR1, 0xf>(se, se);
     const float mm = fmaxf(m, m2);
     float tot = 0.f;
     if (m > -INFINITY) tot += se * __expf(m - mm);
     if (m2 > -INFINITY) tot += se2 * __expf(m2 - mm);
-    sz += __shfl_xor(sz, 1, 64);
-    zg += __shfl_xor(zg, 1, 64);
+    sz += zk_dpp<ZK_DPP_XOR1, 0xf>(0.f, sz);
+    zg += zk_dpp<ZK_DPP_XOR1, 0xf>(0.f, zg);
     if (half == 0 && gm < T) c.part[(size_t)gm * c.tiles_n + tn_] = make_float4(mm, tot, sz, zg);
   } else {
     constexpr int CPRW = BN / 8;

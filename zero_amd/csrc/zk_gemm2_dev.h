@@ -343,32 +343,27 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
                                           const bf16_t* __restrict__ B, int M, int N, int lda, int ldb, int kbeg,
                                           int kend, int m0, int n0, float* __restrict__ slab, const GemmEpi& e,
                                           int vec_ok, const KSegDesc* ks = nullptr, float* __restrict__ colsum = nullptr) {
-  gemm_tile_to_lds<BM, BN, NS, TA, TB, NW, PW, KSEG, FRESH>(smem, A, B, M, N, lda, ldb, kbeg, kend, m0, n0, ks, colsum);
   constexpr int CLD = DldsCfg<BM, BN, NS>::CLD;
   constexpr int NT = (NW + PW) * 64;
   const int tid = threadIdx.x;
-  const float* sC = reinterpret_cast<const float*>(smem);
-  const uint64_t seed = e.thr ? *e.seed : 0;
   constexpr int CPRW = BN / 8;
   // Fast path (interior tile, 16-byte epilogue, no split-K slab): every thread's chunks sit in the same 8
   // columns (NT is a multiple of CPRW), so the loop is fully unrolled with all LDS reads first, then all
   // residual / mask loads, then the arithmetic and the stores -- the latencies overlap instead of adding up
   // once per chunk (the rolled loop below cost ~1200 cycles per chunk, profiles/r01_gemm_kloop_trace.txt).
-  if (slab == nullptr && vec_ok && m0 + BM <= M && n0 + BN <= N) {
-    static_assert(NT % CPRW == 0, "a thread's chunks must share their columns");
-    constexpr int CH = BM * CPRW, ITER = (CH + NT - 1) / NT;
-    const int cc = (tid % CPRW) * 8, gn = n0 + cc, row0 = tid / CPRW;
-    constexpr int RSTEP = NT / CPRW;
-    float v[ITER][8];
-    uint4 rres[ITER], raux[ITER];
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int row = min(row0 + it * RSTEP, BM - 1);
-      const float4 a = *reinterpret_cast<const float4*>(sC + row * CLD + cc);
-      const float4 b = *reinterpret_cast<const float4*>(sC + row * CLD + cc + 4);
-      v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
-      v[it][4] = b.x; v[it][5] = b.y; v[it][6] = b.z; v[it][7] = b.w;
-    }
+  static_assert(NT % CPRW == 0, "a thread's chunks must share their columns");
+  constexpr int CH = BM * CPRW, ITER = (CH + NT - 1) / NT;
+  constexpr int RSTEP = NT / CPRW;
+  const bool fast = slab == nullptr && vec_ok && m0 + BM <= M && n0 + BN <= N;
+  const int cc = (tid % CPRW) * 8, gn = n0 + cc, row0 = tid / CPRW;
+  // The epilogue's inputs (residual, ReLU mask, bias, dropout seed) do not depend on the product: on the small tiles,
+  // where a launch is a chain of a few memory round trips, they are requested BEFORE the K loop instead of after it
+  // (one round trip less per launch; the registers are few: ITER <= 2).
+  constexpr bool PRE = ITER <= 2;
+  uint4 rres[ITER], raux[ITER];
+  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  uint64_t seed = 0;
+  auto load_epi = [&]() {
     if (e.res) {
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
@@ -383,12 +378,30 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
         raux[it] = zk_ld16<FRESH>(e.aux + (size_t)gm * e.ldaux + gn);
       }
     }
-    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (e.bias) {
       const float4 a = *reinterpret_cast<const float4*>(e.bias + gn);
       const float4 b = *reinterpret_cast<const float4*>(e.bias + gn + 4);
       bv[0] = a.x; bv[1] = a.y; bv[2] = a.z; bv[3] = a.w; bv[4] = b.x; bv[5] = b.y; bv[6] = b.z; bv[7] = b.w;
     }
+  };
+  if (PRE && !FRESH) {
+    seed = e.thr ? *e.seed : 0;
+    if (fast) load_epi();
+  }
+  gemm_tile_to_lds<BM, BN, NS, TA, TB, NW, PW, KSEG, FRESH>(smem, A, B, M, N, lda, ldb, kbeg, kend, m0, n0, ks, colsum);
+  const float* sC = reinterpret_cast<const float*>(smem);
+  if (!(PRE && !FRESH)) seed = e.thr ? *e.seed : 0;
+  if (fast) {
+    float v[ITER][8];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int row = min(row0 + it * RSTEP, BM - 1);
+      const float4 a = *reinterpret_cast<const float4*>(sC + row * CLD + cc);
+      const float4 b = *reinterpret_cast<const float4*>(sC + row * CLD + cc + 4);
+      v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
+      v[it][4] = b.x; v[it][5] = b.y; v[it][6] = b.z; v[it][7] = b.w;
+    }
+    if (!(PRE && !FRESH)) load_epi();
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int row = row0 + it * RSTEP;

@@ -11,6 +11,21 @@ __device__ __forceinline__ void add_ln_fwd_row(
     uint32_t thr, float inv_keep, uint64_t seed, uint32_t sid, int lane) {
   float v[MAXC][8];
   float s1 = 0.f;
+  // scale / offset are requested with the row, not after the two reductions (one memory round trip less per launch)
+  float gm[MAXC][8], bt[MAXC][8];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = (i * 64 + lane) * 8;
+    if (c < H) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gamma + c + 4 * q);
+        const float4 b4 = *reinterpret_cast<const float4*>(beta + c + 4 * q);
+        gm[i][4 * q] = g4.x; gm[i][4 * q + 1] = g4.y; gm[i][4 * q + 2] = g4.z; gm[i][4 * q + 3] = g4.w;
+        bt[i][4 * q] = b4.x; bt[i][4 * q + 1] = b4.y; bt[i][4 * q + 2] = b4.z; bt[i][4 * q + 3] = b4.w;
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
     const int c = (i * 64 + lane) * 8;
@@ -53,7 +68,7 @@ __device__ __forceinline__ void add_ln_fwd_row(
     if (c < H) {
       float o[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = gamma[c + j] * (v[i][j] - mean) * rstd + beta[c + j];
+      for (int j = 0; j < 8; ++j) o[j] = gm[i][j] * (v[i][j] - mean) * rstd + bt[i][j];
       *reinterpret_cast<uint4*>(out + (size_t)r * H + c) = pack8(o);
     }
   }

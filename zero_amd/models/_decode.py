@@ -79,6 +79,48 @@ class DecodeState(dict):
                     lay[nm] = e.buf("dc.%s.%d" % (nm, pp), (nl, BK, self["Tmax"], H))[l]
 
 
+def _fuse_att_ok(core, hp, K):
+    """The attention sub-layers of a cached decode step as one launch per (sentence, head) (zk_dec_cross / zk_dec_self)."""
+    import os
+    return (os.environ.get("ZERO_HIP_DECODE_FUSE_ATT", "1") != "0" and core.d == 64
+            and core.H in (128, 256, 512, 1024, 2048) and K <= 8 and not core.rpr and not core.fuse
+            and (not core.aan or os.environ.get("ZERO_HIP_DECODE_FUSE_LN", "1") != "0") and not hp.use_ffn)
+
+
+def _transposed(core, name):
+    """bf16 copy of a projection weight with the input dimension contiguous (row = output channel): the operand layout of
+    the fused decode kernels' matrix-core fragments.  Refreshed per encoded batch (the weights may have been trained on)."""
+    W = core.store.s(name)
+    buf = core.eng.buf("dc.wt." + name, (W.shape[1], W.shape[0]), W.dtype)
+    buf.copy_(W.t())
+    return Mat(buf, W.shape[1], W.shape[0])
+
+
+def _cross_unfused(core, e, hp, state, lay, x, p, pre, l, time, time_dev):
+    """Encoder-decoder attention sub-layer of a decode step, one launch per op."""
+    H, nh, d = core.H, core.nh, core.d
+    BK, K, Ls = state["BK"], state["K"], state["Ls"]
+    q = e.mat("dc.q", BK, H)
+    core._linear(x, p + "q_map", q)
+    att = e.mat("dc.att", BK, H)
+    rk = core.store.s(p + "rpr_keys/embeddings") if core.rpr else None
+    rv = core.store.s(p + "rpr_values/embeddings") if core.rpr else None
+    e.attn_fwd(q, lay["mk"], lay["mv"], att, None, BK, nh, 1, Ls, d, kmask=state["mask"], causal=False,
+               q_pos0=time if time is not None else 0, rpr_k=rk, rpr_v=rv, max_rel=hp.max_relative_position, bsq=H,
+               bsk=Ls * 2 * H, bsv=Ls * 2 * H, kv_group=K, pos_dev=time_dev, pos_flags=1)
+    if core.fuse:
+        # func.py:258-272: v_q = v_map(query); cache += v_q; o += cache / (time + 1)
+        vq = e.mat("dc.vq", BK, H)
+        core._linear(x, p + "v_map", vq)
+        e.lib.call("zk_fuse_decode", vq.ptr, lay["aan"].data_ptr(), att.ptr, BK, H,
+                   1.0 if time_dev is not None else 1.0 / float(time + 1),
+                   time_dev.data_ptr() if time_dev is not None else None, e.stream)
+    y = e.mat("dc.y", BK, H)
+    core._linear(att, p + "o_map", y)
+    x = core._ln_fwd(x, y, pre + "/" + core.cross, "dc%d.ca" % l, False, 0.0, 0)
+    return x
+
+
 def make_infer_fns(params, model_name):
     hp = params
 
@@ -114,6 +156,16 @@ def make_infer_fns(params, model_name):
             state["decoder"]["state"]["layer_%d" % l] = lay
         state["_pp"] = 0
         nl = hp.num_decoder_layer
+        state["wt"] = {}
+        if _fuse_att_ok(core, hp, K):
+            for l in range(nl):
+                blocks = [(core.cross, ("q_map", "o_map"))]
+                if not core.aan:
+                    blocks.append(("self_attention", ("qkv_map", "o_map")))
+                for blk, maps in blocks:
+                    for m in maps:
+                        nm = "decoder/layer_%d/%s/dot_attention/%s/W_0_0" % (l, blk, m)
+                        state["wt"][nm] = _transposed(core, nm)
         if core.aan or core.fuse:
             e.zero(e.buf("dc.aan.0", (nl, BK, H), F32))
             e.buf("dc.aan.1", (nl, BK, H), F32)
@@ -221,6 +273,50 @@ def make_infer_fns(params, model_name):
         e.lib.call("zk_all_equal", target.data_ptr(), BK, hp.tgt_vocab.pad(), zf.data_ptr(), e.stream)
         import os as _os
         fuse_ln = core.aan and _os.environ.get("ZERO_HIP_DECODE_FUSE_LN", "1") != "0"
+        # an attention sub-layer (projection, attention, the head's share of the output projection) as ONE launch per
+        # (sentence, head) with the previous LayerNorm as its prologue (zk_dec_cross / zk_dec_self)
+        fuse_att = bool(state.get("wt")) and _fuse_att_ok(core, hp, K)
+        eps = zdtype.epsilon()
+        tdev = time_dev.data_ptr() if time_dev is not None else None
+
+        def ln_args(pro):
+            """(x, ybuf, gamma, beta, xout, H, eps, z, cat_in, parts, nparts, part_stride, bias, cache, cat_out,
+            inv_count, time_dev) of zk_dec_* / zk_ln_decode's row-local LayerNorm; pro None: no prologue."""
+            if pro is None:
+                return None
+            g = lambda k: pro.get(k)
+            return (g("x"), g("ybuf"), g("gamma"), g("beta"), g("out"), H, eps, g("z"), g("cat"), g("parts"),
+                    g("nparts") or 0, g("stride") or 0, g("bias"), None, None, 1.0, None)
+
+        def ln_scope(scope):
+            return dict(gamma=core.b(scope + "/layer_norm/scale").data_ptr(),
+                        beta=core.b(scope + "/layer_norm/offset").data_ptr())
+
+        def dec_cross(x_in, pro, p, lay, parts):
+            la = ln_args(pro) or (x_in.ptr, None, None, None, None, H, eps, None, None, None, 0, 0, None, None, None,
+                                  1.0, None)
+            Wq, Wo = state["wt"][p + "q_map/W_0_0"], state["wt"][p + "o_map/W_0_0"]
+            e.lib.call("zk_dec_cross", *la, Wq.ptr, Wq.ld, core.b(p + "q_map/b_0").data_ptr(), lay["mk"].ptr,
+                       lay["mv"].ptr, lay["mk"].ld, lay["mv"].ld, Ls * 2 * H, Ls * 2 * H, state["mask"].data_ptr(), Ls,
+                       Wo.ptr, Wo.ld, parts.data_ptr(), B, K, nh, Ls, float(d) ** -0.5, zdtype.inf(), e.stream)
+
+        def dec_self(x_in, pro, p, lay, parts):
+            la = ln_args(pro) or (x_in.ptr, None, None, None, None, H, eps, None, None, None, 0, 0, None, None, None,
+                                  1.0, None)
+            Wq, Wo = state["wt"][p + "qkv_map/W_0_0"], state["wt"][p + "o_map/W_0_0"]
+            e.lib.call("zk_dec_self", *la, Wq.ptr, Wq.ld, core.b(p + "qkv_map/b_0").data_ptr(), lay["k"].data_ptr(),
+                       lay["v"].data_ptr(), Tmax, 0 if time_dev is not None else time, tdev, Wo.ptr, Wo.ld,
+                       parts.data_ptr(), B, K, nh, float(d) ** -0.5, e.stream)
+
+        def ln_parts(x_in, scope, p, parts, tag):
+            """x = LayerNorm(x_in + bf16(sum of the nh partial output projections + o_map bias))"""
+            out = e.mat(tag + ".o", BK, H)
+            ls = ln_scope(scope)
+            e.lib.call("zk_ln_decode", x_in.ptr, e.mat("dc.y", BK, H).ptr, ls["gamma"], ls["beta"], out.ptr, BK, H, eps,
+                       None, None, parts.data_ptr(), nh, BK * H, core.b(p + "o_map/b_0").data_ptr(), None, None, 1.0,
+                       None, e.stream)
+            return out
+        pend = None          # base model: the feed-forward LayerNorm of the previous layer, left to the next prologue
         x = e.mat("dc.x", BK, H)
         e.embed_fwd(target, core.store.s(core.tgt_emb), core.b("bias"), x, BK, 1, H,
                     pos0=0 if time_dev is not None else time, zero_flag=zf, pos0_dev=time_dev, max_pos=Tmax)
@@ -243,16 +339,32 @@ def make_infer_fns(params, model_name):
                 z = e.mat("dc.z", BK, 2 * H)
                 core._linear(cat, a + "/z_project", z)
                 g = e.mat("dc.y", BK, H)
-                if fuse_ln:
+                if fuse_att:
+                    # gate + residual + LayerNorm ride as the prologue of the encoder-decoder attention launch
+                    xo = e.mat("dc%d.aa.o" % l, BK, H)
+                    pend = dict(x=x.ptr, ybuf=g.ptr, out=xo.ptr, z=z.ptr, cat=cat.ptr, **ln_scope(a))
+                    x = xo
+                elif fuse_ln:
                     # gate + residual + LayerNorm in one launch (zk_ln_decode)
                     xo = e.mat("dc%d.aa.o" % l, BK, H)
                     e.lib.call("zk_ln_decode", x.ptr, g.ptr, core.b(a + "/layer_norm/scale").data_ptr(),
                                core.b(a + "/layer_norm/offset").data_ptr(), xo.ptr, BK, H, zdtype.epsilon(),
-                               z.ptr, cat.ptr, None, None, 1.0, None, e.stream)
+                               z.ptr, cat.ptr, None, 0, 0, None, None, None, 1.0, None, e.stream)
                     x = xo
                 else:
                     e.aan_gate_fwd(z, cat, g, BK, H)
                     x = core._ln_fwd(x, g, a, "dc%d.aa" % l, False, 0.0, 0)
+            elif fuse_att:
+                p = pre + "/self_attention/dot_attention/"
+                parts_s = e.buf("dc.parts.s", (nh, BK, H), F32)
+                dec_self(x, pend, p, lay, parts_s)
+                if pend is not None:
+                    x = pend["xmat"]
+                xo = e.mat("dc%d.sa.o" % l, BK, H)
+                pend = dict(x=x.ptr, ybuf=e.mat("dc.y", BK, H).ptr, out=xo.ptr, parts=parts_s.data_ptr(), nparts=nh,
+                            stride=BK * H, bias=core.b(p + "o_map/b_0").data_ptr(),
+                            **ln_scope(pre + "/self_attention"))
+                x = xo
             elif not core.fuse:
                 p = pre + "/self_attention/dot_attention/"
                 qkv = e.mat("dc.qkv", BK, 3 * H)
@@ -276,25 +388,27 @@ def make_infer_fns(params, model_name):
                 core._linear(att, p + "o_map", y)
                 x = core._ln_fwd(x, y, pre + "/self_attention", "dc%d.sa" % l, False, 0.0, 0)
             p = pre + "/" + core.cross + "/dot_attention/"
-            q = e.mat("dc.q", BK, H)
-            core._linear(x, p + "q_map", q)
-            att = e.mat("dc.att", BK, H)
-            rk = core.store.s(p + "rpr_keys/embeddings") if core.rpr else None
-            rv = core.store.s(p + "rpr_values/embeddings") if core.rpr else None
-            e.attn_fwd(q, lay["mk"], lay["mv"], att, None, BK, nh, 1, Ls, d, kmask=state["mask"], causal=False,
-                       q_pos0=time if time is not None else 0, rpr_k=rk, rpr_v=rv, max_rel=hp.max_relative_position, bsq=H,
-                       bsk=Ls * 2 * H, bsv=Ls * 2 * H, kv_group=K, pos_dev=time_dev, pos_flags=1)
-            if core.fuse:
-                # func.py:258-272: v_q = v_map(query); cache += v_q; o += cache / (time + 1)
-                vq = e.mat("dc.vq", BK, H)
-                core._linear(x, p + "v_map", vq)
-                e.lib.call("zk_fuse_decode", vq.ptr, lay["aan"].data_ptr(), att.ptr, BK, H,
-                           1.0 if time_dev is not None else 1.0 / float(time + 1),
-                           time_dev.data_ptr() if time_dev is not None else None, e.stream)
-            y = e.mat("dc.y", BK, H)
-            core._linear(att, p + "o_map", y)
-            x = core._ln_fwd(x, y, pre + "/" + core.cross, "dc%d.ca" % l, False, 0.0, 0)
+            if fuse_att:
+                parts_c = e.buf("dc.parts.c", (nh, BK, H), F32)
+                dec_cross(x, pend, p, lay, parts_c)        # x is already the prologue's output buffer
+                pend = None
+                x = ln_parts(x, pre + "/" + core.cross, p, parts_c, "dc%d.ca" % l)
+            else:
+                x = _cross_unfused(core, e, hp, state, lay, x, p, pre, l, time, time_dev)
             nxt = state["decoder"]["state"].get("layer_%d" % (l + 1))
+            if fuse_att and not core.aan:
+                # feed-forward sub-layer; its residual + LayerNorm is the prologue of the next layer's self-attention
+                f = pre + "/feed_forward"
+                hh = e.mat("dc%d.ff.h" % l, BK, core.F)
+                core._linear(x, f + "/ffn_layer/enlarge", hh, act=1)
+                y = e.mat("dc%d.ff.y" % (l & 1), BK, H)
+                core._linear(hh, f + "/ffn_layer/output", y)
+                if nxt is not None:
+                    xo = e.mat("dc%d.ff.o" % l, BK, H)
+                    pend = dict(x=x.ptr, ybuf=y.ptr, out=xo.ptr, xmat=xo, **ln_scope(f))
+                else:
+                    x = core._ln_fwd(x, y, f, "dc%d.ff" % l, False, 0.0, 0)
+                continue
             if fuse_ln and core.aan and nxt is not None and not hp.use_ffn:
                 # feed-forward sub-layer whose LayerNorm also prepares the next layer's average attention
                 # (cache += x; cat = [x | cache / (time + 1)]) in the same launch
@@ -306,7 +420,7 @@ def make_infer_fns(params, model_name):
                 xo = e.mat("dc%d.ff.o" % l, BK, H)
                 e.lib.call("zk_ln_decode", x.ptr, y.ptr, core.b(f + "/layer_norm/scale").data_ptr(),
                            core.b(f + "/layer_norm/offset").data_ptr(), xo.ptr, BK, H, zdtype.epsilon(), None, None,
-                           nxt["aan"].data_ptr(), e.mat("dc.cat", BK, 2 * H).ptr,
+                           None, 0, 0, None, nxt["aan"].data_ptr(), e.mat("dc.cat", BK, 2 * H).ptr,
                            1.0 if time_dev is not None else 1.0 / float(time + 1),
                            time_dev.data_ptr() if time_dev is not None else None, e.stream)
                 x = xo
