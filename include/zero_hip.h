@@ -383,6 +383,9 @@ int zk_dec_cross(const void* x, void* ybuf, const float* gamma, const float* bet
                  const float* bq, const void* k, const void* v, int ldk, int ldv, long bsk, long bsv, const float* kmask,
                  int ldmask, const void* wot, int ldwo, float* out_parts, int B, int R, int nh, int Lk, float scale,
                  float mask_inf, zk_stream_t stream);
+/* Beam rows per workgroup of zk_dec_cross / zk_dec_self (1 .. 16; 0 = built-in default); returns the previous setting.
+ * A measurement knob (scripts/dec_attn_trace.py): results do not depend on it. */
+int zk_dec_group(int n);
 /* Self-attention over per-beam caches (func.py:199-205): wqkvt = qkv_map^T [3H, H] (q | k | v rows), bias [3H];
  * kcache / vcache bf16 [B*R, Tmax, H]: this step's key / value are written at slot time (*time_dev when given), keys
  * 0 .. time attended. */

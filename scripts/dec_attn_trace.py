@@ -14,7 +14,7 @@ from zero_amd import hip
 
 lib = hip.lib()
 dev = torch.device("cuda:0")
-B, R, nh, H, Ls, Tmax = 32, 4, 8, 512, 30, 80
+B, R, nh, H, Ls, Tmax = 32, 4, 8, 512, 30, 80      # 16-row groups: 8 x 8 workgroups
 self_mode = len(sys.argv) > 1 and sys.argv[1] == "self"
 g = torch.Generator(device="cpu").manual_seed(1)
 bf = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(torch.bfloat16).to(dev)
@@ -47,6 +47,7 @@ def launch():
                  0.125, 1e9, st)
 
 
+lib.raw("zk_dec_group")(int(os.environ.get("GROUP", "0")))
 for _ in range(5):
     launch()
 torch.cuda.synchronize()
@@ -60,10 +61,10 @@ try:
         launch()
         torch.cuda.synchronize()
         rd(buf)
-        rows.append([buf[i] for i in range(8)])
+        rows.append([buf[i] for i in (0, 1, 8, 9, 10, 11, 2, 3, 4, 5, 6, 7)])
     d = np.diff(np.array(rows, dtype=np.float64), axis=1) * 10.0        # ns
-    names = ["prefetch issue", "prologue LN -> LDS", "projection MFMA + combine", "scores", "softmax", "context",
-             "output projection + stores"]
+    names = ["setup", "prologue loads issued", "prefetch issued", "LayerNorm computed", "rows -> LDS", "barrier",
+             "projection MFMA + combine", "scores", "softmax", "context", "output projection + stores"]
     for n, v in zip(names, np.median(d, axis=0)):
         print("%-28s %7.0f ns" % (n, v))
     print("%-28s %7.0f ns (in-kernel span of workgroup 0)" % ("total", np.median(d.sum(axis=1))))
@@ -84,4 +85,4 @@ for _ in range(10):
     lib.call("zk_graph_launch", out, st)
 e.record()
 torch.cuda.synchronize()
-print("MODE=%s" % os.environ.get("MODE", "0"), "PAD_W=%d PAD_KV=%d graph of 20 launches: %.2f us per launch" % (PW, PKV, s.elapsed_time(e) * 1e3 / 200))
+print("GROUP=%s MODE=%s" % (os.environ.get("GROUP", "0"), os.environ.get("MODE", "0")), "PAD_W=%d PAD_KV=%d graph of 20 launches: %.2f us per launch" % (PW, PKV, s.elapsed_time(e) * 1e3 / 200))

@@ -4,15 +4,17 @@
 // A decode step runs on B*K rows (128 at the benchmark shape): every op is a ~5-7 us latency chain whatever it
 // computes, so a step costs (number of launches) x ~7 us.  An attention sub-layer was four launches -- q (or qkv)
 // projection, attention, output projection, residual + LayerNorm -- each a GEMM on 128 rows that kept 16 CUs busy.
-// Here one workgroup owns (sentence b, head h):
-//   prologue  (optional) the PREVIOUS sub-layer's residual + LayerNorm for the sentence's K beam rows, recomputed by each
-//             of the nh workgroups of the sentence (K x H elements: cheaper than a launch; zk_lndec_dev.h);
-//   q_h     = bf16(x . Wq[:, h] + bq[h])          K x 64 on the matrix cores (16x16x32 bf16, rows padded to 16), the
-//             64 KB slice of the TRANSPOSED weight streamed once, every fragment prefetched into registers at entry
+// Here one workgroup owns (16 consecutive beam rows = 4 sentences at beam 4, head h) -- the 16 rows of one MFMA tile;
+// with one sentence per workgroup every workgroup re-read the head's 128 KB of weights and the launch was bound by the
+// L2 -> CU path (32 MB for 32 sentences; profiles/r02_dec_attn_phases.txt):
+//   prologue  (optional) the PREVIOUS sub-layer's residual + LayerNorm for the 16 rows, recomputed by each of the nh
+//             workgroups of the row group (16 x H elements: cheaper than a launch; zk_lndec_dev.h);
+//   q_h     = bf16(x . Wq[:, h] + bq[h])          16 x 64 on the matrix cores (16x16x32 bf16), the 64 KB slice of the
+//             TRANSPOSED weight streamed once, every fragment prefetched into registers at entry
 //             (self-attention: k_h, v_h too; written to the per-beam caches at slot `time`)
 //   P       = softmax(scale * q_h K_h^T + mask)   keys of the sentence (cross) or of the beam's cache (self)
 //   ctx_h   = bf16(P V_h)
-//   part[h] = ctx_h . Wo[h rows, :]               K x H fp32, the head's share of the output projection
+//   part[h] = ctx_h . Wo[h rows, :]               16 x H fp32, the head's share of the output projection
 // and the NEXT launch (zk_ln_decode with parts, or the prologue of the next fused sub-layer) adds the nh partial
 // products in a fixed order, the bias and the residual and normalises.  Nothing is exchanged between workgroups inside the
 // launch.  Values are rounded to bf16 where the launch-per-op path stores bf16 (q, k, v, P, ctx, y), the fp32 sums run in
@@ -43,6 +45,7 @@ __device__ int zk_dec_trace_mode;     // bit 0 / 1 / 2: skip the q-weight / o-we
 #define ZK_DM(bit) 0
 #endif
 
+#define ZK_DEC_GROUP_DEFAULT 4
 struct DecAttnArgs {
   LnDecArgs pro;                 // pro.gamma == NULL: no prologue, pro.x is the block input
   // TRANSPOSED projection weights (row = output channel, K-contiguous: the MFMA B fragment is one 16-byte load)
@@ -56,16 +59,18 @@ struct DecAttnArgs {
   int B, R, nh, Lk;                              // Lk: cross = source length; self = cache capacity
   float scale, mask_inf;
   const int* time_dev; int time;                 // self: this step's slot (the device value wins)
+  int gr;                                        // beam rows per workgroup (<= 16)
 };
 
-// 512 threads = 8 waves.  RT: row capacity of the score / context buffers (4 or 8 >= R).  MAXC = ceil(H / 512).
-template <int RT, bool SELF, int MAXC>
+// 512 threads = 8 waves; one workgroup = (16 consecutive beam rows, head h).  MAXC = ceil(H / 512).
+template <bool SELF, int MAXC>
 __global__ void __launch_bounds__(512) k_dec_attn(DecAttnArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, lk8 = (lane >> 4) * 8;
-  const int b = blockIdx.x / a.nh, h = blockIdx.x % a.nh;
-  const int H = a.pro.H, R = a.R, rows = a.B * a.R, row0 = b * R;
+  const int h = blockIdx.x % a.nh, row0 = (blockIdx.x / a.nh) * a.gr;
+  const int H = a.pro.H, R = a.R, rows = a.B * a.R;
+  const int NR = min(a.gr, rows - row0);                 // valid rows of this group
   const int t = SELF ? (a.time_dev != nullptr ? *a.time_dev : a.time) : 0;
   const int Lk = SELF ? min(a.Lk, t + 1) : a.Lk;
   const int LkPad = (a.Lk + 3) & ~3;
@@ -73,19 +78,21 @@ __global__ void __launch_bounds__(512) k_dec_attn(DecAttnArgs a) {
   constexpr int NP = SELF ? 3 : 1;                      // projections of this head: q (k, v)
   constexpr int KS = 8 * MAXC;                          // 32-wide k steps per half of K (H / 64 of them are real)
   constexpr int NOT = 4 * MAXC;                         // output tiles of 16 columns per wave (H / 128 real)
-  bf16_t* sXb = reinterpret_cast<bf16_t*>(smem);        // [16][XLD] rows >= R are never read back
-  float* sRed = reinterpret_cast<float*>(sXb + 16 * XLD);   // 2048 * RT floats: context partial sums
-  float* sPart = sRed + 2048 * RT;                      // [3][8 waves][8 rows][16]: halves of the projection tiles
-  float* sQ = sPart + 3072;                             // [8][64] each
-  float* sKc = sQ + 512;
-  float* sVc = sKc + 512;
-  float* sS = sVc + 512;                                // [RT][LkPad]
-  bf16_t* sCb = reinterpret_cast<bf16_t*>(sS + RT * LkPad);   // [16][72]
+  bf16_t* sXb = reinterpret_cast<bf16_t*>(smem);        // [16][XLD]; rows >= NR are never read back
+  float* sPart = reinterpret_cast<float*>(sXb + 16 * XLD);   // [3][8 waves][16 rows][16]: halves of the projection tiles
+  float* sQ = sPart + 3 * 8 * 256;                      // [16][64] each
+  float* sKc = sQ + 1024;
+  float* sVc = sKc + 1024;
+  float* sS = sVc + 1024;                               // [16][LkPad]
+  bf16_t* sCb = reinterpret_cast<bf16_t*>(sS + 16 * LkPad);   // [16][72]
+  // keys / values of row r (cross: of its sentence)
+  auto kbase = [&](int r) { return a.k + (size_t)(SELF ? row0 + r : (row0 + r) / R) * a.bsk + h * 64; };
+  auto vbase = [&](int r) { return a.v + (size_t)(SELF ? row0 + r : (row0 + r) / R) * a.bsv + h * 64; };
 
   ZK_DT(0);
   // ---- everything that does not depend on values computed here is requested first: one memory round trip
+  // (H > 512: only the q weights are requested up front, k / v when their turn comes -- register budget)
   const int ptile = w & 3, khalf = w >> 2, nks = H / 64;
-  // (H > 512: only the q weights are requested up front, the others when their turn comes -- register budget)
   constexpr bool EARLY = MAXC == 1;
   constexpr int NPR = EARLY ? NP : 1;
   uint4 wq_r[NPR][KS];
@@ -95,9 +102,6 @@ __global__ void __launch_bounds__(512) k_dec_attn(DecAttnArgs a) {
     for (int ks = 0; ks < KS; ++ks)
       if (ks < nks) dst[ks] = *reinterpret_cast<const uint4*>(wp + ks * 32);
   };
-#pragma unroll
-  for (int p = 0; p < NPR; ++p)
-    if (!ZK_DM(0)) load_wq(p, wq_r[p]);
   uint4 wo_r[NOT][2];
   auto load_wo = [&]() {
 #pragma unroll
@@ -110,56 +114,79 @@ __global__ void __launch_bounds__(512) k_dec_attn(DecAttnArgs a) {
       }
     }
   };
-  if (EARLY && !ZK_DM(1)) load_wo();
-  // keys of the first (row, key) pair of this thread, values of its first context phase
-  uint4 k_r[8];
-  float km_r = 1.f, bq_r[NP];
+  // the block input first (it heads the longest dependent chain): the previous sub-layer's residual + LayerNorm in
+  // registers (wave w: rows w and w + 8), or the given rows
+  uint4 xr[2][MAXC];
+  if (a.pro.gamma == nullptr) {
 #pragma unroll
-  for (int p = 0; p < NP; ++p) bq_r[p] = a.bq[p * H + h * 64 + (tid & 63)];
-  if (!SELF && a.kmask != nullptr && tid < R * Lk) km_r = a.kmask[(size_t)b * a.ldmask + tid % Lk];
-  const bool kpre = tid < R * Lk && (!SELF || (tid % Lk) < t) && !ZK_DM(2);
-  if (kpre) {
-    const int r = tid / Lk, j = tid % Lk;
-    const bf16_t* kp = SELF ? a.k + (size_t)(row0 + r) * a.bsk + (size_t)j * a.ldk + h * 64
-                            : a.k + (size_t)b * a.bsk + (size_t)j * a.ldk + h * 64;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) k_r[u] = *reinterpret_cast<const uint4*>(kp + u * 8);
-  }
-  constexpr int NV = SELF ? RT : 1;
-  uint4 v_r[NV];
-  {
-    const int cg = tid & 7, jp = (tid >> 3) & 31;
-    if (tid < 256 && !ZK_DM(2)) {
-      if (!SELF) {
-        if (jp < Lk) v_r[0] = *reinterpret_cast<const uint4*>(a.v + (size_t)b * a.bsv + (size_t)jp * a.ldv + h * 64 + cg * 8);
-      } else {
-#pragma unroll
-        for (int r = 0; r < NV; ++r)
-          if (r < R && jp < t && jp < Lk)
-            v_r[r] = *reinterpret_cast<const uint4*>(a.v + (size_t)(row0 + r) * a.bsv + (size_t)jp * a.ldv + h * 64 + cg * 8);
-      }
-    }
-  }
-
-  ZK_DT(1);
-  // ---- block input: the previous sub-layer's residual + LayerNorm in registers, or the given rows
-  if (w < R) {
-    uint4 xr[MAXC];
-    if (a.pro.gamma != nullptr) {
-      ln_decode_row<MAXC>(a.pro, row0 + w, lane, h == 0, xr);
-    } else {
+    for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int i = 0; i < MAXC; ++i) {
         const int c = (i * 64 + lane) * 8;
-        if (c < H) xr[i] = *reinterpret_cast<const uint4*>(a.pro.x + (size_t)(row0 + w) * H + c);
+        if (c < H && w + 8 * n < NR) xr[n][i] = *reinterpret_cast<const uint4*>(a.pro.x + (size_t)(row0 + w + 8 * n) * H + c);
+      }
+  }
+  float bq_r[NP][2];
+  // scores: one (row, key) pair per thread (the whole 128-byte key row of the head); context: thread (row, 8 columns,
+  // keys cjp, cjp + 4, ..)
+  const int cr = tid >> 5, ccg = (tid >> 2) & 7, cjp = tid & 3;
+  const int npair = NR * Lk;
+  uint4 k_r[8], v_r[8];
+  float km_r = 1.f;
+  auto pair_key = [&](int e) {       // key row of pair e (clamped: always valid memory)
+    const int ec = min(e, npair - 1), r = ec / Lk;
+    int j = ec - r * Lk;
+    if (SELF) j = min(j, max(t - 1, 0));
+    return kbase(r) + (size_t)j * a.ldk;
+  };
+  auto ctx_val = [&](int j) {
+    const int vr = min(cr, NR - 1);
+    const int jc = SELF ? min(j, max(t - 1, 0)) : min(j, Lk - 1);
+    return vbase(vr) + (size_t)jc * a.ldv + ccg * 8;
+  };
+  auto prefetch = [&]() {
+    ZK_DT(8);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      bq_r[p][0] = a.bq[p * H + h * 64 + (tid & 63)];
+      bq_r[p][1] = bq_r[p][0];
+    }
+    {
+      const bf16_t* kp = pair_key(tid);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) k_r[u] = *reinterpret_cast<const uint4*>(kp + u * 8);
+      if (!SELF && a.kmask != nullptr) {
+        const int ec = min(tid, npair - 1), r = ec / Lk;
+        km_r = a.kmask[(size_t)((row0 + r) / R) * a.ldmask + (ec - r * Lk)];
       }
     }
+    if (!SELF) {                       // (self: register budget)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v_r[q] = *reinterpret_cast<const uint4*>(ctx_val(cjp + 4 * q));
+    }
+    if (EARLY) {
+#pragma unroll
+      for (int p = 0; p < NPR; ++p)
+        if (!ZK_DM(0)) load_wq(p, wq_r[p]);
+    }
+    ZK_DT(9);
+  };
+
+  ZK_DT(1);
+  // the prologue's own loads are requested first, the prefetches behind them (a wave's loads return in order: the
+  // LayerNorm must not wait for the weights), then the LayerNorm is computed while the weights arrive
+  if (a.pro.gamma != nullptr) ln_decode_rows<MAXC, 2>(a.pro, row0 + w, 8, row0 + NR, lane, h == 0, xr, prefetch);
+  else prefetch();
+  if (!EARLY) load_wq(0, wq_r[0]);          // H > 512: after the LayerNorm (register budget)
+  ZK_DT(10);
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = (i * 64 + lane) * 8;
-      if (c < H) *reinterpret_cast<uint4*>(sXb + w * XLD + c) = xr[i];
+      if (c < H && w + 8 * n < NR) *reinterpret_cast<uint4*>(sXb + (w + 8 * n) * XLD + c) = xr[n][i];
     }
-  }
+  ZK_DT(11);
   __syncthreads();
 
   ZK_DT(2);
@@ -189,26 +216,29 @@ __global__ void __launch_bounds__(512) k_dec_attn(DecAttnArgs a) {
           }
         }
       }
-      load_wo();
     }
-    if (lane < 32) {            // C rows (lane >> 4) * 4 + i: rows 0 .. 7
+    // the output-projection fragments are needed last: requested now (the q / k / v fragments are dead), they arrive
+    // behind the scores, the softmax and the context
+    if (!ZK_DM(1)) load_wo();
+    // C rows (lane >> 4) * 4 + i
 #pragma unroll
-      for (int p = 0; p < NP; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sPart[((p * 8 + w) * 8 + (lane >> 4) * 4 + i) * 16 + l15] = acc[p][i];
-    }
+      for (int i = 0; i < 4; ++i) sPart[((p * 8 + w) * 16 + (lane >> 4) * 4 + i) * 16 + l15] = acc[p][i];
   }
   __syncthreads();
-  {
-    const int r = tid >> 6, c = tid & 63, tile = c >> 4, cc = c & 15;
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int o = tid + 512 * n, r = o >> 6, c = o & 63, tile = c >> 4, cc = c & 15;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      const float s = sPart[((p * 8 + tile) * 8 + r) * 16 + cc] + sPart[((p * 8 + 4 + tile) * 8 + r) * 16 + cc] + bq_r[p];
+      const float s = sPart[((p * 8 + tile) * 16 + r) * 16 + cc] + sPart[((p * 8 + 4 + tile) * 16 + r) * 16 + cc] +
+                      bq_r[p][n];
       const bf16_t sb = f2bf(s);
-      if (p == 0) sQ[tid] = bf2f(sb);
+      if (p == 0) sQ[o] = bf2f(sb);
       else {
-        (p == 1 ? sKc : sVc)[tid] = bf2f(sb);
-        if (r < R && t < a.Lk) {
+        (p == 1 ? sKc : sVc)[o] = bf2f(sb);
+        if (r < NR && t < a.Lk) {
           bf16_t* dst = const_cast<bf16_t*>(p == 1 ? a.k : a.v);
           dst[(size_t)(row0 + r) * (p == 1 ? a.bsk : a.bsv) + (size_t)t * (p == 1 ? a.ldk : a.ldv) + h * 64 + c] = sb;
         }
@@ -219,15 +249,15 @@ __global__ void __launch_bounds__(512) k_dec_attn(DecAttnArgs a) {
 
   ZK_DT(3);
   // ---- scores: one (row, key) pair per thread
-  for (int e = tid; e < R * Lk; e += 512) {
-    const int r = e / Lk, j = e % Lk;
+  for (int e = tid; e < npair; e += 512) {
+    const int r = e / Lk, j = e - r * Lk;
     float dot = 0.f;
     if (!SELF || j < t) {
       if (e != tid) {
-        const bf16_t* kp = SELF ? a.k + (size_t)(row0 + r) * a.bsk + (size_t)j * a.ldk + h * 64
-                                : a.k + (size_t)b * a.bsk + (size_t)j * a.ldk + h * 64;
+        const bf16_t* kp = pair_key(e);
 #pragma unroll
         for (int u = 0; u < 8; ++u) k_r[u] = *reinterpret_cast<const uint4*>(kp + u * 8);
+        if (!SELF && a.kmask != nullptr) km_r = a.kmask[(size_t)((row0 + r) / R) * a.ldmask + j];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -239,81 +269,59 @@ __global__ void __launch_bounds__(512) k_dec_attn(DecAttnArgs a) {
     } else {
       for (int i = 0; i < 64; ++i) dot += sQ[r * 64 + i] * sKc[r * 64 + i];
     }
-    float bias = 0.f;
-    if (!SELF && a.kmask != nullptr && (e == tid ? km_r : a.kmask[(size_t)b * a.ldmask + j]) == 0.f) bias = -a.mask_inf;
-    sS[r * LkPad + j] = dot * a.scale + bias;
+    sS[r * LkPad + j] = dot * a.scale + ((!SELF && km_r == 0.f) ? -a.mask_inf : 0.f);
   }
   __syncthreads();
 
   ZK_DT(4);
-  // ---- softmax, one wave per row; P rounded to bf16 as the tile kernels store it
-  if (w < R) {
-    float* s = sS + w * LkPad;
-    float mx = -INFINITY;
-    for (int j = lane; j < Lk; j += 64) mx = fmaxf(mx, s[j]);
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int j = lane; j < Lk; j += 64) { const float e = __expf(s[j] - mx); s[j] = e; sum += e; }
-    sum = wave_sum(sum);
-    const float inv = 1.f / sum;
-    for (int j = lane; j < Lk; j += 64) s[j] = bf2f(f2bf(s[j] * inv));
+  // ---- softmax, wave w: rows w and w + 8; P rounded to bf16 as the tile kernels store it
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int r = w + 8 * n;
+    if (r < NR) {
+      float* s = sS + r * LkPad;
+      float mx = -INFINITY;
+      for (int j = lane; j < Lk; j += 64) mx = fmaxf(mx, s[j]);
+      mx = wave_max(mx);
+      float sum = 0.f;
+      for (int j = lane; j < Lk; j += 64) { const float e = __expf(s[j] - mx); s[j] = e; sum += e; }
+      sum = wave_sum(sum);
+      const float inv = 1.f / sum;
+      for (int j = lane; j < Lk; j += 64) s[j] = bf2f(f2bf(s[j] * inv));
+    }
   }
   __syncthreads();
 
   ZK_DT(5);
-  // ---- context of this head: 256 threads = (column group of 8, key phase of 32), then the phases through LDS
-  if (tid < 256) {
-    const int cg = tid & 7, jp = tid >> 3;
-    float acc[RT][8];
+  // ---- context of this head: thread (row, 8 columns, every 4th key), the four key phases combined inside the quad
+  {
+    float acc[8];
 #pragma unroll
-    for (int r = 0; r < RT; ++r)
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int j0 = 0; j0 < Lk; j0 += 32) {
+      if (j0 > 0 || SELF) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[r][i] = 0.f;
-    if (!SELF) {
-      const bf16_t* vp = a.v + (size_t)b * a.bsv + h * 64 + cg * 8;
-      for (int j = jp; j < Lk; j += 32) {
-        const uint4 vv = j == jp ? v_r[0] : *reinterpret_cast<const uint4*>(vp + (size_t)j * a.ldv);
-        float vf[8];
-        unpack8(vv, vf);
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-          const float pr = sS[r * LkPad + j];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) acc[r][i] += pr * vf[i];
-        }
+        for (int q = 0; q < 8; ++q) v_r[q] = *reinterpret_cast<const uint4*>(ctx_val(j0 + cjp + 4 * q));
       }
-    } else {
 #pragma unroll
-      for (int r = 0; r < RT; ++r) {
-        if (r < R) {
-          const bf16_t* vp = a.v + (size_t)(row0 + r) * a.bsv + h * 64 + cg * 8;
-          for (int j = jp; j < Lk; j += 32) {
-            float vf[8];
-            if (j < t) unpack8(j == jp ? v_r[r] : *reinterpret_cast<const uint4*>(vp + (size_t)j * a.ldv), vf);
-            else {
+      for (int q = 0; q < 8; ++q) {
+        const int j = j0 + cjp + 4 * q;
+        if (j < Lk && cr < NR) {
+          float vf[8];
+          if (!SELF || j < t) unpack8(v_r[q], vf);
+          else {
 #pragma unroll
-              for (int i = 0; i < 8; ++i) vf[i] = sVc[r * 64 + cg * 8 + i];
-            }
-            const float pr = sS[r * LkPad + j];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[r][i] += pr * vf[i];
+            for (int i = 0; i < 8; ++i) vf[i] = sVc[cr * 64 + ccg * 8 + i];
           }
+          const float pr = sS[cr * LkPad + j];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] += pr * vf[i];
         }
       }
     }
 #pragma unroll
-    for (int r = 0; r < RT; ++r) {
-      float4* d = reinterpret_cast<float4*>(sRed + (jp * RT + r) * 64 + cg * 8);
-      d[0] = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
-      d[1] = make_float4(acc[r][4], acc[r][5], acc[r][6], acc[r][7]);
-    }
-  }
-  __syncthreads();
-  for (int o = tid; o < RT * 64; o += 512) {
-    float s = 0.f;
-#pragma unroll 8
-    for (int q = 0; q < 32; ++q) s += sRed[q * RT * 64 + o];
-    sCb[(o >> 6) * 72 + (o & 63)] = f2bf(s);
+    for (int i = 0; i < 8; ++i) acc[i] = quad_sum(acc[i]);
+    if (cjp == 0) *reinterpret_cast<uint4*>(sCb + cr * 72 + ccg * 8) = pack8(acc);
   }
   __syncthreads();
 
@@ -329,12 +337,10 @@ __global__ void __launch_bounds__(512) k_dec_attn(DecAttnArgs a) {
         df32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         acc = dmfma16(a0, wo_r[i][0], acc);
         acc = dmfma16(a1, wo_r[i][1], acc);
-        if (lane < 32) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int r = (lane >> 4) * 4 + q;
-            if (r < R) a.part[((size_t)h * rows + row0 + r) * H + tile * 16 + l15] = acc[q];
-          }
+        for (int q = 0; q < 4; ++q) {
+          const int r = (lane >> 4) * 4 + q;
+          if (r < NR) a.part[((size_t)h * rows + row0 + r) * H + tile * 16 + l15] = acc[q];
         }
       }
     }
@@ -342,41 +348,52 @@ __global__ void __launch_bounds__(512) k_dec_attn(DecAttnArgs a) {
   ZK_DT(7);
 }
 
-static size_t dec_attn_lds(int RT, int H, int Lk) {
-  return 2 * 16 * (size_t)(H + 8) + sizeof(float) * (2048 * (size_t)RT + 3072 + 3 * 512 + (size_t)RT * ((Lk + 3) & ~3)) +
-         2 * 16 * 72;
+static size_t dec_attn_lds(int H, int Lk) {
+  return 2 * 16 * (size_t)(H + 8) + sizeof(float) * (3 * 8 * 256 + 3 * 1024 + 16 * (size_t)((Lk + 3) & ~3)) + 2 * 16 * 72;
 }
 
-template <int RT, bool SELF, int MAXC>
+template <bool SELF, int MAXC>
 static int launch_dec_attn(const DecAttnArgs& a, hipStream_t stream) {
-  const size_t lds = dec_attn_lds(RT, a.pro.H, a.Lk);
-  ZK_CHECK_ARG(lds <= 160 * 1024, "zk_dec_attn: %zu bytes of LDS needed (R=%d, H=%d, Lk=%d)", lds, a.R, a.pro.H, a.Lk);
-  auto kern = k_dec_attn<RT, SELF, MAXC>;
+  const size_t lds = dec_attn_lds(a.pro.H, a.Lk);
+  ZK_CHECK_ARG(lds <= 160 * 1024, "zk_dec_attn: %zu bytes of LDS needed (H=%d, Lk=%d)", lds, a.pro.H, a.Lk);
+  auto kern = k_dec_attn<SELF, MAXC>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return zk_set_error((int)e, "zk_dec_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * a.nh)), dim3(512), lds, stream, a);
+  const int groups = (a.B * a.R + a.gr - 1) / a.gr;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * a.nh)), dim3(512), lds, stream, a);
   ZK_LAUNCH_CHECK();
   return 0;
+}
+
+// Rows per workgroup.  More rows = fewer re-reads of the head's 128 KB of weights through the L2 -> CU path (32 MB per
+// launch at 4 rows, 32 sentences x 8 heads), fewer rows = more CUs sharing the row-wise work (LayerNorm prologue,
+// softmax).  zk_dec_group(n) overrides (n = 0: default) -- scripts/dec_attn_trace.py sweeps it.
+static int g_dec_group = 0;
+extern "C" int zk_dec_group(int n) {
+  const int old = g_dec_group;
+  if (n >= 0 && n <= 16) g_dec_group = n;
+  return old;
+}
+static int dec_group_rows(int R) {
+  if (g_dec_group > 0) return g_dec_group;
+  int g = R;                         // one sentence ...
+  while (g * 2 <= ZK_DEC_GROUP_DEFAULT) g *= 2;   // ... or as many whole sentences as fit the default
+  return g > 16 ? 16 : g;
 }
 
 template <bool SELF>
 static int dispatch_dec_attn(const DecAttnArgs& a, hipStream_t stream) {
   const int H = a.pro.H;
-#define ZK_DA(RT)                                                            \
-  return H <= 512 ? launch_dec_attn<RT, SELF, 1>(a, stream)                  \
-                  : H == 1024 ? launch_dec_attn<RT, SELF, 2>(a, stream) : launch_dec_attn<RT, SELF, 4>(a, stream)
-  if (a.R <= 4) ZK_DA(4);
-  ZK_DA(8);
-#undef ZK_DA
+  return H <= 512 ? launch_dec_attn<SELF, 1>(a, stream)
+                  : H == 1024 ? launch_dec_attn<SELF, 2>(a, stream) : launch_dec_attn<SELF, 4>(a, stream);
 }
 
 static int check_common(const char* who, const LnDecArgs& p, int B, int R, int nh, int Lk, int ldw, int ldwo, const void* wq,
                         const void* wo, const void* part) {
-  ZK_CHECK_ARG(B >= 0 && R >= 1 && R <= 8 && nh >= 1 && Lk >= 1, "%s: bad sizes B=%d R=%d nh=%d Lk=%d (R <= 8)", who, B, R,
-               nh, Lk);
+  ZK_CHECK_ARG(B >= 0 && R >= 1 && nh >= 1 && Lk >= 1, "%s: bad sizes B=%d R=%d nh=%d Lk=%d", who, B, R, nh, Lk);
   ZK_CHECK_ARG(p.H == nh * 64 && p.H >= 128 && p.H <= 2048 && (p.H & (p.H - 1)) == 0,
                "%s: H=%d must be nh * 64 and a power of two in 128 .. 2048", who, p.H);
   ZK_CHECK_ARG(ldw % 8 == 0 && ldwo % 8 == 0 && ldwo >= p.H, "%s: weight strides must be multiples of 8", who);
@@ -426,6 +443,7 @@ int zk_dec_cross(const void* x, void* ybuf, const float* gamma, const float* bet
   a.kmask = kmask; a.ldmask = ldmask;
   a.wot = (const bf16_t*)wot; a.ldwo = ldwo; a.part = out_parts;
   a.B = B; a.R = R; a.nh = nh; a.Lk = Lk; a.scale = scale; a.mask_inf = mask_inf;
+  a.gr = dec_group_rows(R);
   return dispatch_dec_attn<false>(a, stream);
 }
 
@@ -453,6 +471,7 @@ int zk_dec_self(const void* x, void* ybuf, const float* gamma, const float* beta
   a.wot = (const bf16_t*)wot; a.ldwo = ldwo; a.part = out_parts;
   a.B = B; a.R = R; a.nh = nh; a.Lk = Tmax; a.scale = scale; a.mask_inf = 0.f;
   a.time_dev = time_dev; a.time = time;
+  a.gr = dec_group_rows(R);
   return dispatch_dec_attn<true>(a, stream);
 }
 

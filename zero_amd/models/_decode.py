@@ -83,7 +83,7 @@ def _fuse_att_ok(core, hp, K):
     """The attention sub-layers of a cached decode step as one launch per (sentence, head) (zk_dec_cross / zk_dec_self)."""
     import os
     return (os.environ.get("ZERO_HIP_DECODE_FUSE_ATT", "1") != "0" and core.d == 64
-            and core.H in (128, 256, 512, 1024, 2048) and K <= 8 and not core.rpr and not core.fuse
+            and core.H in (128, 256, 512, 1024, 2048) and not core.rpr and not core.fuse
             and (not core.aan or os.environ.get("ZERO_HIP_DECODE_FUSE_LN", "1") != "0") and not hp.use_ffn)
 
 
