@@ -45,6 +45,12 @@ const char* zk_last_error_string(void);
  *   (aux>0)*aux_scale (ReLU+dropout backward through the saved activation).          */
 size_t zk_gemm_workspace(int M, int N, int K);
 size_t zk_gemm_workspace_split(int M, int N, int splits);
+/* Split-K product left as its partial sums (no epilogue, no reduction launch): part z = A[:, K_z] B[K_z, :] as fp32
+ * [M, N] at parts + z*M*N for the z-th of *nparts_out <= splits K ranges (multiples of 64).  The consumer adds them in the
+ * order z = 0, 1, .. : zk_ln_decode(parts, nparts, part_stride = M*N, bias) for the decode step's FFN output projection
+ * (func.py:327-338 ffn_layer "output" at 128 rows: 64 workgroups instead of 16). */
+int zk_gemm_parts(const void* A, const void* B, float* parts, int M, int N, int K, int lda, int ldb, int ta, int tb,
+                  int splits, int* nparts_out, zk_stream_t stream);
 int zk_gemm_plan(int M, int N, int K, int out_f32, int plain);  /* gen | (bm/8)<<8 | (bn/8)<<16 | splits<<24 | producer waves<<28 chosen by impl=0 */
 int zk_gemm_set_generation(int gen);   /* 1 = register-staged kernel, 2 = LDS-DMA ring kernel (default) */
 /* K-segmented GEMM: C bf16 [M, ldc] = sum_s A_s [M, kseg] x B_s (+ bf16 residual, may alias C) in ONE launch --
@@ -345,6 +351,15 @@ int zk_beam_dev_advance(int* ctrl, int* stepbuf, const float* pen_table, const f
                         float* scores, float* fin_scores, int* fin_flags, int* flat_idx, int* next_tok,
                         float* prev, int B, int K, int V, int Tcap, int Tmax, int eos_id, int pad_id,
                         zk_stream_t stream);
+/* zk_beam_topk on the step's logits (k2 = 2K, log-softmax, length penalty and EOS ban read from stepbuf[1..2]) followed by
+ * zk_beam_dev_advance, with the merge of the chunked top-k and the bookkeeping in ONE launch (both are one block per
+ * sentence; search.py:115-236).  Same results as the two calls.  Returns -2 with nothing launched when the shape needs
+ * the unchunked top-k: call the two entry points then.  workspace: zk_beam_topk_workspace(B, K, 2K). */
+int zk_beam_topk_advance(const float* logits, int ld, float temperature, float forbid_value, void* workspace,
+                         size_t ws_bytes, int* ctrl, int* stepbuf, const float* pen_table, const float* max_lp,
+                         const int* mtl_i, const float* topk_scores, const int* topk_idx, int* seq, int* fin_seq,
+                         float* log_probs, float* scores, float* fin_scores, int* fin_flags, int* flat_idx, int* next_tok,
+                         float* prev, int B, int K, int V, int Tcap, int Tmax, int eos_id, int pad_id, zk_stream_t stream);
 /* search.py:143-145 (enable_noise_beam_search): logits += Gumbel noise -log(-log(u + eps) + eps), util.py:189-195 */
 int zk_add_gumbel(float* logits, int rows, int V, int ld, float eps, const uint64_t* seed, uint32_t sid,
                   zk_stream_t stream);
@@ -396,6 +411,13 @@ int zk_dec_self(const void* x, void* ybuf, const float* gamma, const float* beta
                 int ldwo, float* out_parts, int B, int R, int nh, float scale, zk_stream_t stream);
 int zk_aan_decode(const void* x, float* cache, void* cat, int rows, int H, float inv_count, const int* time_dev,
                   zk_stream_t stream);
+/* Decoder input of one decode position in one launch (transformer.py:88-119; was zk_all_equal + zk_embed_fwd +
+ * zk_aan_decode): every fed id == pad_id (first step) -> zero embedding, else table[id] * scale + bias; + timing[pos];
+ * cache / cat != NULL: the first layer's average-attention update (transformer_aan.py:110-112).  *pos_dev overrides
+ * pos0 and inv_count (= 1 / (pos + 1)). */
+int zk_dec_embed(const int* ids, int pad_id, const void* table, const float* bias, const float* timing, void* out, int rows,
+                 int H, float scale, int pos0, const int* pos_dev, float* cache, void* cat, float inv_count,
+                 zk_stream_t stream);
 
 /* hipGraph plumbing: capture a sequence of the calls above once, replay per step */
 int zk_graph_begin(zk_stream_t stream);

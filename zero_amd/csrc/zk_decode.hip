@@ -192,13 +192,11 @@ __global__ void __launch_bounds__(256) k_beam_topk_chunks(const float* __restric
 }
 
 // merge of the chunked form: one block per sentence; thread t owns candidate t of the K*nchunks*k2 (<= 256)
-__global__ void __launch_bounds__(256) k_beam_topk_merge_chunks(const float* __restrict__ part_ms,
-                                                                const float* __restrict__ cand_key,
-                                                                const int* __restrict__ cand_v,
-                                                                const float* __restrict__ prev_lp,
-                                                                float* __restrict__ out_s, int* __restrict__ out_i,
-                                                                int K, int V, int k2, int nchunks, float penalty,
-                                                                const int* __restrict__ scal_dev) {
+__device__ __forceinline__ void beam_merge_chunks_block(const float* __restrict__ part_ms, const float* __restrict__ cand_key,
+                                                        const int* __restrict__ cand_v, const float* __restrict__ prev_lp,
+                                                        float* __restrict__ out_s, int* __restrict__ out_i, int K, int V,
+                                                        int k2, int nchunks, float penalty,
+                                                        const int* __restrict__ scal_dev) {
   __shared__ float ls[256][TOPK_MAX + 1];
   __shared__ int li[256][TOPK_MAX + 1];
   __shared__ float ws[4];
@@ -230,6 +228,15 @@ __global__ void __launch_bounds__(256) k_beam_topk_merge_chunks(const float* __r
     }
   }
   block_select(ls, li, cnt, k2, out_s + (size_t)b * k2, out_i + (size_t)b * k2, ws, wi, wt);
+}
+__global__ void __launch_bounds__(256) k_beam_topk_merge_chunks(const float* __restrict__ part_ms,
+                                                                const float* __restrict__ cand_key,
+                                                                const int* __restrict__ cand_v,
+                                                                const float* __restrict__ prev_lp,
+                                                                float* __restrict__ out_s, int* __restrict__ out_i,
+                                                                int K, int V, int k2, int nchunks, float penalty,
+                                                                const int* __restrict__ scal_dev) {
+  beam_merge_chunks_block(part_ms, cand_key, cand_v, prev_lp, out_s, out_i, K, V, k2, nchunks, penalty, scal_dev);
 }
 
 // stage 2: one block per sentence merges its K*k2 candidates (ties -> lower flat index)
@@ -313,6 +320,51 @@ __global__ void __launch_bounds__(256) k_aan_decode(const bf16_t* __restrict__ x
   for (int j = 0; j < 8; ++j) { const float s = cp[j] + v[j]; cp[j] = s; o[j] = s * inv_count; }
   *reinterpret_cast<uint4*>(cat + r * 2 * H + c) = xv;
   *reinterpret_cast<uint4*>(cat + r * 2 * H + H + c) = pack8(o);
+}
+
+// Input of the decoder at one decode position in ONE launch (was zk_all_equal + zk_embed_fwd + zk_aan_decode):
+// transformer.py:88-119 -- every fed id == pad (the first step) -> zero embedding, else table[id] * scale + bias; plus the
+// timing signal of the position; cache != NULL: the first layer's average-attention update from the row just written
+// (transformer_aan.py:110-112: cache += x; cat = [x | cache / (time + 1)]).  One wave per row; same arithmetic as the
+// separate kernels (x is rounded to bf16 before it enters the running sum, as when it went through memory).
+__global__ void __launch_bounds__(256) k_dec_embed(const int* __restrict__ ids, int pad_id, const bf16_t* __restrict__ table,
+                                                   const float* __restrict__ bias, const float* __restrict__ timing,
+                                                   bf16_t* __restrict__ out, int rows, int H, float scale, int pos0,
+                                                   const int* __restrict__ pos_dev, float* __restrict__ cache,
+                                                   bf16_t* __restrict__ cat, float inv_count) {
+  const int lane = threadIdx.x & 63;
+  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (r >= rows) return;
+  int differs = 0;
+  for (int i = lane; i < rows; i += 64) differs |= (ids[i] != pad_id);
+  const bool zero_all = !__any(differs);
+  if (pos_dev != nullptr) { pos0 = *pos_dev; inv_count = 1.f / (float)(pos0 + 1); }
+  const int id = zero_all ? -1 : ids[r];
+  const float* tim = timing + (size_t)pos0 * H;
+  for (int c = lane * 8; c < H; c += 64 * 8) {
+    float v[8];
+    if (id >= 0) {
+      unpack8(*reinterpret_cast<const uint4*>(table + (size_t)id * H + c), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v[j] * scale + bias[c + j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += tim[c + j];
+    const uint4 xv = pack8(v);
+    *reinterpret_cast<uint4*>(out + (size_t)r * H + c) = xv;
+    if (cache != nullptr) {
+      float o[8];
+      unpack8(xv, v);
+      float* cp = cache + (size_t)r * H + c;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float s = cp[j] + v[j]; cp[j] = s; o[j] = s * inv_count; }
+      *reinterpret_cast<uint4*>(cat + (size_t)r * 2 * H + c) = xv;
+      *reinterpret_cast<uint4*>(cat + (size_t)r * 2 * H + H + c) = pack8(o);
+    }
+  }
 }
 
 // transformer_fuse decode step (func.py:262-272): cache += vq;  att += cache / (time + 1)
@@ -473,6 +525,20 @@ int zk_ln_decode(const void* x, void* ybuf, const float* gamma, const float* bet
   return 0;
 }
 
+// ids int32 [rows] (the tokens fed at this position), table bf16 [V, H], bias fp32 [H], timing fp32 [>= pos + 1, H];
+// pos0 / inv_count are overridden by *pos_dev (then inv_count = 1 / (*pos_dev + 1)); cache / cat NULL: no AAN update.
+int zk_dec_embed(const int* ids, int pad_id, const void* table, const float* bias, const float* timing, void* out, int rows,
+                 int H, float scale, int pos0, const int* pos_dev, float* cache, void* cat, float inv_count,
+                 hipStream_t stream) {
+  ZK_CHECK_ARG(H % 8 == 0 && rows >= 0, "zk_dec_embed: H=%d must be a multiple of 8", H);
+  ZK_CHECK_ARG((cache == nullptr) == (cat == nullptr), "zk_dec_embed: cache and cat go together");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(k_dec_embed, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, ids, pad_id, (const bf16_t*)table,
+                     bias, timing, (bf16_t*)out, rows, H, scale, pos0, pos_dev, cache, (bf16_t*)cat, inv_count);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
 int zk_aan_decode(const void* x, float* cache, void* cat, int rows, int H, float inv_count, const int* time_dev,
                   hipStream_t stream) {
   ZK_CHECK_ARG(H % 8 == 0, "zk_aan_decode: H=%d must be a multiple of 8", H);
@@ -564,8 +630,7 @@ __device__ inline void dev_top_k(const float* x, int n, int k, int* idx) {
 // one block per sentence; dynamic LDS: 2 * K * Tcap ints (the sentence's alive and finished rows).
 // The candidate fields are loaded and derived by 2K threads in parallel and the per-beam results written by K
 // threads; only the two top-k selections (at most 16 of 48 values) run on one thread.
-__global__ void __launch_bounds__(128) k_beam_advance(BeamDev d) {
-  extern __shared__ int s_rows[];
+__device__ __forceinline__ void beam_advance_block(const BeamDev& d, int* s_rows) {
   __shared__ int s_beam[32], s_cur[32], s_cfin[32], s_aidx[16], s_fidx[16], s_allfl[48];
   __shared__ float s_masked[32], s_allsc[48];
   if (d.ctrl[1]) return;
@@ -630,6 +695,22 @@ __global__ void __launch_bounds__(128) k_beam_advance(BeamDev d) {
     else v = t < len ? l_seq[s_beam[j - K] * Tcap + t] : s_cur[j - K];
     fs[k * Tcap + t] = v;
   }
+}
+__global__ void __launch_bounds__(128) k_beam_advance(BeamDev d) {
+  extern __shared__ int s_rows[];
+  beam_advance_block(d, s_rows);
+}
+// merge of the chunked top-k + the bookkeeping of the step in one launch (one block per sentence both ways)
+__global__ void __launch_bounds__(256) k_beam_merge_advance(const float* __restrict__ part_ms,
+                                                            const float* __restrict__ cand_key,
+                                                            const int* __restrict__ cand_v, int k2, int nchunks,
+                                                            BeamDev d) {
+  extern __shared__ int s_rows[];
+  beam_merge_chunks_block(part_ms, cand_key, cand_v, d.prev, const_cast<float*>(d.topk_scores),
+                          const_cast<int*>(d.topk_idx), d.K, d.V, k2, nchunks, 1.f, d.stepbuf + 1);
+  __threadfence_block();
+  __syncthreads();
+  beam_advance_block(d, s_rows);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -774,6 +855,35 @@ int zk_beam_dev_prepare(ZK_BEAM_DEV_ARGS, hipStream_t stream) {
   BeamDev d;
   if (int rc = beam_dev_fill(&d, ZK_BEAM_DEV_PASS)) return rc;
   hipLaunchKernelGGL(k_beam_prepare, dim3(1), dim3(256), 0, stream, d);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+// zk_beam_topk (k2 = 2K candidates per sentence from the logits, log-softmax + length penalty / EOS ban read from
+// stepbuf[1..2]) followed by zk_beam_dev_advance, with the merge of the chunked top-k and the bookkeeping in ONE launch
+// (both are one block per sentence).  Same results as the two calls.  Returns -2 (nothing launched) when the shape needs
+// the unchunked top-k: call the two entry points then.
+int zk_beam_topk_advance(const float* logits, int ld, float temperature, float forbid_value, void* workspace,
+                         size_t ws_bytes, ZK_BEAM_DEV_ARGS, hipStream_t stream) {
+  BeamDev d;
+  if (int rc = beam_dev_fill(&d, ZK_BEAM_DEV_PASS)) return rc;
+  const int k2 = 2 * K;
+  ZK_CHECK_ARG(k2 <= TOPK_MAX, "zk_beam_topk_advance: K=%d too large", K);
+  ZK_CHECK_ARG(ws_bytes >= zk_beam_topk_workspace(B, K, k2), "zk_beam_topk_advance: workspace too small");
+  const int nc = topk_chunks(K, V, k2);
+  if (nc <= 0) return -2;
+  const int chunk = ((V + nc - 1) / nc + 3) & ~3;
+  float* part = (float*)workspace;
+  float* ck = part + (size_t)B * K * nc * 2;
+  int* cv = (int*)(ck + (size_t)B * K * nc * k2);
+  if (chunk <= 4096)
+    hipLaunchKernelGGL(k_beam_topk_chunks<4>, dim3(B * K, nc), dim3(256), 0, stream, logits, part, ck, cv, V, ld, k2, chunk,
+                       nc, 1.f / temperature, -1, forbid_value, (const int*)(stepbuf + 1));
+  else
+    hipLaunchKernelGGL(k_beam_topk_chunks<8>, dim3(B * K, nc), dim3(256), 0, stream, logits, part, ck, cv, V, ld, k2, chunk,
+                       nc, 1.f / temperature, -1, forbid_value, (const int*)(stepbuf + 1));
+  ZK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_beam_merge_advance, dim3(B), dim3(256), (size_t)2 * K * Tcap * sizeof(int), stream,
+                     (const float*)part, (const float*)ck, (const int*)cv, k2, nc, d);
   ZK_LAUNCH_CHECK();
   return 0;
 }

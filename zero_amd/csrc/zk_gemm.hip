@@ -405,4 +405,34 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
   return 0;
 }
 
+// Split-K product left as its partial sums: parts[z] (fp32 [M, N] each, z < splits, part z at parts + z*M*N) =
+// A[:, K_z] B[K_z, :] over the z-th K range; no epilogue and no reduction launch -- the consumer adds them in the
+// fixed order z = 0, 1, .. (zk_ln_decode with parts / nparts / part_stride = M*N and the bias).  For products with few
+// rows and a long K (the decode step's FFN output projection: 128 x 512 x 2048 is 16 tiles of 64 x 64 -- 16 of 256
+// CUs streaming 512 KB each; with splits = 4 it is 64 workgroups of 128 KB).  Returns the number of parts written (the
+// K ranges are multiples of 64, so it can be smaller than `splits`), or < 0 / a hipError_t as a negative-free error.
+int zk_gemm_parts(const void* A, const void* B, float* parts, int M, int N, int K, int lda, int ldb, int ta, int tb,
+                  int splits, int* nparts_out, hipStream_t stream) {
+  ZK_CHECK_ARG(M >= 0 && N >= 0 && K >= 1 && splits >= 1 && splits <= 64, "zk_gemm_parts: bad sizes");
+  ZK_CHECK_ARG(parts != nullptr && nparts_out != nullptr, "zk_gemm_parts: parts and nparts_out are required");
+  ZK_CHECK_ARG(mfma_ok(A, B, M, N, K, lda, ldb, ta, tb), "zk_gemm_parts: shape/alignment not supported by the MFMA kernel "
+               "(M=%d N=%d K=%d lda=%d ldb=%d ta=%d tb=%d)", M, N, K, lda, ldb, ta, tb);
+  ZK_CHECK_ARG(!zk_prog_active(), "zk_gemm_parts cannot be part of a layer program");
+  int kchunk = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+  const int n = (K + kchunk - 1) / kchunk;
+  *nparts_out = n;
+  if (M == 0 || N == 0) return 0;
+  GemmEpi e;
+  e.C = nullptr; e.ldc = N; e.out_f32 = 1; e.alpha = 1.f; e.bias = nullptr; e.res = nullptr; e.ldr = 0; e.act = 0;
+  e.aux = nullptr; e.ldaux = 0; e.aux_scale = 1.f; e.thr = 0; e.inv_keep = 1.f; e.seed = nullptr; e.sid = 0;
+  // the slab path of the tile kernels writes part z only when there is more than one; a single part is a plain product
+  if (n == 1) {
+    e.C = parts;
+    return zk_gemm_dlds_dispatch((const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, ta, tb, 64, 64, 1, K, nullptr, e, 0,
+                                 stream);
+  }
+  return zk_gemm_dlds_dispatch((const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, ta, tb, 64, 64, n, kchunk, parts, e, 0,
+                               stream);
+}
+
 }  // extern "C"

@@ -87,6 +87,11 @@ def _fuse_att_ok(core, hp, K):
             and (not core.aan or os.environ.get("ZERO_HIP_DECODE_FUSE_LN", "1") != "0") and not hp.use_ffn)
 
 
+def _fuse_tail():
+    import os
+    return os.environ.get("ZERO_HIP_DECODE_FUSE_TAIL", "1") != "0"
+
+
 def _transposed(core, name):
     """bf16 copy of a projection weight with the input dimension contiguous (row = output channel): the operand layout of
     the fused decode kernels' matrix-core fragments.  Refreshed per encoded batch (the weights may have been trained on)."""
@@ -228,10 +233,22 @@ def make_infer_fns(params, model_name):
                 e.lib.call("zk_add_gumbel", logits.ptr, state["BK"], core.V, logits.ld, float(zdtype.epsilon()),
                            e.seed.data_ptr(), 7001, e.stream)
                 e.lib.call("zk_seed_advance", e.seed.data_ptr(), 1, e.stream)
-            e.beam_topk(logits, state["prev"], state["ts"], state["ti"], state["B"], state["K"], core.V,
-                        2 * state["K"], temperature, 1.0, -1, forbid_value, scal_dev=sb[1:3])
-            if book is not None:
-                e.lib.call("zk_beam_dev_advance", *book, e.stream)
+            fused_tail = False
+            if book is not None and _fuse_tail():
+                # merge of the chunked top-2K and the alive / finished bookkeeping in one launch
+                ws = e.workspace(e.lib.query("zk_beam_topk_workspace", state["B"], state["K"], 2 * state["K"]))
+                e.lib.ncalls += 1
+                rc = e.lib.raw("zk_beam_topk_advance")(logits.ptr, logits.ld, float(temperature), float(forbid_value),
+                                                       ws.data_ptr(), ws.numel(), *book, e.stream)
+                if rc not in (0, -2):
+                    e.lib.call("zk_beam_topk_advance", logits.ptr, logits.ld, float(temperature), float(forbid_value),
+                               ws.data_ptr(), ws.numel(), *book, e.stream)      # raises with the library's message
+                fused_tail = rc == 0
+            if not fused_tail:
+                e.beam_topk(logits, state["prev"], state["ts"], state["ti"], state["B"], state["K"], core.V,
+                            2 * state["K"], temperature, 1.0, -1, forbid_value, scal_dev=sb[1:3])
+                if book is not None:
+                    e.lib.call("zk_beam_dev_advance", *book, e.stream)
         if g is None and core.__dict__.get("_decode_warm_rows", 0) >= state["BK"]:
             # A batch of at least this many beam rows has already been decoded on this engine, so the step's
             # scratch buffers exist: capture straight away instead of spending an eager pass first.  If the
@@ -269,8 +286,11 @@ def make_infer_fns(params, model_name):
         BK, K, B, Ls, Tmax = state["BK"], state["K"], state["B"], state["Ls"], state["Tmax"]
         if time_dev is None and time >= Tmax:
             raise RuntimeError("decode step %d exceeds the allocated cache length %d" % (time, Tmax))
+        import os as _os
         zf = state["zero_flag"]
-        e.lib.call("zk_all_equal", target.data_ptr(), BK, hp.tgt_vocab.pad(), zf.data_ptr(), e.stream)
+        fuse_head = _os.environ.get("ZERO_HIP_DECODE_FUSE_HEAD", "1") != "0"
+        if not fuse_head:
+            e.lib.call("zk_all_equal", target.data_ptr(), BK, hp.tgt_vocab.pad(), zf.data_ptr(), e.stream)
         import os as _os
         fuse_ln = core.aan and _os.environ.get("ZERO_HIP_DECODE_FUSE_LN", "1") != "0"
         # an attention sub-layer (projection, attention, the head's share of the output projection) as ONE launch per
@@ -316,10 +336,36 @@ def make_infer_fns(params, model_name):
                        None, None, parts.data_ptr(), nh, BK * H, core.b(p + "o_map/b_0").data_ptr(), None, None, 1.0,
                        None, e.stream)
             return out
+        ffn_split = int(_os.environ.get("ZERO_HIP_DECODE_FFN_SPLIT", "4")) if fuse_att else 0
+
+        def ffn_parts(x_in, f, l):
+            """feed-forward sub-layer up to the output projection, left as split-K partial products (zk_gemm_parts: 64
+            workgroups instead of 16 on 128 rows); the LayerNorm that follows adds them and the bias.  Returns the
+            arguments of the row-local LayerNorm form (ln_args / zk_ln_decode)."""
+            import ctypes
+            hh = e.mat("dc%d.ff.h" % l, BK, core.F)
+            core._linear(x_in, f + "/ffn_layer/enlarge", hh, act=1)
+            W2 = core.W(f + "/ffn_layer/output/W_0_0")
+            parts = e.buf("dc.ff.parts.%d" % (l & 1), (ffn_split, BK, H), F32)
+            n = ctypes.c_int(0)
+            e.lib.call("zk_gemm_parts", hh.ptr, W2.ptr, parts.data_ptr(), BK, H, core.F, hh.ld, W2.ld, 0, 0, ffn_split,
+                       ctypes.byref(n), e.stream)
+            return dict(x=x_in.ptr, parts=parts.data_ptr(), nparts=n.value, stride=BK * H,
+                        bias=core.b(f + "/ffn_layer/output/b_0").data_ptr(), **ln_scope(f))
         pend = None          # base model: the feed-forward LayerNorm of the previous layer, left to the next prologue
         x = e.mat("dc.x", BK, H)
-        e.embed_fwd(target, core.store.s(core.tgt_emb), core.b("bias"), x, BK, 1, H,
-                    pos0=0 if time_dev is not None else time, zero_flag=zf, pos0_dev=time_dev, max_pos=Tmax)
+        if fuse_head:
+            # all-pad test + embedding + timing (+ the first layer's average-attention update) in one launch
+            lay0 = state["decoder"]["state"]["layer_0"]
+            aan0 = core.aan
+            e.lib.call("zk_dec_embed", target.data_ptr(), hp.tgt_vocab.pad(), core.store.s(core.tgt_emb).data_ptr(),
+                       core.b("bias").data_ptr(), e.timing(Tmax + 1, H).data_ptr(), x.ptr, BK, H, float(H) ** 0.5,
+                       0 if time_dev is not None else time, time_dev.data_ptr() if time_dev is not None else None,
+                       lay0["aan"].data_ptr() if aan0 else None, e.mat("dc.cat", BK, 2 * H).ptr if aan0 else None,
+                       1.0 if time_dev is not None else 1.0 / float(time + 1), e.stream)
+        else:
+            e.embed_fwd(target, core.store.s(core.tgt_emb), core.b("bias"), x, BK, 1, H,
+                        pos0=0 if time_dev is not None else time, zero_flag=zf, pos0_dev=time_dev, max_pos=Tmax)
         for l in range(hp.num_decoder_layer):
             pre = "decoder/layer_%d" % l
             lay = state["decoder"]["state"]["layer_%d" % l]
@@ -328,7 +374,8 @@ def make_infer_fns(params, model_name):
                 cat = e.mat("dc.cat", BK, 2 * H)
                 inv = 1.0 if time_dev is not None else 1.0 / float(time + 1)
                 tdev = time_dev.data_ptr() if time_dev is not None else None
-                if not (fuse_ln and l > 0 and not hp.use_ffn):      # else the previous layer's last LayerNorm did it
+                if not (fuse_ln and l > 0 and not hp.use_ffn) and not (fuse_head and l == 0):
+                    # else the previous layer's last LayerNorm (or the input launch) did it
                     e.lib.call("zk_aan_decode", x.ptr, lay["aan"].data_ptr(), cat.ptr, BK, H, inv, tdev, e.stream)
                 if hp.use_ffn:           # transformer_aan.py:176-183
                     ya = e.mat("dc.ya", BK, H)
@@ -399,30 +446,42 @@ def make_infer_fns(params, model_name):
             if fuse_att and not core.aan:
                 # feed-forward sub-layer; its residual + LayerNorm is the prologue of the next layer's self-attention
                 f = pre + "/feed_forward"
-                hh = e.mat("dc%d.ff.h" % l, BK, core.F)
-                core._linear(x, f + "/ffn_layer/enlarge", hh, act=1)
-                y = e.mat("dc%d.ff.y" % (l & 1), BK, H)
-                core._linear(hh, f + "/ffn_layer/output", y)
-                if nxt is not None:
-                    xo = e.mat("dc%d.ff.o" % l, BK, H)
-                    pend = dict(x=x.ptr, ybuf=y.ptr, out=xo.ptr, xmat=xo, **ln_scope(f))
+                xo = e.mat("dc%d.ff.o" % l, BK, H)
+                if ffn_split > 1:
+                    la = ffn_parts(x, f, l)
                 else:
-                    x = core._ln_fwd(x, y, f, "dc%d.ff" % l, False, 0.0, 0)
+                    hh = e.mat("dc%d.ff.h" % l, BK, core.F)
+                    core._linear(x, f + "/ffn_layer/enlarge", hh, act=1)
+                    y = e.mat("dc%d.ff.y" % (l & 1), BK, H)
+                    core._linear(hh, f + "/ffn_layer/output", y)
+                    la = dict(x=x.ptr, ybuf=y.ptr, **ln_scope(f))
+                la.update(out=xo.ptr, xmat=xo)
+                if nxt is not None:
+                    pend = la
+                else:
+                    e.lib.call("zk_ln_decode", *ln_args(la)[:5], BK, *ln_args(la)[5:], e.stream)
+                    x = xo
                 continue
-            if fuse_ln and core.aan and nxt is not None and not hp.use_ffn:
+            if fuse_ln and core.aan and not hp.use_ffn and (nxt is not None or ffn_split > 1):
                 # feed-forward sub-layer whose LayerNorm also prepares the next layer's average attention
                 # (cache += x; cat = [x | cache / (time + 1)]) in the same launch
                 f = pre + "/feed_forward"
-                hh = e.mat("dc%d.ff.h" % l, BK, core.F)
-                core._linear(x, f + "/ffn_layer/enlarge", hh, act=1)
-                y = e.mat("dc.y", BK, H)
-                core._linear(hh, f + "/ffn_layer/output", y)
                 xo = e.mat("dc%d.ff.o" % l, BK, H)
-                e.lib.call("zk_ln_decode", x.ptr, y.ptr, core.b(f + "/layer_norm/scale").data_ptr(),
-                           core.b(f + "/layer_norm/offset").data_ptr(), xo.ptr, BK, H, zdtype.epsilon(), None, None,
-                           None, 0, 0, None, nxt["aan"].data_ptr(), e.mat("dc.cat", BK, 2 * H).ptr,
+                if ffn_split > 1:
+                    la = ffn_parts(x, f, l)
+                else:
+                    hh = e.mat("dc%d.ff.h" % l, BK, core.F)
+                    core._linear(x, f + "/ffn_layer/enlarge", hh, act=1)
+                    y = e.mat("dc.y", BK, H)
+                    core._linear(hh, f + "/ffn_layer/output", y)
+                    la = dict(x=x.ptr, ybuf=y.ptr, **ln_scope(f))
+                g = lambda k: la.get(k)
+                e.lib.call("zk_ln_decode", la["x"], g("ybuf"), la["gamma"], la["beta"], xo.ptr, BK, H, eps, None, None,
+                           g("parts"), g("nparts") or 0, g("stride") or 0, g("bias"),
+                           nxt["aan"].data_ptr() if nxt is not None else None,
+                           e.mat("dc.cat", BK, 2 * H).ptr if nxt is not None else None,
                            1.0 if time_dev is not None else 1.0 / float(time + 1),
-                           time_dev.data_ptr() if time_dev is not None else None, e.stream)
+                           (time_dev.data_ptr() if time_dev is not None else None) if nxt is not None else None, e.stream)
                 x = xo
             else:
                 x = core._ffn_fwd(x, pre + "/feed_forward", "dc%d.ff" % l, False, 0, False)
