@@ -846,7 +846,9 @@ def test_attention_rpr_mfma_forward_long_keys_and_dropout():
     assert errs["out"] < 1.5e-2 and max(errs[k] for k in ("dq", "dk", "dv", "drk", "drv")) < 3e-2, errs
 
 
-@pytest.mark.parametrize("T,V,H,ls", [(70, 300, 64, 0.1), (256, 1000, 128, 0.0), (130, 129, 64, 0.1), (5, 11, 16, 0.1)])
+@pytest.mark.parametrize("T,V,H,ls", [(70, 300, 64, 0.1), (256, 1000, 128, 0.0), (130, 129, 64, 0.1), (5, 11, 16, 0.1),
+                                      # the 256 x 256-tile kernels (T >= 256, V >= 1024): ragged T, V, Vpad > V, K tail
+                                      (700, 3001, 512, 0.1), (256, 1024, 64, 0.0), (1025, 5000, 200, 0.1)])
 def test_logits_ce_fused_matches_gemm_plus_ce(T, V, H, ls):
     """zk_logits_ce_fwd / _bwd against torch: ce, lse and w*(softmax - soft labels)."""
     e = eng()

@@ -1220,7 +1220,7 @@ size_t zk_add_ln_bwd_workspace(int rows, int H) {
   return (size_t)g * 3 * H * sizeof(float);
 }
 
-int g_tune[8] = {1, 0, 0, 0, 0, 0, 0x44, 0};   // [0] wide LayerNorm backward kernel; [1] GEMM: legacy split-K rule (A/B)
+int g_tune[12] = {1, 0, 0, 0, 0, 0, 0x44, 0, 0, 0, 0, 0};   // [0] wide LayerNorm backward kernel; [1] GEMM: legacy split-K rule (A/B)
 static int ln_bwd_blocks(int rows) {
   int g = (rows + 15) / 16;
   if (g > 256) g = 256;
@@ -1230,7 +1230,7 @@ static int ln_bwd_blocks(int rows) {
 
 // tuning switches for A/B measurements (key 0: wide LayerNorm-backward kernel); returns the old value
 int zk_tune(int key, int value) {
-  if (key < 0 || key >= 8) return -1;
+  if (key < 0 || key >= 12) return -1;
   const int old = g_tune[key];
   g_tune[key] = value;
   return old;

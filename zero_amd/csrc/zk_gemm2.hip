@@ -91,34 +91,19 @@ __global__ void __launch_bounds__((4 + PW) * 64) k_gemm_grouped(const GroupDesc*
 // stages of 64 KiB.  The tile leaves straight from the accumulators (a 32x32 MFMA tile stores two full 128-byte
 // lines per instruction for fp32) -- the fp32 tile would not fit in LDS.  fp32 output only, no epilogue options.
 // =====================================================================================
+// accumulators of one 256x256 tile: acc[i][j][e] = element (row m0 + wm*128 + i*32 + (e&3) + 8*(e>>2) + 4*(lane>>5),
+// column n0 + wn*64 + j*32 + (lane&31)) with wave = wm * 4 + wn.  smem: the 128 KiB ring (free again on return, after a
+// barrier by the caller).
 template <bool TA, bool TB, bool SPREAD>
-__global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __restrict__ descs, int nprob) {
+__device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                            int lda, int ldb, int M, int N, int K, int m0, int n0, f32x16_t (&acc)[4][2]) {
   constexpr int BM = 256, BN = 256, NS = 2, NW = 8, NWN = 4, WTM = 128, WTN = 64, TM = 4, TN = 2;
   constexpr int STAGE = (BM + BN) * 64;
-  constexpr int PER_STAGE = (BM * 8 / NW + BN * 8 / NW) / 64;   // 8 LDS-DMA instructions per wave per stage
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE * 2];   // the ONLY LDS object (128 KiB)
-  const int nb = gridDim.x, bid = blockIdx.x;
-  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
-  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  int p = 0;
-  {   // the last problem whose first tile is <= t: binary search (a linear scan is one dependent global load per
-      // problem -- 6 us before the first K tile with the 49 problems of a weight-gradient group)
-    int hi = nprob - 1;
-    while (p < hi) {
-      const int mid = (p + hi + 1) >> 1;
-      if (descs[mid].tile_start <= t) p = mid; else hi = mid - 1;
-    }
-  }
-  const GroupDesc d = descs[p];
-  const int local = t - d.tile_start;
-  const int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN, M = d.M, N = d.N, K = d.K;
   bf16_t* ring = reinterpret_cast<bf16_t*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
   const int nk = (K + 63) >> 6;
-  f32x16_t acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -127,10 +112,10 @@ __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __rest
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   DmaPlan<BM, NW> planA;
   DmaPlan<BN, NW> planB;
-  dma_plan<BM, TA, NW>(planA, d.A, d.lda, m0, M, 0, wave, lane);
-  dma_plan<BN, !TB, NW>(planB, d.B, d.ldb, n0, N, 0, wave, lane);
-  const size_t stepA = TA ? (size_t)64 * d.lda : (size_t)64;
-  const size_t stepB = !TB ? (size_t)64 * d.ldb : (size_t)64;
+  dma_plan<BM, TA, NW>(planA, A, lda, m0, M, 0, wave, lane);
+  dma_plan<BN, !TB, NW>(planB, B, ldb, n0, N, 0, wave, lane);
+  const size_t stepA = TA ? (size_t)64 * lda : (size_t)64;
+  const size_t stepB = !TB ? (size_t)64 * ldb : (size_t)64;
   const uint32_t ring_addr = lds_addr(ring);
   // LDS-DMA of K tile t, pieces [j0, j1) of this wave's 4 + 4
   auto issue_part = [&](int tt, int j0, int j1) {
@@ -184,6 +169,34 @@ __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __rest
     __builtin_amdgcn_sched_barrier(0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (all-zero) pieces
+}
+
+template <bool TA, bool TB, bool SPREAD>
+__global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __restrict__ descs, int nprob) {
+  constexpr int BM = 256, BN = 256, NS = 2, NWN = 4, WTM = 128, WTN = 64, TM = 4, TN = 2;
+  constexpr int STAGE = (BM + BN) * 64;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE * 2];   // the ONLY LDS object (128 KiB)
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  int p = 0;
+  {   // the last problem whose first tile is <= t: binary search (a linear scan is one dependent global load per
+      // problem -- 6 us before the first K tile with the 49 problems of a weight-gradient group)
+    int hi = nprob - 1;
+    while (p < hi) {
+      const int mid = (p + hi + 1) >> 1;
+      if (descs[mid].tile_start <= t) p = mid; else hi = mid - 1;
+    }
+  }
+  const GroupDesc d = descs[p];
+  const int local = t - d.tile_start;
+  const int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN, M = d.M, N = d.N;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  f32x16_t acc[TM][TN];
+  gemm256_acc<TA, TB, SPREAD>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc);
   float* C = reinterpret_cast<float*>(d.C);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -288,6 +301,146 @@ __global__ void __launch_bounds__(256) k_ce_combine(const float4* __restrict__ p
     if (v.x > -INFINITY) se += v.y * __expf(v.x - m);
     sz += v.z;
     zg += v.w;
+  }
+  se = wave_sum(se); sz = wave_sum(sz); zg = wave_sum(zg);
+  if (lane == 0) {
+    const float lse = m + __logf(se);
+    if (lse_out != nullptr) lse_out[row] = lse;
+    if (ce != nullptr) ce[row] = lse - p * zg - q * (sz - zg) - normalizer;
+  }
+}
+
+// ---- the same on 256x256 tiles (gemm256_acc: ~1.0 PF on these shapes against ~0.6 for the 128x128 tile above)
+// forward: the TRANSPOSED product Z^T = E . feat^T, so that a token is a COLUMN of the tile: its 64 vocabulary entries of a
+// wave sit in one lane's accumulator registers (rows spread over e, i) and max / sum exp / sum z are in-lane VALU work --
+// with tokens as rows every row statistic is a 32-lane reduction per accumulator register.  z_gold is left to the
+// combine kernel (one K-length dot product per token).  part[T][tiles_v] = {max, sum exp, sum z, 0}.
+__global__ void __launch_bounds__(512) k_logits_ce256_fwd(const bf16_t* __restrict__ feat, const bf16_t* __restrict__ E,
+                                                          int T, int K, int ldf, int lde, int tiles_t, CeEpi c) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 512 * 64 * 2];
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  const int tv = t / tiles_t, tt = t - tv * tiles_t;       // an XCD walks the token tiles of one vocabulary panel
+  const int m0 = tv * 256, n0 = tt * 256;                  // rows: vocabulary, columns: tokens
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  f32x16_t acc[4][2];
+  gemm256_acc<false, true, true>(smem, E, feat, lde, ldf, c.V, T, K, m0, n0, acc);
+  __syncthreads();                                         // the ring is free
+  float* sStat = reinterpret_cast<float*>(smem);           // [2 wm][256 tokens][4]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int vrow = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (vrow < c.V) m = fmaxf(m, acc[i][j][e]);
+      }
+    float se = 0.f, sz = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int vrow = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (vrow < c.V) { se += __expf(acc[i][j][e] - m); sz += acc[i][j][e]; }
+      }
+    // the other half of the token's rows lives in lane ^ 32
+    const float m2 = __shfl_xor(m, 32, 64), se2 = __shfl_xor(se, 32, 64), sz2 = __shfl_xor(sz, 32, 64);
+    const float mm = fmaxf(m, m2);
+    float tot = 0.f;
+    if (m > -INFINITY) tot += se * __expf(m - mm);
+    if (m2 > -INFINITY) tot += se2 * __expf(m2 - mm);
+    if (lane < 32) {
+      float4* d = reinterpret_cast<float4*>(sStat + ((size_t)(wm * 256 + wn * 64 + j * 32 + lane)) * 4);
+      *d = make_float4(mm, tot, sz + sz2, 0.f);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int tok = n0 + threadIdx.x;
+    if (tok < T) {
+      const float4 a = *reinterpret_cast<const float4*>(sStat + (size_t)threadIdx.x * 4);
+      const float4 b = *reinterpret_cast<const float4*>(sStat + (size_t)(256 + threadIdx.x) * 4);
+      const float mm = fmaxf(a.x, b.x);
+      float tot = 0.f;
+      if (a.x > -INFINITY) tot += a.y * __expf(a.x - mm);
+      if (b.x > -INFINITY) tot += b.y * __expf(b.x - mm);
+      c.part[(size_t)tok * c.tiles_n + tv] = make_float4(mm, tot, a.z + b.z, 0.f);
+    }
+  }
+}
+
+// backward: tokens as rows (the dlogits rows are vocabulary-contiguous: a half-wave stores 64 contiguous bytes); the per-row
+// scalars wait in LDS
+__global__ void __launch_bounds__(512) k_logits_ce256_bwd(const bf16_t* __restrict__ feat, const bf16_t* __restrict__ E,
+                                                          int T, int K, int ldf, int lde, int tiles_m, CeEpi c) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 512 * 64 * 2];
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  const int tn = t / tiles_m, tm = t - tn * tiles_m;       // an XCD walks the token tiles of one vocabulary panel
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  f32x16_t acc[4][2];
+  gemm256_acc<false, true, true>(smem, feat, E, ldf, lde, T, c.V, K, m0, n0, acc);
+  __syncthreads();
+  float* sL = reinterpret_cast<float*>(smem);
+  float* sW = sL + 256;
+  int* sG = reinterpret_cast<int*>(sW + 256);
+  if (threadIdx.x < 256) {
+    const int gm = min(m0 + (int)threadIdx.x, T - 1);
+    sL[threadIdx.x] = c.lse[gm]; sW[threadIdx.x] = c.w[gm]; sG[threadIdx.x] = c.ids[gm];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rl = wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      const int gm = m0 + rl;
+      const float lse = sL[rl], wr = sW[rl];
+      const int gold = sG[rl];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        const float v = col < c.V ? wr * (__expf(acc[i][j][e] - lse) - (col == gold ? c.p : c.q)) : 0.f;
+        if (gm < T && col < c.ldd) c.dlogits[(size_t)gm * c.ldd + col] = f2bf(v);
+      }
+    }
+}
+
+// z_gold of the 256-tile forward: one wave per token, feat[t] . E[gold[t]] (bf16 products, fp32 sum)
+__global__ void __launch_bounds__(256) k_ce_combine_gold(const float4* __restrict__ part, int T, int tiles_n, float p,
+                                                         float q, float normalizer, float* __restrict__ ce,
+                                                         float* __restrict__ lse_out, const bf16_t* __restrict__ feat,
+                                                         const bf16_t* __restrict__ E, const int* __restrict__ ids, int K,
+                                                         int ldf, int lde) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T) return;
+  const int gold = ids[row];
+  float zg = 0.f;
+  for (int c0 = lane * 8; c0 < K; c0 += 512) {
+    float a[8], b[8];
+    unpack8(*reinterpret_cast<const uint4*>(feat + (size_t)row * ldf + c0), a);
+    unpack8(*reinterpret_cast<const uint4*>(E + (size_t)gold * lde + c0), b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zg += a[j] * b[j];
+  }
+  float m = -INFINITY;
+  for (int t = lane; t < tiles_n; t += 64) m = fmaxf(m, part[(size_t)row * tiles_n + t].x);
+  m = wave_max(m);
+  float se = 0.f, sz = 0.f;
+  for (int t = lane; t < tiles_n; t += 64) {
+    const float4 v = part[(size_t)row * tiles_n + t];
+    if (v.x > -INFINITY) se += v.y * __expf(v.x - m);
+    sz += v.z;
   }
   se = wave_sum(se); sz = wave_sum(sz); zg = wave_sum(zg);
   if (lane == 0) {
@@ -417,6 +570,8 @@ static void ce_smoothing(int V, float label_smooth, float* p, float* q, float* n
     *normalizer = -(*p * logf(*p) + n * *q * logf(*q + 1e-20f));
   }
 }
+// 256x256 tiles when the problem fills them (tuning key 8 = 1: always the 128x128 kernels)
+static bool ce_use_256(int T, int V, int K) { return g_tune[8] != 1 && T >= 256 && V >= 1024 && K % 8 == 0; }
 size_t zk_logits_ce_workspace(int T, int V) { return (size_t)T * ((V + 127) / 128) * sizeof(float4); }
 
 // feat bf16 [T, K] (ldf), E bf16 [>= V rows, K] (lde; the softmax embedding), ids int32 [T].
@@ -432,6 +587,17 @@ int zk_logits_ce_fwd(const void* feat, const void* E, const int* ids, float* ce,
   c.V = V; c.ldd = 0; c.tiles_n = (V + 127) / 128;
   float normalizer;
   ce_smoothing(V, label_smooth, &c.p, &c.q, &normalizer);
+  if (ce_use_256(T, V, K)) {
+    c.tiles_n = (V + 255) / 256;
+    const int tiles_t = (T + 255) / 256;
+    hipLaunchKernelGGL(k_logits_ce256_fwd, dim3((unsigned)((long)c.tiles_n * tiles_t)), dim3(512), 0, stream,
+                       (const bf16_t*)feat, (const bf16_t*)E, T, K, ldf, lde, tiles_t, c);
+    ZK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ce_combine_gold, dim3((T + 3) / 4), dim3(256), 0, stream, (const float4*)workspace, T, c.tiles_n,
+                       c.p, c.q, normalizer, ce, lse, (const bf16_t*)feat, (const bf16_t*)E, ids, K, ldf, lde);
+    ZK_LAUNCH_CHECK();
+    return 0;
+  }
   TileSched ts;
   ts.tiles_m = (T + 127) / 128; ts.tiles_n = c.tiles_n; ts.n_major = 1; ts.xcd_remap = 1;
   hipLaunchKernelGGL(k_logits_ce<1>, dim3((unsigned)((long)ts.tiles_m * ts.tiles_n)), dim3(256), 0, stream,
@@ -456,6 +622,14 @@ int zk_logits_ce_bwd(const void* feat, const void* E, const int* ids, const floa
   c.V = V; c.ldd = ldd; c.tiles_n = (ldd + 127) / 128;
   float normalizer;
   ce_smoothing(V, label_smooth, &c.p, &c.q, &normalizer);
+  if (ce_use_256(T, V, K)) {
+    c.tiles_n = (ldd + 255) / 256;
+    const int tiles_m = (T + 255) / 256;
+    hipLaunchKernelGGL(k_logits_ce256_bwd, dim3((unsigned)((long)c.tiles_n * tiles_m)), dim3(512), 0, stream,
+                       (const bf16_t*)feat, (const bf16_t*)E, T, K, ldf, lde, tiles_m, c);
+    ZK_LAUNCH_CHECK();
+    return 0;
+  }
   TileSched ts;
   ts.tiles_m = (T + 127) / 128; ts.tiles_n = c.tiles_n; ts.n_major = 1; ts.xcd_remap = 1;
   hipLaunchKernelGGL(k_logits_ce<2>, dim3((unsigned)((long)ts.tiles_m * ts.tiles_n)), dim3(256), 0, stream,
