@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 OUT=${1:-profiles/r02_asan_host.log}
 B=/tmp/zk_asan; rm -rf $B; mkdir -p $B
 HIPCC=/opt/rocm/bin/hipcc
-for f in zk_elem zk_gemm zk_gemm2 zk_attn zk_decode zk_probe zk_comm zk_layer; do
+for f in zk_elem zk_gemm zk_gemm2 zk_attn zk_decode zk_probe zk_comm zk_layer zk_decfuse; do
   $HIPCC --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-value -Xarch_host -fsanitize=address \
      -Xarch_host -fno-omit-frame-pointer -c zero_amd/csrc/$f.hip -o $B/$f.o || exit 1 &
 done
