@@ -205,24 +205,35 @@ __device__ __forceinline__ void beam_merge_chunks_block(const float* __restrict_
   __shared__ float lse[TOPK_MAX];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (scal_dev != nullptr) penalty = __int_as_float(scal_dev[0]);
+  // every global load of the block is requested up front (nchunks <= 8: a rolled loop over the chunk partials is one
+  // dependent round trip per chunk)
+  const int per_row = nchunks * k2, n = K * per_row;
+  const int ck = min(tid, n - 1) / per_row;
+  const size_t co = (size_t)(b * K + ck) * per_row + (min(tid, n - 1) - ck * per_row);
+  const int cv_r = cand_v[co];
+  const float ckey_r = cand_key[co], cprev_r = prev_lp[b * K + ck];
   if (tid < K) {
-    const float* pm = part_ms + ((size_t)(b * K + tid) * nchunks) * 2;
+    const float2* pm = reinterpret_cast<const float2*>(part_ms + ((size_t)(b * K + tid) * nchunks) * 2);
+    float2 pv[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) pv[c] = pm[min(c, nchunks - 1)];
     float m = -INFINITY;
-    for (int c = 0; c < nchunks; ++c) m = fmaxf(m, pm[2 * c]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < nchunks) m = fmaxf(m, pv[c].x);
     float s = 0.f;
-    for (int c = 0; c < nchunks; ++c)
-      if (pm[2 * c] > -INFINITY) s += pm[2 * c + 1] * __expf(pm[2 * c] - m);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < nchunks && pv[c].x > -INFINITY) s += pv[c].y * __expf(pv[c].x - m);
     lse[tid] = m + __logf(s);
   }
   __syncthreads();
-  const int per_row = nchunks * k2, n = K * per_row;
   int cnt = 0;
   if (tid < n) {
-    const int k = tid / per_row;
-    const size_t o = (size_t)(b * K + k) * per_row + (tid - k * per_row);
-    const int v = cand_v[o];
+    const int k = ck;
+    const int v = cv_r;
     if (v != 0x7fffffff) {
-      ls[tid][0] = (prev_lp[b * K + k] + (cand_key[o] - lse[k])) / penalty;
+      ls[tid][0] = (cprev_r + (ckey_r - lse[k])) / penalty;
       li[tid][0] = k * V + v;
       cnt = 1;
     }
@@ -630,7 +641,22 @@ __device__ inline void dev_top_k(const float* x, int n, int k, int* idx) {
 // one block per sentence; dynamic LDS: 2 * K * Tcap ints (the sentence's alive and finished rows).
 // The candidate fields are loaded and derived by 2K threads in parallel and the per-beam results written by K
 // threads; only the two top-k selections (at most 16 of 48 values) run on one thread.
-__device__ __forceinline__ void beam_advance_block(const BeamDev& d, int* s_rows) {
+// the alive / finished sequences of the sentence -> LDS (does not depend on this step's candidates: the fused launch
+// requests them before the top-k merge)
+__device__ __forceinline__ void beam_advance_stage(const BeamDev& d, int* s_rows) {
+  const int b = blockIdx.x, K = d.K, Tcap = d.Tcap, tid = threadIdx.x;
+  const int len = d.stepbuf[0] + 1;
+  const int* sq = d.seq + (size_t)b * K * Tcap;
+  const int* fs = d.fin_seq + (size_t)b * K * Tcap;
+  int* l_seq = s_rows;
+  int* l_fin = s_rows + K * Tcap;
+  for (int i = tid; i < K * len; i += blockDim.x) {
+    const int k = i / len, t = i - k * len;
+    l_seq[k * Tcap + t] = sq[k * Tcap + t];
+    l_fin[k * Tcap + t] = fs[k * Tcap + t];
+  }
+}
+__device__ __forceinline__ void beam_advance_block(const BeamDev& d, int* s_rows, bool staged) {
   __shared__ int s_beam[32], s_cur[32], s_cfin[32], s_aidx[16], s_fidx[16], s_allfl[48];
   __shared__ float s_masked[32], s_allsc[48];
   if (d.ctrl[1]) return;
@@ -653,11 +679,7 @@ __device__ __forceinline__ void beam_advance_block(const BeamDev& d, int* s_rows
     s_allsc[tid - 64] = d.fin_scores[b * K + tid - 64];
     s_allfl[tid - 64] = d.fin_flags[b * K + tid - 64];
   }
-  for (int i = tid; i < K * len; i += blockDim.x) {
-    const int k = i / len, t = i - k * len;
-    l_seq[k * Tcap + t] = sq[k * Tcap + t];
-    l_fin[k * Tcap + t] = fs[k * Tcap + t];
-  }
+  if (!staged) beam_advance_stage(d, s_rows);
   __syncthreads();
   if (tid == 0) {                                          // alive (search.py:192-210)
     float x[32]; int idx[16];
@@ -698,7 +720,7 @@ __device__ __forceinline__ void beam_advance_block(const BeamDev& d, int* s_rows
 }
 __global__ void __launch_bounds__(128) k_beam_advance(BeamDev d) {
   extern __shared__ int s_rows[];
-  beam_advance_block(d, s_rows);
+  beam_advance_block(d, s_rows, false);
 }
 // merge of the chunked top-k + the bookkeeping of the step in one launch (one block per sentence both ways)
 __global__ void __launch_bounds__(256) k_beam_merge_advance(const float* __restrict__ part_ms,
@@ -706,11 +728,12 @@ __global__ void __launch_bounds__(256) k_beam_merge_advance(const float* __restr
                                                             const int* __restrict__ cand_v, int k2, int nchunks,
                                                             BeamDev d) {
   extern __shared__ int s_rows[];
+  beam_advance_stage(d, s_rows);
   beam_merge_chunks_block(part_ms, cand_key, cand_v, d.prev, const_cast<float*>(d.topk_scores),
                           const_cast<int*>(d.topk_idx), d.K, d.V, k2, nchunks, 1.f, d.stepbuf + 1);
   __threadfence_block();
   __syncthreads();
-  beam_advance_block(d, s_rows);
+  beam_advance_block(d, s_rows, true);
 }
 
 // ---------------------------------------------------------------------------------------------
