@@ -414,10 +414,12 @@ int zk_aan_decode(const void* x, float* cache, void* cat, int rows, int H, float
 /* Decoder input of one decode position in one launch (transformer.py:88-119; was zk_all_equal + zk_embed_fwd +
  * zk_aan_decode): every fed id == pad_id (first step) -> zero embedding, else table[id] * scale + bias; + timing[pos];
  * cache / cat != NULL: the first layer's average-attention update (transformer_aan.py:110-112).  *pos_dev overrides
- * pos0 and inv_count (= 1 / (pos + 1)). */
+ * pos0 and inv_count (= 1 / (pos + 1)).
+ * gather_src != NULL: the beam reorder of the running sums of all nl layers rides along (search.py:206-209):
+ * cache [nl, rows, H] <- gather_src[l][gather_idx[r]] (+ the new row for layer 0). */
 int zk_dec_embed(const int* ids, int pad_id, const void* table, const float* bias, const float* timing, void* out, int rows,
                  int H, float scale, int pos0, const int* pos_dev, float* cache, void* cat, float inv_count,
-                 zk_stream_t stream);
+                 const float* gather_src, const int* gather_idx, int nl, zk_stream_t stream);
 
 /* hipGraph plumbing: capture a sequence of the calls above once, replay per step */
 int zk_graph_begin(zk_stream_t stream);

@@ -401,10 +401,12 @@ static int check_common(const char* who, const LnDecArgs& p, int B, int R, int n
   ZK_CHECK_ARG((((uintptr_t)p.x | (uintptr_t)wq | (uintptr_t)wo | (uintptr_t)part) & 15) == 0, "%s: 16-byte alignment", who);
   if (p.gamma != nullptr) {
     ZK_CHECK_ARG(p.beta && p.out && (p.ybuf || p.z || p.parts), "%s: the LayerNorm prologue needs beta, xout and y", who);
-    ZK_CHECK_ARG((p.z == nullptr) == (p.cat_in == nullptr) && (p.cache == nullptr) == (p.cat_out == nullptr),
-                 "%s: z / cat_in and cache / cat_out go together", who);
-    ZK_CHECK_ARG(p.parts == nullptr || (p.z == nullptr && p.nparts >= 1 && p.part_stride >= (long)B * R * p.H),
-                 "%s: partial sums exclude the gate and need nparts >= 1, part_stride >= rows * H", who);
+    ZK_CHECK_ARG((p.cat_in != nullptr || p.z == nullptr) && (p.cat_in == nullptr || p.z != nullptr || p.parts != nullptr) &&
+                 (p.cache == nullptr) == (p.cat_out == nullptr),
+                 "%s: the gate needs cat_in and z (or its partial sums); cache / cat_out go together", who);
+    ZK_CHECK_ARG(p.parts == nullptr ||
+                 (p.z == nullptr && p.nparts >= 1 && p.part_stride >= (long)B * R * p.H * (p.cat_in ? 2 : 1)),
+                 "%s: partial sums exclude z and need nparts >= 1, part_stride >= rows * H (2H for the gate)", who);
   }
   return 0;
 }

@@ -342,10 +342,22 @@ __global__ void __launch_bounds__(256) k_dec_embed(const int* __restrict__ ids, 
                                                    const float* __restrict__ bias, const float* __restrict__ timing,
                                                    bf16_t* __restrict__ out, int rows, int H, float scale, int pos0,
                                                    const int* __restrict__ pos_dev, float* __restrict__ cache,
-                                                   bf16_t* __restrict__ cat, float inv_count) {
+                                                   bf16_t* __restrict__ cat, float inv_count,
+                                                   const float* __restrict__ gsrc, const int* __restrict__ gidx, int nl) {
   const int lane = threadIdx.x & 63;
   const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (r >= rows) return;
+  // beam reorder of the running sums of every layer (search.py:206-209): cache[l][r] <- gsrc[l][gidx[r]]; layer 0's row
+  // is updated below
+  const int parent = gsrc != nullptr ? gidx[r] : r;
+  if (blockIdx.y > 0) {                       // grid.y = nl: the rows of layers 1 .. nl-1 are plain copies
+    const int l = blockIdx.y;
+    for (int c = lane * 4; c < H; c += 256)
+      *reinterpret_cast<float4*>(cache + ((size_t)l * rows + r) * H + c) =
+          *reinterpret_cast<const float4*>(gsrc + ((size_t)l * rows + parent) * H + c);
+    return;
+  }
+  const float* cin = gsrc != nullptr ? gsrc + (size_t)parent * H : cache + (size_t)r * H;
   int differs = 0;
   for (int i = lane; i < rows; i += 64) differs |= (ids[i] != pad_id);
   const bool zero_all = !__any(differs);
@@ -371,7 +383,7 @@ __global__ void __launch_bounds__(256) k_dec_embed(const int* __restrict__ ids, 
       unpack8(xv, v);
       float* cp = cache + (size_t)r * H + c;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float s = cp[j] + v[j]; cp[j] = s; o[j] = s * inv_count; }
+      for (int j = 0; j < 8; ++j) { const float s = cin[c + j] + v[j]; cp[j] = s; o[j] = s * inv_count; }
       *reinterpret_cast<uint4*>(cat + (size_t)r * 2 * H + c) = xv;
       *reinterpret_cast<uint4*>(cat + (size_t)r * 2 * H + H + c) = pack8(o);
     }
@@ -521,10 +533,11 @@ int zk_ln_decode(const void* x, void* ybuf, const float* gamma, const float* bet
                  const void* z, const void* cat_in, const float* parts, int nparts, long part_stride, const float* bias,
                  float* cache, void* cat_out, float inv_count, const int* time_dev, hipStream_t stream) {
   ZK_CHECK_ARG(H % 8 == 0 && H <= 2048, "zk_ln_decode: H=%d must be a multiple of 8 and <= 2048", H);
-  ZK_CHECK_ARG((z == nullptr) == (cat_in == nullptr) && (cache == nullptr) == (cat_out == nullptr),
-               "zk_ln_decode: z / cat_in and cache / cat_out go together");
-  ZK_CHECK_ARG(parts == nullptr || (z == nullptr && nparts >= 1 && part_stride >= (long)rows * H),
-               "zk_ln_decode: partial sums exclude the gate and need nparts >= 1, part_stride >= rows * H");
+  ZK_CHECK_ARG((cat_in != nullptr || z == nullptr) && (cat_in == nullptr || z != nullptr || parts != nullptr) &&
+               (cache == nullptr) == (cat_out == nullptr),
+               "zk_ln_decode: the gate needs cat_in and z (or its partial sums); cache / cat_out go together");
+  ZK_CHECK_ARG(parts == nullptr || (z == nullptr && nparts >= 1 && part_stride >= (long)rows * H * (cat_in ? 2 : 1)),
+               "zk_ln_decode: partial sums exclude z and need nparts >= 1, part_stride >= rows * H (2H for the gate)");
   if (rows == 0) return 0;
   const dim3 grid((unsigned)((rows + 3) / 4));
   LnDecArgs a{(const bf16_t*)x, (bf16_t*)ybuf, gamma, beta, (bf16_t*)out, rows, H, eps, (const bf16_t*)z,
@@ -538,14 +551,20 @@ int zk_ln_decode(const void* x, void* ybuf, const float* gamma, const float* bet
 
 // ids int32 [rows] (the tokens fed at this position), table bf16 [V, H], bias fp32 [H], timing fp32 [>= pos + 1, H];
 // pos0 / inv_count are overridden by *pos_dev (then inv_count = 1 / (*pos_dev + 1)); cache / cat NULL: no AAN update.
+// gather_src != NULL: the running sums of all nl layers ([nl, rows, H] fp32, `cache` = the destination of the same shape)
+// are reordered in the same launch: cache[l][r] = gather_src[l][gather_idx[r]] (+ x for layer 0).
 int zk_dec_embed(const int* ids, int pad_id, const void* table, const float* bias, const float* timing, void* out, int rows,
                  int H, float scale, int pos0, const int* pos_dev, float* cache, void* cat, float inv_count,
-                 hipStream_t stream) {
+                 const float* gather_src, const int* gather_idx, int nl, hipStream_t stream) {
   ZK_CHECK_ARG(H % 8 == 0 && rows >= 0, "zk_dec_embed: H=%d must be a multiple of 8", H);
   ZK_CHECK_ARG((cache == nullptr) == (cat == nullptr), "zk_dec_embed: cache and cat go together");
+  ZK_CHECK_ARG(gather_src == nullptr || (cache != nullptr && gather_idx != nullptr && nl >= 1 && gather_src != cache),
+               "zk_dec_embed: the reorder needs cache, an index and a source distinct from the destination");
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(k_dec_embed, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, ids, pad_id, (const bf16_t*)table,
-                     bias, timing, (bf16_t*)out, rows, H, scale, pos0, pos_dev, cache, (bf16_t*)cat, inv_count);
+  hipLaunchKernelGGL(k_dec_embed, dim3((unsigned)((rows + 3) / 4), gather_src != nullptr ? nl : 1), dim3(256), 0, stream, ids,
+                     pad_id, (const bf16_t*)table,
+                     bias, timing, (bf16_t*)out, rows, H, scale, pos0, pos_dev, cache, (bf16_t*)cat, inv_count, gather_src,
+                     gather_idx, nl);
   ZK_LAUNCH_CHECK();
   return 0;
 }

@@ -3,7 +3,9 @@
 // prologue of the fused decode attention (zk_decfuse.hip: every workgroup of a sentence recomputes its rows).
 //   y of the sub-layer is one of
 //     ybuf                              (bf16 [rows, H], read)
-//     gate(z, cat_in)   z != NULL       bf16(sigmoid(z_i) x_cat + sigmoid(z_f) y_cat) (k_aan_gate_fwd)
+//     gate(z, cat_in)   cat_in != NULL  bf16(sigmoid(z_i) x_cat + sigmoid(z_f) y_cat) (k_aan_gate_fwd); z bf16 [rows, 2H],
+//                                       or z == NULL: z = bf16(sum_p parts[p][r][0 .. 2H) + bias) (the z_project GEMM
+//                                       left as split-K partial products)
 //     sum of partials   parts != NULL   bf16(sum_p parts[p][r][:] + bias) (the o_map / FFN output projection left as
 //                                       per-head / per-slice fp32 partial products by the producer)
 //   out = LayerNorm(x + y);
@@ -68,11 +70,46 @@ __device__ __forceinline__ void ln_decode_rows(const LnDecArgs& a, int r0, int r
             cv[n][i][4 * q] = c4.x; cv[n][i][4 * q + 1] = c4.y; cv[n][i][4 * q + 2] = c4.z; cv[n][i][4 * q + 3] = c4.w;
           }
         }
-        if (a.z != nullptr) {
-          ya[n][i] = *reinterpret_cast<const uint4*>(a.z + (size_t)r * 2 * H + c);
-          yb[n][i] = *reinterpret_cast<const uint4*>(a.z + (size_t)r * 2 * H + H + c);
+        if (a.cat_in != nullptr) {
           yc[n][i] = *reinterpret_cast<const uint4*>(a.cat_in + (size_t)r * 2 * H + c);
           yd[n][i] = *reinterpret_cast<const uint4*>(a.cat_in + (size_t)r * 2 * H + H + c);
+          if (a.z != nullptr) {
+            ya[n][i] = *reinterpret_cast<const uint4*>(a.z + (size_t)r * 2 * H + c);
+            yb[n][i] = *reinterpret_cast<const uint4*>(a.z + (size_t)r * 2 * H + H + c);
+          } else {
+            // the gate's pre-activation z [rows, 2H] as split-K partial products (zk_gemm_parts) + bias, rounded to
+            // bf16 as the GEMM epilogue would have stored it
+            float zi[8], zf[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { zi[j] = 0.f; zf[j] = 0.f; }
+            const float* pp = a.parts + (size_t)r * 2 * H + c;
+            for (int p0 = 0; p0 < a.nparts; p0 += 4) {
+              float4 u[4][4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float* pq = pp + (size_t)min(p0 + q, a.nparts - 1) * a.part_stride;
+                u[q][0] = *reinterpret_cast<const float4*>(pq);
+                u[q][1] = *reinterpret_cast<const float4*>(pq + 4);
+                u[q][2] = *reinterpret_cast<const float4*>(pq + H);
+                u[q][3] = *reinterpret_cast<const float4*>(pq + H + 4);
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                if (p0 + q < a.nparts) {
+                  zi[0] += u[q][0].x; zi[1] += u[q][0].y; zi[2] += u[q][0].z; zi[3] += u[q][0].w;
+                  zi[4] += u[q][1].x; zi[5] += u[q][1].y; zi[6] += u[q][1].z; zi[7] += u[q][1].w;
+                  zf[0] += u[q][2].x; zf[1] += u[q][2].y; zf[2] += u[q][2].z; zf[3] += u[q][2].w;
+                  zf[4] += u[q][3].x; zf[5] += u[q][3].y; zf[6] += u[q][3].z; zf[7] += u[q][3].w;
+                }
+              }
+            }
+            if (a.bias != nullptr) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { zi[j] += a.bias[c + j]; zf[j] += a.bias[H + c + j]; }
+            }
+            ya[n][i] = pack8(zi);
+            yb[n][i] = pack8(zf);
+          }
         } else if (a.parts != nullptr) {
           float ps[8];
 #pragma unroll
@@ -121,7 +158,7 @@ __device__ __forceinline__ void ln_decode_rows(const LnDecArgs& a, int r0, int r
       const int c = (i * 64 + lane) * 8;
       if (c < H) {
         float xa[8], y[8];
-        if (a.z != nullptr) {
+        if (a.cat_in != nullptr) {
           float zi[8], zf[8], xv[8], yv[8], o[8];
           unpack8(ya[n][i], zi);
           unpack8(yb[n][i], zf);

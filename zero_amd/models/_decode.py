@@ -36,7 +36,7 @@ F32 = torch.float32
 class DecodeState(dict):
     """Nested-dict state with the cache plumbing the search needs."""
 
-    def reorder(self, index_dev, time_dev=None):
+    def reorder(self, index_dev, time_dev=None, defer_aan=False):
         """Gather every per-beam cache by flat beam index [B*K] (device int32).  time_dev: the
         number of filled cache slots lives in device memory (hipGraph replay).  The caches of all
         layers are slabs of one buffer, so each kind (aan / k / v) is ONE launch."""
@@ -49,8 +49,12 @@ class DecodeState(dict):
         if "aan" in lay0:
             src = e.buf("dc.aan.%d" % pp, (nl, BK, H), F32)
             dst = e.buf("dc.aan.%d" % (1 - pp), (nl, BK, H), F32)
-            e.lib.call("zk_gather_rows_ex", src.data_ptr(), H * 4, index_dev.data_ptr(), dst.data_ptr(), H * 4,
-                       nl * BK, H * 4, BK, e.stream)
+            if defer_aan:
+                # the decoder-input launch of the step does it (zk_dec_embed: gather_src / gather_idx)
+                self["_aan_gather"] = (src, index_dev)
+            else:
+                e.lib.call("zk_gather_rows_ex", src.data_ptr(), H * 4, index_dev.data_ptr(), dst.data_ptr(), H * 4,
+                           nl * BK, H * 4, BK, e.stream)
         if "k" in lay0:
             Tmax = self["Tmax"]
             for nm in ("k", "v"):
@@ -227,7 +231,10 @@ def make_infer_fns(params, model_name):
             sb = state["stepbuf"]
             if book is not None:
                 e.lib.call("zk_beam_dev_prepare", *book, e.stream)
-            state.reorder(state["idx"], time_dev=sb[0:1])
+            import os
+            state.reorder(state["idx"], time_dev=sb[0:1],
+                          defer_aan=core.aan and os.environ.get("ZERO_HIP_DECODE_FUSE_HEAD", "1") != "0"
+                          and os.environ.get("ZERO_HIP_DECODE_FUSE_GATHER", "1") != "0")
             logits, _ = _step_cache(state["tok"], state, None, time_dev=sb[0:1])
             if hp.enable_noise_beam_search:      # search.py:143-145; a fresh stream position every step
                 e.lib.call("zk_add_gumbel", logits.ptr, state["BK"], core.V, logits.ld, float(zdtype.epsilon()),
@@ -358,11 +365,14 @@ def make_infer_fns(params, model_name):
             # all-pad test + embedding + timing (+ the first layer's average-attention update) in one launch
             lay0 = state["decoder"]["state"]["layer_0"]
             aan0 = core.aan
+            gat = state.pop("_aan_gather", None)       # the beam reorder of the running sums, deferred to this launch
             e.lib.call("zk_dec_embed", target.data_ptr(), hp.tgt_vocab.pad(), core.store.s(core.tgt_emb).data_ptr(),
                        core.b("bias").data_ptr(), e.timing(Tmax + 1, H).data_ptr(), x.ptr, BK, H, float(H) ** 0.5,
                        0 if time_dev is not None else time, time_dev.data_ptr() if time_dev is not None else None,
                        lay0["aan"].data_ptr() if aan0 else None, e.mat("dc.cat", BK, 2 * H).ptr if aan0 else None,
-                       1.0 if time_dev is not None else 1.0 / float(time + 1), e.stream)
+                       1.0 if time_dev is not None else 1.0 / float(time + 1),
+                       gat[0].data_ptr() if gat else None, gat[1].data_ptr() if gat else None,
+                       hp.num_decoder_layer if gat else 0, e.stream)
         else:
             e.embed_fwd(target, core.store.s(core.tgt_emb), core.b("bias"), x, BK, 1, H,
                         pos0=0 if time_dev is not None else time, zero_flag=zf, pos0_dev=time_dev, max_pos=Tmax)
@@ -384,12 +394,24 @@ def make_infer_fns(params, model_name):
                     core._linear(ya, a + "/ffn_layer/enlarge", hh, act=1)
                     core._linear(hh, a + "/ffn_layer/output", cat.cols_slice(H, 2 * H))
                 z = e.mat("dc.z", BK, 2 * H)
-                core._linear(cat, a + "/z_project", z)
+                gate_split = int(_os.environ.get("ZERO_HIP_DECODE_GATE_SPLIT", "1")) if fuse_att else 0
+                if gate_split <= 1:
+                    core._linear(cat, a + "/z_project", z)
                 g = e.mat("dc.y", BK, H)
                 if fuse_att:
                     # gate + residual + LayerNorm ride as the prologue of the encoder-decoder attention launch
                     xo = e.mat("dc%d.aa.o" % l, BK, H)
                     pend = dict(x=x.ptr, ybuf=g.ptr, out=xo.ptr, z=z.ptr, cat=cat.ptr, **ln_scope(a))
+                    if gate_split > 1:
+                        # z_project (K = 2H) as split-K partial products, summed (+ bias) by the prologue
+                        import ctypes
+                        Wz = core.W(a + "/z_project/W_0_0")
+                        zp = e.buf("dc.z.parts", (gate_split, BK, 2 * H), F32)
+                        n = ctypes.c_int(0)
+                        e.lib.call("zk_gemm_parts", cat.ptr, Wz.ptr, zp.data_ptr(), BK, 2 * H, 2 * H, cat.ld, Wz.ld, 0, 0,
+                                   gate_split, ctypes.byref(n), e.stream)
+                        pend.update(z=None, parts=zp.data_ptr(), nparts=n.value, stride=BK * 2 * H,
+                                    bias=core.b(a + "/z_project/b_0").data_ptr())
                     x = xo
                 elif fuse_ln:
                     # gate + residual + LayerNorm in one launch (zk_ln_decode)
