@@ -23,3 +23,22 @@ for _ in range(20): run()
 t.record(); torch.cuda.synchronize()
 us = s.elapsed_time(t) / 20 * 1e3
 print("zk_adam: %.1f us  -> %.2f TB/s (30 B/param)" % (us, n * 30 / us / 1e6))
+
+# the single-pass norm-free update of the training step (zk_adam_step), float4 per thread and round = tuning key 9
+ws2 = torch.empty(e.lib.query("zk_adam_step_workspace"), dtype=torch.uint8, device="cuda")
+seed = torch.zeros(1, dtype=torch.int64, device="cuda")
+def run2():
+    e.lib.call("zk_adam_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr(), n, hyper.data_ptr(),
+               pn.data_ptr(), seed.data_ptr(), 1, ws2.data_ptr(), ws2.numel(), e.stream)
+for u, gb in ((0, 0), (1, 0), (2, 0), (4, 0), (2, 1024), (4, 1024), (4, 512), (2, 512), (1, 1024), (0, 0), (1, 0)):
+    e.lib.raw("zk_tune")(9, u)
+    e.lib.raw("zk_tune")(10, gb)
+    for _ in range(3): run2()
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(20): run2()
+    t.record(); torch.cuda.synchronize()
+    us = s.elapsed_time(t) / 20 * 1e3
+    print("zk_adam_step order/unroll=%d blocks=%d: %.1f us  -> %.2f TB/s (30 B/param)" % (u, gb or 2048, us, n * 30 / us / 1e6))
+e.lib.raw("zk_tune")(9, 0)
+e.lib.raw("zk_tune")(10, 0)

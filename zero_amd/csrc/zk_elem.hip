@@ -553,7 +553,7 @@ __global__ void __launch_bounds__(256) k_ce_fused(
 // Same computation with the whole row held in registers (V <= NV*4096): one HBM read of the
 // logits row, no second pass -- 1024 threads (16 waves) per row.
 template <int NV>
-__global__ void __launch_bounds__(1024) k_ce_fused_reg(
+__global__ void __launch_bounds__(1024, 8) k_ce_fused_reg(
     const float* __restrict__ logits, const int* __restrict__ ids, const float* __restrict__ w,
     float* __restrict__ ce_out, bf16_t* __restrict__ dlogits, int V, int ld, float p, float q,
     float normalizer) {
@@ -999,7 +999,7 @@ __global__ void __launch_bounds__(256) k_norm_final(const float* __restrict__ pa
 //              of a pass of its own over the 308 MB.  The update is applied whatever the norm turns out to be --
 //              exactly what the reference does without safe_nan (train_op and the norm are fetched together).
 // seed (may be NULL): the per-step dropout seed is advanced here (one launch fewer per step).
-template <bool GSQ>
+template <bool GSQ, int U = 1, bool CONTIG = false>
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g,
                                               float* __restrict__ m, float* __restrict__ v,
                                               bf16_t* __restrict__ shadow, size_t n,
@@ -1022,26 +1022,48 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
     if (clip > 0.f) f *= clip / fmaxf(gnorm, clip);  // tf.clip_by_global_norm
   }
   const size_t n4 = n / 4;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    float4 pp = reinterpret_cast<float4*>(p)[i];
-    pacc += pp.x * pp.x + pp.y * pp.y + pp.z * pp.z + pp.w * pp.w;
-    const float4 gg = reinterpret_cast<const float4*>(g)[i];
-    float4 mm = reinterpret_cast<float4*>(m)[i];
-    float4 vv = reinterpret_cast<float4*>(v)[i];
-    float* P = &pp.x; const float* G = &gg.x; float* M = &mm.x; float* Vv = &vv.x;
+  // U float4 per thread and round, all 4 U loads requested before the first use (tuning key 9 selects U)
+  // CONTIG: every block streams ONE contiguous range of each array (fewer open DRAM pages than the grid-stride order)
+  const bool contig = CONTIG;
+  constexpr int UU = U;
+  const size_t per_block = ((n4 + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+  const size_t stride = contig ? 256 : (size_t)gridDim.x * 256;
+  const size_t ibeg = contig ? (size_t)blockIdx.x * per_block + threadIdx.x : (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t iend = contig ? min(n4, (size_t)(blockIdx.x + 1) * per_block) : n4;
+  for (size_t i0 = ibeg; i0 < iend; i0 += UU * stride) {
+    float4 pp[UU], gg[UU], mm[UU], vv[UU];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float gj = G[j] * f;
-      if (GSQ) gacc += gj * gj;
-      M[j] = b1 * M[j] + (1.f - b1) * gj;
-      Vv[j] = b2 * Vv[j] + (1.f - b2) * gj * gj;
-      P[j] -= lr * M[j] / (sqrtf(Vv[j]) + eps);
+    for (int u = 0; u < UU; ++u) {
+      const size_t i = i0 + u * stride;
+      if (i < iend) {
+        pp[u] = reinterpret_cast<float4*>(p)[i];
+        const zk_f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const zk_f32x4*>(g) + i);   // read once
+        gg[u] = make_float4(t4.x, t4.y, t4.z, t4.w);
+        mm[u] = reinterpret_cast<float4*>(m)[i];
+        vv[u] = reinterpret_cast<float4*>(v)[i];
+      }
     }
-    reinterpret_cast<float4*>(p)[i] = pp;
-    reinterpret_cast<float4*>(m)[i] = mm;
-    reinterpret_cast<float4*>(v)[i] = vv;
-    if (shadow != nullptr)
-      reinterpret_cast<uint2*>(shadow)[i] = make_uint2(pack2bf(P[0], P[1]), pack2bf(P[2], P[3]));
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+      const size_t i = i0 + u * stride;
+      if (i < iend) {
+        pacc += pp[u].x * pp[u].x + pp[u].y * pp[u].y + pp[u].z * pp[u].z + pp[u].w * pp[u].w;
+        float* P = &pp[u].x; const float* G = &gg[u].x; float* M = &mm[u].x; float* Vv = &vv[u].x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float gj = G[j] * f;
+          if (GSQ) gacc += gj * gj;
+          M[j] = b1 * M[j] + (1.f - b1) * gj;
+          Vv[j] = b2 * Vv[j] + (1.f - b2) * gj * gj;
+          P[j] -= lr * M[j] / (sqrtf(Vv[j]) + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp[u];
+        reinterpret_cast<float4*>(m)[i] = mm[u];
+        reinterpret_cast<float4*>(v)[i] = vv[u];
+        if (shadow != nullptr)
+          reinterpret_cast<uint2*>(shadow)[i] = make_uint2(pack2bf(P[0], P[1]), pack2bf(P[2], P[3]));
+      }
+    }
   }
   for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float gj = g[i] * f;
@@ -1220,7 +1242,7 @@ size_t zk_add_ln_bwd_workspace(int rows, int H) {
   return (size_t)g * 3 * H * sizeof(float);
 }
 
-int g_tune[12] = {1, 0, 0, 0, 0, 0, 0x44, 0, 0, 0, 0, 0};   // [0] wide LayerNorm backward kernel; [1] GEMM: legacy split-K rule (A/B)
+int g_tune[12] = {1, 0, 0, 0, 0, 0, 0x44, 0, 0, 2, 512, 0};   // [0] wide LayerNorm backward kernel; [1] GEMM: legacy split-K rule (A/B)
 static int ln_bwd_blocks(int rows) {
   int g = (rows + 15) / 16;
   if (g > 256) g = 256;
@@ -1541,9 +1563,18 @@ int zk_adam_step(float* p, const float* g, float* m, float* v, void* shadow, siz
   float* psq = (float*)workspace;
   float* gsq = psq + 2048;
   if (norm_free) {
-    hipLaunchKernelGGL(k_adam<true>, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n, hyper, psq, gsq, seed);
+    // tuning key 9: 0 grid-stride, 1 / 2 / 4 contiguous range per block with that many float4 per thread and round
+    // (default 2); tuning key 10: blocks (default 512; 0 = 2048).  scripts/adam_bench.py: 405 -> 391 us on one box
+    // (fewer open DRAM pages); the box-to-box spread of this pass is larger than that (405 .. 477 us)
+    const int gb = g_tune[10] > 0 && g_tune[10] <= 2048 ? (grid < g_tune[10] ? grid : g_tune[10]) : grid;
+#define ZK_ADAM_L(...) hipLaunchKernelGGL((k_adam<__VA_ARGS__>), dim3(gb), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n, hyper, psq, gsq, seed)
+    if (g_tune[9] == 1) ZK_ADAM_L(true, 1, true);
+    else if (g_tune[9] == 2) ZK_ADAM_L(true, 2, true);
+    else if (g_tune[9] == 4) ZK_ADAM_L(true, 4, true);
+    else ZK_ADAM_L(true, 1, false);
+#undef ZK_ADAM_L
     ZK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_norm_final2, dim3(1), dim3(256), 0, stream, (const float*)psq, (const float*)gsq, grid, hyper,
+    hipLaunchKernelGGL(k_norm_final2, dim3(1), dim3(256), 0, stream, (const float*)psq, (const float*)gsq, gb, hyper,
                        pnorm_out);
   } else {
     hipLaunchKernelGGL(k_adam<false>, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n, hyper, psq,
