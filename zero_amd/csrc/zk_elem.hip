@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(1024) k_add_ln_bwd_wide(
     const float* __restrict__ rstd, const float* __restrict__ gamma, bf16_t* __restrict__ dsum,
     bf16_t* __restrict__ dy, float* __restrict__ partials, int rows, int H, uint32_t thr,
     float inv_keep, const uint64_t* __restrict__ seedp, uint32_t sid) {
-  __shared__ float red[16][512 + 8];
+  __shared__ float red[3][16][512 + 8];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = lane * 8;
   const bool on = c < H;
@@ -291,18 +291,18 @@ __global__ void __launch_bounds__(1024) k_add_ln_bwd_wide(
       for (int j = 0; j < 8; ++j) acc[2][j] += oy[j];
     }
   }
+  // the three column partials of the 16 waves through LDS in ONE pass (one barrier instead of six)
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    __syncthreads();
+  for (int q = 0; q < 3; ++q)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[w][c + j] = acc[q][j];
-    __syncthreads();
-    if (threadIdx.x < H) {
-      float t = 0.f;
+    for (int j = 0; j < 8; ++j) red[q][w][c + j] = acc[q][j];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 3 * H; e += 1024) {
+    const int q = e / H, col = e - q * H;
+    float t = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
-      partials[((size_t)blockIdx.x * 3 + q) * H + threadIdx.x] = t;
-    }
+    for (int i = 0; i < 16; ++i) t += red[q][i][col];
+    partials[((size_t)blockIdx.x * 3 + q) * H + col] = t;
   }
 }
 
