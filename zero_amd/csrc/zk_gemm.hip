@@ -270,6 +270,9 @@ static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, 
   else if (out >= 3L * 1024 * 1024) { if (N >= M) { *bm = 64; *bn = 128; } else { *bm = 128; *bn = 64; } }
   else if (g_tune[2] == 1 || g_tune[2] == 3) { if (N >= M) { *bm = 64; *bn = 128; } else { *bm = 128; *bn = 64; } }   // A/B switches (3: deep ring, see dispatch)
   else if (g_tune[2] == 2) { *bm = 128; *bn = 128; }
+  else if (g_tune[11] > 0 && K >= g_tune[11] && out >= 1024L * 1024) {   // A/B: long-K products with a small output on 128x64
+    if (N >= M) { *bm = 64; *bn = 128; } else { *bm = 128; *bn = 64; }
+  }
   else { *bm = 64; *bn = 64; }
   const long tiles = (long)((M + *bm - 1) / *bm) * ((N + *bn - 1) / *bn);
   int s = 1;
