@@ -166,7 +166,8 @@ def make_infer_fns(params, model_name):
         state["_pp"] = 0
         nl = hp.num_decoder_layer
         state["wt"] = {}
-        if _fuse_att_ok(core, hp, K):
+        # (the fused launches keep a sentence's scores in LDS: 64 bytes per key for 16 rows)
+        if _fuse_att_ok(core, hp, K) and max(Ls, max_steps) <= 1024:
             for l in range(nl):
                 blocks = [(core.cross, ("q_map", "o_map"))]
                 if not core.aan:
