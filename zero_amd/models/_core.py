@@ -84,6 +84,7 @@ class TransformerCore(object):
         import torch.distributed as _dist
         _multi = _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1
         self.group_layers = int(os.environ.get("ZERO_HIP_GROUP_LAYERS", "2" if _multi else "6"))
+        self.group_all = (not _multi) and os.environ.get("ZERO_HIP_GROUP_ALL", "0") != "0"
         self._pending_wgrads = []
         self._pending_colsums = []     # (dY Mat, bias-gradient view, private partial buffer)
         self._pending_lnred = []       # (partials, rows, H, dgamma, dbeta, dbias_prev)
@@ -656,7 +657,9 @@ class TransformerCore(object):
                                     "d%d.sa" % l, None, True, sid + 1, "d", P[cur ^ 1])
                 cur ^= 1
             ready_d.append(pre)
-            if len(ready_d) >= self.group_layers or l == 0:
+            # (ZERO_HIP_GROUP_ALL=1, one rank: the decoder's weight gradients wait for the encoder's -- ONE grouped launch
+            # per step, one partial last round of tiles instead of two)
+            if len(ready_d) >= self.group_layers or (l == 0 and not self.group_all):
                 self._flush_wgrads()
                 for key in ready_d:
                     self._side(lambda key=key: on_ready(key))
@@ -668,7 +671,8 @@ class TransformerCore(object):
             e.embed_bwd_sorted(batch["tgt_sort"], dxt, st.g(self.tgt_emb), H,
                                accumulate=(self.tgt_emb == self.soft_emb), drop_p=hp.dropout, sid=9002)
             e.colsum(dxt, st.g("bias"), skip_L=Lt, accumulate=False, drop_p=hp.dropout, sid=9002)
-        self._side(tgt_embed_grads)
+        if not self.group_all:
+            self._side(tgt_embed_grads)
         if self.soft_emb != self.src_emb:
             self._side(lambda: on_ready(self.soft_emb))
         if self.tgt_emb != self.soft_emb and self.tgt_emb != self.src_emb:
@@ -698,6 +702,8 @@ class TransformerCore(object):
                     self._side(lambda key=key: on_ready(key))
                 ready_e = []
         dxs = Q[cur]
+        if self.group_all:
+            self._side(tgt_embed_grads)       # after the (single) grouped launch that overwrote the shared softmax table
 
         def src_embed_grads():
             e.embed_bwd_sorted(batch["src_sort"], dxs, st.g(self.src_emb), H,
