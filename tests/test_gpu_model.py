@@ -616,6 +616,33 @@ def test_many_shapes_many_replays_match_eager():
     assert not any(b for _, _, b in traces[True])
 
 
+def test_length_bucketing_leaves_losses_and_updates_unchanged(monkeypatch):
+    """ZERO_HIP_PAD_LEN=8 (Trainer.prepare_static: both sides padded to a multiple of 8 so that token-sized batches
+    fall into few graph-cache shapes): padded keys are masked, padded target positions follow the real ones and carry
+    no loss -- losses and the updated weights equal the unpadded run's up to the order of fp32 sums (dropout 0)."""
+    from zero_amd.main import Trainer
+    hp, Pn, _, _ = _setup("transformer")
+    rng = np.random.default_rng(9)
+    batches = [make_batch(rng, 4, ls, lt, hp.src_vocab.size(), hp.tgt_vocab.size()) for ls, lt in ((5, 7), (9, 3), (13, 10))]
+    runs = {}
+    for pad in ("1", "8"):
+        monkeypatch.setenv("ZERO_HIP_PAD_LEN", pad)
+        reset_cores()
+        tr = Trainer(hp, initializer=Pn)
+        losses = []
+        for src, tgt in batches * 2:
+            loss = tr.step({"source": src, "target": tgt})
+            losses.append(float(loss.reshape(-1)[0].cpu()))
+        torch.cuda.synchronize()
+        if pad == "8":
+            assert tr.batch["Ls"] % 8 == 0 and tr.batch["Lt"] % 8 == 0
+        runs[pad] = (np.array(losses), tr.store.export("master"))
+    assert np.abs(runs["1"][0] - runs["8"][0]).max() < 2e-4 * np.abs(runs["1"][0]).max()
+    for k, w in runs["1"][1].items():
+        d = np.abs(w - runs["8"][1][k]).max()
+        assert d <= 2e-3 * max(np.abs(w).max(), 1e-6), (k, d)
+
+
 @pytest.mark.parametrize("K", [1, 4])
 def test_aan_decode_ln_fusions_are_bit_identical(K, monkeypatch):
     """zk_ln_decode (gate + residual + LayerNorm, and LayerNorm + the next layer's average-attention update, in one

@@ -64,6 +64,8 @@ class Trainer(object):
         self.force_segmented = _os.environ.get("ZERO_HIP_FORCE_SEGMENTED", "0") != "0"
         # data parallelism: update each gradient bucket behind its own all-reduce (see _reduced_update)
         self.overlap_update = _os.environ.get("ZERO_HIP_OVERLAP_UPDATE", "1") != "0"
+        # pad both sides of a batch to a multiple of this many positions (1 = the reference's exact shapes); see prepare_static
+        self.pad_len = max(1, int(_os.environ.get("ZERO_HIP_PAD_LEN", "1")))
         # one rank: update the decoder-side parameters on a side stream while the encoder backward still runs
         # (the Adam pass is HBM-bound, the backward chain latency-bound: they overlap well); needs the norm-free
         # update (no clipping / safe_nan), see _train_and_update
@@ -359,7 +361,21 @@ class Trainer(object):
     def prepare_static(self, features):
         """Upload one batch into the static id buffers; later steps may overwrite the
         same buffers (same shapes) with :meth:`refill`."""
-        self.batch = self.core.upload(features["source"], features["target"])
+        src, tgt = features["source"], features["target"]
+        m = self.pad_len
+        if m > 1:
+            # Length bucketing for the shape-keyed graph cache: both sides padded (id 0 = pad) up to a multiple of m.
+            # Padded source keys are masked, padded target positions follow every real one (causal) and carry no loss:
+            # the real tokens' values and every gradient are unchanged (with dropout > 0 the random stream is indexed by
+            # the padded row numbers, i.e. another draw of the same distribution).  Token-sized batches otherwise
+            # produce a new (B, Ls, Lt) -- one eager step + one capture -- almost every step.
+            from zero_amd.models._core import trim_columns
+            src, tgt = (trim_columns(np.asarray(t.cpu() if torch.is_tensor(t) else t)) for t in (src, tgt))
+            src = np.pad(src, ((0, 0), (0, -src.shape[1] % m)))
+            tgt = np.pad(tgt, ((0, 0), (0, -tgt.shape[1] % m)))
+            self.batch = self.core.upload(src, tgt, trim=False)
+            return self.batch
+        self.batch = self.core.upload(src, tgt)
         return self.batch
 
     def step_static(self, use_graph=True):
