@@ -372,7 +372,7 @@ def main():
     from zero_amd import hip as _hip
     for kv in os.environ.get("ZERO_HIP_TUNE", "").split(","):     # e.g. ZERO_HIP_TUNE=0:0 (A/B switches)
         if ":" in kv:
-            _hip.lib().raw("zk_tune")(int(kv.split(":")[0]), int(kv.split(":")[1]))
+            _hip.lib().raw("zk_tune")(int(kv.split(":")[0]), int(kv.split(":")[1], 0))
     if args.mode == "decode":
         decode_main(args, rank, world)
         if world > 1:
