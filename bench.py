@@ -39,11 +39,12 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md chip t
 B, LS, LT, V = 64, 64, 64, 32000
 
 
-def synthetic_batch(rank):
+def synthetic_batch(rank, b=None):
     """ids ~ U{3..V-1}, last column eos(2), no padding, seed 1234+rank."""
+    b = B if b is None else b
     rng = np.random.default_rng(1234 + rank)
-    src = rng.integers(3, V, size=(B, LS), dtype=np.int64)
-    tgt = rng.integers(3, V, size=(B, LT), dtype=np.int64)
+    src = rng.integers(3, V, size=(b, LS), dtype=np.int64)
+    tgt = rng.integers(3, V, size=(b, LT), dtype=np.int64)
     src[:, -1] = 2
     tgt[:, -1] = 2
     return src, tgt
@@ -185,38 +186,76 @@ def pmc_traffic(kernel):
     return None, None, None
 
 
-def cpu_baseline(hp, budget_s=45.0):
+def pmc_mfma(kernel):
+    """MFMA-pipe utilisation of `kernel` from the newest committed counter summary (profiles/*_pmc_mfma.json,
+    written by scripts/pmc_mfma.sh: one rocprofv3 --pmc pass with SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES and
+    GRBM_GUI_ACTIVE over bench.py --steps 2 --no-graph).  mfma_busy = MFMA-busy cycles / (4 SIMDs x 256 CUs x
+    kernel cycles); None when no summary holds the kernel."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_mfma.json")), reverse=True):
+        try:
+            meta = json.load(open(f))
+            rec = meta["kernels"].get(kernel)
+        except (OSError, ValueError, KeyError):
+            continue
+        if rec:
+            return rec.get("mfma_busy"), os.path.basename(f), meta.get("commit")
+    return None, None, None
+
+
+def cpu_baseline(hp, b=None, budget_s=90.0):
     """Oracle (torch-CPU fp32, unfused, autograd: kind "port") train step on the BENCH batch -- the same
-    B=64 x (64+64) synthetic batch the GPU step runs --, 1 warm-up + up to 3 timed steps
-    (fewer only if one step alone exceeds the budget)."""
+    B=64 x (64+64) synthetic batch the GPU step runs.  Protocol of SURVEY.md 8(d): 3 warm-up + 10 timed steps on
+    all host cores when that fits `budget_s` of CPU wall time (judged from the warm-up steps), otherwise as many
+    timed steps (>= 1) as fit; the line says which.  The first two warm-up steps double as a thread-count probe
+    (all cores vs 64 threads: torch's intra-op pool stops scaling on small matrices); the faster one is used and
+    reported in `cores`."""
     from oracle import ref_torch as rt
     import copy
     hp = copy.copy(hp)
-    src, tgt = synthetic_batch(0)
+    src, tgt = synthetic_batch(0, b)
     bs = src.shape[0]
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(64, avail))
-    torch.set_num_threads(cores)
     P = rt.to_torch(rt.init_params(hp, "transformer", seed=1234))
     M = {k: torch.zeros_like(v) for k, v in P.items()}
     Vv = {k: torch.zeros_like(v) for k, v in P.items()}
     feats = {"source": torch.tensor(src), "target": torch.tensor(tgt)}
-    rt.train_step(P, M, Vv, feats, hp, "transformer", 0, training=True)   # warm-up
+    t_begin = time.time()
+    probe = {}
+    step_no = 0
+    for cores in sorted({avail, max(1, min(64, avail))}, reverse=True):     # warm-up steps 1 (and 2)
+        torch.set_num_threads(cores)
+        t0 = time.time()
+        rt.train_step(P, M, Vv, feats, hp, "transformer", step_no, training=True)
+        probe[cores] = time.time() - t0
+        step_no += 1
+    cores = min(probe, key=probe.get)
+    torch.set_num_threads(cores)
+    per = probe[cores]
+    warm = len(probe)
+    while warm < 3 and (time.time() - t_begin) + (10 + 3 - warm) * per <= budget_s:
+        rt.train_step(P, M, Vv, feats, hp, "transformer", step_no, training=True)
+        step_no += 1
+        warm += 1
+    left = budget_s - (time.time() - t_begin)
+    want = 10 if left >= 10 * per else max(1, int(left / per))
     n, t0 = 0, time.time()
-    while True:
-        rt.train_step(P, M, Vv, feats, hp, "transformer", n + 1, training=True)
+    while n < want:
+        rt.train_step(P, M, Vv, feats, hp, "transformer", step_no, training=True)
+        step_no += 1
         n += 1
-        if time.time() - t0 > budget_s or n >= 3:
-            break
     dt = time.time() - t0
-    return {"value": bs * (LS + LT) * n / dt, "unit": "src+tgt tokens/s", "cores": cores,
-            "kind": "port",
-            "sample": "%d timed steps (+1 warm-up) of the bench batch itself: %d sentences x (64+64) tokens, "
+    return {"value": bs * (LS + LT) * n / dt, "unit": "src+tgt tokens/s", "cores": cores, "host_cores": avail,
+            "kind": "port", "warmup_steps": warm, "timed_steps": n, "s_per_step": dt / n,
+            "thread_probe_s_per_step": {str(k): round(v, 3) for k, v in probe.items()},
+            "sample": "%d timed steps (+%d warm-up) of the bench batch itself: %d sentences x (64+64) tokens, "
                       "Transformer-base, fwd+bwd+Adam, torch-CPU fp32 restatement of the TF1 path "
-                      "(oracle/ref_torch.py; TF1 cannot run here)" % (n, bs)}
+                      "(oracle/ref_torch.py; TF1 cannot run here); protocol SURVEY 8(d) = 3+10 when it fits %d s"
+                      % (n, warm, bs, int(budget_s))}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -259,7 +298,8 @@ def decode_step_bytes(hp, model, rows, sent, ls):
     return weights + cross + NL * cache + logits
 
 
-def decode_main(args, rank, world):
+def decode_measure(args, rank, world):
+    """BASELINE configs[3] on this rank's shard; returns the result dict on rank 0 (None elsewhere)."""
     from zero_amd.models import model as registry, load_all
     from zero_amd.search import beam_search
     load_all()
@@ -299,7 +339,7 @@ def decode_main(args, rank, world):
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.cpu()[0])
     if rank != 0:
-        return
+        return None
     out = {
         "metric": "sentences/sec beam-search decode, %s d=512 L=6, beam 4" % model,
         "value": world * n_sent / dt, "unit": "sentences/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -319,9 +359,17 @@ def decode_main(args, rank, world):
                      "note": "achieved = algorithmic bytes of every decode step / wall time of the whole job "
                              "(includes encoder passes and per-batch start-up)"},
     }
+    from zero_amd.models._factory import get_core
+    out["launches_per_step"] = getattr(get_core(hp, model), "_decode_step_launches", None)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_decode_baseline(hp, model, batches)
-    print(json.dumps(out))
+    return out
+
+
+def decode_main(args, rank, world):
+    out = decode_measure(args, rank, world)
+    if out is not None:
+        print(json.dumps(out))
 
 
 def cpu_decode_baseline(hp, model, batches):
@@ -346,6 +394,21 @@ def cpu_decode_baseline(hp, model, batches):
                       "torch-CPU fp32 restatement of search.py + transformer_aan.py" % r["steps"]}
 
 
+def spawn_ranks(n):
+    """Re-launch this command line under `python -m torch.distributed.run --standalone --nproc-per-node n`."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -360,11 +423,20 @@ def main():
                     help="base = BASELINE configs[1] (the metric's config, default); big = configs[2]")
     ap.add_argument("--mode", choices=["train", "decode"], default="train",
                     help="train = the headline metric (default); decode = BASELINE configs[3] (beam-4 decode, sentences/s)")
-    ap.add_argument("--sentences", type=int, default=3000, help="--mode decode: sentences per GPU")
+    ap.add_argument("--sentences", type=int, default=3000, help="decode leg: sentences per GPU")
+    ap.add_argument("--sentences-per-gpu", type=int, default=B,
+                    help="training batch in sentences per GPU (default 64 = the metric's 4096+4096 tokens; other "
+                         "values are SIDE measurements that separate kernel quality from 'problem too small for 256 CUs')")
+    ap.add_argument("--no-decode", action="store_true", help="skip the decode leg of the default line")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: spawn the N ranks ourselves (one process per GPU, torchrun's
+        # standalone rendezvous on 127.0.0.1) and pass rank 0's JSON line through.  The torchrun form of the contract
+        # (WORLD_SIZE set by the launcher) goes straight on below.
+        sys.exit(spawn_ranks(args.gpus))
     rank, world, local = parallel.init_distributed()
-    assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local)
 
@@ -381,7 +453,8 @@ def main():
     hp = make_params(args.dropout, args.size, args.model)
     hp.random_seed = 1234   # identical initial replicas on every rank
     tr = Trainer(hp)
-    src, tgt = synthetic_batch(rank)
+    nb = args.sentences_per_gpu
+    src, tgt = synthetic_batch(rank, nb)
     tr.prepare_static({"source": src, "target": tgt})
     tr.core.eng.set_seed(1234 + rank)
     # one rank: the whole step is one hipGraph; several ranks: hipGraph segments between the
@@ -407,6 +480,25 @@ def main():
     dt = float(tmax.cpu()[0])
     loss_v = float(loss.cpu()[0])
     gnorm, pnorm, skipped = tr.train_op.stats()
+    step_launches = getattr(tr.core.eng, "last_graph_nodes", None) if (use_graph and world == 1) else None
+
+    # ---- what the exchange costs: the same K steps with the gradient buckets NOT handed to RCCL (every rank updates
+    # from its local gradients; the replicas drift apart, which is harmless after the timed region).  exposed =
+    # step time - this.  Runs the eager multi-rank path without collectives, so it is an upper bound of the one-rank step.
+    ms_nocomm = None
+    if world > 1:
+        tr.reducer.disabled = True
+        for _ in range(2):
+            tr.step_static(use_graph)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.step_static(use_graph)
+        barrier()
+        tn = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(tn, op=torch.distributed.ReduceOp.MAX)
+        ms_nocomm = float(tn.cpu()[0]) / args.steps * 1e3
+        tr.reducer.disabled = False
 
     # ---- roofline of the dominant kernel: instrumented eager pass (HIP events per launch).  Every
     # rank runs it (the step contains collectives); only rank 0 reports.
@@ -429,9 +521,9 @@ def main():
         if world > 1:
             torch.distributed.destroy_process_group()
         return
-    tokens = world * B * (LS + LT) * args.steps
+    tokens = world * nb * (LS + LT) * args.steps
     ms = dt / args.steps * 1e3
-    flops = train_flops_per_step(hp)
+    flops = train_flops_per_step(hp, b=nb)
     out = {
         "metric": "src+tgt tokens/sec training, Transformer-%s d=%d L=6" % (args.size, hp.hidden_size),
         "value": tokens / dt, "unit": "src+tgt tokens/s", "n_gpus": world, "steps": args.steps,
@@ -439,20 +531,32 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"model_name": args.model,
                    "workload": "Transformer-%s (d=%d, L=6+6, F=%d, h=%d, V=32000) training step, "
-                               "B=64 x (src 64 + tgt 64) tokens per GPU, dropout %.2f, label_smooth 0.1, "
-                               "fwd+bwd+allreduce+Adam" % (args.size, hp.hidden_size, hp.filter_size,
-                                                           hp.num_heads, args.dropout),
-                   "global_batch_tokens": world * B * (LS + LT), "parallelism": "dp%d" % world,
+                               "B=%d x (src 64 + tgt 64) tokens per GPU, dropout %.2f, label_smooth 0.1, "
+                               "fwd+bwd+allreduce+Adam%s" % (args.size, hp.hidden_size, hp.filter_size,
+                                                             hp.num_heads, nb, args.dropout,
+                                                             "" if nb == B else " [SIDE MEASUREMENT: not the metric's batch]"),
+                   "global_batch_tokens": world * nb * (LS + LT), "parallelism": "dp%d" % world,
                    "hip_graph": ("whole step" if world == 1 else "segments between all-reduce buckets") if use_graph else False},
         "loss": loss_v, "gnorm": gnorm, "update_skipped": skipped,
         "step_mfma_frac": flops / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12),
+        "launches_per_step": step_launches,
     }
+    tp = parallel.transport()
+    out["rccl"] = {"ranks": world,
+                   "transport": None if world == 1 else ("zk_comm" if tp is not None else "torch.distributed:%s"
+                                                         % torch.distributed.get_backend()),
+                   "bucket_dtype": tr.reducer.bucket_dtype_name() if world > 1 else None,
+                   "sparse_rows_exchange": tr.reducer.sparse_keys() if world > 1 else None,
+                   "bytes_per_rank_per_step": tr.reducer.bytes_last_step if world > 1 else 0,
+                   "ms_per_step_without_exchange": ms_nocomm,
+                   "exposed_allreduce_ms": (ms - ms_nocomm) if ms_nocomm is not None else 0.0}
     # the dominant kernel = the kernel instance with the largest TOTAL time per step (the rule rocprofv3 --stats
     # ranks by: profiles/*_rocprof_kernel_stats_*.txt); the runner-up is printed beside it because the two
     # leading GEMM instances are within a few per cent of each other
     ranked = sorted(agg, key=lambda k: -agg[k][1])
     key = ranked[0]
     traffic, traffic_src, traffic_commit = pmc_traffic(key)
+    mfma_busy, mfma_src, mfma_commit = pmc_mfma(key)
     fl, sec, cnt = agg[key]
     tot_fl = sum(v[0] for v in agg.values())
     tot_s = sum(v[1] for v in agg.values())
@@ -461,6 +565,7 @@ def main():
         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS,
         "traffic": traffic, "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC)",
         "traffic_source": traffic_src, "traffic_measured_at_commit": traffic_commit,
+        "mfma_busy": mfma_busy, "mfma_busy_source": mfma_src, "mfma_busy_measured_at_commit": mfma_commit,
         "step_frac": flops / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12),
         "runner_up": ({"kernel": ranked[1], "frac": agg[ranked[1]][0] / agg[ranked[1]][1] / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                        "total_us_per_step": agg[ranked[1]][1] / NPROF * 1e6} if len(ranked) > 1 else None),
@@ -471,8 +576,16 @@ def main():
         "by_kernel": {k: {"launches_per_step": v[2] // NPROF, "avg_us": v[1] / v[2] * 1e6,
                           "tflops": v[0] / v[1] / 1e12} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])},
     }
+    if world == 1 and not args.no_decode and args.model == "transformer" and args.size == "base" and nb == B:
+        # BASELINE configs[3] under the same clock: its own model / parameter store, after the training leg
+        try:
+            dargs = argparse.Namespace(**vars(args))
+            dargs.warmup = 2
+            out["decode"] = decode_measure(dargs, rank, world)
+        except Exception as exc:      # noqa: BLE001 -- the headline line must still be printed
+            out["decode"] = {"error": repr(exc)}
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(hp)     # bounded sample, see cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(hp, nb)     # bounded sample, see cpu_baseline()
     print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -250,6 +250,20 @@ int zk_norm_flag(float* hyper, zk_stream_t stream);
 int zk_cast_f32_bf16(const float* x, void* y, size_t n, zk_stream_t stream);
 int zk_cast_bf16_f32(const void* x, float* y, size_t n, zk_stream_t stream);
 int zk_zero(void* p, size_t bytes, zk_stream_t stream);
+/* Row-sparse exchange of an embedding-table gradient between data-parallel ranks (the reference moves it as
+ * tf.IndexedSlices: values / indices concatenated across towers and de-duplicated, utils/parallel.py:142-181).
+ * Payload of one rank = [ids int32 x R][rows x R x H] (fp32 or bf16 rows; unused slots carry id -1):
+ *   zk_rows_pack        slot u < *n_uniq_dev: ids[u] = uid[u], rows[u] = dtable[uid[u]] (cast); clear_rows != 0 also
+ *                       zeroes that table row, so that the table is rebuilt from the payloads of ALL ranks
+ *   zk_rows_scatter_add dtable[ids[u]] += rows[u] for every valid slot of ONE payload (ids unique inside a payload: no
+ *                       atomics; the payloads of the N ranks are added by N launches in rank order, so every rank ends
+ *                       with a bit-identical table)
+ * R, H multiples of 4. */
+size_t zk_rows_payload_bytes(int R, int H, int bf16);
+int zk_rows_pack(float* dtable, const int* uid, const int* n_uniq_dev, void* out, int R, int H, int out_bf16,
+                 int clear_rows, zk_stream_t stream);
+int zk_rows_scatter_add(float* dtable, const void* payload, int R, int H, int in_bf16, int vocab_rows,
+                        zk_stream_t stream);
 /* host-only CRC32C of a byte range (seed crc = 0 for a fresh checksum): TensorFlow-bundle checkpoint
    tensors, utils/saver.py:75,131-170 */
 uint32_t zk_crc32c(const void* data, size_t n, uint32_t crc);
@@ -426,6 +440,9 @@ int zk_graph_begin(zk_stream_t stream);
 int zk_graph_end(zk_stream_t stream, void** exec_out);
 int zk_graph_launch(void* exec, zk_stream_t stream);
 int zk_graph_destroy(void* exec);
+/* number of nodes (= kernel launches) of the graph the last zk_graph_end instantiated: lets bench.py report the
+ * launches per captured step without a profiler */
+int zk_graph_last_nodes(void);
 
 /* hardware-layout probes used by the GPU tests */
 int zk_probe_mfma32(const void* A, const void* Bt, float* D, zk_stream_t stream);

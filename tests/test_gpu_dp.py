@@ -23,9 +23,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, use_graph, overlap="1"):
+def _worker(rank, world, port, out_dir, use_graph, overlap="1", exchange=None):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), ZERO_HIP_GROUP_LAYERS="1", ZERO_HIP_OVERLAP_UPDATE=overlap)
+    if exchange is not None:         # (bucket dtype, row-sparse tables on / off); default = the product's defaults
+        # payload capacity 40 rows: the toy batch has 36 source tokens and a 120-row table (the rule from the
+        # batching limits, 3000 rows, would exceed the table and select the dense exchange)
+        os.environ.update(ZERO_HIP_BUCKET_DTYPE=exchange[0], ZERO_HIP_SPARSE_EMBED=exchange[1], ZERO_HIP_SPARSE_ROWS="40")
     from tests.common import make_hp, make_batch
     from zero_amd.utils import parallel
     from zero_amd.main import Trainer
@@ -45,17 +49,23 @@ def _worker(rank, world, port, out_dir, use_graph, overlap="1"):
         losses.append(float(tr.step_static(use_graph=use_graph).cpu()[0]))
     torch.cuda.synchronize()
     g_, p_, bad_ = tr.train_op.stats()
-    np.savez(os.path.join(out_dir, "r%d_%d%s.npz" % (rank, int(use_graph), "" if overlap == "1" else "_plain")),
+    tag = "" if overlap == "1" else "_plain"
+    if exchange is not None:
+        tag += "_%s_%s" % exchange
+    np.savez(os.path.join(out_dir, "r%d_%d%s.npz" % (rank, int(use_graph), tag)),
              loss=np.array(losses), gnorm=np.array([g_, p_]),
+             exchange=np.array([tr.reducer.bucket_dtype_name(), ",".join(tr.reducer.sparse_keys()),
+                                str(tr.reducer.bytes_last_step), str(tr.store.numel)]),
              grad=tr.store.grad.cpu().numpy(), master=tr.store.master.cpu().numpy(),
              kinds=np.array([k for k, _ in next((v for k, v in tr._graphs.items() if k[0] == "seg"), [])] or ["none"]))
     torch.distributed.destroy_process_group()
 
 
-def _run(world, out_dir, use_graph, overlap="1"):
+def _run(world, out_dir, use_graph, overlap="1", exchange=None):
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, out_dir, use_graph, overlap)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out_dir, use_graph, overlap, exchange))
+             for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -101,6 +111,34 @@ def test_two_rank_step_on_one_gpu(tmp_path):
     assert abs(both - l0) / abs(l0) < 2e-3, (both, l0)
 
 
+def test_exchange_modes_bf16_buckets_and_sparse_rows(tmp_path):
+    """The two byte reductions of the gradient exchange against the dense fp32 all-reduce, on the REAL two-rank step
+    (HIP cast / pack / scatter kernels, segmented graphs): fp32 + row-sparse source table == dense fp32 up to fp32
+    summation order; bf16 buckets + bf16 rows stay within bf16 rounding of it; replicas bit-identical in every mode;
+    the row payload replaces the dense table in the byte count (utils/parallel.py:142-181)."""
+    out = str(tmp_path)
+    modes = [("fp32", "0"), ("fp32", "1"), ("bf16", "1")]
+    for m in modes:
+        _run(2, out, True, exchange=m)
+    res = {m: [np.load(os.path.join(out, "r%d_1_%s_%s.npz" % (r, m[0], m[1]))) for r in range(2)] for m in modes}
+    for m in modes:
+        assert np.array_equal(res[m][0]["master"], res[m][1]["master"]), m       # replicas identical
+        assert np.array_equal(res[m][0]["grad"], res[m][1]["grad"]), m
+        assert res[m][0]["exchange"][0] == m[0]
+        assert res[m][0]["exchange"][1] == ("src_embedding" if m[1] == "1" else "")
+    dense, sp32, sp16 = (res[m][0] for m in modes)
+    # fp32 rows in rank order vs ring order of the dense all-reduce: two addends -> identical
+    assert np.array_equal(dense["grad"], sp32["grad"]) and np.array_equal(dense["master"], sp32["master"])
+    gd, gb = dense["grad"], sp16["grad"]
+    scale = np.abs(gd).max()
+    assert np.abs(gd - gb).max() <= 2.0 ** -7 * scale, (np.abs(gd - gb).max(), scale)
+    assert abs(sp16["gnorm"][0] - dense["gnorm"][0]) <= 5e-3 * dense["gnorm"][0]
+    assert np.allclose(sp16["loss"], dense["loss"], rtol=2e-3)
+    numel = int(dense["exchange"][3])
+    assert int(dense["exchange"][2]) == numel * 4
+    assert int(sp32["exchange"][2]) < int(dense["exchange"][2]) and int(sp16["exchange"][2]) < int(sp32["exchange"][2])
+
+
 def test_bench_contract_with_two_ranks_on_one_gpu():
     """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per process),
     with the gloo backend and both ranks on cuda:0: one JSON line from rank 0 with the N-rank fields."""
@@ -121,6 +159,27 @@ def test_bench_contract_with_two_ranks_on_one_gpu():
     assert out["config"]["parallelism"] == "dp2" and out["config"]["global_batch_tokens"] == 2 * 64 * 128
     assert out["value"] > 0 and np.isfinite(out["loss"]) and not out["update_skipped"]
     assert "roofline" in out and "cpu_baseline" not in out          # the CPU baseline is a 1-rank field
+    assert out["rccl"]["ranks"] == 2 and out["rccl"]["transport"] == "torch.distributed:gloo"
+    assert out["rccl"]["bucket_dtype"] == "bf16" and out["rccl"]["sparse_rows_exchange"] == ["src_embedding"]
+    assert out["rccl"]["ms_per_step_without_exchange"] > 0 and "exposed_allreduce_ms" in out["rccl"]
+
+
+def test_bench_spawns_its_own_ranks_when_not_under_a_launcher():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the way the driver calls --gpus 1): bench.py starts the
+    ranks itself and still prints ONE JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PYTHONPATH=root, ZERO_DIST_BACKEND="gloo", ZERO_SINGLE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl"]["ranks"] == 2 and out["value"] > 0
 
 
 def test_rccl_communicator_through_the_c_abi_single_rank():

@@ -88,3 +88,112 @@ def test_single_process_is_a_noop():
     red = parallel.GradientAllReduce(store)
     red.ready("bias"); red.wait()
     assert float(store.grad.sum()) == store.numel and parallel.world_size() == 1
+
+
+# ---------------------------------------------------------------------------------------------
+# bf16 buckets and the row-sparse table exchange: the HOST logic of GradientAllReduce on CPU tensors.  The
+# device side (casts, row pack / scatter) is the HIP kernel set behind parallel.HipBucketOps; this torch
+# stand-in with the same interface exists only here (the GPU twin of this test is tests/test_gpu_dp.py).
+# ---------------------------------------------------------------------------------------------
+class TorchBucketOps(object):
+    def cast_to_bf16(self, src, dst):
+        dst.copy_(src.to(torch.bfloat16))
+
+    def cast_to_f32(self, src, dst):
+        dst.copy_(src.float())
+
+    def payload_words(self, R, H, bf16):
+        return R + R * H // (2 if bf16 else 1)
+
+    def rows_pack(self, table, uid, n_dev, out, R, H, bf16):
+        n = min(int(n_dev[0]), R)
+        ids = torch.full((R,), -1, dtype=torch.int32)
+        ids[:n] = uid[:n]
+        rows = torch.zeros(R, H)
+        rows[:n] = table[uid[:n].long()]
+        table[uid[:n].long()] = 0.0
+        out[:R] = ids
+        out[R:] = (rows.to(torch.bfloat16) if bf16 else rows).reshape(-1).view(torch.int32)
+
+    def rows_scatter_add(self, table, payload, R, H, bf16, vocab_rows):
+        ids = payload[:R]
+        rows = payload[R:].view(torch.bfloat16 if bf16 else torch.float32).view(R, H).float()
+        ok = (ids >= 0) & (ids < vocab_rows)
+        table[ids[ok].long()] += rows[ok]
+
+
+def _sparse_worker(rank, world, port, q, dtype):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    parallel.init_distributed("gloo")
+    hp = make_hp("transformer", H=16, F=32, heads=2, layers=2, Vs=41, Vt=11)
+    store = VariableStore(hp, "transformer", "cpu")
+
+    def local_grad(r):
+        gen = torch.Generator().manual_seed(200 + r)
+        g = torch.randn(store.numel, generator=gen)
+        # the source table only has rows for the ids of rank r's "batch"
+        lo, hi = parallel.layer_buckets(store)[0]["src_embedding"]
+        Vp = (hi - lo) // 16
+        ids = torch.unique(torch.randint(1, 41, (12,), generator=gen)).to(torch.int32)
+        t = torch.zeros(Vp, 16)
+        t[ids.long()] = torch.randn(len(ids), 16, generator=gen)
+        g[lo:hi] = t.reshape(-1)
+        return g, ids
+
+    g, ids = local_grad(rank)
+    store.grad.copy_(g)
+    red = parallel.GradientAllReduce(store, bucket_elems=3000, ops=TorchBucketOps(), bucket_dtype=dtype)
+    red.sparse_enabled = True
+    uid = torch.zeros(16, dtype=torch.int32)
+    uid[:len(ids)] = ids
+    red.set_sparse("src_embedding", store.g("src_embedding"), uid, torch.tensor([len(ids)], dtype=torch.int32), 16,
+                   rows=12)
+    for key in _backward_order(store, hp):
+        red.ready(key)
+    covered = sum(hi - lo for lo, hi in red.drain())
+    alls = [local_grad(k)[0] for k in range(world)]
+    if dtype == "fp32":
+        expect = sum(alls)
+        ok = bool(torch.allclose(store.grad, expect, atol=1e-6))
+    else:
+        # dense ranges: sum of the bf16-rounded gradients, itself rounded to bf16 (the collective's dtype); table rows:
+        # fp32 sum of the bf16-rounded rows in rank order
+        r16 = [a.to(torch.bfloat16) for a in alls]
+        dense = (r16[0] + r16[1]).float()
+        lo, hi = red.ranges["src_embedding"]
+        table = sum(a[lo:hi].to(torch.bfloat16).float() for a in alls)
+        expect = dense.clone()
+        expect[lo:hi] = table
+        ok = bool(torch.equal(store.grad, expect))
+    ok = ok and covered == store.numel and red.sparse_keys() == ["src_embedding"]
+    # payload bytes: ids + rows of the capacity, not the dense table
+    lo, hi = red.ranges["src_embedding"]
+    es = 4 if dtype == "fp32" else 2
+    ok = ok and red.bytes_last_step == (store.numel - (hi - lo)) * es + 16 * 4 + 16 * 16 * es
+    q.put((rank, ok, store.grad.clone().numpy().tobytes()))
+    dist.destroy_process_group()
+
+
+import pytest
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_two_rank_sparse_rows_and_bucket_dtype(dtype):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sparse_worker, args=(r, 2, port, q, dtype)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted((r, ok) for r, ok, _ in res) == [(0, True), (1, True)]
+    assert res[0][2] == res[1][2]           # replicas hold bit-identical reduced gradients
+
+
+def test_transport_rule_without_gpu_is_torch_distributed():
+    parallel._TRANSPORT.clear()
+    assert parallel.transport() is None     # no GPU / no process group: torch.distributed (or nothing) carries the buckets
+    parallel._TRANSPORT.clear()

@@ -1748,6 +1748,8 @@ int zk_graph_begin(hipStream_t stream) {
   if (e != hipSuccess) return zk_set_error((int)e, "hipStreamBeginCapture: %s", hipGetErrorString(e));
   return 0;
 }
+static int g_last_graph_nodes = 0;
+int zk_graph_last_nodes(void) { return g_last_graph_nodes; }
 int zk_graph_end(hipStream_t stream, void** exec_out) {
   hipGraph_t graph = nullptr;
   hipError_t e = hipStreamEndCapture(stream, &graph);
@@ -1758,6 +1760,7 @@ int zk_graph_end(hipStream_t stream, void** exec_out) {
     *exec_out = nullptr;
     return 0;
   }
+  g_last_graph_nodes = (int)n_nodes;
   hipGraphExec_t exec = nullptr;
   e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
   hipGraphDestroy(graph);

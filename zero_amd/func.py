@@ -556,6 +556,7 @@ class Engine(object):
         finally:
             exec_ = ctypes.c_void_p()
             self.lib.call("zk_graph_end", s.cuda_stream, ctypes.byref(exec_))
+        self.last_graph_nodes = int(self.lib.raw("zk_graph_last_nodes")())
         return exec_
 
     def graph_launch(self, exec_):

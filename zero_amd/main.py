@@ -43,6 +43,14 @@ def tower_infer_graph(eval_features, graph, params):
     return out["seq"], out["score"]
 
 
+def _os_environ_int(name):
+    import os as _os
+    try:
+        return int(_os.environ.get(name, "0"))
+    except ValueError:
+        return 0
+
+
 class Trainer(object):
     """One data-parallel replica of the training step (main.py:255-332)."""
 
@@ -74,7 +82,41 @@ class Trainer(object):
         # edges of the graph cost the rest -- so it is opt-in
         self.overlap_adam = _os.environ.get("ZERO_HIP_OVERLAP_ADAM", "0") != "0"
         self._adam_stream = None
+        self._empty_ids = None
         self.reseed()
+
+    # -- row-sparse exchange of lookup-table gradients (utils/parallel.py:142-181) -----------------
+    def _sparse_capacity(self):
+        """Slots of a row payload: the most token rows one batch of one side can have under the batching limits
+        (data.py token_indexer: count * max_len < token_size unless a single sample is longer; batch mode:
+        batch_size sentences of at most max_len + 1 positions).  Derived from the hyper-parameters alone, hence the
+        same on every rank."""
+        hp = self.params
+        over = _os_environ_int("ZERO_HIP_SPARSE_ROWS")
+        if over:
+            return over
+        if getattr(hp, "batch_or_token", "token") == "batch":
+            return int(hp.batch_size) * (int(hp.max_len) + 1)
+        return max(int(hp.token_size), int(hp.max_len) + 1)
+
+    def _declare_sparse(self, batch):
+        """Tell the reducer which tables of THIS step's batch travel as (ids, rows) payloads.  batch None = a tower
+        without sentences: it still takes part in the all-gather, with zero rows."""
+        red = self.reducer
+        red.clear_sparse()
+        hp = self.params
+        if parallel.world_size() == 1 or not red.sparse_enabled or self.pad_len > 1 or hp.update_cycle > 1:
+            return
+        cap = self._sparse_capacity()
+        for key, sort_name in self.core.lookup_tables():
+            if batch is None:
+                if self._empty_ids is None:
+                    self._empty_ids = torch.zeros(4, dtype=torch.int32, device=self.store.device)
+                uid, n, rows = self._empty_ids, self._empty_ids[:1], 0
+            else:
+                srt = batch[sort_name]
+                uid, n, rows = srt["uid"], srt["n"], srt["max_uniq"]
+            red.set_sparse(key, self.store.g(key), uid, n, cap, rows=rows)
 
     def reseed(self):
         """Position the dropout / Gumbel-noise stream: high word = params.random_seed mixed with the rank (every
@@ -103,6 +145,12 @@ class Trainer(object):
         last = (self.cycle_counter + 1) >= hp.update_cycle
         self.lr.step(self.global_step)
         overlap = last and hp.update_cycle == 1
+        if overlap and world > 1:
+            # upload here (train_fn accepts the uploaded batch) so that the reducer knows the touched ids of the
+            # lookup tables before the backward reports them
+            if "B" not in features and features["source"].shape[0] > 0:
+                features = self.core.upload(features["source"], features["target"])
+            self._declare_sparse(features if "B" in features else None)
         loss, _ = tower_train_graph(features, self.graph, hp, self.reducer if overlap else None)
         if not last:
             self.train_op.collect()
@@ -374,8 +422,10 @@ class Trainer(object):
             src = np.pad(src, ((0, 0), (0, -src.shape[1] % m)))
             tgt = np.pad(tgt, ((0, 0), (0, -tgt.shape[1] % m)))
             self.batch = self.core.upload(src, tgt, trim=False)
+            self._declare_sparse(self.batch)
             return self.batch
         self.batch = self.core.upload(src, tgt)
+        self._declare_sparse(self.batch)
         return self.batch
 
     def step_static(self, use_graph=True):

@@ -470,6 +470,18 @@ class TransformerCore(object):
             out.update({"Lt": Lt, "tgt": ids_t, "tgt_sort": self._sort_arrays("tgt", tgt, True)})
         return out
 
+    def lookup_tables(self):
+        """[(variable, 'src_sort' | 'tgt_sort')]: embedding tables whose ONLY use is the lookup of one side's ids, so
+        that their gradient has rows for the ids of the batch and zeros elsewhere (the reference hands such gradients
+        around as tf.IndexedSlices, utils/parallel.py:142-181).  A table shared with the softmax (dense gradient) or
+        looked up by both sides is not listed."""
+        out = []
+        if self.src_emb != self.soft_emb and self.src_emb != self.tgt_emb:
+            out.append((self.src_emb, "src_sort"))
+        if self.tgt_emb != self.soft_emb and self.tgt_emb != self.src_emb:
+            out.append((self.tgt_emb, "tgt_sort"))
+        return out
+
     def _sort_arrays(self, name, ids, shift):
         """Group the token rows by embedding id on the host (it owns the ids), for the atomics-free
         embedding-gradient kernel.  shift: row (b,t) uses id[b,t-1]; rows with t==0 have no embedding."""

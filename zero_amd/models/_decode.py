@@ -265,6 +265,7 @@ def make_infer_fns(params, model_name):
             pp0, gen0 = state["_pp"], e.realloc_gen
             try:
                 gexec = e.graph_capture(body)
+                core._decode_step_launches = e.last_graph_nodes
                 if e.realloc_gen != gen0:
                     e.lib.call("zk_graph_destroy", gexec)
                     raise RuntimeError("buffer replaced during capture")
@@ -282,6 +283,7 @@ def make_infer_fns(params, model_name):
         elif g == "warm":
             # capture: python-side ping-pong bookkeeping runs during capture exactly as in an eager call
             state["graphs"][parity] = e.graph_capture(body)
+            core._decode_step_launches = e.last_graph_nodes
             e.graph_launch(state["graphs"][parity])
         else:
             state["_pp"] = 1 - state["_pp"]           # replay: redo the python-side pointer flip

@@ -98,6 +98,7 @@ class RcclComm(object):
         with torch.cuda.device(self.device):
             self.lib.call("zk_comm_init", uid, self.world, self.rank, ctypes.byref(self.handle))
         self.stream = torch.cuda.Stream(self.device)
+        self.calls = 0
 
     def _after_compute(self):
         ev = torch.cuda.Event()
@@ -106,6 +107,7 @@ class RcclComm(object):
 
     def all_reduce(self, t):
         """In-place sum over the ranks of a contiguous fp32 / bf16 tensor; returns the completion event."""
+        self.calls += 1
         assert t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)
         self._after_compute()
         self.lib.call("zk_comm_allreduce", self.handle, t.data_ptr(), t.numel(), 0 if t.dtype == torch.float32 else 1,
@@ -150,21 +152,85 @@ class _EventWork(object):
 _TRANSPORT = {}
 
 
+def _all_ranks_ok(ok):
+    """Collective AND of a local success flag over the torch.distributed group (so that either EVERY rank takes the
+    direct transport or none does: a rank falling back on its own would leave the others blocked in a collective)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(ok)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.cpu()[0]))
+
+
+def _transport_self_test(t):
+    """One small sum all-reduce and one all-gather through the direct communicator, checked against the values
+    every rank can compute locally (rank-dependent integers, exact in fp32 / bf16)."""
+    r, w = t.rank, t.world
+    dev = t.device
+    x = torch.arange(1024, dtype=torch.float32, device=dev) % 7 + float(r)
+    t.all_reduce(x).synchronize()
+    want = (torch.arange(1024, dtype=torch.float32, device=dev) % 7) * w + float(w * (w - 1) // 2)
+    if not torch.equal(x, want):
+        return False
+    xb = torch.full((512,), float(r + 1), dtype=torch.bfloat16, device=dev)
+    t.all_reduce(xb).synchronize()
+    if float(xb.float().max()) != float(w * (w + 1) // 2) or float(xb.float().min()) != float(w * (w + 1) // 2):
+        return False
+    send = torch.full((256,), r, dtype=torch.int32, device=dev)
+    recv = torch.empty(256 * w, dtype=torch.int32, device=dev)
+    t.all_gather(send, recv).synchronize()
+    return bool(torch.equal(recv.view(w, 256)[:, 0].cpu(), torch.arange(w, dtype=torch.int32)))
+
+
 def transport():
-    """``ZERO_HIP_COMM=rccl``: collectives go through the C-ABI communicator (``zk_comm_*``) on its own side
-    stream; default ``torch``: ``torch.distributed`` (whose ``nccl`` backend IS RCCL on ROCm, and which is the only
-    choice for the gloo tests).  Both are sum all-reduces of the same buckets; results are identical.  The direct
-    transport has only ever been exercised with ONE rank on the 1-GPU test box (tests/test_gpu_dp.py), so it is
-    opt-in until an 8-GPU run has seen it; any failure to set it up falls back to torch.distributed."""
+    """Which library call carries the gradient buckets.  Decided by rule, once per process, COLLECTIVELY:
+
+      ZERO_HIP_COMM=auto (default)  the C-ABI communicator (``zk_comm_*`` = RCCL on a side HIP stream of its own) when
+                                    librccl is loadable, world > 1 and every rank owns its own GPU (torch.distributed
+                                    backend ``nccl``); otherwise ``torch.distributed``
+      ZERO_HIP_COMM=rccl            the same attempt, also with a single process
+      ZERO_HIP_COMM=torch           ``torch.distributed`` (whose ``nccl`` backend IS RCCL on ROCm; the only choice for
+                                    gloo and for several ranks sharing one GPU)
+
+    After the local attempt (dlopen, ncclCommInitRank, a small all-reduce / all-gather self-test) the ranks
+    all-reduce(MIN) their success flags over the torch.distributed group: the direct transport is used only if it came
+    up on EVERY rank; otherwise every rank destroys its communicator and logs the fallback.  Both transports issue the
+    same sum all-reduces / all-gathers of the same buffers."""
     if "t" not in _TRANSPORT:
-        t = None
-        if os.environ.get("ZERO_HIP_COMM", "torch").lower() == "rccl" and torch.cuda.is_available() \
-                and (not dist.is_initialized() or dist.get_backend() != "gloo" or os.environ.get("ZERO_SINGLE_DEVICE", "0") == "0"):
-            try:
-                t = RcclComm()
-            except Exception as exc:      # noqa: BLE001 -- never lose the job to the optional transport
-                import logging
-                logging.getLogger("zero_amd").warning("direct RCCL transport unavailable (%s); torch.distributed", exc)
+        import logging
+        log = logging.getLogger("zero_amd")
+        mode = os.environ.get("ZERO_HIP_COMM", "auto").lower()
+        world = world_size()
+        distinct = dist.is_initialized() and dist.get_backend() == "nccl" and os.environ.get("ZERO_SINGLE_DEVICE", "0") == "0"
+        want = torch.cuda.is_available() and ((mode == "auto" and world > 1 and distinct) or
+                                              (mode == "rccl" and (world == 1 or distinct)))
+        t, why = None, None
+        if want:
+            # step 1, before any collective of the attempt: is librccl loadable on EVERY rank?  (a rank that fails here
+            # must not leave the others waiting in the id broadcast)
+            from zero_amd import hip
+            avail = bool(hip.lib().raw("zk_comm_available")())
+            if not _all_ranks_ok(avail):
+                why = "librccl not loadable on every rank"
+            else:
+                try:
+                    t = RcclComm()
+                    if not _transport_self_test(t):
+                        why = "self-test mismatch"
+                except Exception as exc:      # noqa: BLE001 -- never lose the job to the optional transport
+                    why = repr(exc)
+                if not _all_ranks_ok(t is not None and why is None):
+                    why = why or "another rank failed to set it up"
+            if why is not None:
+                if t is not None:
+                    try:
+                        t.close()
+                    except Exception:     # noqa: BLE001
+                        pass
+                t = None
+                log.warning("direct RCCL transport (zk_comm) NOT used on rank %d: %s; every rank falls back to "
+                            "torch.distributed", rank(), why)
         _TRANSPORT["t"] = t
     return _TRANSPORT["t"]
 
@@ -174,27 +240,171 @@ def barrier():
         dist.barrier()
 
 
-class GradientAllReduce(object):
-    """Bucketed, overlapped sum all-reduce of ``store.grad``."""
+class HipBucketOps(object):
+    """Device side of the exchange (casts of a bucket, pack / scatter of table rows): HIP kernels through the C-ABI on
+    the current stream.  The host logic of GradientAllReduce only talks to this interface; the CPU tests of that logic
+    plug in a torch stand-in (tests/test_parallel_gloo.py), the product never does."""
 
-    def __init__(self, store, bucket_elems=8 * 1024 * 1024):
+    def __init__(self):
+        from zero_amd import hip
+        self.lib = hip.lib()
+
+    @staticmethod
+    def _s(t):
+        return torch.cuda.current_stream(t.device).cuda_stream
+
+    def cast_to_bf16(self, src, dst):
+        self.lib.call("zk_cast_f32_bf16", src.data_ptr(), dst.data_ptr(), src.numel(), self._s(src))
+
+    def cast_to_f32(self, src, dst):
+        self.lib.call("zk_cast_bf16_f32", src.data_ptr(), dst.data_ptr(), src.numel(), self._s(src))
+
+    def payload_words(self, R, H, bf16):
+        return int(self.lib.query("zk_rows_payload_bytes", R, H, 1 if bf16 else 0)) // 4
+
+    def rows_pack(self, table, uid, n_dev, out, R, H, bf16):
+        self.lib.call("zk_rows_pack", table.data_ptr(), uid.data_ptr(), n_dev.data_ptr(), out.data_ptr(), R, H,
+                      1 if bf16 else 0, 1, self._s(table))
+
+    def rows_scatter_add(self, table, payload, R, H, bf16, vocab_rows):
+        self.lib.call("zk_rows_scatter_add", table.data_ptr(), payload.data_ptr(), R, H, 1 if bf16 else 0, vocab_rows,
+                      self._s(table))
+
+
+class GradientAllReduce(object):
+    """Bucketed, overlapped exchange of ``store.grad`` between the data-parallel ranks.
+
+    * dense buckets: sum all-reduce of contiguous ranges of the flat fp32 gradient buffer, handed over as the backward
+      finishes them.  ``bucket_dtype`` bf16 (default on GPUs; ``ZERO_HIP_BUCKET_DTYPE=fp32`` restores the fp32
+      exchange): the range is cast into a bf16 staging buffer, all-reduced there (half the bytes on xGMI) and cast back
+      into the fp32 gradient buffer before its Adam pass, which accumulates in fp32 as before.
+    * row-sparse tables (``set_sparse``): an embedding table that is only ever looked up receives gradient rows for
+      the <= T ids of the batch; the ranks all-gather their packed (ids, rows) payloads and every rank adds all N
+      payloads into its zeroed table in rank order (utils/parallel.py:142-181: IndexedSlices concatenated across the
+      towers, then de-duplicated).  8 ranks x 4096 rows x 512 x 2 B = 33.6 MB received per rank instead of the
+      2 x 7/8 x 65.5 MB a ring all-reduce of the dense fp32 table moves.
+    """
+
+    def __init__(self, store, bucket_elems=8 * 1024 * 1024, ops=None, bucket_dtype=None):
         self.store = store
         self.bucket_elems = bucket_elems
         self.ranges, _ = layer_buckets(store)
         self.pending = []
         self._open = None   # (lo, hi) of the bucket being filled (adjacent ranges only)
+        on_gpu = store.grad.is_cuda
+        self.ops = ops if ops is not None else (HipBucketOps() if on_gpu else None)
+        if bucket_dtype is None:
+            bucket_dtype = os.environ.get("ZERO_HIP_BUCKET_DTYPE", "bf16" if self.ops is not None else "fp32")
+        if isinstance(bucket_dtype, str):
+            bucket_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[bucket_dtype.lower()]
+        if bucket_dtype == torch.bfloat16 and self.ops is None:
+            raise ValueError("bf16 gradient buckets need the device-side cast ops")
+        self.bucket_dtype = bucket_dtype
+        self._stage = None          # bf16 staging buffer, same length as the gradient buffer (allocated on first use)
+        self._sparse = {}           # key -> dict(table, uid, n, R, H, V) for the CURRENT batch
+        self._payload = {}          # (key, "send" | "recv") -> int32 buffer
+        self.sparse_enabled = os.environ.get("ZERO_HIP_SPARSE_EMBED", "1") != "0" and self.ops is not None
+        self.disabled = False       # measurement aid (bench.py): no exchange at all, buckets are only bookkept
+        self.bytes_step = 0         # bytes this rank hands to the collectives in the current step
+        self.bytes_last_step = 0
 
+    # -- reporting ---------------------------------------------------------------------------------------------
+    def bucket_dtype_name(self):
+        return "bf16" if self.bucket_dtype == torch.bfloat16 else "fp32"
+
+    def sparse_keys(self):
+        return sorted(self._sparse)
+
+    # -- row-sparse tables ---------------------------------------------------------------------------------------
+    def set_sparse(self, key, table, uid, n_dev, capacity, rows=None):
+        """Declare ``key`` (a variable of the flat buffer that is a pure lookup table) row-sparse for the current batch:
+        ``uid`` the sorted distinct ids the batch touched, ``n_dev`` their count (device int32), ``rows`` the number of
+        token rows of the batch (an upper bound of the count), ``capacity`` the slot count of a payload -- the SAME on
+        every rank (derived from the batching limits, Trainer._sparse_capacity)."""
+        if not self.sparse_enabled or world_size() == 1:
+            return
+        V, H = table.shape
+        R = (int(capacity) + 3) // 4 * 4
+        if R * world_size() >= V:
+            return          # the payloads of all ranks would outweigh the table: dense exchange (same decision on every rank)
+        if rows is not None and rows > R:
+            # every rank sizes its payload from the same batching limits; a batch beyond them cannot be exchanged
+            # row-sparsely and the other ranks cannot be told in time: fail loudly rather than drop gradient rows
+            raise ValueError("sparse exchange of %s: the batch has %d token rows, payload capacity is %d "
+                             "(set ZERO_HIP_SPARSE_EMBED=0 or raise token_size)" % (key, rows, R))
+        self._sparse[key] = {"table": table, "uid": uid, "n": n_dev, "R": R, "H": H, "V": V}
+
+    def clear_sparse(self):
+        self._sparse = {}
+
+    def _buf(self, key, kind, words, device):
+        b = self._payload.get((key, kind))
+        if b is None or b.numel() != words:
+            b = torch.empty(words, dtype=torch.int32, device=device)
+            self._payload[(key, kind)] = b
+        return b
+
+    def _exchange_rows(self, key):
+        sp = self._sparse[key]
+        w = world_size()
+        bf16 = self.bucket_dtype == torch.bfloat16
+        table, R, H = sp["table"], sp["R"], sp["H"]
+        words = self.ops.payload_words(R, H, bf16)
+        send = self._buf(key, "send", words, table.device)
+        recv = self._buf(key, "recv", words * w, table.device)
+        self.ops.rows_pack(table, sp["uid"], sp["n"], send, R, H, bf16)
+        tr = transport()
+        if tr is not None:
+            work = _EventWork(tr.all_gather(send, recv))
+        elif dist.get_backend() == "nccl":
+            work = dist.all_gather_into_tensor(recv, send, async_op=True)
+        else:
+            # gloo (the CPU tests; the GPU tests with several ranks on one device): blocking, staged through the host
+            host = send.cpu()
+            outs = [torch.empty_like(host) for _ in range(w)]
+            dist.all_gather(outs, host)
+            for r in range(w):
+                recv[r * words:(r + 1) * words].copy_(outs[r])
+            work = None
+        self.bytes_step += words * 4
+
+        def post():
+            for r in range(w):      # fixed order: bit-identical tables on every rank
+                self.ops.rows_scatter_add(table, recv[r * words:(r + 1) * words], R, H, bf16, sp["V"])
+        lo, hi = self.ranges[key]
+        self.pending.append((lo, hi, work, post))
+
+    # -- dense buckets -------------------------------------------------------------------------------------------
     def _all_reduce(self, t):
         tr = transport()
         if tr is not None:
             return _EventWork(tr.all_reduce(t))
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
+    def _exchange_range(self, lo, hi):
+        g = self.store.grad[lo:hi]
+        if self.bucket_dtype == torch.float32:
+            self.bytes_step += (hi - lo) * 4
+            return self._all_reduce(g), None
+        if self._stage is None:
+            self._stage = torch.empty(self.store.numel, dtype=torch.bfloat16, device=g.device)
+        st = self._stage[lo:hi]
+        self.ops.cast_to_bf16(g, st)
+        self.bytes_step += (hi - lo) * 2
+        return self._all_reduce(st), (lambda: self.ops.cast_to_f32(st, g))
+
     def ready(self, key):
         """Called by the backward when every gradient under ``key`` is final."""
         if world_size() == 1:
             return
         lo, hi = self.ranges[key]
+        if self.disabled:
+            self.pending.append((lo, hi, None, None))
+            return
+        if key in self._sparse:
+            self.flush()
+            self._exchange_rows(key)
+            return
         if self._open is not None and (self._open[0] == hi or self._open[1] == lo):
             self._open = (min(lo, self._open[0]), max(hi, self._open[1]))
         else:
@@ -209,7 +419,8 @@ class GradientAllReduce(object):
             return
         lo, hi = self._open
         self._open = None
-        self.pending.append((lo, hi, self._all_reduce(self.store.grad[lo:hi])))
+        work, post = self._exchange_range(lo, hi)
+        self.pending.append((lo, hi, work, post))
 
     def wait(self):
         """Flush the tail and make the current stream wait for every bucket."""
@@ -218,17 +429,21 @@ class GradientAllReduce(object):
 
     def drain(self):
         """Flush the tail, then yield (lo, hi) of every bucket in launch order as soon as the current stream
-        has been made to wait for ITS all-reduce: work queued per bucket (the Adam update of that range)
-        overlaps the collectives still in flight."""
+        has been made to wait for ITS exchange (and the cast back / row scatter of that bucket is enqueued): work
+        queued per bucket (the Adam update of that range) overlaps the collectives still in flight."""
         self.flush()
         pending, self.pending = self.pending, []
-        for lo, hi, w in pending:
-            w.wait()
+        self.bytes_last_step, self.bytes_step = self.bytes_step, 0
+        for lo, hi, w, post in pending:
+            if w is not None:
+                w.wait()
+            if post is not None:
+                post()
             yield lo, hi
 
     def all_reduce_everything(self):
         """Unbucketed path (used after gradient accumulation: one exchange per update,
-        cycle.py:86-88 semantics)."""
+        cycle.py:86-88 semantics).  Dense and fp32: the accumulated table gradients are no longer row-sparse."""
         if world_size() > 1:
             self._all_reduce(self.store.grad).wait()
 
