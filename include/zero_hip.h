@@ -76,6 +76,7 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
 int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int tb, int tile,
                     zk_stream_t stream);
 
+#ifdef ZK_EXPERIMENTS   /* measured slower than GEMM + zk_ce_fused (profiles/r02_fused_ce_256_tile.txt): make EXPERIMENTS=1 */
 /* ---- transformer.py:182-216 + util.py:88-103 fused for training: logits = feat . E^T and the label-smoothed
  * cross entropy WITHOUT materialising the [T, V] logits.  fwd: ce fp32 [T] (may be NULL), lse fp32 [T]
  * (log-sum-exp of every row, kept for the backward); bwd: recomputes the logits tile by tile and writes
@@ -88,6 +89,7 @@ int zk_logits_ce_fwd(const void* feat, const void* E, const int* ids, float* ce,
 int zk_logits_ce_bwd(const void* feat, const void* E, const int* ids, const float* w, const float* lse,
                      void* dlogits, int T, int V, int K, int ldf, int lde, int ldd, float label_smooth,
                      zk_stream_t stream);
+#endif /* ZK_EXPERIMENTS */
 
 /* ---- func.py:218-256 dot_attention core (+ modules/rpr.py:10-75 relative positions).
  * q/k/v/out: [B*L, ld] bf16, head h at columns [h*d,(h+1)*d) (split/combine_heads,
@@ -238,6 +240,7 @@ size_t zk_adam_step_workspace(void);
 int zk_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n, float* hyper,
                  float* pnorm_out, uint64_t* seed, int norm_free, void* workspace, size_t ws_bytes,
                  zk_stream_t stream);
+#ifdef ZK_EXPERIMENTS   /* Adam beside the encoder backward: 5.01 vs 4.94 ms (DESIGN 6b): make EXPERIMENTS=1 */
 /* the norm-free update in pieces: TF1 Adam on n elements writing its partial sums of squares into workspace slot
  * `slot` (< 16); zk_adam_finish sums nslots slots -> hyper[6] (+ flags), pnorm_out, seed += 1.  Lets the update of
  * the parameters whose gradients are final run beside the rest of the backward (and behind per-bucket all-reduces). */
@@ -246,6 +249,7 @@ int zk_adam_range(float* p, const float* g, float* m, float* v, void* shadow_bf1
                   void* workspace, size_t ws_bytes, zk_stream_t stream);
 int zk_adam_finish(float* hyper, float* pnorm_out, uint64_t* seed, int nslots, const void* workspace, size_t ws_bytes,
                    zk_stream_t stream);
+#endif /* ZK_EXPERIMENTS */
 int zk_norm_flag(float* hyper, zk_stream_t stream);
 int zk_cast_f32_bf16(const float* x, void* y, size_t n, zk_stream_t stream);
 int zk_cast_bf16_f32(const void* x, float* y, size_t n, zk_stream_t stream);
@@ -292,6 +296,7 @@ int zk_comm_allreduce_multi(void* comm, void* const* bufs, const size_t* counts,
 /* recv[r*count .. (r+1)*count) <- send of rank r (row-sparse source-embedding gradient, parallel.py:142-181) */
 int zk_comm_allgather(void* comm, const void* send, void* recv, size_t count, int dtype, zk_stream_t stream);
 
+#ifdef ZK_EXPERIMENTS   /* measured 1.25x slower than launch-per-op (profiles/r02_layer_program_experiment.txt) */
 /* ---- Layer program (zk_layer.hip): a run of dependent, sentence-local ops -- the linear / attention / residual +
  * LayerNorm chain of the encoder and decoder stacks (transformer.py:35-69, 121-181; func.py:194-338) -- executed by ONE
  * persistent launch instead of one launch per op.  The B sentences are dealt to the 8 XCDs; every XCD walks the op list
@@ -311,6 +316,7 @@ size_t zk_prog_state_bytes(void);
 int zk_prog_begin(int sentences);
 int zk_prog_end(void* ops_out, size_t cap_bytes, int* nops, int* is_backward);
 int zk_prog_launch(const void* ops_dev, int nops, int sentences, int backward, void* state_dev, zk_stream_t stream);
+#endif /* ZK_EXPERIMENTS */
 
 /* dropout plumbing */
 int zk_dropout_mask(float* out, size_t n, float drop_p, const uint64_t* seed, uint32_t sid, zk_stream_t stream);

@@ -700,6 +700,7 @@ def beam_search(features, encoding_fn, decoding_fn, hp):
     pad_id = hp.tgt_vocab.pad()
     source = features["source"]
     batch_size = source.shape[0]
+    trace = getattr(hp, "search_trace", None)      # a list to append per-step candidate tables to, or None
     if hp.search_mode == "cache":
         model_state = encoding_fn(source)
     else:
@@ -769,6 +770,11 @@ def beam_search(features, encoding_fn, decoding_fn, hp):
         curr_scores = curr_lp / length_penalty
         flat_scores = _merge(curr_scores, 1)
         topk_scores, topk_idx = _top_k(flat_scores, 2 * beam_size)
+        if trace is not None:
+            # checker aid (tests/test_gpu_fullsize.py): the 2K candidates search.py:172-176 keeps PLUS the runner-up, so
+            # that a path that leaves this one at some step can be judged by the score gap it had to bridge there
+            ts, ti = _top_k(flat_scores, min(2 * beam_size + 1, flat_scores.shape[1]))
+            trace.append((ts.numpy().copy(), ti.numpy().copy()))
         beam_idx = topk_idx // V
         sym_idx = topk_idx % V
         curr_seq = _gather_beams(seq, beam_idx)

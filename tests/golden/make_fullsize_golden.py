@@ -78,10 +78,27 @@ def beam_fixture():
     for K in (1, 4):
         hp.beam_size = K
         t0 = time.time()
-        seqs, scores = [], []
+        seqs, scores, traces = [], [], []
         for i in range(0, src.shape[0], 32):
+            hp.search_trace = []
             r = rt.beam_search({"source": torch.tensor(src[i:i + 32])}, enc, dec, hp)
             seqs.append(np.asarray(r["seq"])); scores.append(np.asarray(r["score"]))
+            traces.append(hp.search_trace)
+            hp.search_trace = None
+        # per-step candidate tables of the oracle: the 2K candidates search.py:172-176 keeps + the runner-up (scores
+        # fp32, flat index beam * V + token), [steps, sentences, 2K+1], steps past a batch's end are NaN / -1.
+        # tests/test_gpu_fullsize.py uses them to measure the score gap at the step where the HIP search first
+        # leaves the oracle's path.
+        T = max(len(t) for t in traces)
+        W = 2 * K + 1
+        tsc = np.full((T, src.shape[0], W), np.nan, dtype=np.float32)
+        tix = np.full((T, src.shape[0], W), -1, dtype=np.int32)
+        for bi, tr in enumerate(traces):
+            for t, (a, b) in enumerate(tr):
+                tsc[t, bi * 32:bi * 32 + a.shape[0], :a.shape[1]] = a
+                tix[t, bi * 32:bi * 32 + a.shape[0], :a.shape[1]] = b
+        out["trace_scores_k%d" % K] = tsc
+        out["trace_idx_k%d" % K] = tix
         L = max(s.shape[-1] for s in seqs)
         seqs = [np.pad(s, [(0, 0)] * (s.ndim - 1) + [(0, L - s.shape[-1])]) for s in seqs]
         out["seqs_k%d" % K] = np.concatenate(seqs, 0).astype(np.int32)

@@ -15,10 +15,13 @@ Tolerances:
                   global norm within 1e-2, EVERY variable's gradient norm within 2e-2 (measured <= 0.8 %, also
                   for the variables whose gradient is 1e-4 of the largest), slices within SLICE_TOL relative L2;
                   against the pure fp32 oracle the global norm must stay within 3e-2;
-  beam search     no sharpening of the random model: >= 90 % of the 64 best hypotheses token-exact over their
+  beam search     no sharpening of the random model: >= 60 of the 64 best hypotheses token-exact over their
                   whole length (~80 decode steps each; measured 62/64 and 63/64), >= 90 % agree on the first 8
-                  tokens, and the scores of the token-exact ones within 0.3 absolute (length-normalised sums of
-                  ~80 log-probabilities, around -85: 3.5e-3 relative); the rates are written to gpurun_out/fullsize_beam_k*.json.
+                  tokens, the scores of the token-exact ones within 0.3 absolute (length-normalised sums of
+                  ~80 log-probabilities, around -85: 3.5e-3 relative), and EVERY non-exact hypothesis must leave the
+                  oracle's path at a step where the oracle's own score gap between the two candidates is below
+                  2e-3 |score| (a near-tie no two bf16 implementations order alike); the per-divergence margins are
+                  written to gpurun_out/fullsize_beam_k*.json (copied to profiles/r03_parity_fullsize_beam_k*.json).
 """
 import copy
 import json
@@ -126,9 +129,42 @@ def test_big_widths_six_layers():
     _train_case("big_synth_seed1234", hidden_size=1024, embed_size=1024, filter_size=4096, num_heads=16)
 
 
+NEAR_TIE_REL = 2e-3      # bf16 noise: a gap below this fraction of |score| can flip between two implementations
+
+
+def _first_divergence(hip_trace, ref_scores, ref_idx, s_local, s_global, K):
+    """First decode step at which the HIP search's 2K candidates of sentence s differ from the oracle's, and the gap
+    the ORACLE saw there between the candidate it kept at that rank and the one the HIP path put there.  Up to that
+    step both searches hold the same alive set, so flat indices (beam * V + token) are comparable."""
+    T = min(len(hip_trace), ref_idx.shape[0])
+    for t in range(T):
+        r_idx = ref_idx[t, s_global]
+        if r_idx[0] < 0:
+            break
+        h_idx = hip_trace[t][1][s_local]
+        r_sc = ref_scores[t, s_global]
+        # candidates parked at -inf / f32.min (finished or masked) carry no order information
+        live = int(np.sum(r_sc[:2 * K] > -1e30))
+        for j in range(live):
+            if int(h_idx[j]) == int(r_idx[j]):
+                continue
+            where = np.nonzero(r_idx == h_idx[j])[0]
+            gap = float(r_sc[j] - r_sc[int(where[0])]) if len(where) else None
+            return {"step": t, "rank": j, "oracle_flat_index": int(r_idx[j]), "hip_flat_index": int(h_idx[j]),
+                    "oracle_score": float(r_sc[j]), "oracle_gap": gap,
+                    "hip_gap_seen": float(hip_trace[t][0][s_local][j] - hip_trace[t][0][s_local][min(j + 1, 2 * K - 1)]),
+                    "tolerance": NEAR_TIE_REL * max(abs(float(r_sc[j])), 1.0)}
+    return None
+
+
 @pytest.mark.parametrize("K", [1, 4])
 def test_aan_beam_search_base_size(K):
-    """BASELINE configs[3] subset: transformer_aan, d=512, V=32000, 64 length-sorted sentences, eval batch 32."""
+    """BASELINE configs[3] subset: transformer_aan, d=512, V=32000, 64 length-sorted sentences, eval batch 32.
+    north_star: token-id exact greedy decode.  Every hypothesis that is NOT token-exact must be explained: the test
+    finds the first step at which the HIP search's candidate table leaves the oracle's (fixture `trace_*`: the
+    oracle's 2K kept candidates + the runner-up of every step) and requires the oracle's own score gap between the two
+    candidates involved to be a near-tie (< 2e-3 |score|: two bf16 implementations cannot be expected to order them
+    alike).  A divergence with a larger gap fails the test -- that would be a bug in zk_dec_* / zk_beam_*."""
     from zero_amd.main import tower_infer_graph
     from zero_amd.search import decode_hypothesis
     fx = np.load(os.path.join(GOLD, "aan_base_beam.npz"))
@@ -142,31 +178,63 @@ def test_aan_beam_search_base_size(K):
     assert np.array_equal(src, fx["source"])
     get_core(hp, model, Pn)
     ref_seq, ref_score = fx["seqs_k%d" % K], fx["scores_k%d" % K]
+    ref_tsc, ref_tix = fx["trace_scores_k%d" % K], fx["trace_idx_k%d" % K]
     exact = first8 = n = 0
     prefix = []
     dscore = dscore_same = 0.0
+    divergences = []
     for i in range(0, src.shape[0], 32):
         seqs, scores = tower_infer_graph({"source": src[i:i + 32]}, registry.get_model(model), hp)
         hyp = decode_hypothesis(seqs, hp)
         ref_hyp = decode_hypothesis(ref_seq[i:i + 32], hp)
+        miss = []
         for j, (a, b) in enumerate(zip(hyp, ref_hyp)):
             n += 1
             exact += int(list(a) == list(b))
             if list(a) == list(b):
                 dscore_same = max(dscore_same, abs(float(scores[j, 0]) - float(ref_score[i + j, 0])))
+            else:
+                miss.append(j)
             m = 0
             while m < min(len(a), len(b)) and a[m] == b[m]:
                 m += 1
             prefix.append(m / float(max(len(b), 1)))
             first8 += int(m >= min(8, len(b)))
         dscore = max(dscore, float(np.abs(scores[:, 0] - ref_score[i:i + 32, 0]).max()))
+        if miss:
+            # the same batch again with the per-step candidate tables recorded (host bookkeeping path: bit-identical
+            # hypotheses, tests/test_gpu_model.py::test_device_resident_search_equals_host_bookkeeping)
+            hp.search_trace = []
+            seqs2, _ = tower_infer_graph({"source": src[i:i + 32]}, registry.get_model(model), hp)
+            trace, hp.search_trace = hp.search_trace, None
+            assert np.array_equal(np.asarray(seqs2), np.asarray(seqs)), "traced search differs from the default one"
+            for j in miss:
+                d = _first_divergence(trace, ref_tsc, ref_tix, j, i + j, K)
+                d = dict(d or {"step": None, "oracle_gap": None}, sentence=i + j)
+                if d.get("oracle_gap") is not None and d.get("rank") == 0:
+                    # where this gap stands among the best-vs-second gaps of ALL (sentence, step) pairs of the fixture
+                    allgaps = (ref_tsc[:, :, 0] - ref_tsc[:, :, 1])[ref_tix[:, :, 0] >= 0]
+                    d["gap_rank_among_all_top2_gaps"] = int(np.sum(allgaps < d["oracle_gap"]))
+                    d["all_top2_gaps"] = int(allgaps.size)
+                divergences.append(d)
+    # how common near-ties are in this random model: (sentence, step) pairs whose best two candidates are closer than
+    # the tolerance, out of all pairs
+    valid = ref_tix[:, :, 0] >= 0
+    top_gap = ref_tsc[:, :, 0] - ref_tsc[:, :, 1]
+    tol = NEAR_TIE_REL * np.maximum(np.abs(ref_tsc[:, :, 0]), 1.0)
+    near = int(np.sum(valid & (top_gap < tol)))
     rep = {"beam": K, "sentences": n, "token_exact": exact, "token_exact_rate": exact / float(n),
            "first8_rate": first8 / float(n), "mean_common_prefix_frac": float(np.mean(prefix)),
-           "best_score_abs_diff_max": dscore, "best_score_abs_diff_max_same_hypothesis": dscore_same}
+           "best_score_abs_diff_max": dscore, "best_score_abs_diff_max_same_hypothesis": dscore_same,
+           "divergences": divergences, "near_tie_rel_tolerance": NEAR_TIE_REL,
+           "oracle_top2_near_ties": near, "oracle_sentence_steps": int(valid.sum())}
     print(json.dumps(rep, sort_keys=True))
     _report("beam_k%d" % K, rep)
     # measured on MI355X: 62/64 (beam 1) and 63/64 (beam 4) whole hypotheses token-exact; the others leave the
     # oracle's path at a near-tie of this random model (no sharpening) and end with a different score
-    assert rep["token_exact_rate"] >= 0.9, rep
+    assert rep["token_exact_rate"] >= 60.0 / 64.0, rep
     assert rep["first8_rate"] >= 0.9, rep
     assert dscore_same < 0.3, rep       # scores are sums of ~80 log-probabilities around -85: 0.3 = 3.5e-3 relative
+    for d in divergences:
+        assert d["step"] is not None and d["oracle_gap"] is not None, ("unexplained divergence", d)
+        assert 0.0 <= d["oracle_gap"] < d["tolerance"], ("divergence at a gap that bf16 noise does not explain", d)

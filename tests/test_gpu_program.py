@@ -6,7 +6,11 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+from zero_amd import hip as _hip
+
+# an experiment (negative result): only in a `make EXPERIMENTS=1` library
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not _hip.lib().experiments, reason="layer program needs `make EXPERIMENTS=1`")]
 
 from oracle import ref_torch as rt  # noqa: E402
 from tests.common import make_hp, perturb  # noqa: E402

@@ -213,6 +213,7 @@ __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __rest
     }
 }
 
+#ifdef ZK_EXPERIMENTS   // fused logits + cross entropy kernels (profiles/r02_fused_ce_256_tile.txt: 449 vs 392 us)
 // =====================================================================================
 // Fused logits + label-smoothed cross entropy (transformer.py:182-216, util.py:88-103) for the training
 // path: the [T, V] fp32 logits (524 MB at the bench shapes) are never written.
@@ -449,6 +450,7 @@ __global__ void __launch_bounds__(256) k_ce_combine_gold(const float4* __restric
     if (ce != nullptr) ce[row] = lse - p * zg - q * (sz - zg) - normalizer;
   }
 }
+#endif  // ZK_EXPERIMENTS
 
 template <int BM, int BN, int NS, int NW = 4, int PW = 0>
 static int launch_dlds(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
@@ -555,6 +557,7 @@ int zk_gemm_kseg(const void* const* a_segs, const void* const* b_segs, int nseg,
   return 0;
 }
 
+#ifdef ZK_EXPERIMENTS   // fused logits + cross entropy: measured slower than GEMM + zk_ce_fused, make EXPERIMENTS=1
 static int ce_check(const void* feat, const void* E, int T, int V, int K, int ldf, int lde) {
   ZK_CHECK_ARG(T >= 0 && V >= 1 && K >= 8, "zk_logits_ce: bad dims T=%d V=%d K=%d", T, V, K);
   ZK_CHECK_ARG(K % 8 == 0 && ldf % 8 == 0 && lde % 8 == 0, "zk_logits_ce: K, ldf, lde must be multiples of 8");
@@ -637,6 +640,7 @@ int zk_logits_ce_bwd(const void* feat, const void* E, const int* ids, const floa
   ZK_LAUNCH_CHECK();
   return 0;
 }
+#endif  // ZK_EXPERIMENTS
 #ifdef ZK_GEMM_TRACE
 int zk_debug_trace_read(unsigned long long* out, int n) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;

@@ -99,7 +99,8 @@ class Engine(object):
         self.realloc_gen = 0
         self._timing = None
         # layer programs (run_program): one persistent launch per sentence-local chain instead of one launch per op
-        self.programs_enabled = os.environ.get("ZERO_HIP_PROGRAM", "0") != "0"
+        # layer program (zk_layer.hip): an experiment, only present in a `make EXPERIMENTS=1` library
+        self.programs_enabled = os.environ.get("ZERO_HIP_PROGRAM", "0") != "0" and self.lib.experiments
         # relative positions folded into the attention forward tile (zk_attn_dev.h attn_fwd_tile<.., RPR>)
         self.rpr_fold = os.environ.get("ZERO_HIP_RPR_FOLD", "1") != "0"
         self._prog_host = None
@@ -497,7 +498,7 @@ class Engine(object):
         ordinary launches.  ``fn`` is run in recording mode first -- the entry points append ops instead of
         launching -- so the host-side schedule is written once (zero_amd/models/_core.py) for both forms.
         The device copy of the op table is cached by content: replays and hipGraph captures only launch."""
-        if not self.programs_enabled:
+        if not self.programs_enabled or not self.lib.experiments:
             return fn()
         lib = self.lib
         op_bytes = lib.query("zk_prog_op_bytes")

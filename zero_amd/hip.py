@@ -42,10 +42,13 @@ def _ctype_of(decl):
     raise ValueError("unknown C type in %r" % decl)
 
 
-def parse_header(path=HEADER_PATH):
-    """-> {name: (restype, [argtypes], [argnames])} for every prototype."""
+def parse_header(path=HEADER_PATH, experiments=True):
+    """-> {name: (restype, [argtypes], [argnames])} for every prototype.  experiments=False leaves out the
+    ``#ifdef ZK_EXPERIMENTS`` sections (entry points only a ``make EXPERIMENTS=1`` library exports)."""
     text = open(path).read()
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    if not experiments:
+        text = re.sub(r"#ifdef ZK_EXPERIMENTS.*?#endif", " ", text, flags=re.S)
     protos = {}
     for m in re.finditer(r"(const char\*|size_t|uint32_t|int)\s+(zk_\w+)\s*\(([^)]*)\)\s*;", text):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
@@ -76,7 +79,11 @@ class _Lib(object):
         self._dll = ctypes.CDLL(LIB_PATH)
         self.ncalls = 0
         self.recording = False        # a layer program is being recorded (func.Engine.run_program)
-        self.protos = parse_header()
+        core = parse_header(experiments=False)
+        every = parse_header(experiments=True)
+        # the experiment entry points (negative results kept as evidence, `make EXPERIMENTS=1`) come as a set
+        self.experiments = all(hasattr(self._dll, n) for n in every if n not in core)
+        self.protos = every if self.experiments else core
         for name, (restype, argtypes, _) in self.protos.items():
             try:
                 fn = getattr(self._dll, name)

@@ -80,7 +80,8 @@ class Trainer(object):
         # measured on MI355X (bench.py, same box): 5.01 ms with the overlap, 4.94 ms without -- the streaming Adam
         # blocks take HBM bandwidth and wave slots from the latency-bound chain they run beside, and the fork / join
         # edges of the graph cost the rest -- so it is opt-in
-        self.overlap_adam = _os.environ.get("ZERO_HIP_OVERLAP_ADAM", "0") != "0"
+        # (an experiment: needs a `make EXPERIMENTS=1` library for zk_adam_range / zk_adam_finish)
+        self.overlap_adam = _os.environ.get("ZERO_HIP_OVERLAP_ADAM", "0") != "0" and self.core.eng.lib.experiments
         self._adam_stream = None
         self._empty_ids = None
         self.reseed()

@@ -70,7 +70,7 @@ class TransformerCore(object):
         # HIP stream, concurrently with the dgrad chain (both are latency-bound at this size)
         # (measured in round 1: with one rank the second stream LOSES ~3 % -- cross-stream graph
         # edges cost more than the overlap buys once the small GEMMs are grouped -- so it is opt-in)
-        self.use_side = os.environ.get("ZERO_HIP_SIDE_STREAM", "0") != "0"
+        self.use_side = os.environ.get("ZERO_HIP_SIDE_STREAM", "0") != "0" and self.eng.lib.experiments
         # weight-gradient GEMMs are deferred and launched as ONE grouped grid per `group_layers`
         # layers (each is far too small to fill 256 CUs on its own)
         self.group_wgrad = os.environ.get("ZERO_HIP_GROUP_WGRAD", "1") != "0"
@@ -96,7 +96,7 @@ class TransformerCore(object):
         # 224 + 8 us forward and 287 us backward against 291 + 208 us for GEMM + k_ce_fused -- the second
         # pass over the 137-GFLOP GEMM costs what the saved 1 GB of traffic buys, so it is opt-in (it frees
         # T*V*4 bytes, which matters for larger batches / vocabularies)
-        self.fused_ce = os.environ.get("ZERO_HIP_FUSED_CE", "0") != "0"
+        self.fused_ce = os.environ.get("ZERO_HIP_FUSED_CE", "0") != "0" and self.eng.lib.experiments
         self.logits_tile256 = os.environ.get("ZERO_HIP_LOGITS_256", "1") != "0"
         self._red_id = 0
         self.side = torch.cuda.Stream(self.eng.device) if self.eng.device.type == "cuda" else None

@@ -92,7 +92,8 @@ def _beam_search(features, encoding_fn, decoding_fn, params):
         and os.environ.get("ZERO_HIP_DECODE_GRAPH", "1") != "0"
     if static_step and K <= 16 and os.environ.get("ZERO_HIP_DECODE_HOST_C", "1") != "0":
         Tcap = int(state["Tmax"]) + 2
-        if os.environ.get("ZERO_HIP_DECODE_DEVICE_BOOK", "1") != "0" and 2 * K * Tcap * 4 <= 64 * 1024:
+        if os.environ.get("ZERO_HIP_DECODE_DEVICE_BOOK", "1") != "0" and 2 * K * Tcap * 4 <= 64 * 1024 \
+                and getattr(params, "search_trace", None) is None:
             return _beam_search_device(state, decoding_fn, params, B, K, V, eos_id, pad_id, alpha, max_target_length)
         return _beam_search_static(state, decoding_fn, params, B, K, V, eos_id, pad_id, alpha, max_target_length)
     if static_step:
@@ -230,6 +231,9 @@ def _beam_search_static(state, decoding_fn, params, B, K, V, eos_id, pad_id, alp
     p_mtl, p_mtli, p_ts, p_ti, p_idx, p_tok = P(mtl), P(mtl_i), P(out_np[0]), P(out_np[1]), P(idx), P(tok)
     stop = lib.raw("zk_beam_host_should_stop")
     step = lib.raw("zk_beam_host_step")
+    # params.search_trace (a list, diagnostic): the 2K (score, flat index) survivors of every step, as they came off
+    # the device -- lets a test find the step at which this search first leaves another one's path
+    trace = getattr(params, "search_trace", None)
     time = 0
     while True:
         if stop(B, K, p_lp, p_fs, p_ff, p_mtl, p_mtli, time, float(alpha)):
@@ -243,6 +247,8 @@ def _beam_search_static(state, decoding_fn, params, B, K, V, eos_id, pad_id, alp
         state["pack_dev"].copy_(state["pack_host"], non_blocking=True)
         decoding_fn.step_static(state, params.beam_search_temperature, zdtype.inf())
         out_host.copy_(state["out_dev"])           # one D2H for scores and indices (synchronises)
+        if trace is not None:
+            trace.append((out_np[0].view(f32).copy(), out_np[1].copy()))
         rc = step(B, K, V, Tcap, time, p_ts, p_ti, p_seq, p_fin, p_lp, p_sc, p_fs, p_ff, p_mtli, eos_id, pad_id,
                   float(penalty), p_idx, p_tok)
         if rc != 0:

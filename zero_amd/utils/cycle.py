@@ -42,8 +42,10 @@ class TrainOp(object):
             self.ema = store.master.clone()      # shadows start at the variables' initial values
         self.pnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.count = 0
-        self._ws = torch.empty(max(hip.lib().query("zk_norm_workspace") * 2, hip.lib().query("zk_adam_step_workspace"),
-                                   hip.lib().query("zk_adam_range_workspace")), dtype=torch.uint8, device=dev)
+        _lib = hip.lib()
+        self._ws = torch.empty(max(_lib.query("zk_norm_workspace") * 2, _lib.query("zk_adam_step_workspace"),
+                                   _lib.query("zk_adam_range_workspace") if _lib.experiments else 0),
+                               dtype=torch.uint8, device=dev)
 
     # cycle.py:58-71
     def zero(self):
