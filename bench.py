@@ -207,10 +207,8 @@ def pmc_mfma(kernel):
 def cpu_baseline(hp, b=None, budget_s=90.0):
     """Oracle (torch-CPU fp32, unfused, autograd: kind "port") train step on the BENCH batch -- the same
     B=64 x (64+64) synthetic batch the GPU step runs.  Protocol of SURVEY.md 8(d): 3 warm-up + 10 timed steps on
-    all host cores when that fits `budget_s` of CPU wall time (judged from the warm-up steps), otherwise as many
-    timed steps (>= 1) as fit; the line says which.  The first two warm-up steps double as a thread-count probe
-    (all cores vs 64 threads: torch's intra-op pool stops scaling on small matrices); the faster one is used and
-    reported in `cores`."""
+    the host cores when that fits `budget_s` of CPU wall time (judged from the warm-up steps), otherwise as many
+    timed steps (>= 1) as fit; the line says which."""
     from oracle import ref_torch as rt
     import copy
     hp = copy.copy(hp)
@@ -224,23 +222,21 @@ def cpu_baseline(hp, b=None, budget_s=90.0):
     M = {k: torch.zeros_like(v) for k, v in P.items()}
     Vv = {k: torch.zeros_like(v) for k, v in P.items()}
     feats = {"source": torch.tensor(src), "target": torch.tensor(tgt)}
+    # threads: torch's intra-op pool stops scaling on these matrix sizes long before a 256-core host is used up
+    # (one step with 256 threads was measured at 425 s against 5.5 s with 64 on the GPU box), so the oracle runs
+    # on min(64, cores) threads; `cores` reports that number, `host_cores` what the box has
+    cores = max(1, min(64, avail))
+    torch.set_num_threads(cores)
     t_begin = time.time()
-    probe = {}
-    step_no = 0
-    for cores in sorted({avail, max(1, min(64, avail))}, reverse=True):     # warm-up steps 1 (and 2)
-        torch.set_num_threads(cores)
+    step_no, warm, per = 0, 0, None
+    while warm < 3:
         t0 = time.time()
         rt.train_step(P, M, Vv, feats, hp, "transformer", step_no, training=True)
-        probe[cores] = time.time() - t0
-        step_no += 1
-    cores = min(probe, key=probe.get)
-    torch.set_num_threads(cores)
-    per = probe[cores]
-    warm = len(probe)
-    while warm < 3 and (time.time() - t_begin) + (10 + 3 - warm) * per <= budget_s:
-        rt.train_step(P, M, Vv, feats, hp, "transformer", step_no, training=True)
+        per = time.time() - t0
         step_no += 1
         warm += 1
+        if (time.time() - t_begin) + (10 + 3 - warm) * per > budget_s:
+            break
     left = budget_s - (time.time() - t_begin)
     want = 10 if left >= 10 * per else max(1, int(left / per))
     n, t0 = 0, time.time()
@@ -251,7 +247,6 @@ def cpu_baseline(hp, b=None, budget_s=90.0):
     dt = time.time() - t0
     return {"value": bs * (LS + LT) * n / dt, "unit": "src+tgt tokens/s", "cores": cores, "host_cores": avail,
             "kind": "port", "warmup_steps": warm, "timed_steps": n, "s_per_step": dt / n,
-            "thread_probe_s_per_step": {str(k): round(v, 3) for k, v in probe.items()},
             "sample": "%d timed steps (+%d warm-up) of the bench batch itself: %d sentences x (64+64) tokens, "
                       "Transformer-base, fwd+bwd+Adam, torch-CPU fp32 restatement of the TF1 path "
                       "(oracle/ref_torch.py; TF1 cannot run here); protocol SURVEY 8(d) = 3+10 when it fits %d s"

@@ -198,6 +198,12 @@ int zk_colsum_rowchunks(int rows);
  * = w[r]*(softmax - soft).                                                            */
 int zk_ce_fused(const float* logits, const int* ids, const float* w, float* ce_out, void* dlogits, int rows,
                 int V, int ld, float label_smooth, zk_stream_t stream);
+/* the same on bf16 logits (what the 256x256-tile logits GEMM of the training step writes: half the bytes out of the
+ * GEMM and into this pass); zgold (may be NULL): fp32 [rows], the gold-label logit of every row as the GEMM's fp32
+ * accumulator held it (zk_gemm_grouped, GroupDesc.gold / .colsum), so that the dominant term of the loss is not
+ * rounded to bf16.  8192 < ld <= 32768, ld % 8 == 0. */
+int zk_ce_fused16(const void* logits, const int* ids, const float* w, const float* zgold, float* ce_out, void* dlogits,
+                  int rows, int V, int ld, float label_smooth, zk_stream_t stream);
 /* transformer.py:208-216: mask=(id!=0); w = loss_scale*mask/(len_b*B); per-sentence loss and mean */
 int zk_target_stats(const int* ids, float* mask, float* w, int B, int L, float loss_scale, zk_stream_t stream);
 int zk_loss_reduce(const float* ce, const int* ids, float* per_sample, float* loss, int B, int L,

@@ -1,0 +1,176 @@
+# coding: utf-8
+"""Lower-bound budget of the training step as THIS decomposition launches it.
+
+For every kernel class of the step (BASELINE configs[1]: B=64 x (64+64) tokens, Transformer-base, V=32000):
+
+    floor = max(FLOPs / 2.5 PF, algorithmic HBM bytes / 6.3 TB/s, L2->LDS staged bytes / 12 TB/s) + 5 us fixed
+
+per launch (the formula of VERDICT r02 item 1a; 6.3 TB/s = measured copy rate, 12 TB/s = the chip-wide L2 -> LDS
+rate the GEMM K loops sustain, 5 us = launch boundary + cold first loads + drain), summed over the launches of a
+step.  The GEMM tiles are the ones the library picks (zk_gemm_plan: a host function, no GPU needed); the staged
+bytes of a tile grid are tiles x (BM + BN) x K x 2.  `measured` columns come from a rocprof summary
+(profiles/*_rocprof_kernel_stats_*.txt) when one is given.
+
+    python scripts/step_budget.py [profiles/r02_rocprof_kernel_stats_final.txt] [--sentences 64]
+"""
+import argparse
+import collections
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from zero_amd import hip  # noqa: E402
+
+PF, HBM, L2LDS, FIXED = 2.5e15, 6.3e12, 12e12, 5e-6
+
+
+def plan(M, N, K, out_f32=0, plain=0):
+    code = hip.lib().raw("zk_gemm_plan")(M, N, K, out_f32, plain)
+    return ((code >> 8) & 255) * 8, ((code >> 16) & 255) * 8, max(1, (code >> 24) & 15)
+
+
+class Budget(object):
+    def __init__(self):
+        self.rows = collections.OrderedDict()
+
+    def add(self, cls, n, flops=0.0, hbm=0.0, staged=0.0):
+        """n launches, each with these per-launch figures."""
+        t = max(flops / PF, hbm / HBM, staged / L2LDS) + FIXED
+        r = self.rows.setdefault(cls, {"n": 0, "flops": 0.0, "hbm": 0.0, "staged": 0.0, "floor": 0.0, "fixed": 0.0})
+        r["n"] += n
+        r["flops"] += n * flops
+        r["hbm"] += n * hbm
+        r["staged"] += n * staged
+        r["floor"] += n * t
+        r["fixed"] += n * FIXED
+
+    def gemm(self, cls, n, M, N, K, out_bytes=2, extra_in=0.0, tile=None, splits=None):
+        bm, bn, s = plan(M, N, K, 1 if out_bytes == 4 else 0)
+        if tile is not None:
+            bm, bn = tile
+        if splits is not None:
+            s = splits
+        tiles = -(-M // bm) * -(-N // bn)
+        staged = tiles * (bm + bn) * K * 2.0
+        hbm = (M * K + K * N) * 2.0 + M * N * out_bytes + extra_in
+        self.add(cls, n, 2.0 * M * N * K, hbm, staged)
+
+
+def build(B, L=64, H=512, F=2048, V=32000, NE=6, ND=6, nh=8):
+    T = B * L
+    b = Budget()
+    act = T * H * 2.0                     # one bf16 activation
+    # ---- forward + dgrad chain of 4096-row GEMMs (func.py:14-65 and its mirrors)
+    c = "small GEMM chain (linear fwd + dgrad, %d-row)" % T
+    for _ in range(NE):
+        b.gemm(c, 1, T, 3 * H, H)                        # qkv
+        b.gemm(c, 1, T, H, H)                            # o_map
+        b.gemm(c, 1, T, F, H)                            # ffn enlarge
+        b.gemm(c, 1, T, H, F)                            # ffn output
+        b.gemm(c, 1, T, H, 3 * H, extra_in=act)          # d qkv -> dx (+ residual)
+        b.gemm(c, 1, T, H, H)                            # d o_map
+        b.gemm(c, 1, T, F, H, extra_in=T * F * 2.0)      # d ffn output (ReLU mask)
+        b.gemm(c, 1, T, H, F, extra_in=act)              # d ffn enlarge (+ residual)
+    for _ in range(ND):
+        for (n_, k_) in ((3 * H, H), (H, H), (H, H), (H, H), (F, H), (H, F)):      # self qkv, o, cross q, o, ffn
+            b.gemm(c, 1, T, n_, k_)
+        for (n_, k_, ex) in ((H, 3 * H, act), (H, H, 0), (H, H, act), (H, H, 0), (F, H, T * F * 2.0), (H, F, act)):
+            b.gemm(c, 1, T, n_, k_, extra_in=ex)
+    # cross-attention K/V of all layers (one grouped launch), d(encoder output) (one K-segmented launch)
+    c2 = "grouped K/V projections + K-segmented d(enc)"
+    b.add(c2, 1, 2.0 * T * (2 * H * ND) * H, act + 2 * ND * H * H * 2 + 2 * ND * act,
+          (T // 128) * (2 * ND * H // 128) * 256 * H * 2.0)
+    b.add(c2, 1, 2.0 * T * H * (2 * ND * H), 2 * ND * act + 2 * ND * H * H * 2 + act,
+          (T // 64) * (H // 64) * 128 * (2 * ND * H) * 2.0)
+    # ---- weight gradients: two grouped launches (fp32 out), K = T tokens
+    c3 = "grouped weight gradients (fp32 out, K = %d)" % T
+    wg_enc = NE * (H * 3 * H + H * H + 2 * H * F)
+    wg_dec = ND * (H * 3 * H + 5 * H * H + 2 * H * F) + V * H
+    for params in (wg_enc, wg_dec):
+        # 128 x 256 tiles: staged bytes per output element = (128 + 256) * K * 2 / (128 * 256)
+        b.add(c3, 1, 2.0 * params * T, params * 4.0 + 2 * 30 * act, params / (128.0 * 256) * 384 * T * 2.0)
+    # ---- logits: forward GEMM (bf16 or fp32 logits), dlogits x E
+    c4 = "logits forward + dlogits x E"
+    b.add(c4, 1, 2.0 * T * V * H, act + V * H * 2 + T * V * 2.0, (T // 256) * (V // 256) * 512 * H * 2.0)
+    b.add(c4, 1, 2.0 * T * V * H, T * V * 2.0 + V * H * 2 + act, (T // 128) * (H // 256) * 384 * V * 2.0)
+    # ---- attention (func.py:218-256): forward reads q, k, v, writes out; backward reads q, k, v, dO, writes dq, dk, dv
+    c5 = "attention forward / backward (one (sentence, head) tile per workgroup)"
+    n_att = NE + 2 * ND
+    b.add(c5, n_att, 4.0 * B * L * L * H, 4 * act)
+    b.add(c5, n_att, 10.0 * B * L * L * H, 7 * act)
+    # ---- residual + LayerNorm
+    c6 = "residual + LayerNorm forward / backward"
+    n_ln = 2 * NE + 3 * ND
+    b.add(c6, n_ln, 0, 4 * act)           # x, y in; out, saved sum out
+    b.add(c6, n_ln, 0, 4 * act)           # dout, saved sum in; dsum (+ dy with dropout) out
+    # ---- cross entropy, Adam, the rest
+    b.add("cross entropy (bf16 logits in, bf16 dlogits out)", 1, 0, T * V * 4.0)
+    nparam = wg_enc + wg_dec + V * H + (NE * 2 + ND * 3) * 2 * H + H
+    b.add("Adam (30 B / parameter)", 1, 0, nparam * 30.0)
+    b.add("embeddings, masks, loss, column / LayerNorm-parameter reductions, zero fill, norm", 17, 0, 12e6)
+    return b, nparam
+
+
+def measured(path):
+    """kernel-class -> (launches/step, us/step) from a profiles/*_rocprof_kernel_stats_*.txt file."""
+    out = collections.defaultdict(lambda: [0.0, 0.0])
+    text = open(path).read()
+    m = re.search(r"over ([0-9.]+) steps", text)
+    steps = float(m.group(1)) if m else 1.0
+    for line in text.splitlines():
+        f = line.split(None, 6)
+        if len(f) < 7 or not f[0].endswith("%") or not f[1][0].isdigit():
+            continue
+        name, calls, total_ms = f[6], float(f[2]), float(f[1])
+        if "k_gemm_dlds<128, 256" in name or "k_gemm_grouped256" in name:
+            cls = "logits forward + dlogits x E"
+        elif "k_gemm_grouped<128, 256" in name or "k_gemm_grouped<256" in name or "k_gemm_sk256" in name:
+            cls = "grouped weight gradients"
+        elif "k_gemm_grouped<128, 128" in name or "k_gemm_kseg" in name:
+            cls = "grouped K/V projections + K-segmented d(enc)"
+        elif "k_gemm_dlds" in name:
+            cls = "small GEMM chain"
+        elif "k_attn" in name:
+            cls = "attention forward / backward"
+        elif "k_add_ln" in name:
+            cls = "residual + LayerNorm forward / backward"
+        elif "k_ce_fused" in name:
+            cls = "cross entropy"
+        elif "k_adam" in name:
+            cls = "Adam"
+        elif "at::native" in name or "rocclr" in name or "k_seed_advance" in name or "k_cast" in name:
+            continue                                   # warm-up / eager-pass only
+        else:
+            cls = "embeddings, masks, loss"
+        out[cls][0] += calls / steps
+        out[cls][1] += total_ms / steps * 1e3
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("stats", nargs="?")
+    ap.add_argument("--sentences", type=int, default=64)
+    a = ap.parse_args()
+    b, nparam = build(a.sentences)
+    meas = measured(a.stats) if a.stats else {}
+    print("| kernel class | launches | GFLOP | HBM MB | L2->LDS MB | fixed us | **floor us** | measured us |")
+    print("|---|---|---|---|---|---|---|---|")
+    tot = [0, 0.0, 0.0, 0.0]
+    for cls, r in b.rows.items():
+        m = next((v for k, v in meas.items() if cls.startswith(k)), None)
+        print("| %s | %d | %.0f | %.0f | %.0f | %.0f | **%.0f** | %s |" % (
+            cls, r["n"], r["flops"] / 1e9, r["hbm"] / 1e6, r["staged"] / 1e6, r["fixed"] * 1e6, r["floor"] * 1e6,
+            ("%.0f (%d launches)" % (m[1], round(m[0]))) if m else "-"))
+        tot[0] += r["n"]; tot[1] += r["flops"]; tot[2] += r["floor"]; tot[3] += m[1] if m else 0.0
+    print("| **step** | %d | %.0f | | | %.0f | **%.0f** | %s |" % (
+        tot[0], tot[1] / 1e9, tot[0] * FIXED * 1e6, tot[2] * 1e6, ("%.0f" % tot[3]) if meas else "-"))
+    print("\nparameters %.1f M; FLOPs / 2.5 PF alone = %.0f us; the 40 %% bar = %.0f us" % (
+        nparam / 1e6, tot[1] / PF * 1e6, tot[1] / PF * 1e6 / 0.4))
+
+
+if __name__ == "__main__":
+    main()

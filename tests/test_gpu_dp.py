@@ -45,8 +45,12 @@ def _worker(rank, world, port, out_dir, use_graph, overlap="1", exchange=None):
     tr = Trainer(hp)
     tr.prepare_static({"source": src[half], "target": tgt[half]})
     losses = []
+    grad1 = None
     for _ in range(3):
         losses.append(float(tr.step_static(use_graph=use_graph).cpu()[0]))
+        if grad1 is None:
+            torch.cuda.synchronize()
+            grad1 = tr.store.grad.cpu().numpy().copy()      # the exchanged gradient of step 1 (identical weights in every mode)
     torch.cuda.synchronize()
     g_, p_, bad_ = tr.train_op.stats()
     tag = "" if overlap == "1" else "_plain"
@@ -56,7 +60,7 @@ def _worker(rank, world, port, out_dir, use_graph, overlap="1", exchange=None):
              loss=np.array(losses), gnorm=np.array([g_, p_]),
              exchange=np.array([tr.reducer.bucket_dtype_name(), ",".join(tr.reducer.sparse_keys()),
                                 str(tr.reducer.bytes_last_step), str(tr.store.numel)]),
-             grad=tr.store.grad.cpu().numpy(), master=tr.store.master.cpu().numpy(),
+             grad=tr.store.grad.cpu().numpy(), grad1=grad1, master=tr.store.master.cpu().numpy(),
              kinds=np.array([k for k, _ in next((v for k, v in tr._graphs.items() if k[0] == "seg"), [])] or ["none"]))
     torch.distributed.destroy_process_group()
 
@@ -129,11 +133,15 @@ def test_exchange_modes_bf16_buckets_and_sparse_rows(tmp_path):
     dense, sp32, sp16 = (res[m][0] for m in modes)
     # fp32 rows in rank order vs ring order of the dense all-reduce: two addends -> identical
     assert np.array_equal(dense["grad"], sp32["grad"]) and np.array_equal(dense["master"], sp32["master"])
-    gd, gb = dense["grad"], sp16["grad"]
-    scale = np.abs(gd).max()
-    assert np.abs(gd - gb).max() <= 2.0 ** -7 * scale, (np.abs(gd - gb).max(), scale)
-    assert abs(sp16["gnorm"][0] - dense["gnorm"][0]) <= 5e-3 * dense["gnorm"][0]
-    assert np.allclose(sp16["loss"], dense["loss"], rtol=2e-3)
+    # bf16 exchange, step 1 (same weights in both runs): every element within bf16 rounding of the fp32 sum -- each
+    # rank's contribution rounded once (2^-9 relative) and the sum rounded once more
+    gd, gb = dense["grad1"], sp16["grad1"]
+    assert np.array_equal(dense["grad1"], sp32["grad1"])
+    err = np.abs(gd - gb)
+    assert (err <= 2.0 ** -7 * np.abs(gd) + 2.0 ** -8 * np.abs(gd).max() * 1e-2).all(), float(err.max())
+    assert abs(np.linalg.norm(gb) - np.linalg.norm(gd)) <= 2e-3 * np.linalg.norm(gd)
+    assert sp16["loss"][0] == dense["loss"][0]                 # the forward of step 1 does not see the exchange
+    assert np.allclose(sp16["loss"], dense["loss"], rtol=2e-2)  # later steps: Adam amplifies the rounding of tiny gradients
     numel = int(dense["exchange"][3])
     assert int(dense["exchange"][2]) == numel * 4
     assert int(sp32["exchange"][2]) < int(dense["exchange"][2]) and int(sp16["exchange"][2]) < int(sp32["exchange"][2])

@@ -98,6 +98,7 @@ class TransformerCore(object):
         # T*V*4 bytes, which matters for larger batches / vocabularies)
         self.fused_ce = os.environ.get("ZERO_HIP_FUSED_CE", "0") != "0" and self.eng.lib.experiments
         self.logits_tile256 = os.environ.get("ZERO_HIP_LOGITS_256", "1") != "0"
+        self.logits_bf16 = os.environ.get("ZERO_HIP_LOGITS_BF16", "1") != "0"
         self._red_id = 0
         self.side = torch.cuda.Stream(self.eng.device) if self.eng.device.type == "cuda" else None
 
@@ -576,15 +577,27 @@ class TransformerCore(object):
             e.logits_ce_fwd(feat, E, batch["tgt"], ce, lse, Tt, self.V, label_smooth)
             self._ce_ctx = (lse, w, label_smooth) if need_grad else None
         else:
-            logits = e.mat("logits", Tt, self.Vpad, F32)
-            if self.logits_tile256 and e.gemm_impl == 0 and self.H % 8 == 0:
+            zgold = None
+            tile256 = self.logits_tile256 and e.gemm_impl == 0 and self.H % 8 == 0
+            if tile256 and self.logits_bf16 and 8192 < self.Vpad <= 32768:
+                # 256x256 tiles leaving as bf16 (half the bytes out of the GEMM and into the cross-entropy pass: 524 ->
+                # 262 MB each way at the bench shapes); the gold-label logit of every row is kept UNROUNDED beside the
+                # tile, so the loss' dominant term stays fp32 (ZERO_HIP_LOGITS_BF16=0: fp32 logits as before)
+                logits = e.mat("logits16", Tt, self.Vpad)
+                zgold = e.buf("zgold", (Tt,), F32)
+                e.gemm_grouped([(feat, E, logits, Tt, self.V, self.H, None, None, zgold, batch["tgt"])], 0, 1,
+                               tile=(256, 256))
+            elif tile256:
                 # 256x256 tiles, fp32 tile stored straight from the accumulators (scripts/gemm_big_bench.py:
                 # 223 us against 274-291 us for the 128x128 kernels on the 4096 x 32000 x 512 problem)
+                logits = e.mat("logits", Tt, self.Vpad, F32)
                 e.gemm_grouped([(feat, E, logits, Tt, self.V, self.H, None)], 0, 1, tile=(256, 256))
             else:
+                logits = e.mat("logits", Tt, self.Vpad, F32)
                 e.gemm(feat, E, logits, Tt, self.V, self.H, 0, 1)
             dlogits = e.mat("dlogits", Tt, self.Vpad) if need_grad else None
-            e.ce_fused(logits, batch["tgt"], w if need_grad else None, ce, dlogits, Tt, self.V, label_smooth)
+            e.ce_fused(logits, batch["tgt"], w if need_grad else None, ce, dlogits, Tt, self.V, label_smooth,
+                       zgold=zgold)
         per_sample = e.buf("per_sample", (B,), F32)
         loss = e.buf("loss", (1,), F32)
         e.loss_reduce(ce, batch["tgt"], per_sample, loss, B, Lt)
