@@ -96,9 +96,13 @@ __global__ void __launch_bounds__((4 + PW) * 64) k_gemm_grouped(const GroupDesc*
 // accumulators of one 256x256 tile: acc[i][j][e] = element (row m0 + wm*128 + i*32 + (e&3) + 8*(e>>2) + 4*(lane>>5),
 // column n0 + wn*64 + j*32 + (lane&31)) with wave = wm * 4 + wn.  smem: the 128 KiB ring (free again on return, after a
 // barrier by the caller).
-template <bool TA, bool TB, bool SPREAD>
+// CS (tb = 0 only): acc_cs[j] additionally accumulates ones[32 x 16] x B-fragment, i.e. every row of it holds the column
+// sums over k of this wave's 32 columns of B -- the bias gradient sum_k dY[k][n] (func.py:16, 58-60) of a weight-gradient
+// problem, from the fragments the wave has in registers anyway (2 extra MFMAs per 8; waves with cs_on only).
+template <bool TA, bool TB, bool SPREAD, bool CS = false>
 __device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                            int lda, int ldb, int M, int N, int K, int m0, int n0, f32x16_t (&acc)[4][2]) {
+                                            int lda, int ldb, int M, int N, int K, int m0, int n0, f32x16_t (&acc)[4][2],
+                                            bool cs_on = false, f32x16_t* acc_cs = nullptr) {
   constexpr int BM = 256, BN = 256, NS = 2, NW = 8, NWN = 4, WTM = 128, WTN = 64, TM = 4, TN = 2;
   constexpr int STAGE = (BM + BN) * 64;
   bf16_t* ring = reinterpret_cast<bf16_t*>(smem);
@@ -112,6 +116,16 @@ __device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* _
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  bf16x8_t ones;
+  if (CS) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc_cs[j][e] = 0.f;
+    typedef short v8s_ __attribute__((ext_vector_type(8)));
+    const v8s_ o = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};     // bf16 1.0
+    ones = __builtin_bit_cast(bf16x8_t, o);
+  }
   DmaPlan<BM, NW> planA;
   DmaPlan<BN, NW> planB;
   dma_plan<BM, TA, NW>(planA, A, lda, m0, M, 0, wave, lane);
@@ -166,6 +180,11 @@ __device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* _
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
+      if (CS && cs_on) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc_cs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bfr[kk & 1][j], acc_cs[j], 0, 0, 0);
+      }
       if (SPREAD) issue_part(kt + 1, kk * 2, kk * 2 + 2);   // the other stage is free since this step's barrier
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -173,7 +192,7 @@ __device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* _
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (all-zero) pieces
 }
 
-template <bool TA, bool TB, bool SPREAD>
+template <bool TA, bool TB, bool SPREAD, bool CS = false>
 __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __restrict__ descs, int nprob) {
   constexpr int BM = 256, BN = 256, NS = 2, NWN = 4, WTM = 128, WTN = 64, TM = 4, TN = 2;
   constexpr int STAGE = (BM + BN) * 64;
@@ -198,8 +217,22 @@ __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __rest
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
   f32x16_t acc[TM][TN];
-  gemm256_acc<TA, TB, SPREAD>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc);
-  if (!d.out_f32) {
+  if (CS) {
+    // fp32 tile + bias gradient: the waves of the first row of waves (wm = 0) of the tm = 0 tiles carry the column sums
+    f32x16_t acc_cs[TN];
+    const bool cs_on = d.colsum != nullptr && tm == 0 && wm == 0;
+    gemm256_acc<TA, TB, SPREAD, true>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, cs_on, acc_cs);
+    if (cs_on && lane < 32) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WTN + j * 32 + lane;
+        if (col < N) d.colsum[col] = acc_cs[j][0];
+      }
+    }
+  } else {
+    gemm256_acc<TA, TB, SPREAD>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc);
+  }
+  if (!CS && !d.out_f32) {
     // bf16 tile (the logits of the training step: half the bytes of the fp32 tile on the way out and again into the
     // cross-entropy pass).  Adjacent lanes hold adjacent columns: a quad-perm DPP swap pairs them so that every lane
     // stores one dword (two bf16) per register pair instead of two shorts.  The gold-label logit of every row leaves
@@ -525,8 +558,12 @@ extern "C" {
 // fields are the running sum of ceil(M/bm)*ceil(N/bn); total_tiles = that sum.
 int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int tb, int tile, hipStream_t stream) {
   ZK_CHECK_ARG(nprob >= 1 && total_tiles >= 1, "zk_gemm_grouped: empty group");
+  // bit 8 of `tile` (256x256 tiles, ta = 1, tb = 0): some problem carries a column-sum output (GroupDesc.colsum)
+  const bool cs = (tile & 256) != 0;
+  tile &= 255;
   ZK_CHECK_ARG(tile == 1 || tile == 4 || tile == 5 || tile == 6 || tile == 7 || tile == 8,
                "zk_gemm_grouped: tile must be 1 (128x128), 4 (64x64), 5 (256x128), 6 (128x256) or 7 / 8 (256x256)");
+  ZK_CHECK_ARG(!cs || ((tile == 7 || tile == 8) && ta && !tb), "zk_gemm_grouped: column sums on 256x256 tiles need ta = 1, tb = 0");
   const GroupDesc* d = (const GroupDesc*)descs;
   dim3 grid((unsigned)total_tiles);
   if (tile == 7 || tile == 8) {     // fp32 outputs without epilogue options only (checked on the host copy by the caller)
@@ -535,6 +572,7 @@ int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int t
     do {                                                                                                     \
       if (!ta && !tb) hipLaunchKernelGGL((k_gemm_grouped256<false, false, SP_>), grid, blk, 0, stream, d, nprob);   \
       else if (!ta && tb) hipLaunchKernelGGL((k_gemm_grouped256<false, true, SP_>), grid, blk, 0, stream, d, nprob); \
+      else if (ta && !tb && cs) hipLaunchKernelGGL((k_gemm_grouped256<true, false, SP_, true>), grid, blk, 0, stream, d, nprob); \
       else if (ta && !tb) hipLaunchKernelGGL((k_gemm_grouped256<true, false, SP_>), grid, blk, 0, stream, d, nprob); \
       else hipLaunchKernelGGL((k_gemm_grouped256<true, true, SP_>), grid, blk, 0, stream, d, nprob);               \
     } while (0)

@@ -190,11 +190,15 @@ class Engine(object):
         bm, bn = (tile, tile) if isinstance(tile, int) else tile[:2]
         code = {(128, 128): 1, (64, 64): 4, (256, 128): 5, (128, 256): 6, (256, 256): 7 if spread else 8}[(bm, bn)]
         if (bm, bn) == (256, 256):
-            # fp32 tile, or bf16 tile (+ optional capture of C[row][gold[row]] in fp32: the logits of the training step)
+            # fp32 tile (+ optional column sums of B when ta = 1, tb = 0: the bias gradient beside a weight gradient, by
+            # two extra MFMAs per eight in the tm = 0 tiles), or bf16 tile (+ optional capture of C[row][gold[row]] in
+            # fp32: the logits of the training step)
             assert all(bias is None and r is None and
-                       ((c.t.dtype == torch.float32 and cs is None and gold is None) or
+                       ((c.t.dtype == torch.float32 and gold is None and (cs is None or (ta and not tb))) or
                         (c.t.dtype == torch.bfloat16 and c.ld % 2 == 0 and (gold is None) == (cs is None)))
                        for _, _, c, _, _, _, bias, r, cs, gold in problems)
+            if any(p[8] is not None and p[2].t.dtype == torch.float32 for p in problems):
+                code |= 256
         elif any(p[8] is not None for p in problems):
             assert code in (5, 6) and not tb, "column sums ride on the producer waves of the wide tiles (tb = 0)"
         key = (ta, tb, bm, bn, spread) + tuple((a.ptr, b.ptr, c.ptr, M, N, K, hip.ptr(bias) or 0, r.ptr if r is not None else 0,

@@ -76,15 +76,19 @@ class TransformerCore(object):
         self.group_wgrad = os.environ.get("ZERO_HIP_GROUP_WGRAD", "1") != "0"
         # tile of the grouped weight-gradient launch: 128x256 (four waves with a 128x64 register tile each + four
         # producer waves, scripts/gemm_big_bench.py: 780 -> 856 TF on the decoder side incl. the logits problem)
-        wt = os.environ.get("ZERO_HIP_WGRAD_TILE", "128x256").lower()
-        self.wgrad_tile = {"128": 128, "128x128": 128, "256x128": (256, 128), "128x256": (128, 256),
-                           "256x256": (256, 256), "256x256n": (256, 256, 0)}[wt]
         # one group per side of the model with a single rank (fewest launches); smaller groups with
         # data parallelism so that the gradient all-reduce of finished layers starts early
         import torch.distributed as _dist
         _multi = _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1
         self.group_layers = int(os.environ.get("ZERO_HIP_GROUP_LAYERS", "2" if _multi else "6"))
-        self.group_all = (not _multi) and os.environ.get("ZERO_HIP_GROUP_ALL", "0") != "0"
+        # Single rank (round 3): EVERY weight gradient of the step in ONE grouped launch of 256x256 tiles (7.8 KB staged
+        # per MFLOP against 11.7 for 128x256).  The coarse tile needs the big group: 922 tiles on 256 CUs = 3.6 rounds,
+        # while the encoder's 288 tiles alone would be 1.1 -- which is why the 256x256 tile lost inside the per-side
+        # groups of round 2.  The bias gradients ride along as column sums by MFMA (gemm256_acc<.., CS>).
+        self.group_all = (not _multi) and os.environ.get("ZERO_HIP_GROUP_ALL", "1") != "0"
+        wt = os.environ.get("ZERO_HIP_WGRAD_TILE", "256x256" if self.group_all else "128x256").lower()
+        self.wgrad_tile = {"128": 128, "128x128": 128, "256x128": (256, 128), "128x256": (128, 256),
+                           "256x256": (256, 256), "256x256n": (256, 256, 0)}[wt]
         self._pending_wgrads = []
         self._pending_colsums = []     # (dY Mat, bias-gradient view, private partial buffer)
         self._pending_lnred = []       # (partials, rows, H, dgamma, dbeta, dbias_prev)
@@ -189,8 +193,8 @@ class TransformerCore(object):
 
         # bias gradient = column sums of dY: on the wide (producer-wave) tiles the producers of the weight-gradient GEMM
         # compute them from the dY tiles they stage anyway (no separate pass over dY)
-        fold_cs = bias_grad and isinstance(self.wgrad_tile, tuple) and self.wgrad_tile[:2] != (256, 256) and \
-            os.environ.get("ZERO_HIP_FOLD_COLSUM", "1") != "0"
+        # (256x256 tiles: by two extra MFMAs per eight on the fragments the tm = 0 tiles hold anyway)
+        fold_cs = bias_grad and isinstance(self.wgrad_tile, tuple) and os.environ.get("ZERO_HIP_FOLD_COLSUM", "1") != "0"
         if self.group_wgrad and self.eng.gemm_impl == 0:
             self._pending_wgrads.append((x, dy, gW, Wm.rows, Wm.cols, x.rows, None, None, gb if fold_cs else None))
             if bias_grad and not fold_cs:
@@ -684,7 +688,7 @@ class TransformerCore(object):
             ready_d.append(pre)
             # (ZERO_HIP_GROUP_ALL=1, one rank: the decoder's weight gradients wait for the encoder's -- ONE grouped launch
             # per step, one partial last round of tiles instead of two)
-            if len(ready_d) >= self.group_layers or (l == 0 and not self.group_all):
+            if not self.group_all and (len(ready_d) >= self.group_layers or l == 0):
                 self._flush_wgrads()
                 for key in ready_d:
                     self._side(lambda key=key: on_ready(key))
@@ -696,12 +700,14 @@ class TransformerCore(object):
             e.embed_bwd_sorted(batch["tgt_sort"], dxt, st.g(self.tgt_emb), H,
                                accumulate=(self.tgt_emb == self.soft_emb), drop_p=hp.dropout, sid=9002)
             e.colsum(dxt, st.g("bias"), skip_L=Lt, accumulate=False, drop_p=hp.dropout, sid=9002)
+        def tables_ready():
+            if self.soft_emb != self.src_emb:
+                self._side(lambda: on_ready(self.soft_emb))
+            if self.tgt_emb != self.soft_emb and self.tgt_emb != self.src_emb:
+                self._side(lambda: on_ready(self.tgt_emb))
         if not self.group_all:
             self._side(tgt_embed_grads)
-        if self.soft_emb != self.src_emb:
-            self._side(lambda: on_ready(self.soft_emb))
-        if self.tgt_emb != self.soft_emb and self.tgt_emb != self.src_emb:
-            self._side(lambda: on_ready(self.tgt_emb))
+            tables_ready()
         if self._use_kseg():
             self._finish_mem_grad(d_enc)
         # encoder
@@ -721,14 +727,19 @@ class TransformerCore(object):
             Q[cur ^ 1] = other
             cur ^= 1
             ready_e.append(pre)
-            if len(ready_e) >= self.group_layers or l == 0:
+            if (not self.group_all and len(ready_e) >= self.group_layers) or l == 0:
                 self._flush_wgrads()
-                for key in ready_e:
+                for key in ready_d + ready_e:      # (group_all: the decoder's keys were held back with its weight gradients)
                     self._side(lambda key=key: on_ready(key))
-                ready_e = []
+                ready_d, ready_e = [], []
         dxs = Q[cur]
         if self.group_all:
+            if ready_d:                            # a model without encoder layers
+                self._flush_wgrads()
+                for key in ready_d:
+                    self._side(lambda key=key: on_ready(key))
             self._side(tgt_embed_grads)       # after the (single) grouped launch that overwrote the shared softmax table
+            tables_ready()
 
         def src_embed_grads():
             e.embed_bwd_sorted(batch["src_sort"], dxs, st.g(self.src_emb), H,
