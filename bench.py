@@ -293,6 +293,10 @@ def decode_step_bytes(hp, model, rows, sent, ls):
     return weights + cross + NL * cache + logits
 
 
+import threading as _threading
+_LANE_FNS = _threading.local()
+
+
 def decode_measure(args, rank, world):
     """BASELINE configs[3] on this rank's shard; returns the result dict on rank 0 (None elsewhere)."""
     from zero_amd.models import model as registry, load_all
@@ -312,19 +316,28 @@ def decode_measure(args, rank, world):
     enc, dec = graph.infer_fn(hp)
     bsz = hp.eval_batch_size
     batches = [decode_batch(lens, order[b0:b0 + bsz], rng) for b0 in range(0, n_sent, bsz)]
-    for src in batches[-max(args.warmup, 1):]:        # warm-up on the LONGEST batches: sizes every buffer
-        beam_search({"source": src}, enc, dec, hp)
+    from zero_amd.evalu import decode_many, decode_streams
+    streams = decode_streams() if getattr(args, "decode_streams", 0) <= 0 else args.decode_streams
+
+    def work(src):
+        # the thread's own (encoding_fn, decoding_fn): they bind the execution lane of the calling thread
+        fns = _LANE_FNS.__dict__.get("fns")
+        if fns is None:
+            fns = _LANE_FNS.fns = graph.infer_fn(hp)
+        return beam_search({"source": src}, fns[0], fns[1], hp)["steps"]
+    # warm-up on the LONGEST batches, once per lane: sizes every buffer of every lane
+    warm = batches[-max(args.warmup, 1):]
+    decode_many([b for b in warm for _ in range(streams)], work, streams)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    steps = 0
+    step_counts = decode_many(batches, work, streams)
+    steps = sum(step_counts)
     bytes_total = 0.0
-    for src in batches:
-        out = beam_search({"source": src}, enc, dec, hp)
-        steps += out["steps"]
-        bytes_total += out["steps"] * decode_step_bytes(hp, model, src.shape[0] * hp.beam_size, src.shape[0],
-                                                        int((src != 0).sum(1).mean()))
+    for src, n_steps in zip(batches, step_counts):
+        bytes_total += n_steps * decode_step_bytes(hp, model, src.shape[0] * hp.beam_size, src.shape[0],
+                                                   int((src != 0).sum(1).mean()))
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -344,6 +357,7 @@ def decode_measure(args, rank, world):
                                "(lengths ~ clipped N(28,14) in [4,100] + eos), eval batch 32, length-sorted, cache mode; "
                                "random weights: every batch decodes to its length cap" % (model, n_sent),
                    "rows_per_step": bsz * hp.beam_size, "parallelism": "dp%d (sentences sharded, no exchange)" % world,
+                   "batches_in_flight": streams,
                    "hip_graph": "one replay per decode step, search state on the device"},
         "decode_steps_per_s": steps / dt,
         "roofline": {"bound": "hbm", "kernel": "decode step (hipGraph of the whole step: cache reorder + decoder + logits "
@@ -423,6 +437,8 @@ def main():
                     help="training batch in sentences per GPU (default 64 = the metric's 4096+4096 tokens; other "
                          "values are SIDE measurements that separate kernel quality from 'problem too small for 256 CUs')")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode leg of the default line")
+    ap.add_argument("--decode-streams", type=int, default=0,
+                    help="decode batches in flight at once (0 = ZERO_HIP_DECODE_STREAMS or its default)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -198,12 +198,6 @@ int zk_colsum_rowchunks(int rows);
  * = w[r]*(softmax - soft).                                                            */
 int zk_ce_fused(const float* logits, const int* ids, const float* w, float* ce_out, void* dlogits, int rows,
                 int V, int ld, float label_smooth, zk_stream_t stream);
-/* the same on bf16 logits (what the 256x256-tile logits GEMM of the training step writes: half the bytes out of the
- * GEMM and into this pass); zgold (may be NULL): fp32 [rows], the gold-label logit of every row as the GEMM's fp32
- * accumulator held it (zk_gemm_grouped, GroupDesc.gold / .colsum), so that the dominant term of the loss is not
- * rounded to bf16.  8192 < ld <= 32768, ld % 8 == 0. */
-int zk_ce_fused16(const void* logits, const int* ids, const float* w, const float* zgold, float* ce_out, void* dlogits,
-                  int rows, int V, int ld, float label_smooth, zk_stream_t stream);
 /* transformer.py:208-216: mask=(id!=0); w = loss_scale*mask/(len_b*B); per-sentence loss and mean */
 int zk_target_stats(const int* ids, float* mask, float* w, int B, int L, float loss_scale, zk_stream_t stream);
 int zk_loss_reduce(const float* ce, const int* ids, float* per_sample, float* loss, int B, int L,
@@ -270,6 +264,9 @@ int zk_zero(void* p, size_t bytes, zk_stream_t stream);
  *                       with a bit-identical table)
  * R, H multiples of 4. */
 size_t zk_rows_payload_bytes(int R, int H, int bf16);
+/* dst bf16 [cols, ld_dst] = transpose of src bf16 [rows, ld_src]: the operand layout of the fused decode kernels (a
+ * projection weight with its input dimension contiguous), made once per weight version */
+int zk_transpose_bf16(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, zk_stream_t stream);
 int zk_rows_pack(float* dtable, const int* uid, const int* n_uniq_dev, void* out, int R, int H, int out_bf16,
                  int clear_rows, zk_stream_t stream);
 int zk_rows_scatter_add(float* dtable, const void* payload, int R, int H, int in_bf16, int vocab_rows,

@@ -137,8 +137,10 @@ def test_exchange_modes_bf16_buckets_and_sparse_rows(tmp_path):
     # rank's contribution rounded once (2^-9 relative) and the sum rounded once more
     gd, gb = dense["grad1"], sp16["grad1"]
     assert np.array_equal(dense["grad1"], sp32["grad1"])
+    # (the two ranks' contributions may cancel, so the bound is against the largest gradient, not element by element)
     err = np.abs(gd - gb)
-    assert (err <= 2.0 ** -7 * np.abs(gd) + 2.0 ** -8 * np.abs(gd).max() * 1e-2).all(), float(err.max())
+    assert err.max() <= 2.0 ** -7 * np.abs(gd).max(), (float(err.max()), float(np.abs(gd).max()))
+    assert np.linalg.norm(gd - gb) <= 1e-2 * np.linalg.norm(gd)
     assert abs(np.linalg.norm(gb) - np.linalg.norm(gd)) <= 2e-3 * np.linalg.norm(gd)
     assert sp16["loss"][0] == dense["loss"][0]                 # the forward of step 1 does not see the exchange
     assert np.allclose(sp16["loss"], dense["loss"], rtol=2e-2)  # later steps: Adam amplifies the rounding of tiny gradients

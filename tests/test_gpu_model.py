@@ -370,6 +370,68 @@ def test_beam_search_token_ids(model, K):
         assert np.array_equal(outs["cache"][0], outs["dev"][0])
 
 
+@pytest.mark.parametrize("model", ["transformer_aan", "transformer"])
+def test_batches_in_flight_on_lanes_equal_the_sequential_loop(model):
+    """evalu.decode_many: several decode batches in flight at once, each on its own execution lane (own engine, HIP
+    stream, caches, captured graphs; shared variable store), must return exactly what the one-after-the-other loop of
+    evalu.py:49-139 returns -- hypotheses, scores, step counts, in the order of the input."""
+    from zero_amd.evalu import decode_many
+    from zero_amd.search import beam_search
+    import threading
+    hp, Pn, src, tgt = _setup(model, seed=11, beam_size=4)
+    Pn["tgt_embedding"] = (Pn["tgt_embedding"] * 6.0).astype(np.float32)
+    hp = copy.copy(hp); hp.search_mode = "cache"
+    get_core(hp, model, Pn)
+    rng = np.random.default_rng(5)
+    batches = []
+    for i in range(7):                       # different batch sizes and lengths: every lane re-sizes and re-captures
+        s_, _ = make_batch(rng, 3 + (i % 3), 6 + i, 5, hp.src_vocab.size(), hp.tgt_vocab.size())
+        batches.append(s_)
+    graph = registry.get_model(model)
+    tl = threading.local()
+
+    def work(s_):
+        if not hasattr(tl, "fns"):
+            tl.fns = graph.infer_fn(hp)
+        out = beam_search({"source": s_}, tl.fns[0], tl.fns[1], hp)
+        return np.asarray(out["seq"]).copy(), np.asarray(out["score"]).copy(), out["steps"]
+    seq = decode_many(batches, work, streams=1)
+    for n in (2, 3):
+        par = decode_many(batches, work, streams=n)
+        assert len(par) == len(seq)
+        for (a, b, c), (x, y, z) in zip(seq, par):
+            assert np.array_equal(a, x) and np.array_equal(b, y) and c == z, n
+    # an exception in a lane reaches the caller
+    def boom(s_):
+        raise ValueError("lane failure")
+    with pytest.raises(ValueError):
+        decode_many(batches, boom, streams=2)
+
+
+def test_transposed_decode_weights_follow_the_weight_version():
+    """The transposed weight copies of the fused decode kernels are made by zk_transpose_bf16 once per weight version:
+    reused across batches, refreshed after an optimiser update."""
+    from zero_amd.models import _decode
+    from zero_amd.main import Trainer
+    model = "transformer_aan"
+    hp, Pn, src, tgt = _setup(model, seed=2)
+    core = get_core(hp, model, Pn)
+    name = "decoder/layer_0/%s/dot_attention/q_map/W_0_0" % core.cross
+    m1 = _decode._transposed(core, name)
+    torch.cuda.synchronize()
+    W = core.store.s(name)
+    assert torch.equal(m1.t, W.t().contiguous())
+    calls = core.eng.lib.ncalls
+    assert _decode._transposed(core, name) is m1 and core.eng.lib.ncalls == calls       # same version: no launch
+    tr = Trainer(hp)
+    assert tr.core is core
+    tr.micro_step({"source": src, "target": tgt})
+    torch.cuda.synchronize()
+    m2 = _decode._transposed(core, name)
+    torch.cuda.synchronize()
+    assert core.eng.lib.ncalls > calls and torch.equal(m2.t, core.store.s(name).t().contiguous())
+
+
 @pytest.mark.parametrize("model", MODELS)
 @pytest.mark.parametrize("K", [1, 4, 8])
 def test_device_resident_search_equals_host_bookkeeping(model, K, monkeypatch):

@@ -632,84 +632,6 @@ __global__ void __launch_bounds__(1024, 8) k_ce_fused_reg(
   }
 }
 
-// The same pass over bf16 logits (the 256x256-tile logits GEMM of the training step writes them): 8 columns per
-// 16-byte load, the row in registers (V <= NV8*8192), and the gold-label logit taken from `zgold` -- the fp32
-// accumulator value the GEMM kept beside the rounded tile -- so that the dominant term of the loss is not rounded.
-template <int NV8>
-__global__ void __launch_bounds__(1024, 8) k_ce_fused_reg16(
-    const bf16_t* __restrict__ logits, const int* __restrict__ ids, const float* __restrict__ w,
-    const float* __restrict__ zgold, float* __restrict__ ce_out, bf16_t* __restrict__ dlogits, int V, int ld, float p,
-    float q, float normalizer) {
-  __shared__ float sm[16];
-  __shared__ float bc;
-  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const bf16_t* z = logits + (size_t)r * ld;
-  const float wr = (w != nullptr) ? w[r] : 0.f;
-  const int gold = ids[r];
-  float v[NV8][8];
-  float m = -INFINITY, sz = 0.f;
-#pragma unroll
-  for (int i = 0; i < NV8; ++i) {
-    const int c = (i * 1024 + tid) * 8;
-    if (c + 7 < V) {
-      const zk_u32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const zk_u32x4*>(z + c));   // read once
-      unpack8(make_uint4(t4.x, t4.y, t4.z, t4.w), v[i]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[i][j] = (c + j < V) ? bf2f(z[c + j]) : -INFINITY;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      m = fmaxf(m, v[i][j]);
-      sz += (v[i][j] > -INFINITY) ? v[i][j] : 0.f;
-    }
-  }
-  m = wave_max(m);
-  if (lane == 0) sm[wv] = m;
-  __syncthreads();
-  if (tid == 0) { float t = sm[0]; for (int i = 1; i < 16; ++i) t = fmaxf(t, sm[i]); bc = t; }
-  __syncthreads();
-  const float gm = bc;
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < NV8; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { v[i][j] = __expf(v[i][j] - gm); s += v[i][j]; }
-  s = wave_sum(s);
-  sz = wave_sum(sz);
-  __syncthreads();
-  if (lane == 0) sm[wv] = s;
-  __syncthreads();
-  if (tid == 0) { float t = 0.f; for (int i = 0; i < 16; ++i) t += sm[i]; bc = t; }
-  __syncthreads();
-  const float gs = bc;
-  __syncthreads();
-  if (lane == 0) sm[wv] = sz;
-  __syncthreads();
-  if (tid == 0) {
-    float t = 0.f;
-    for (int i = 0; i < 16; ++i) t += sm[i];
-    const float lse = gm + __logf(gs);
-    const float zg = (zgold != nullptr) ? zgold[r] : bf2f(z[gold]);
-    if (ce_out != nullptr) ce_out[r] = lse - p * zg - q * (t - zg) - normalizer;
-  }
-  if (dlogits == nullptr) return;
-  bf16_t* d = dlogits + (size_t)r * ld;
-  const float inv = wr / gs;
-#pragma unroll
-  for (int i = 0; i < NV8; ++i) {
-    const int c = (i * 1024 + tid) * 8;
-    if (c >= ld) continue;
-    float o[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int cc = c + j;
-      o[j] = (cc < V) ? v[i][j] * inv - wr * ((cc == gold) ? p : q) : 0.f;    // exp(-inf) = 0 past V
-    }
-    *reinterpret_cast<uint4*>(d + c) = pack8(o);
-  }
-}
-
 // target statistics: mask=(id!=0), w = loss_scale*mask/(len_b*B) (gradient weight of each
 // token under loss = mean_b( sum_t ce*mask / sum_t mask ), transformer.py:209-211)
 __global__ void __launch_bounds__(256) k_target_stats(const int* __restrict__ ids, float* __restrict__ mask,
@@ -1463,31 +1385,6 @@ int zk_ce_fused(const float* logits, const int* ids, const float* w, float* ce_o
   else
     hipLaunchKernelGGL(k_ce_fused, dim3(rows), dim3(256), 0, stream, logits, ids, w, ce_out, (bf16_t*)dlogits,
                        V, ld, p, q, normalizer);
-  ZK_LAUNCH_CHECK();
-  return 0;
-}
-
-// bf16 logits [rows, ld] (+ the unrounded gold logits, may be NULL): ld a multiple of 8, 8192 < ld <= 32768 (the
-// vocabulary sizes of the 256x256-tile logits path; smaller ones keep fp32 logits and zk_ce_fused)
-int zk_ce_fused16(const void* logits, const int* ids, const float* w, const float* zgold, float* ce_out, void* dlogits,
-                  int rows, int V, int ld, float label_smooth, hipStream_t stream) {
-  ZK_CHECK_ARG(ld % 8 == 0 && ld >= V, "zk_ce_fused16: ld=%d must be a multiple of 8 and >= V=%d", ld, V);
-  ZK_CHECK_ARG(ld > 8192 && ld <= 32768, "zk_ce_fused16: ld=%d outside (8192, 32768]", ld);
-  ZK_CHECK_ARG((((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0, "zk_ce_fused16: buffers must be 16-byte aligned");
-  if (rows == 0) return 0;
-  float p = 1.f, q = 0.f, normalizer = 0.f;
-  if (label_smooth > 0.f && label_smooth < 1.f) {  // util.py:90-97, fp32 arithmetic
-    const float n = (float)(V - 1);
-    p = 1.f - label_smooth;
-    q = label_smooth / n;
-    normalizer = -(p * logf(p) + n * q * logf(q + 1e-20f));
-  }
-  if (ld > 16384)
-    hipLaunchKernelGGL(k_ce_fused_reg16<4>, dim3(rows), dim3(1024), 0, stream, (const bf16_t*)logits, ids, w, zgold, ce_out,
-                       (bf16_t*)dlogits, V, ld, p, q, normalizer);
-  else
-    hipLaunchKernelGGL(k_ce_fused_reg16<2>, dim3(rows), dim3(1024), 0, stream, (const bf16_t*)logits, ids, w, zgold, ce_out,
-                       (bf16_t*)dlogits, V, ld, p, q, normalizer);
   ZK_LAUNCH_CHECK();
   return 0;
 }

@@ -50,9 +50,8 @@ struct GroupDesc {
   const bf16_t* res;          // optional bf16 residual added in the epilogue (may alias C), row stride ldr
   int M, N, K, lda, ldb, ldc, out_f32, tile_start, tiles_n, ldr;
   float* colsum;              // optional fp32 [N]: column sums of B (tb = 0) over K, written by the producer waves of the
-                              // tm = 0 tiles (bias gradient beside a weight gradient); needs a producer-wave tile.
-                              // 256x256 tiles with a bf16 output: fp32 [M] receiving C[row][gold[row]] UNROUNDED
-  const int* gold;            // 256x256 tiles with a bf16 output: int [M] column index per row (or NULL)
+                              // tm = 0 tiles (bias gradient beside a weight gradient): by the producer waves of the
+  long pad_;                  // wide tiles, by two extra MFMAs per eight on the 256x256 tiles (gemm256_acc<.., CS>)
 };                            // 96 bytes; mirrored by zero_amd/func.py:_GroupDesc
 
 template <int BM, int BN, int NS, bool TA, bool TB, int PW = 0>
@@ -231,46 +230,6 @@ __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __rest
     }
   } else {
     gemm256_acc<TA, TB, SPREAD>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc);
-  }
-  if (!CS && !d.out_f32) {
-    // bf16 tile (the logits of the training step: half the bytes of the fp32 tile on the way out and again into the
-    // cross-entropy pass).  Adjacent lanes hold adjacent columns: a quad-perm DPP swap pairs them so that every lane
-    // stores one dword (two bf16) per register pair instead of two shorts.  The gold-label logit of every row leaves
-    // UNROUNDED (fp32) beside the tile, so the loss keeps its fp32 gold term (transformer.py:198-207).
-    bf16_t* C16 = reinterpret_cast<bf16_t*>(d.C);
-    const int* __restrict__ gold = d.gold;
-    float* __restrict__ zg = d.colsum;
-    const bool odd = lane & 1;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      int g[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        g[e] = (gold != nullptr && row < M) ? gold[row] : -1;
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * WTN + j * 32 + (lane & 31);
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const float a0 = acc[i][j][e], a1 = acc[i][j][e + 1];
-          const int r0 = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), r1 = r0 + 1;
-          if (g[e] == col && r0 < M) zg[r0] = a0;
-          if (g[e + 1] == col && r1 < M) zg[r1] = a1;
-          // even lane: (own a0, neighbour's a0) -> row r0, columns col, col+1;  odd lane: (neighbour's a1, own a1) -> row r1
-          const float mine = odd ? a1 : a0, give = odd ? a0 : a1;
-          const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
-          const int row = odd ? r1 : r0, c0 = col & ~1;
-          const uint32_t pk = odd ? pack2bf(got, mine) : pack2bf(mine, got);
-          if (row < M) {
-            if (c0 + 1 < N) __builtin_nontemporal_store(pk, reinterpret_cast<uint32_t*>(&C16[(size_t)row * d.ldc + c0]));
-            else if (c0 < N) C16[(size_t)row * d.ldc + c0] = (bf16_t)(pk & 0xffffu);
-          }
-        }
-      }
-    }
-    return;
   }
   float* C = reinterpret_cast<float*>(d.C);
 #pragma unroll

@@ -12,6 +12,7 @@
 #include "zk_common.h"
 
 extern "C" {
+int zk_transpose_bf16(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, hipStream_t stream);
 int zk_rows_pack(float* dtable, const int* uid, const int* n_uniq_dev, void* out, int R, int H, int out_bf16,
                  int clear_rows, hipStream_t stream);
 int zk_rows_scatter_add(float* dtable, const void* payload, int R, int H, int in_bf16, int vocab_rows,
@@ -79,7 +80,35 @@ __global__ void __launch_bounds__(256) k_rows_scatter_add(float* __restrict__ dt
   }
 }
 
+// dst[c][r] = src[r][c] on bf16 matrices through a 64 x 64 LDS tile (+1 column of padding: conflict-free both ways).
+// Used once per weight version for the operand layout of the fused decode kernels (a projection weight with the input
+// dimension contiguous); HBM-bound, 4 bytes per element.
+__global__ void __launch_bounds__(256) k_transpose_bf16(const bf16_t* __restrict__ src, int ld_src, bf16_t* __restrict__ dst,
+                                                        int ld_dst, int rows, int cols) {
+  __shared__ bf16_t tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? src[(size_t)r * ld_src + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) dst[(size_t)c * ld_dst + r] = tile[tx][i];
+  }
+}
+
 extern "C" {
+
+int zk_transpose_bf16(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, hipStream_t stream) {
+  ZK_CHECK_ARG(src != nullptr && dst != nullptr && ld_src >= cols && ld_dst >= rows, "zk_transpose_bf16: bad arguments");
+  if (rows == 0 || cols == 0) return 0;
+  hipLaunchKernelGGL(k_transpose_bf16, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, stream,
+                     (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, rows, cols);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
 
 size_t zk_rows_payload_bytes(int R, int H, int bf16) {
   return (size_t)R * 4 + (size_t)R * H * (bf16 ? 2 : 4);

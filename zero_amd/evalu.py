@@ -59,24 +59,89 @@ def _batches(dataset, params):
     )
 
 
+def decode_streams(default=2):
+    """How many decode batches are kept in flight at once (ZERO_HIP_DECODE_STREAMS; 1 = one after the other)."""
+    try:
+        return max(1, min(8, int(os.environ.get("ZERO_HIP_DECODE_STREAMS", str(default)))))
+    except ValueError:
+        return default
+
+
+def decode_many(items, work, streams=None):
+    """``[work(item) for item in items]`` with up to ``streams`` items in flight at once, each on its own execution
+    lane (zero_amd.models._factory.lane: own HIP stream, scratch and cache buffers, captured step graphs; the variable
+    store is shared).  Results come back in the order of ``items``.
+
+    Why: one beam-search decode step works on eval_batch_size x beam rows (32 x 4 = 128) -- ~40 dependent launches of
+    which none fills a quarter of the 256 CUs; the step is a latency chain.  Independent batches
+    have no data in common but the weights, so their chains interleave on the device for nothing: the reference's
+    evaluation loop (evalu.py:49-139) decodes its batches one after the other only because a TF session runs one
+    ``session.run`` at a time.  Every batch's arithmetic is exactly what it is alone (same kernels, same buffers
+    per lane), so hypotheses and scores are bit-identical to the sequential loop (tests/test_gpu_loops.py).
+
+    Host side: one worker thread per lane (ctypes calls and stream / event waits release the GIL; the Python work
+    per decode step is ~30 us against ~360 us of device time)."""
+    import threading
+    streams = decode_streams() if streams is None else max(1, int(streams))
+    it = iter(items)
+    if streams == 1:
+        return [work(x) for x in it]
+    import torch
+    from zero_amd.models._factory import lane
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+    lock = threading.Lock()
+    results, errors = {}, []
+    counter = [0]
+
+    def worker(idx):
+        try:
+            if dev is not None:
+                torch.cuda.set_device(dev)
+            with lane(idx):
+                while not errors:
+                    with lock:
+                        try:
+                            x = next(it)
+                        except StopIteration:
+                            return
+                        k = counter[0]
+                        counter[0] += 1
+                    results[k] = work(x)
+        except BaseException as exc:      # noqa: BLE001 -- re-raised in the caller's thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(i,), name="decode-lane-%d" % i) for i in range(streams)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return [results[k] for k in range(counter[0])]
+
+
 def decoding(graph, dataset, params, infer=None):
     """Translate ``dataset``; ``infer(features, graph, params) -> (seqs [B,K,L], scores [B,K])``
-    defaults to zero_amd.main.tower_infer_graph."""
+    defaults to zero_amd.main.tower_infer_graph.  Batches are decoded ``decode_streams()`` at a time (decode_many)."""
     if infer is None:
         from zero_amd.main import tower_infer_graph as infer
     translations, scores, indices = [], [], []
     begin = time.time()
-    for bidx, data in enumerate(_batches(dataset, params)):
-        if bidx == 0:
-            begin = time.time()              # reading time excluded, evalu.py:99-101
+
+    def work(data):
         start = time.time()
         seqs, sc = infer({"source": data['src']}, graph, params)
-        hyp, marks = decode_hypothesis([np.asarray(seqs)], [np.asarray(sc)], params)
+        return data, np.asarray(seqs), np.asarray(sc), time.time() - start
+
+    # (dev-mode search re-encodes on the training path of lane 0's engine: one batch at a time)
+    streams = decode_streams() if getattr(params, "search_mode", "cache") == "cache" else 1
+    for bidx, (data, seqs, sc, used) in enumerate(decode_many(_batches(dataset, params), work, streams)):
+        hyp, marks = decode_hypothesis([seqs], [sc], params)
         translations.extend(hyp)
         scores.extend(float(m) for m in marks)
         indices.extend(data['index'])
         log.info("Decoding Batch %s using %.3f s, translating %d sentences using %.3f s in total",
-                 bidx, time.time() - start, len(translations), time.time() - begin)
+                 bidx, used, len(translations), time.time() - begin)
     return translations, scores, indices
 
 

@@ -29,7 +29,7 @@ class _GroupDesc(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p),
                 ("bias", ctypes.c_void_p), ("res", ctypes.c_void_p)] + \
                [(n, ctypes.c_int) for n in ("M", "N", "K", "lda", "ldb", "ldc", "out_f32", "tile_start",
-                                            "tiles_n", "ldr")] + [("colsum", ctypes.c_void_p), ("gold", ctypes.c_void_p)]
+                                            "tiles_n", "ldr")] + [("colsum", ctypes.c_void_p), ("pad", ctypes.c_long)]
 
 
 class _ColsumDesc(ctypes.Structure):
@@ -182,40 +182,34 @@ class Engine(object):
         problems: list of (A, B, C, M, N, K, bias-or-None[, residual Mat-or-None]) with Mat operands.
         The device descriptor table is cached per problem list (buffers are static, so it is built
         once)."""
-        # ..., residual, column-sum output (256x256 tiles with a bf16 output: fp32 [M] gold-column values), gold ids
-        problems = [tuple(p) + (None,) * (10 - len(p)) for p in problems]
+        problems = [tuple(p) + (None,) * (9 - len(p)) for p in problems]     # ..., residual, column-sum output
         # 128, 64, (256, 128), (128, 256), (256, 256) [fp32 outputs only] or (256, 256, 0) = the same without spreading
         # the LDS-DMA issue between the MFMA groups
         spread = not (isinstance(tile, tuple) and len(tile) == 3 and not tile[2])
         bm, bn = (tile, tile) if isinstance(tile, int) else tile[:2]
         code = {(128, 128): 1, (64, 64): 4, (256, 128): 5, (128, 256): 6, (256, 256): 7 if spread else 8}[(bm, bn)]
         if (bm, bn) == (256, 256):
-            # fp32 tile (+ optional column sums of B when ta = 1, tb = 0: the bias gradient beside a weight gradient, by
-            # two extra MFMAs per eight in the tm = 0 tiles), or bf16 tile (+ optional capture of C[row][gold[row]] in
-            # fp32: the logits of the training step)
-            assert all(bias is None and r is None and
-                       ((c.t.dtype == torch.float32 and gold is None and (cs is None or (ta and not tb))) or
-                        (c.t.dtype == torch.bfloat16 and c.ld % 2 == 0 and (gold is None) == (cs is None)))
-                       for _, _, c, _, _, _, bias, r, cs, gold in problems)
-            if any(p[8] is not None and p[2].t.dtype == torch.float32 for p in problems):
+            # fp32 tile, + optional column sums of B when ta = 1, tb = 0: the bias gradient beside a weight gradient, by
+            # two extra MFMAs per eight in the tm = 0 tiles
+            assert all(bias is None and r is None and c.t.dtype == torch.float32 and (cs is None or (ta and not tb))
+                       for _, _, c, _, _, _, bias, r, cs in problems)
+            if any(p[8] is not None for p in problems):
                 code |= 256
         elif any(p[8] is not None for p in problems):
             assert code in (5, 6) and not tb, "column sums ride on the producer waves of the wide tiles (tb = 0)"
         key = (ta, tb, bm, bn, spread) + tuple((a.ptr, b.ptr, c.ptr, M, N, K, hip.ptr(bias) or 0, r.ptr if r is not None else 0,
-                                                hip.ptr(cs) or 0, hip.ptr(gold) or 0)
-                                               for a, b, c, M, N, K, bias, r, cs, gold in problems)
+                                                hip.ptr(cs) or 0) for a, b, c, M, N, K, bias, r, cs in problems)
         cache = self.__dict__.setdefault("_group_cache", {})
         ent = cache.get(key)
         if ent is None:
             arr = (_GroupDesc * len(problems))()
             start = 0
-            for i, (a, b, c, M, N, K, bias, res, cs, gold) in enumerate(problems):
+            for i, (a, b, c, M, N, K, bias, res, cs) in enumerate(problems):
                 tn = (N + bn - 1) // bn
                 d = arr[i]
                 d.A, d.B, d.C, d.bias = a.ptr, b.ptr, c.ptr, hip.ptr(bias) or 0
                 d.res, d.ldr = (res.ptr, res.ld) if res is not None else (0, 0)
                 d.colsum = hip.ptr(cs) or 0
-                d.gold = hip.ptr(gold) or 0
                 d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, a.ld, b.ld, c.ld
                 d.out_f32 = 1 if c.t.dtype == torch.float32 else 0
                 d.tile_start, d.tiles_n = start, tn
@@ -453,12 +447,7 @@ class Engine(object):
                       hip.ptr(dbias_prev), self.stream)
 
     # ---- loss (util.py:88-103; transformer.py:198-216) ------------------------------
-    def ce_fused(self, logits, ids, w, ce, dlogits, rows, V, label_smooth, zgold=None):
-        if logits.t.dtype == torch.bfloat16:
-            self.lib.call("zk_ce_fused16", logits.ptr, ids.data_ptr(), hip.ptr(w), hip.ptr(zgold), hip.ptr(ce),
-                          dlogits.ptr if dlogits is not None else None, rows, V, logits.ld, float(label_smooth),
-                          self.stream)
-            return
+    def ce_fused(self, logits, ids, w, ce, dlogits, rows, V, label_smooth):
         self.lib.call("zk_ce_fused", logits.ptr, ids.data_ptr(), hip.ptr(w), hip.ptr(ce),
                       dlogits.ptr if dlogits is not None else None, rows, V, logits.ld, float(label_smooth),
                       self.stream)

@@ -79,7 +79,8 @@ class TransformerCore(object):
         # one group per side of the model with a single rank (fewest launches); smaller groups with
         # data parallelism so that the gradient all-reduce of finished layers starts early
         import torch.distributed as _dist
-        _multi = _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1
+        _multi = (_dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1) or \
+            os.environ.get("ZERO_HIP_FORCE_SEGMENTED", "0") != "0"      # (test hook: the multi-rank step with one rank)
         self.group_layers = int(os.environ.get("ZERO_HIP_GROUP_LAYERS", "2" if _multi else "6"))
         # Single rank (round 3): EVERY weight gradient of the step in ONE grouped launch of 256x256 tiles (7.8 KB staged
         # per MFLOP against 11.7 for 128x256).  The coarse tile needs the big group: 922 tiles on 256 CUs = 3.6 rounds,
@@ -102,7 +103,6 @@ class TransformerCore(object):
         # T*V*4 bytes, which matters for larger batches / vocabularies)
         self.fused_ce = os.environ.get("ZERO_HIP_FUSED_CE", "0") != "0" and self.eng.lib.experiments
         self.logits_tile256 = os.environ.get("ZERO_HIP_LOGITS_256", "1") != "0"
-        self.logits_bf16 = os.environ.get("ZERO_HIP_LOGITS_BF16", "1") != "0"
         self._red_id = 0
         self.side = torch.cuda.Stream(self.eng.device) if self.eng.device.type == "cuda" else None
 
@@ -581,27 +581,17 @@ class TransformerCore(object):
             e.logits_ce_fwd(feat, E, batch["tgt"], ce, lse, Tt, self.V, label_smooth)
             self._ce_ctx = (lse, w, label_smooth) if need_grad else None
         else:
-            zgold = None
-            tile256 = self.logits_tile256 and e.gemm_impl == 0 and self.H % 8 == 0
-            if tile256 and self.logits_bf16 and 8192 < self.Vpad <= 32768:
-                # 256x256 tiles leaving as bf16 (half the bytes out of the GEMM and into the cross-entropy pass: 524 ->
-                # 262 MB each way at the bench shapes); the gold-label logit of every row is kept UNROUNDED beside the
-                # tile, so the loss' dominant term stays fp32 (ZERO_HIP_LOGITS_BF16=0: fp32 logits as before)
-                logits = e.mat("logits16", Tt, self.Vpad)
-                zgold = e.buf("zgold", (Tt,), F32)
-                e.gemm_grouped([(feat, E, logits, Tt, self.V, self.H, None, None, zgold, batch["tgt"])], 0, 1,
-                               tile=(256, 256))
-            elif tile256:
+            logits = e.mat("logits", Tt, self.Vpad, F32)
+            if self.logits_tile256 and e.gemm_impl == 0 and self.H % 8 == 0:
                 # 256x256 tiles, fp32 tile stored straight from the accumulators (scripts/gemm_big_bench.py:
-                # 223 us against 274-291 us for the 128x128 kernels on the 4096 x 32000 x 512 problem)
-                logits = e.mat("logits", Tt, self.Vpad, F32)
+                # 223 us against 274-291 us for the 128x128 kernels on the 4096 x 32000 x 512 problem).  bf16 logits
+                # were measured and are slower (profiles/r03_bf16_logits_experiment.txt: a bf16 32x32 MFMA tile leaves
+                # as 64-byte half lines, +118 us on a GEMM that is not output-bound, for -16 us of cross entropy)
                 e.gemm_grouped([(feat, E, logits, Tt, self.V, self.H, None)], 0, 1, tile=(256, 256))
             else:
-                logits = e.mat("logits", Tt, self.Vpad, F32)
                 e.gemm(feat, E, logits, Tt, self.V, self.H, 0, 1)
             dlogits = e.mat("dlogits", Tt, self.Vpad) if need_grad else None
-            e.ce_fused(logits, batch["tgt"], w if need_grad else None, ce, dlogits, Tt, self.V, label_smooth,
-                       zgold=zgold)
+            e.ce_fused(logits, batch["tgt"], w if need_grad else None, ce, dlogits, Tt, self.V, label_smooth)
         per_sample = e.buf("per_sample", (B,), F32)
         loss = e.buf("loss", (1,), F32)
         e.loss_reduce(ce, batch["tgt"], per_sample, loss, B, Lt)

@@ -98,11 +98,19 @@ def _fuse_tail():
 
 def _transposed(core, name):
     """bf16 copy of a projection weight with the input dimension contiguous (row = output channel): the operand layout of
-    the fused decode kernels' matrix-core fragments.  Refreshed per encoded batch (the weights may have been trained on)."""
+    the fused decode kernels' matrix-core fragments.  Made by zk_transpose_bf16 once per WEIGHT VERSION (an optimiser
+    update, a checkpoint load or an EMA swap makes a new one: variables.VariableStore.weight_version), not per
+    encoded batch."""
     W = core.store.s(name)
-    buf = core.eng.buf("dc.wt." + name, (W.shape[1], W.shape[0]), W.dtype)
-    buf.copy_(W.t())
-    return Mat(buf, W.shape[1], W.shape[0])
+    cache = core.__dict__.setdefault("_wt_cache", {})
+    ver = core.store.weight_version
+    ent = cache.get(name)
+    if ent is None or ent[0] != ver or ent[2] != core.eng.realloc_gen:
+        buf = core.eng.buf("dc.wt." + name, (W.shape[1], W.shape[0]), W.dtype)
+        core.eng.lib.call("zk_transpose_bf16", W.data_ptr(), W.shape[1], buf.data_ptr(), W.shape[0], W.shape[0],
+                          W.shape[1], core.eng.stream)
+        ent = cache[name] = (ver, Mat(buf, W.shape[1], W.shape[0]), core.eng.realloc_gen)
+    return ent[1]
 
 
 def _cross_unfused(core, e, hp, state, lay, x, p, pre, l, time, time_dev):

@@ -17,6 +17,7 @@ loss, for the build's ``tower_train_graph`` counterpart (zero_amd/main.py).
 """
 
 import copy
+import threading
 
 import torch
 
@@ -36,17 +37,48 @@ def closing_dropout(params):
     return params
 
 
+_LANE = threading.local()
+_CORES_LOCK = threading.Lock()
+
+
+class lane(object):
+    """``with lane(i):`` -- the calling THREAD works on execution lane i of its model: get_core() then hands out a
+    TransformerCore with its own engine (HIP stream, scratch and cache buffers, captured graphs) that SHARES the
+    variable store of lane 0.  Lanes exist so that several independent decode batches can be in flight at once
+    (zero_amd.evalu.decode_many: a 128-row decode step is a latency chain that leaves most of the 256 CUs idle);
+    training always runs on lane 0."""
+
+    def __init__(self, idx):
+        self.idx = int(idx)
+
+    def __enter__(self):
+        self.prev = getattr(_LANE, "idx", 0)
+        _LANE.idx = self.idx
+        return self
+
+    def __exit__(self, *a):
+        _LANE.idx = self.prev
+
+
+def current_lane():
+    return getattr(_LANE, "idx", 0)
+
+
 def get_core(params, model_name, initializer=None):
-    """One TransformerCore per (scope, device): AUTO_REUSE of transformer.py:222-226."""
+    """One TransformerCore per (scope, device, lane): AUTO_REUSE of transformer.py:222-226."""
     dev = "cuda:%d" % torch.cuda.current_device() if torch.cuda.is_available() else "cpu"
-    key = (params.scope_name or "model", model_name, dev)
+    ln = current_lane()
+    key = (params.scope_name or "model", model_name, dev) + ((ln,) if ln else ())
     core = _CORES.get(key)
     if core is None:
-        store = get_store(params, model_name, dev)
-        if isinstance(initializer, dict):
-            store.load(initializer)
-        core = TransformerCore(params, model_name, store, dev)
-        _CORES[key] = core
+        with _CORES_LOCK:
+            core = _CORES.get(key)
+            if core is None:
+                store = get_store(params, model_name, dev)
+                if isinstance(initializer, dict):
+                    store.load(initializer)
+                core = TransformerCore(params, model_name, store, dev)
+                _CORES[key] = core
     else:
         core.hp = params
     return core

@@ -168,6 +168,7 @@ class VariableStore(object):
         self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev)
         self.accum = None     # update_cycle slots (utils/cycle.py:27-36), created on demand
         self.step = 0         # number of applied updates (Adam's t)
+        self.shadow_loads = 0  # refresh_shadow() calls; (shadow_loads, step) identifies the bf16 weights ("weight version")
 
     # -- views --------------------------------------------------------------
     def _view(self, flat, name):
@@ -207,7 +208,14 @@ class VariableStore(object):
                 dst.copy_(v)
         self.refresh_shadow()
 
+    @property
+    def weight_version(self):
+        """Changes whenever the bf16 weights the kernels read may have changed: a load / EMA swap (refresh_shadow) or an
+        optimiser update (utils/cycle.py advances ``step``).  Derived copies of weights are cached against it."""
+        return (self.shadow_loads, self.step)
+
     def refresh_shadow(self):
+        self.shadow_loads += 1
         if self.device.type == "cuda":
             from zero_amd import hip
             hip.lib().call("zk_cast_f32_bf16", self.master.data_ptr(), self.shadow.data_ptr(), self.numel,
