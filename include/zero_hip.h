@@ -123,7 +123,11 @@ size_t zk_attn_bwd_workspace(int B, int nh, int Lq);
 /* zk_attn_bwd with impl | 256, rpr_k / rpr_v / drpr_k / drpr_v but no decomposed products, Lq, Lk <= 64, d = 64 and a
  * workspace of zk_attn_bwd_rpr_workspace bytes: relative positions FOLDED into the single-tile backward kernel (tables,
  * G = Q.Rk^T, Gd = dO.Rv^T, bucket sums of dS / P and dQ += dsb.Rk in LDS; per-(sentence, head) table-gradient partials
- * in the workspace, summed into drpr_k / drpr_v -- which are OVERWRITTEN -- by one reduction launch). */
+ * in the workspace, summed into drpr_k / drpr_v by one reduction launch).
+ * Table-gradient contract: WITH impl | 256 the call OVERWRITES drpr_k / drpr_v on every path (when the folded kernel
+ * declines a shape -- alignment, ld % 8, Lq / Lk > 64, workspace -- the reference kernels run on tables the entry
+ * point has cleared itself); WITHOUT the bit the reference kernels ADD to drpr_k / drpr_v with atomics and the
+ * caller clears them beforehand. */
 size_t zk_attn_bwd_rpr_workspace(int B, int nh, int Lq);
 int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                 const float* lse, void* dq, void* dk, void* dv, float* drpr_k, float* drpr_v, int B, int nh,
@@ -434,6 +438,9 @@ int zk_dec_self(const void* x, void* ybuf, const float* gamma, const float* beta
                 int ldwo, float* out_parts, int B, int R, int nh, float scale, zk_stream_t stream);
 int zk_aan_decode(const void* x, float* cache, void* cat, int rows, int H, float inv_count, const int* time_dev,
                   zk_stream_t stream);
+/* dynamic LDS bytes a zk_dec_cross / zk_dec_self workgroup needs for hidden size H and Lk keys (a CU has 160 KiB):
+ * lets the caller choose the launch-per-op path for shapes that do not fit, before the batch starts decoding */
+size_t zk_dec_attn_lds(int H, int Lk);
 /* Decoder input of one decode position in one launch (transformer.py:88-119; was zk_all_equal + zk_embed_fwd +
  * zk_aan_decode): every fed id == pad_id (first step) -> zero embedding, else table[id] * scale + bias; + timing[pos];
  * cache / cat != NULL: the first layer's average-attention update (transformer_aan.py:110-112).  *pos_dev overrides

@@ -191,3 +191,23 @@ def test_beam_host_step_in_c_matches_the_numpy_bookkeeping():
         assert np.array_equal(c_ff.astype(bool), fin_flags)
         assert np.array_equal(c_idx, flat) and np.array_equal(c_tok, seq[:, :, -1].reshape(-1))
     assert time >= 3
+
+
+def test_config_file_values_may_be_arithmetic_but_never_code(tmp_path):
+    """run.py:367-376 eval()s the --config file; here: literals, arithmetic over them and names of earlier keywords,
+    nothing executable."""
+    from zero_amd import run
+    cfg = tmp_path / "cfg.py"
+    cfg.write_text("dict(hidden_size=256, filter_size=hidden_size*4, lrate=1e-3*4, token_size=2**12, safe_nan=True and False,\n"
+                   "     strategies=['aan'], max_len=-(-100), warmup_steps=8000//2)\n")
+    hp = run.build_params("", str(cfg))
+    assert (hp.hidden_size, hp.filter_size, hp.token_size, hp.max_len, hp.warmup_steps) == (256, 1024, 4096, 100, 4000)
+    assert abs(hp.lrate - 4e-3) < 1e-12 and hp.strategies == ["aan"]
+    for bad in ("dict(a=__import__('os').system('true'))", "dict(a=open('/etc/passwd'))", "dict(a=(1).__class__)",
+                "dict(a=b)", "dict(a=[x for x in (1,)])", "dict(a=9**9**9)"):
+        cfg.write_text(bad)
+        try:
+            run.build_params("", str(cfg))
+        except (ValueError, SyntaxError):
+            continue
+        raise AssertionError("accepted: " + bad)

@@ -532,6 +532,7 @@ static bool attn_mfma_ok(const AttnArgs& a, int extra_ld_or) {
   return true;
 }
 
+extern "C" int zk_zero(void* p, size_t bytes, hipStream_t stream);   // zk_elem.hip
 extern "C" {
 size_t zk_attn_bwd_rpr_workspace(int B, int nh, int Lq) {
   return (size_t)B * nh * Lq * sizeof(float) + (size_t)B * nh * 2 * TQ * AD * sizeof(float);
@@ -631,6 +632,10 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
   const bool fold = (impl & 256) && rpr_k != nullptr && rpr_gq == nullptr && d == AD && 2 * max_rel + 1 <= 64 &&
                     drpr_k != nullptr && drpr_v != nullptr && ((((uintptr_t)rpr_k | (uintptr_t)rpr_v) & 15) == 0) &&
                     ws_bytes >= zk_attn_bwd_workspace(B, nh, Lq) + (size_t)B * nh * 2 * TQ * AD * sizeof(float);
+  // impl | 256 is also a CONTRACT on the table gradients: the call overwrites drpr_k / drpr_v whichever kernels end up
+  // running (the folded kernel writes them; the reference kernels below accumulate with atomics, so they are cleared
+  // first).  Without the bit the table gradients are accumulated into and the caller clears them.
+  const bool overwrite_tables = (impl & 256) && drpr_k != nullptr && drpr_v != nullptr;
   impl &= 255;
   if (fold) { a.rpr_k = nullptr; a.rpr_v = nullptr; }
   bool ok = attn_mfma_ok(a, ldo | lddo | lddq | lddk | lddv) &&
@@ -680,6 +685,10 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
                NAIVE_MAXK * 64);
   ZK_CHECK_ARG(d <= 256, "zk_attn_bwd: d=%d > 256", d);
   if (zk_prog_active()) return zk_prog_reject("attention backward on the reference kernels");
+  if (overwrite_tables && rpr_k != nullptr) {
+    const size_t nb = (size_t)(2 * max_rel + 1) * d * sizeof(float);
+    if (zk_zero(drpr_k, nb, stream) != 0 || zk_zero(drpr_v, nb, stream) != 0) return -1;
+  }
   const long qrows = (long)B * nh * Lq, krows = (long)B * nh * Lk;
   hipLaunchKernelGGL(k_attn_bwd_dq_naive, dim3((unsigned)((qrows + 3) / 4)), dim3(256), 0, stream, a,
                      (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, Dbuf, drpr_k, drpr_v);

@@ -352,6 +352,10 @@ static size_t dec_attn_lds(int H, int Lk) {
   return 2 * 16 * (size_t)(H + 8) + sizeof(float) * (3 * 8 * 256 + 3 * 1024 + 16 * (size_t)((Lk + 3) & ~3)) + 2 * 16 * 72;
 }
 
+// LDS bytes one workgroup of zk_dec_cross / zk_dec_self needs for (H, Lk): the host asks BEFORE it commits a decode batch
+// to the fused path (a shape over the 160 KiB of a CU takes the launch-per-op path instead of failing mid-decode)
+extern "C" size_t zk_dec_attn_lds(int H, int Lk) { return dec_attn_lds(H, Lk); }
+
 template <bool SELF, int MAXC>
 static int launch_dec_attn(const DecAttnArgs& a, hipStream_t stream) {
   const size_t lds = dec_attn_lds(a.pro.H, a.Lk);

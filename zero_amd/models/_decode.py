@@ -32,6 +32,31 @@ from zero_amd.utils import dtype as zdtype
 
 F32 = torch.float32
 
+# Start-up of a decode batch = the part that allocates (engine buffers, pinned staging) and captures the two step
+# graphs.  With several batches in flight on execution lanes (evalu.decode_many, one host thread per lane) the
+# start-ups are serialised by this lock: an allocation or a host-memory pin in one thread while another thread is
+# inside a stream capture invalidated that capture on ROCm 7.x ("operation failed due to a previous error during
+# capture"), whereas a thread that only replays graphs beside a capturing one is fine.  The replay loop -- ~95 % of a
+# batch's time -- runs unlocked; a single-threaded caller never waits.
+import threading as _threading
+STARTUP_LOCK = _threading.RLock()
+
+
+def startup_begin():
+    STARTUP_LOCK.acquire()
+
+
+def startup_end(state):
+    """Release the start-up lock of this batch (idempotent)."""
+    if state is not None and state.get("_startup_held"):
+        state["_startup_held"] = False
+        STARTUP_LOCK.release()
+
+
+def _startup_settled(state):
+    g = state.get("graphs")
+    return bool(g) and len(g) >= 2 and all(not isinstance(v, str) for v in g.values())
+
 
 class DecodeState(dict):
     """Nested-dict state with the cache plumbing the search needs."""
@@ -175,7 +200,10 @@ def make_infer_fns(params, model_name):
         nl = hp.num_decoder_layer
         state["wt"] = {}
         # (the fused launches keep a sentence's scores in LDS: 64 bytes per key for 16 rows)
-        if _fuse_att_ok(core, hp, K) and max(Ls, max_steps) <= 1024:
+        # and the whole workgroup state must fit the 160 KiB of a CU: otherwise 'wt' stays empty and the step takes the
+        # launch-per-op path (_cross_unfused) instead of failing mid-decode
+        if _fuse_att_ok(core, hp, K) and max(Ls, max_steps) <= 1024 and \
+                e.lib.query("zk_dec_attn_lds", H, max(Ls, max_steps)) <= 160 * 1024:
             for l in range(nl):
                 blocks = [(core.cross, ("q_map", "o_map"))]
                 if not core.aan:
@@ -225,6 +253,11 @@ def make_infer_fns(params, model_name):
         return state
 
     def step_static(state, temperature, forbid_value):
+        _step_static(state, temperature, forbid_value)
+        if state.get("_startup_held") and _startup_settled(state):
+            startup_end(state)
+
+    def _step_static(state, temperature, forbid_value):
         """One whole decode step with every per-step value read from device memory: beam reorder of
         the caches (indices chosen by the previous step), the AAN decoder step, logits, fused
         log-softmax + length penalty + top-2K.  The launch sequence is identical every step (per

@@ -46,12 +46,55 @@ def load_parameters(params, output_dir):
     return params
 
 
+def _safe_value(node, names):
+    """Value of one config expression WITHOUT evaluating code: literals, lists / tuples / dicts of them, arithmetic
+    (+ - * / // % **, unary + - not), comparisons-free boolean and / or, and names that refer to keywords defined
+    EARLIER in the same ``dict(...)`` call (``hidden_size * 4``).  The reference eval()s the file (run.py:371), so
+    configs with such expressions keep working; anything else (calls, attributes, subscripts, imports) is refused."""
+    import operator as op
+    bin_ops = {ast.Add: op.add, ast.Sub: op.sub, ast.Mult: op.mul, ast.Div: op.truediv, ast.FloorDiv: op.floordiv,
+               ast.Mod: op.mod, ast.Pow: op.pow}
+    if isinstance(node, ast.Constant):
+        return node.value
+    if isinstance(node, (ast.List, ast.Tuple)):
+        vals = [_safe_value(e, names) for e in node.elts]
+        return vals if isinstance(node, ast.List) else tuple(vals)
+    if isinstance(node, ast.Dict):
+        return {_safe_value(k, names): _safe_value(v, names) for k, v in zip(node.keys, node.values)}
+    if isinstance(node, ast.Name):
+        if node.id in names:
+            return names[node.id]
+        raise ValueError("--config: unknown name %r (only keywords defined earlier in the dict may be used)" % node.id)
+    if isinstance(node, ast.UnaryOp) and isinstance(node.op, (ast.UAdd, ast.USub, ast.Not)):
+        v = _safe_value(node.operand, names)
+        return +v if isinstance(node.op, ast.UAdd) else (-v if isinstance(node.op, ast.USub) else (not v))
+    if isinstance(node, ast.BinOp) and type(node.op) in bin_ops:
+        a, b = _safe_value(node.left, names), _safe_value(node.right, names)
+        if isinstance(node.op, ast.Pow) and isinstance(b, (int, float)) and abs(b) > 64:
+            raise ValueError("--config: exponent too large")
+        return bin_ops[type(node.op)](a, b)
+    if isinstance(node, ast.BoolOp):
+        vals = [_safe_value(v, names) for v in node.values]
+        out = vals[0]
+        for v in vals[1:]:
+            out = (out and v) if isinstance(node.op, ast.And) else (out or v)
+        return out
+    raise ValueError("--config: unsupported expression %s" % ast.dump(node)[:80])
+
+
 def _parse_dict_call(text):
     node = ast.parse(text.strip(), mode="eval").body
+    if isinstance(node, ast.Dict):
+        return _safe_value(node, {})
     if not (isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id == "dict"
             and not node.args):
         raise ValueError("--config file must hold a dict literal or a dict(k=v, ...) expression")
-    return {kw.arg: ast.literal_eval(kw.value) for kw in node.keywords}
+    out = {}
+    for kw in node.keywords:
+        if kw.arg is None:
+            raise ValueError("--config: **kwargs are not supported")
+        out[kw.arg] = _safe_value(kw.value, out)
+    return out
 
 
 def build_params(parameters="", config=""):
@@ -64,8 +107,8 @@ def build_params(parameters="", config=""):
         try:
             cfg = ast.literal_eval(text.strip())
         except (ValueError, SyntaxError):
-            # the reference eval()s a ``dict(k=v, ...)`` expression (run.py:371); accept exactly that shape --
-            # one call of ``dict`` with literal keyword values -- without evaluating any code
+            # the reference eval()s a ``dict(k=v, ...)`` expression (run.py:371); accept that shape -- one call of
+            # ``dict`` (or a dict display) whose values are literals and arithmetic over them -- without evaluating code
             cfg = _parse_dict_call(text)
         params.override_from_dict(cfg)
     if params.output_dir:

@@ -49,6 +49,18 @@ def beam_search(features, encoding_fn, decoding_fn, params):
 
 
 def _beam_search(features, encoding_fn, decoding_fn, params):
+    box = []
+    try:
+        return _beam_search_body(features, encoding_fn, decoding_fn, params, box)
+    finally:
+        # the batch's start-up lock (models/_decode.py: allocations and graph captures of concurrent batches are
+        # serialised) must not outlive the search, whatever happened
+        if box and hasattr(box[0], "get"):
+            from zero_amd.models._decode import startup_end
+            startup_end(box[0])
+
+
+def _beam_search_body(features, encoding_fn, decoding_fn, params, box):
     f32 = np.float32
     K = params.beam_size
     alpha = params.decode_alpha
@@ -62,8 +74,18 @@ def _beam_search(features, encoding_fn, decoding_fn, params):
     max_target_length = src_len + f32(params.decode_length)
     cache_mode = params.search_mode == "cache"
     if cache_mode:
-        state = encoding_fn(source, beam_size=K,
-                            max_steps=int(max_target_length.max()) + 2)
+        # start-up (allocations, pinned staging, the two graph captures) is serialised between concurrent batches
+        # (models/_decode.py STARTUP_LOCK); step_static releases it once both step graphs exist, _beam_search at the end
+        from zero_amd.models import _decode as _dec
+        _dec.startup_begin()
+        try:
+            state = encoding_fn(source, beam_size=K,
+                                max_steps=int(max_target_length.max()) + 2)
+        except BaseException:
+            _dec.STARTUP_LOCK.release()
+            raise
+        state["_startup_held"] = True
+        box.append(state)
         core = state["_core"]
     else:
         from zero_amd.models._factory import get_core
