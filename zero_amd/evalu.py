@@ -59,7 +59,7 @@ def _batches(dataset, params):
     )
 
 
-def decode_streams(default=2):
+def decode_streams(default=3):
     """How many decode batches are kept in flight at once (ZERO_HIP_DECODE_STREAMS; 1 = one after the other)."""
     try:
         return max(1, min(8, int(os.environ.get("ZERO_HIP_DECODE_STREAMS", str(default)))))

@@ -325,8 +325,10 @@ class GradientAllReduce(object):
             return
         V, H = table.shape
         R = (int(capacity) + 3) // 4 * 4
-        if R * world_size() >= V:
-            return          # the payloads of all ranks would outweigh the table: dense exchange (same decision on every rank)
+        if R * world_size() >= 2 * V:
+            # a ring all-gather moves (N-1) x R rows per rank, a ring all-reduce of the dense table 2 (N-1)/N x V rows:
+            # the payloads only pay while R < 2 V / N (same decision on every rank: it depends on the limits alone)
+            return
         if rows is not None and rows > R:
             # every rank sizes its payload from the same batching limits; a batch beyond them cannot be exchanged
             # row-sparsely and the other ranks cannot be told in time: fail loudly rather than drop gradient rows
