@@ -343,6 +343,32 @@ def test_embed_fwd_bwd():
     assert rel_err(out, tim[4][None].expand(B, H)) < 5e-3
 
 
+@pytest.mark.parametrize("H", [64, 512, 1024])
+def test_embed_bwd_sorted_long_runs_of_one_id(H):
+    """A frequent id (the eos of every sentence) owns a long run of rows: runs of 1 .. 150 rows (more than the 64
+    indices one coalesced load brings in, not a multiple of the 8-row batches), with dropout regenerated per element;
+    the sums must equal the serial walk's (fp32, same order) -- checked against an index_add in float64."""
+    import types
+    from zero_amd.models._core import TransformerCore
+    e = eng()
+    B, L, V = 30, 17, 40
+    rng = np.random.default_rng(11)
+    ids_np = rng.integers(3, V, (B, L))
+    ids_np[:, -1] = 2                      # eos in every sentence: a run of 30
+    ids_np[:10, 3:] = 7                    # a run of 140
+    ids_np[rng.random((B, L)) < 0.2] = 5   # and a scattered one
+    dout = rand_bf(B * L, H, seed=7)
+    fake = types.SimpleNamespace(eng=e)
+    srt = TransformerCore._sort_arrays(fake, "runs%d" % H, ids_np, False)
+    dtab = torch.zeros(V, H, device="cuda")
+    e.embed_bwd_sorted(srt, mat(dout), dtab, H, accumulate=False)
+    torch.cuda.synchronize()
+    ref = torch.zeros(V, H, dtype=torch.float64, device="cuda")
+    ref.index_add_(0, torch.tensor(ids_np.reshape(-1), device="cuda"), dout.double() * H ** 0.5)
+    assert rel_err(dtab, ref.float()) < 2e-6
+    assert float(dtab[0].abs().max()) == 0.0
+
+
 def test_embed_bwd_sorted_and_bias_colsum():
     # atomics-free table gradient (host-sorted rows) + shared-bias gradient with skipped rows
     import types

@@ -458,19 +458,40 @@ __global__ void __launch_bounds__(256) k_embed_bwd_sorted(
   for (int u = wave; u < nu; u += nwaves) {
     const int s0 = seg[u], s1 = seg[u + 1];
     float* dst = dtable + (size_t)uid[u] * H;
-    for (int c = lane * 8; c < H; c += 64 * 8) {
+    for (int cbase = 0; cbase < H; cbase += 64 * 8) {     // wave-uniform control flow: every lane takes part in the shuffles
+      const int c = cbase + lane * 8;
+      const bool active = c < H;
       float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int k = s0; k < s1; ++k) {
-        const int r = rows_sorted[k];
-        float v[8];
-        unpack8(*reinterpret_cast<const uint4*>(dout + (size_t)r * H + c), v);
-        if (thr) {
+      // A frequent id (the eos of every sentence, punctuation) owns a long run of rows.  Walking it one dependent
+      // load chain at a time (index -> row) cost ~1 us per row -- 64 eos rows = the whole 55-us launch of the bench
+      // batch.  Now: the run's row indices in ONE coalesced load per 64 rows, then the rows eight at a time with all
+      // eight loads in flight; the additions keep the order of the run, so the sums are bit-identical to the serial walk.
+      for (int k0 = s0; k0 < s1; k0 += 64) {
+        const int nb = min(64, s1 - k0);
+        const int my_r = (lane < nb) ? rows_sorted[k0 + lane] : 0;
+        for (int j0 = 0; j0 < nb; j0 += 8) {
+          uint4 raw[8];
+          int rr[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] *= zk_drop_scale(seed, sid, (uint64_t)r * H + c + j, thr, inv_keep);
+          for (int j = 0; j < 8; ++j) {
+            rr[j] = __shfl(my_r, (j0 + j) & 63);
+            if (active && j0 + j < nb) raw[j] = *reinterpret_cast<const uint4*>(dout + (size_t)rr[j] * H + c);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (!active || j0 + j >= nb) break;
+            float v[8];
+            unpack8(raw[j], v);
+            if (thr) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q] *= zk_drop_scale(seed, sid, (uint64_t)rr[j] * H + c + q, thr, inv_keep);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] += v[q];
+          }
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += v[j];
       }
+      if (!active) continue;
       float4* d4 = reinterpret_cast<float4*>(dst + c);
       float4 lo = make_float4(acc[0] * scale, acc[1] * scale, acc[2] * scale, acc[3] * scale);
       float4 hi = make_float4(acc[4] * scale, acc[5] * scale, acc[6] * scale, acc[7] * scale);
