@@ -456,8 +456,6 @@ def main():
     for kv in os.environ.get("ZERO_HIP_TUNE", "").split(","):     # e.g. ZERO_HIP_TUNE=0:0 (A/B switches)
         if ":" in kv:
             _hip.lib().raw("zk_tune")(int(kv.split(":")[0]), int(kv.split(":")[1], 0))
-    if os.environ.get("ZERO_HIP_DEC_GROUP"):      # A/B: rows per workgroup of the fused decode attention (zk_dec_group)
-        _hip.lib().raw("zk_dec_group")(int(os.environ["ZERO_HIP_DEC_GROUP"]))
     if args.mode == "decode":
         decode_main(args, rank, world)
         if world > 1:

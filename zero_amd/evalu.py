@@ -59,7 +59,7 @@ def _batches(dataset, params):
     )
 
 
-def decode_streams(default=3):
+def decode_streams(default=4):
     """How many decode batches are kept in flight at once (ZERO_HIP_DECODE_STREAMS; 1 = one after the other)."""
     try:
         return max(1, min(8, int(os.environ.get("ZERO_HIP_DECODE_STREAMS", str(default)))))
@@ -88,6 +88,7 @@ def decode_many(items, work, streams=None):
         return [work(x) for x in it]
     import torch
     from zero_amd.models._factory import lane
+    from zero_amd.models._decode import lanes_mode
     dev = torch.cuda.current_device() if torch.cuda.is_available() else None
     lock = threading.Lock()
     results, errors = {}, []
@@ -111,10 +112,11 @@ def decode_many(items, work, streams=None):
             errors.append(exc)
 
     threads = [threading.Thread(target=worker, args=(i,), name="decode-lane-%d" % i) for i in range(streams)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    with lanes_mode(streams):
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
     if errors:
         raise errors[0]
     return [results[k] for k in range(counter[0])]

@@ -58,6 +58,30 @@ def _startup_settled(state):
     return bool(g) and len(g) >= 2 and all(not isinstance(v, str) for v in g.values())
 
 
+class lanes_mode(object):
+    """Kernel geometry for ``n`` decode batches in flight (evalu.decode_many).  Alone, the fused attention launch is
+    fastest with one sentence (4 beam rows) per workgroup: 256 workgroups of 121 KB LDS, i.e. the whole chip, 12.7 us
+    against 16.5 us with 16 rows per workgroup.  With several batches in flight that launch is the one kernel of a step
+    the lanes cannot overlap (it owns every CU's LDS); at 16 rows per workgroup it covers a quarter of the chip and the
+    lanes' launches run side by side (measured: 4 lanes 1.5-1.6 k -> 1.9-2.2 k sentences/s).  ZERO_HIP_DEC_GROUP=n
+    pins the value (0 = the single-batch default)."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        import os
+        from zero_amd import hip
+        env = os.environ.get("ZERO_HIP_DEC_GROUP")
+        rows = int(env) if env else (16 if self.n > 1 else 0)
+        self.prev = hip.lib().raw("zk_dec_group")(rows)
+        return self
+
+    def __exit__(self, *a):
+        from zero_amd import hip
+        hip.lib().raw("zk_dec_group")(self.prev)
+
+
 class DecodeState(dict):
     """Nested-dict state with the cache plumbing the search needs."""
 
