@@ -382,7 +382,13 @@ __global__ void __launch_bounds__(256) k_colsum_grouped(const ColsumDesc* __rest
   __shared__ float red[32][64 + 1];
   const int bid = blockIdx.x;
   int p = 0;
-  while (p + 1 < nprob && descs[p + 1].block_start <= bid) ++p;
+  {
+    int hi = nprob - 1;              // binary search: see k_reduce_grouped
+    while (p < hi) {
+      const int mid = (p + hi + 1) >> 1;
+      if (descs[mid].block_start <= bid) p = mid; else hi = mid - 1;
+    }
+  }
   const ColsumDesc d = descs[p];
   const int local = bid - d.block_start;
   const int bx = local / d.gy, by = local - bx * d.gy;
@@ -420,7 +426,14 @@ __global__ void __launch_bounds__(256) k_reduce_grouped(const ReduceDesc* __rest
   __shared__ float red[16][17];
   const int bid = blockIdx.x;
   int p = 0;
-  while (p + 1 < nprob && descs[p + 1].block_start <= bid) ++p;
+  {   // the last problem whose first block is <= bid: binary search (a linear scan is one dependent global load per
+      // problem -- ~8 us before the first partial is read with the ~80 problems of a whole-step group)
+    int hi = nprob - 1;
+    while (p < hi) {
+      const int mid = (p + hi + 1) >> 1;
+      if (descs[mid].block_start <= bid) p = mid; else hi = mid - 1;
+    }
+  }
   const ReduceDesc d = descs[p];
   const int local = bid - d.block_start;
   const int ncb = (d.H + 15) / 16;

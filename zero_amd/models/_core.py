@@ -463,6 +463,11 @@ class TransformerCore(object):
         ids_s = e.buf("ids.src", (B, Ls), torch.int32)
         ids_s.copy_(torch.from_numpy(src.astype(np.int32)), non_blocking=False)
         out = {"B": B, "Ls": Ls, "src": ids_s}
+        # quantities that depend on the ids alone are computed here, once per batch, instead of inside every (replayed)
+        # step: the source mask now, the target mask / loss weights below
+        if B > 0:
+            out["smask"] = e.buf("smask", (B, Ls), F32)
+            e.make_mask(ids_s, out["smask"], B * Ls)
         if target is not None:
             out["src_sort"] = self._sort_arrays("src", src, False)
         if target is not None:
@@ -473,6 +478,10 @@ class TransformerCore(object):
             ids_t = e.buf("ids.tgt", (B, Lt), torch.int32)
             ids_t.copy_(torch.from_numpy(tgt.astype(np.int32)), non_blocking=False)
             out.update({"Lt": Lt, "tgt": ids_t, "tgt_sort": self._sort_arrays("tgt", tgt, True)})
+            if B > 0:
+                out["tmask"], out["tw"] = e.buf("tmask", (B, Lt), F32), e.buf("tw", (B, Lt), F32)
+                out["tw_scale"] = float(self.hp.loss_scale)
+                e.target_stats(ids_t, out["tmask"], out["tw"], B, Lt, out["tw_scale"])
         return out
 
     def lookup_tables(self):
@@ -519,8 +528,10 @@ class TransformerCore(object):
         e, hp, H = self.eng, self.hp, self.H
         B, Ls = batch["B"], batch["Ls"]
         Ts = B * Ls
-        smask = e.buf("smask", (B, Ls), F32)
-        e.make_mask(batch["src"], smask, Ts)
+        smask = batch.get("smask")
+        if smask is None:
+            smask = e.buf("smask", (B, Ls), F32)
+            e.make_mask(batch["src"], smask, Ts)
         x = e.mat("enc.x0", Ts, H)
         e.embed_fwd(batch["src"], self.store.s(self.src_emb), self.b("bias"), x, B, Ls, H,
                     drop_p=hp.dropout if train else 0.0, sid=9001)
@@ -541,9 +552,13 @@ class TransformerCore(object):
         e, hp, H = self.eng, self.hp, self.H
         B, Ls, Lt = batch["B"], batch["Ls"], batch["Lt"]
         Tt = B * Lt
-        tmask = e.buf("tmask", (B, Lt), F32)
-        w = e.buf("tw", (B, Lt), F32)
-        e.target_stats(batch["tgt"], tmask, w, B, Lt, hp.loss_scale if train else 1.0)
+        want = float(hp.loss_scale) if train else 1.0
+        if batch.get("tw_scale") == want and "tmask" in batch:
+            tmask, w = batch["tmask"], batch["tw"]           # made by upload(), once per batch
+        else:
+            tmask = e.buf("tmask", (B, Lt), F32)
+            w = e.buf("tw", (B, Lt), F32)
+            e.target_stats(batch["tgt"], tmask, w, B, Lt, want)
         x = e.mat("dec.x0", Tt, H)
         e.embed_fwd(batch["tgt"], self.store.s(self.tgt_emb), self.b("bias"), x, B, Lt, H, shift=True,
                     drop_p=hp.dropout if train else 0.0, sid=9002)
