@@ -16,9 +16,9 @@ for st in $STAGES; do
     bench)  timeout 900 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "rc=$?"; tail -c 1500 gpurun_out/bench.json; tail -3 gpurun_out/bench.err ;;
     benchq) timeout 600 python bench.py --no-cpu-baseline --no-decode > gpurun_out/benchq.json 2> gpurun_out/benchq.err; echo "rc=$?"; grep -o '"ms_per_step": [0-9.]*' gpurun_out/benchq.json ;;
     prof)   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o r1 -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-decode > $OLDPWD/gpurun_out/prof.log 2>&1); echo "rc=$?"
-            python scripts/prof_summary.py $(find gpurun_out/prof -name "*.db" | head -1) > gpurun_out/rocprof_kernel_stats.txt 2>&1; head -45 gpurun_out/rocprof_kernel_stats.txt ;;
+            python scripts/prof_summary.py $(find gpurun_out/prof -name "*.db" | head -1) > gpurun_out/rocprof_kernel_stats.txt 2>&1; rm -rf gpurun_out/prof; head -45 gpurun_out/rocprof_kernel_stats.txt ;;
     profd)  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/profd -o r1 -- python $OLDPWD/bench.py --mode decode --sentences 600 --no-cpu-baseline > $OLDPWD/gpurun_out/profd.log 2>&1); echo "rc=$?"
-            python scripts/prof_summary.py $(find gpurun_out/profd -name "*.db" | head -1) 1 > gpurun_out/rocprof_decode.txt 2>&1; head -40 gpurun_out/rocprof_decode.txt ;;
+            python scripts/prof_summary.py $(find gpurun_out/profd -name "*.db" | head -1) 1 > gpurun_out/rocprof_decode.txt 2>&1; rm -rf gpurun_out/profd; head -40 gpurun_out/rocprof_decode.txt ;;
     mfma)   bash scripts/pmc_mfma.sh ;;
     traffic) bash scripts/pmc_traffic.sh ;;
     side)   timeout 600 python bench.py --sentences-per-gpu 256 --no-cpu-baseline --no-decode > gpurun_out/bench_b256.json 2> gpurun_out/bench_b256.err; echo "rc=$?"; grep -o '"ms_per_step": [0-9.]*\|"step_mfma_frac": [0-9.]*' gpurun_out/bench_b256.json ;;

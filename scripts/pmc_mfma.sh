@@ -9,4 +9,5 @@ rm -rf gpurun_out/pmcm
    -d $OLDPWD/gpurun_out/pmcm -o p --output-format csv -- \
    python $OLDPWD/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-decode --no-graph > $OLDPWD/gpurun_out/pmcm.log 2>&1); echo "pmc_mfma rc=$?"
 python scripts/pmc_mfma.py gpurun_out/pmcm > gpurun_out/pmc_mfma.json
+rm -rf gpurun_out/pmcm
 head -c 900 gpurun_out/pmc_mfma.json; echo
