@@ -408,6 +408,41 @@ def test_batches_in_flight_on_lanes_equal_the_sequential_loop(model):
         decode_many(batches, boom, streams=2)
 
 
+@pytest.mark.parametrize("model", ["transformer_aan", "transformer"])
+def test_step_graphs_are_reused_across_batches_of_one_shape(model, monkeypatch):
+    """The two parity graphs of a decode batch are kept per (beam rows, padded source length, cache length) and replayed
+    by later batches of that shape; source length and cache length are bucketed to multiples of 8 (masked keys add
+    exact zeros).  Same hypotheses, scores and step counts as with a fresh capture per batch on unpadded shapes."""
+    from zero_amd.search import beam_search
+    hp, Pn, src, tgt = _setup(model, seed=13, beam_size=4)
+    Pn["tgt_embedding"] = (Pn["tgt_embedding"] * 6.0).astype(np.float32)
+    hp = copy.copy(hp); hp.search_mode = "cache"
+    rng = np.random.default_rng(9)
+    batches = []
+    for ls in (6, 7, 13, 6, 9, 7, 13):        # 6 / 7 and 9 / 13 share a bucket; repeats must hit the cache
+        s_, _ = make_batch(rng, 4, ls, 5, hp.src_vocab.size(), hp.tgt_vocab.size())
+        batches.append(s_)
+    outs = {}
+    for name, env in (("fresh", {"ZERO_HIP_DECODE_GRAPH_CACHE": "0", "ZERO_HIP_DECODE_PAD_LEN": "1"}), ("cached", {})):
+        for k in ("ZERO_HIP_DECODE_GRAPH_CACHE", "ZERO_HIP_DECODE_PAD_LEN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        reset_cores()
+        core = get_core(hp, model, Pn)
+        enc, dec = registry.get_model(model).infer_fn(hp)
+        res = []
+        for s_ in batches:
+            o = beam_search({"source": s_}, enc, dec, hp)
+            res.append((np.asarray(o["seq"]).copy(), np.asarray(o["score"]).copy(), o["steps"]))
+        outs[name] = (res, core.__dict__.get("_graph_adoptions", 0), len(core.__dict__.get("_step_graph_cache", {})))
+    assert outs["fresh"][1] == 0 and outs["cached"][1] >= 3, (outs["fresh"][1:], outs["cached"][1:])
+    assert 1 <= outs["cached"][2] <= 3
+    for (a, b, c), (x, y, z) in zip(outs["fresh"][0], outs["cached"][0]):
+        L = min(a.shape[-1], x.shape[-1])
+        assert np.array_equal(a[..., :L], x[..., :L]) and np.array_equal(b, y) and c == z
+
+
 def test_transposed_decode_weights_follow_the_weight_version():
     """The transposed weight copies of the fused decode kernels are made by zk_transpose_bf16 once per weight version:
     reused across batches, refreshed after an optimiser update."""

@@ -208,19 +208,10 @@ def _beam_search_body(features, encoding_fn, decoding_fn, params, box):
 
 
 def _release_graphs(state):
-    """The decode-step graphs of a batch die with it (they point at this batch's cache layout)."""
-    graphs = state.get("graphs") if hasattr(state, "get") else None
-    if not graphs:
-        return
-    core = state["_core"]
-    if all(not isinstance(g, str) for g in graphs.values()):
-        # a whole batch ran from captured graphs: the step's scratch exists for this many beam rows
-        core._decode_warm_rows = max(core.__dict__.get("_decode_warm_rows", 0), state["BK"])
-    torch.cuda.current_stream(core.eng.device).synchronize()
-    for g in graphs.values():
-        if not isinstance(g, str):
-            core.eng.lib.call("zk_graph_destroy", g)
-    graphs.clear()
+    """End of a batch: its step graphs go to the per-shape cache of their core or are destroyed (models/_decode.py)."""
+    if hasattr(state, "get") and state.get("graphs"):
+        from zero_amd.models._decode import retire_graphs
+        retire_graphs(state)
 
 
 def _beam_search_static(state, decoding_fn, params, B, K, V, eos_id, pad_id, alpha, max_target_length):
