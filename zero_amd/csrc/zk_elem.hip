@@ -417,13 +417,16 @@ __global__ void __launch_bounds__(256) k_colsum_grouped(const ColsumDesc* __rest
     }
   }
 }
-// stage 2: out[c] = sum_b partials[b][q][c]; one block = 16 columns of one quantity of one problem
+// stage 2: out[c] = sum_b partials[b][q][c]; one block = ZK_RED_COLS columns of one quantity of one problem (32 columns:
+// every row of partials is read as a full 128-byte line; with 16 the L2 fetched twice the bytes it delivered)
+#define ZK_RED_COLS 32
 struct ReduceDesc {
   const float* partials; float* out[3];
   int nblk, nq, H, block_start;
 };
 __global__ void __launch_bounds__(256) k_reduce_grouped(const ReduceDesc* __restrict__ descs, int nprob) {
-  __shared__ float red[16][17];
+  constexpr int NG = 256 / ZK_RED_COLS;
+  __shared__ float red[NG][ZK_RED_COLS + 1];
   const int bid = blockIdx.x;
   int p = 0;
   {   // the last problem whose first block is <= bid: binary search (a linear scan is one dependent global load per
@@ -436,25 +439,24 @@ __global__ void __launch_bounds__(256) k_reduce_grouped(const ReduceDesc* __rest
   }
   const ReduceDesc d = descs[p];
   const int local = bid - d.block_start;
-  const int ncb = (d.H + 15) / 16;
+  const int ncb = (d.H + ZK_RED_COLS - 1) / ZK_RED_COLS;
   const int q = local / ncb, cb = local - q * ncb;
   float* o = d.out[q];
   if (o == nullptr) return;
-  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int c = cb * 16 + cl;
+  const int cl = threadIdx.x % ZK_RED_COLS, g = threadIdx.x / ZK_RED_COLS;
+  const int c = cb * ZK_RED_COLS + cl;
   float t = 0.f;
   if (c < d.H)
-    for (int b = g; b < d.nblk; b += 16) t += d.partials[((size_t)b * d.nq + q) * d.H + c];
+    for (int b = g; b < d.nblk; b += NG) t += d.partials[((size_t)b * d.nq + q) * d.H + c];
   red[g][cl] = t;
   __syncthreads();
   if (g == 0 && c < d.H) {
     float v = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v += red[i][cl];
+    for (int i = 0; i < NG; ++i) v += red[i][cl];
     o[c] = v;
   }
 }
-
 // Embedding-table gradient without atomics: the host sorts the token rows by id (it owns the
 // ids anyway); one wave per DISTINCT id sums its rows in fp32 and does a single read-modify-write
 // of the table row.  `rows_sorted` [n_used] = token-row indices grouped by id, `seg` [n_uniq+1]
@@ -477,21 +479,21 @@ __global__ void __launch_bounds__(256) k_embed_bwd_sorted(
       float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       // A frequent id (the eos of every sentence, punctuation) owns a long run of rows.  Walking it one dependent
       // load chain at a time (index -> row) cost ~1 us per row -- 64 eos rows = the whole 55-us launch of the bench
-      // batch.  Now: the run's row indices in ONE coalesced load per 64 rows, then the rows eight at a time with all
-      // eight loads in flight; the additions keep the order of the run, so the sums are bit-identical to the serial walk.
+      // batch.  Now: the run's row indices in ONE coalesced load per 64 rows, then the rows sixteen at a time with all
+      // sixteen loads in flight; the additions keep the order of the run, so the sums are bit-identical to the serial walk.
       for (int k0 = s0; k0 < s1; k0 += 64) {
         const int nb = min(64, s1 - k0);
         const int my_r = (lane < nb) ? rows_sorted[k0 + lane] : 0;
-        for (int j0 = 0; j0 < nb; j0 += 8) {
-          uint4 raw[8];
-          int rr[8];
+        for (int j0 = 0; j0 < nb; j0 += 16) {
+          uint4 raw[16];
+          int rr[16];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
+          for (int j = 0; j < 16; ++j) {
             rr[j] = __shfl(my_r, (j0 + j) & 63);
             if (active && j0 + j < nb) raw[j] = *reinterpret_cast<const uint4*>(dout + (size_t)rr[j] * H + c);
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
+          for (int j = 0; j < 16; ++j) {
             if (!active || j0 + j >= nb) break;
             float v[8];
             unpack8(raw[j], v);

@@ -32,6 +32,9 @@ class _GroupDesc(ctypes.Structure):
                                             "tiles_n", "ldr")] + [("colsum", ctypes.c_void_p), ("pad", ctypes.c_long)]
 
 
+RED_COLS = 32      # columns per block of k_reduce_grouped (ZK_RED_COLS in zero_amd/csrc/zk_elem.hip)
+
+
 class _ColsumDesc(ctypes.Structure):
     _fields_ = [("a", ctypes.c_void_p), ("partials", ctypes.c_void_p)] + \
                [(n, ctypes.c_int) for n in ("rows", "N", "lda", "gy", "block_start", "pad")]
@@ -244,13 +247,13 @@ class Engine(object):
                 r = rd[k]
                 r.partials, r.nblk, r.nq, r.H, r.block_start = pw.data_ptr(), gy, 1, a.cols, rstart
                 r.out[0], r.out[1], r.out[2] = o.data_ptr(), None, None
-                rstart += (a.cols + 15) // 16
+                rstart += (a.cols + RED_COLS - 1) // RED_COLS
                 k += 1
             for (pw, rows, H, dg, db, dbp) in ln_parts:
                 r = rd[k]
                 r.partials, r.nblk, r.nq, r.H, r.block_start = pw.data_ptr(), lib.raw("zk_ln_bwd_blocks")(rows), 3, H, rstart
                 r.out[0], r.out[1], r.out[2] = dg.data_ptr(), db.data_ptr(), hip.ptr(dbp)
-                rstart += 3 * ((H + 15) // 16)
+                rstart += 3 * ((H + RED_COLS - 1) // RED_COLS)
                 k += 1
             cdev = torch.frombuffer(bytearray(bytes(cd)), dtype=torch.uint8).to(self.device)
             rdev = torch.frombuffer(bytearray(bytes(rd)), dtype=torch.uint8).to(self.device)
