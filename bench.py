@@ -325,9 +325,10 @@ def decode_measure(args, rank, world):
         if fns is None:
             fns = _LANE_FNS.fns = graph.infer_fn(hp)
         return beam_search({"source": src}, fns[0], fns[1], hp)["steps"]
-    # warm-up on the LONGEST batches, once per lane: sizes every buffer of every lane
+    # warm-up on the LONGEST batches, by EVERY lane: sizes the buffers, pins and kernels of each lane (a lane that meets
+    # its first batch inside the ~1.5-s timed region pays ~0.1 s of first-use costs there)
     warm = batches[-max(args.warmup, 1):]
-    decode_many([b for b in warm for _ in range(streams)], work, streams)
+    decode_many(warm, work, streams, each_lane=True)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()

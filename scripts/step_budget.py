@@ -85,16 +85,16 @@ def build(B, L=64, H=512, F=2048, V=32000, NE=6, ND=6, nh=8):
           (T // 128) * (2 * ND * H // 128) * 256 * H * 2.0)
     b.add(c2, 1, 2.0 * T * H * (2 * ND * H), 2 * ND * act + 2 * ND * H * H * 2 + act,
           (T // 64) * (H // 64) * 128 * (2 * ND * H) * 2.0)
-    # ---- weight gradients: two grouped launches (fp32 out), K = T tokens
-    c3 = "grouped weight gradients (fp32 out, K = %d)" % T
+    # ---- weight gradients: ONE grouped launch of 256 x 256 tiles (fp32 out), K = T tokens
+    c3 = "grouped weight gradients (one launch, 256x256 tiles, fp32 out, K = %d)" % T
     wg_enc = NE * (H * 3 * H + H * H + 2 * H * F)
     wg_dec = ND * (H * 3 * H + 5 * H * H + 2 * H * F) + V * H
-    for params in (wg_enc, wg_dec):
-        # 128 x 256 tiles: staged bytes per output element = (128 + 256) * K * 2 / (128 * 256)
-        b.add(c3, 1, 2.0 * params * T, params * 4.0 + 2 * 30 * act, params / (128.0 * 256) * 384 * T * 2.0)
-    # ---- logits: forward GEMM (bf16 or fp32 logits), dlogits x E
+    params = wg_enc + wg_dec
+    # staged bytes per output element = (256 + 256) * K * 2 / (256 * 256); operands: every X / dY of the step + dlogits
+    b.add(c3, 1, 2.0 * params * T, params * 4.0 + 2 * 30 * act + T * V * 2.0, params / (256.0 * 256) * 512 * T * 2.0)
+    # ---- logits: forward GEMM (fp32 logits), dlogits x E
     c4 = "logits forward + dlogits x E"
-    b.add(c4, 1, 2.0 * T * V * H, act + V * H * 2 + T * V * 2.0, (T // 256) * (V // 256) * 512 * H * 2.0)
+    b.add(c4, 1, 2.0 * T * V * H, act + V * H * 2 + T * V * 4.0, (T // 256) * (V // 256) * 512 * H * 2.0)
     b.add(c4, 1, 2.0 * T * V * H, T * V * 2.0 + V * H * 2 + act, (T // 128) * (H // 256) * 384 * V * 2.0)
     # ---- attention (func.py:218-256): forward reads q, k, v, writes out; backward reads q, k, v, dO, writes dq, dk, dv
     c5 = "attention forward / backward (one (sentence, head) tile per workgroup)"
@@ -107,7 +107,7 @@ def build(B, L=64, H=512, F=2048, V=32000, NE=6, ND=6, nh=8):
     b.add(c6, n_ln, 0, 4 * act)           # x, y in; out, saved sum out
     b.add(c6, n_ln, 0, 4 * act)           # dout, saved sum in; dsum (+ dy with dropout) out
     # ---- cross entropy, Adam, the rest
-    b.add("cross entropy (bf16 logits in, bf16 dlogits out)", 1, 0, T * V * 4.0)
+    b.add("cross entropy (fp32 logits in, bf16 dlogits out)", 1, 0, T * V * 6.0)
     nparam = wg_enc + wg_dec + V * H + (NE * 2 + ND * 3) * 2 * H + H
     b.add("Adam (30 B / parameter)", 1, 0, nparam * 30.0)
     b.add("embeddings, masks, loss, column / LayerNorm-parameter reductions, zero fill, norm", 17, 0, 12e6)
@@ -125,10 +125,10 @@ def measured(path):
         if len(f) < 7 or not f[0].endswith("%") or not f[1][0].isdigit():
             continue
         name, calls, total_ms = f[6], float(f[2]), float(f[1])
-        if "k_gemm_dlds<128, 256" in name or "k_gemm_grouped256" in name:
-            cls = "logits forward + dlogits x E"
-        elif "k_gemm_grouped<128, 256" in name or "k_gemm_grouped<256" in name or "k_gemm_sk256" in name:
+        if "k_gemm_grouped256<true, false" in name or "k_gemm_grouped<128, 256" in name or "k_gemm_grouped<256" in name:
             cls = "grouped weight gradients"
+        elif "k_gemm_dlds<128, 256" in name or "k_gemm_grouped256" in name or "k_splitk_reduce" in name:
+            cls = "logits forward + dlogits x E"
         elif "k_gemm_grouped<128, 128" in name or "k_gemm_kseg" in name:
             cls = "grouped K/V projections + K-segmented d(enc)"
         elif "k_gemm_dlds" in name:

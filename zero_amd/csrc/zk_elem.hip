@@ -446,8 +446,21 @@ __global__ void __launch_bounds__(256) k_reduce_grouped(const ReduceDesc* __rest
   const int cl = threadIdx.x % ZK_RED_COLS, g = threadIdx.x / ZK_RED_COLS;
   const int c = cb * ZK_RED_COLS + cl;
   float t = 0.f;
-  if (c < d.H)
-    for (int b = g; b < d.nblk; b += NG) t += d.partials[((size_t)b * d.nq + q) * d.H + c];
+  if (c < d.H) {
+    // eight independent loads in flight per thread (the loop is a chain of ~0.5-us round trips otherwise); the
+    // additions keep the order b = g, g + NG, ...
+    const float* src = d.partials + (size_t)q * d.H + c;
+    const size_t rs = (size_t)d.nq * d.H;
+    int b = g;
+    for (; b + 7 * NG < d.nblk; b += 8 * NG) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = src[(size_t)(b + i * NG) * rs];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t += v[i];
+    }
+    for (; b < d.nblk; b += NG) t += src[(size_t)b * rs];
+  }
   red[g][cl] = t;
   __syncthreads();
   if (g == 0 && c < d.H) {

@@ -67,7 +67,7 @@ def decode_streams(default=4):
         return default
 
 
-def decode_many(items, work, streams=None):
+def decode_many(items, work, streams=None, each_lane=False):
     """``[work(item) for item in items]`` with up to ``streams`` items in flight at once, each on its own execution
     lane (zero_amd.models._factory.lane: own HIP stream, scratch and cache buffers, captured step graphs; the variable
     store is shared).  Results come back in the order of ``items``.
@@ -77,12 +77,16 @@ def decode_many(items, work, streams=None):
     have no data in common but the weights, so their chains interleave on the device for nothing: the reference's
     evaluation loop (evalu.py:49-139) decodes its batches one after the other only because a TF session runs one
     ``session.run`` at a time.  Every batch's arithmetic is exactly what it is alone (same kernels, same buffers
-    per lane), so hypotheses and scores are bit-identical to the sequential loop (tests/test_gpu_loops.py).
+    per lane), so hypotheses and scores are bit-identical to the sequential loop (tests/test_gpu_model.py).
+    each_lane=True: EVERY lane works through all items (sizing its buffers and its graph cache: the warm-up of a
+    measurement); the results of lane 0 are returned.
 
     Host side: one worker thread per lane (ctypes calls and stream / event waits release the GIL; the Python work
     per decode step is ~30 us against ~360 us of device time)."""
     import threading
     streams = decode_streams() if streams is None else max(1, int(streams))
+    if each_lane:
+        items = list(items)
     it = iter(items)
     if streams == 1:
         return [work(x) for x in it]
@@ -99,6 +103,12 @@ def decode_many(items, work, streams=None):
             if dev is not None:
                 torch.cuda.set_device(dev)
             with lane(idx):
+                if each_lane:
+                    out = [work(x) for x in items]
+                    if idx == 0:
+                        results.update(enumerate(out))
+                        counter[0] = len(out)
+                    return
                 while not errors:
                     with lock:
                         try:

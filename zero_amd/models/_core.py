@@ -87,7 +87,9 @@ class TransformerCore(object):
         # while the encoder's 288 tiles alone would be 1.1 -- which is why the 256x256 tile lost inside the per-side
         # groups of round 2.  The bias gradients ride along as column sums by MFMA (gemm256_acc<.., CS>).
         self.group_all = (not _multi) and os.environ.get("ZERO_HIP_GROUP_ALL", "1") != "0"
-        wt = os.environ.get("ZERO_HIP_WGRAD_TILE", "256x256" if self.group_all else "128x256").lower()
+        # ("256x256n": the LDS-DMA pieces of a K step issued right behind the barrier instead of spread between the MFMA
+        # groups -- same-box A/B of the whole step: 4.708 ms spread, 4.673 ms not, 4.80 ms for the round-2 grouping)
+        wt = os.environ.get("ZERO_HIP_WGRAD_TILE", "256x256n" if self.group_all else "128x256").lower()
         self.wgrad_tile = {"128": 128, "128x128": 128, "256x128": (256, 128), "128x256": (128, 256),
                            "256x256": (256, 256), "256x256n": (256, 256, 0)}[wt]
         self._pending_wgrads = []
