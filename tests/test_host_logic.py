@@ -211,3 +211,41 @@ def test_config_file_values_may_be_arithmetic_but_never_code(tmp_path):
         except (ValueError, SyntaxError):
             continue
         raise AssertionError("accepted: " + bad)
+
+
+def test_decode_many_order_lanes_and_errors():
+    """evalu.decode_many (host logic only): results in input order whatever lane finished first, every lane bound to its
+    own execution lane index, each_lane warm-up runs every item on every lane, a worker's exception reaches the caller,
+    and one stream is the plain sequential loop."""
+    import threading
+    import time
+    from zero_amd.evalu import decode_many
+    from zero_amd.models._factory import current_lane
+    seen = {}
+    lock = threading.Lock()
+
+    def work(x):
+        time.sleep(0.001 * (7 - x % 7))             # later items finish earlier
+        with lock:
+            seen.setdefault(current_lane(), []).append(x)
+        return x * x
+    items = list(range(23))
+    assert decode_many(iter(items), work, streams=1) == [x * x for x in items] and set(seen) == {0}
+    seen.clear()
+    assert decode_many(iter(items), work, streams=3) == [x * x for x in items]
+    assert set(seen) <= {0, 1, 2} and sorted(sum(seen.values(), [])) == items and len(seen) >= 2
+    assert current_lane() == 0                      # the caller's lane is untouched
+    seen.clear()
+    assert decode_many(items[:4], work, streams=3, each_lane=True) == [0, 1, 4, 9]
+    assert {k: sorted(v) for k, v in seen.items()} == {0: [0, 1, 2, 3], 1: [0, 1, 2, 3], 2: [0, 1, 2, 3]}
+
+    def boom(x):
+        if x == 5:
+            raise KeyError("lane failure")
+        return x
+    try:
+        decode_many(items, boom, streams=2)
+    except KeyError:
+        pass
+    else:
+        raise AssertionError("the worker's exception was swallowed")
