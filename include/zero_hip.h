@@ -451,6 +451,14 @@ int zk_dec_embed(const int* ids, int pad_id, const void* table, const float* bia
                  int H, float scale, int pos0, const int* pos_dev, float* cache, void* cat, float inv_count,
                  const float* gather_src, const int* gather_idx, int nl, zk_stream_t stream);
 
+/* The replay loop of the device-resident search in one call (no interpreter between two decode steps): the two parity
+ * graphs of the step alternately (starting with `parity`), poll replays per group, the search's 16-byte control block
+ * {time, stop, overflow, -} copied into one of two pinned 4-int slots behind every group and read one group later; ends
+ * when the stop flag is up or more than max_launch replays went out, with the stream drained.  search.py:85-113 (the stop
+ * test) decides on the device; this only carries the flag to the host. */
+int zk_beam_dev_run(void* graph_even, void* graph_odd, int parity, const int* ctrl_dev, int* ctrl_pinned8, int max_launch,
+                    int poll, zk_stream_t stream, int* launched_out, int* newest_slot_out);
+
 /* hipGraph plumbing: capture a sequence of the calls above once, replay per step */
 int zk_graph_begin(zk_stream_t stream);
 int zk_graph_end(zk_stream_t stream, void** exec_out);

@@ -936,4 +936,52 @@ int zk_beam_dev_advance(ZK_BEAM_DEV_ARGS, hipStream_t stream) {
   ZK_LAUNCH_CHECK();
   return 0;
 }
+
+// The replay loop of the device-resident search (zero_amd/search.py _beam_search_device) without the interpreter: launch
+// the two parity graphs of the decode step alternately, `poll` replays per group; behind every group copy the 16-byte
+// control block {time, stop, overflow, -} of the search into a pinned slot and read it one group LATER, so the device
+// never idles on the poll; stop when the flag is up or max_launch replays went out (the state is frozen from the stop
+// on, replays past it change nothing).  One call per batch: a host thread that drives a batch holds no interpreter lock
+// while it does -- with several batches in flight (evalu.decode_many) the per-step Python of the lanes no longer
+// serialises them.  ctrl_pinned8: two pinned 4-int slots; *newest_slot_out: the slot of the last copy (complete when
+// the call returns: the stream is drained); *launched_out: replays issued.
+int zk_beam_dev_run(void* graph_even, void* graph_odd, int parity, const int* ctrl_dev, int* ctrl_pinned8, int max_launch,
+                    int poll, hipStream_t stream, int* launched_out, int* newest_slot_out) {
+  ZK_CHECK_ARG(graph_even != nullptr && graph_odd != nullptr && ctrl_dev != nullptr && ctrl_pinned8 != nullptr &&
+               launched_out != nullptr && newest_slot_out != nullptr, "zk_beam_dev_run: null argument");
+  ZK_CHECK_ARG(poll >= 1 && poll <= 64 && (parity == 0 || parity == 1), "zk_beam_dev_run: poll %d / parity %d", poll, parity);
+  hipGraphExec_t g[2] = {(hipGraphExec_t)graph_even, (hipGraphExec_t)graph_odd};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  hipError_t e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+  int launched = 0, group = 0, pending = -1;
+  volatile int* slots = ctrl_pinned8;
+  while (e == hipSuccess) {
+    for (int i = 0; i < poll && e == hipSuccess; ++i) {
+      e = hipGraphLaunch(g[parity], stream);
+      parity ^= 1;
+      ++launched;
+    }
+    if (e != hipSuccess) break;
+    const int slot = group & 1;
+    e = hipMemcpyAsync(ctrl_pinned8 + 4 * slot, ctrl_dev, 16, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipEventRecord(ev[slot], stream);
+    if (e != hipSuccess) break;
+    if (pending >= 0) {
+      e = hipEventSynchronize(ev[pending]);
+      if (e != hipSuccess) break;
+      if (slots[4 * pending + 1] != 0 || launched > max_launch) break;
+    }
+    pending = slot;
+    ++group;
+  }
+  const hipError_t e2 = hipStreamSynchronize(stream);
+  if (ev[0]) hipEventDestroy(ev[0]);
+  if (ev[1]) hipEventDestroy(ev[1]);
+  *launched_out = launched;
+  *newest_slot_out = group & 1;
+  if (e != hipSuccess) return zk_set_error((int)e, "zk_beam_dev_run: %s", hipGetErrorString(e));
+  if (e2 != hipSuccess) return zk_set_error((int)e2, "zk_beam_dev_run: %s", hipGetErrorString(e2));
+  return 0;
+}
 }  // extern "C"

@@ -294,9 +294,10 @@ def _beam_search_device(state, decoding_fn, params, B, K, V, eos_id, pad_id, alp
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
     total = int(offs[-1])
     pinned = core.__dict__.get("_book_host")          # pinned staging, kept across batches (pinning costs ~0.2 ms)
-    if pinned is None or pinned[0].numel() < total:
+    if pinned is None or pinned[0].numel() < total or len(pinned) < 4:
         pinned = (torch.zeros(total + total // 4, dtype=torch.int32).pin_memory(),
-                  torch.zeros(4, dtype=torch.int32).pin_memory(), torch.zeros(4, dtype=torch.int32).pin_memory())
+                  torch.zeros(4, dtype=torch.int32).pin_memory(), torch.zeros(4, dtype=torch.int32).pin_memory(),
+                  torch.zeros(8, dtype=torch.int32).pin_memory())       # [3]: the two control slots of zk_beam_dev_run
         core._book_host = pinned
     host, ctrl_host = pinned[0][:total], pinned[1]
     host.zero_()
@@ -328,7 +329,38 @@ def _beam_search_device(state, decoding_fn, params, B, K, V, eos_id, pad_id, alp
     stream = torch.cuda.current_stream(e.device)
     slots = [(ctrl_host[0:4], torch.cuda.Event()), (pinned[2], torch.cuda.Event())]
     launched, group, pending = 0, 0, None
+    # Once both parity graphs of the step exist (at once when the shape's graphs were adopted from the cache), the rest of
+    # the loop runs inside ONE C call (zk_beam_dev_run: same launches, same one-group-behind poll): no interpreter between
+    # two decode steps, and with several batches in flight the lanes' host threads stop serialising on it.
+    run_c = os.environ.get("ZERO_HIP_DECODE_RUN_C", "1") != "0"
+    from zero_amd.models import _decode as _dec
+    if run_c and "_gkey" not in state:
+        _dec.adopt_graphs(state, state["book"], params.beam_search_temperature, zdtype.inf(),
+                          params.enable_noise_beam_search)
+    stopped = False
     while True:
+        if run_c and _dec._startup_settled(state):
+            if pending is not None:            # drain the Python loop's poll before handing over
+                stream.synchronize()
+                ctrl_host = slots[(group - 1) & 1][0]
+                if int(ctrl_host[1]) or launched > Tcap + 2 * poll:
+                    stopped = True
+                    break
+            _dec.startup_end(state)
+            import ctypes
+            p8 = pinned[3]
+            p8.zero_()
+            g = state["graphs"]
+            n_c, newest = ctypes.c_int(0), ctypes.c_int(0)
+            e.lib.call("zk_beam_dev_run", g[0], g[1], int(state["_pp"]), ctrl_dev.data_ptr(), p8.data_ptr(),
+                       int(Tcap + 2 * poll - launched), poll, stream.cuda_stream, ctypes.byref(n_c), ctypes.byref(newest))
+            launched += n_c.value
+            if n_c.value & 1:                  # the python-side ping-pong pointers follow the replays
+                state["_pp"] = 1 - state["_pp"]
+                state.bind_caches()
+            ctrl_host = p8[4 * newest.value:4 * newest.value + 4]
+            stopped = True
+            break
         for _ in range(poll):
             decoding_fn.step_static(state, params.beam_search_temperature, zdtype.inf())
         launched += poll
@@ -343,7 +375,8 @@ def _beam_search_device(state, decoding_fn, params, B, K, V, eos_id, pad_id, alp
         pending = (buf, ev)
         group += 1
     stream.synchronize()
-    ctrl_host = slots[group & 1][0]                   # the newest copy: same stop state, final step count
+    if not stopped:
+        ctrl_host = slots[group & 1][0]               # the newest copy: same stop state, final step count
     _release_graphs(state)
     state.pop("book", None)
     if int(ctrl_host[2]) or not int(ctrl_host[1]):
