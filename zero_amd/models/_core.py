@@ -603,7 +603,7 @@ class TransformerCore(object):
             if self.logits_tile256 and e.gemm_impl == 0 and self.H % 8 == 0:
                 # 256x256 tiles, fp32 tile stored straight from the accumulators (scripts/gemm_big_bench.py:
                 # 223 us against 274-291 us for the 128x128 kernels on the 4096 x 32000 x 512 problem).  bf16 logits
-                # were measured and are slower (profiles/r03_bf16_logits_experiment.txt: a bf16 32x32 MFMA tile leaves
+                # were measured and are slower (profiles/r03_negative_results.txt: a bf16 32x32 MFMA tile leaves
                 # as 64-byte half lines, +118 us on a GEMM that is not output-bound, for -16 us of cross entropy)
                 e.gemm_grouped([(feat, E, logits, Tt, self.V, self.H, None)], 0, 1, tile=(256, 256))
             else:
