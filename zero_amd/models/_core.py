@@ -87,7 +87,6 @@ class TransformerCore(object):
         # while the encoder's 288 tiles alone would be 1.1 -- which is why the 256x256 tile lost inside the per-side
         # groups of round 2.  The bias gradients ride along as column sums by MFMA (gemm256_acc<.., CS>).
         self.group_all = (not _multi) and os.environ.get("ZERO_HIP_GROUP_ALL", "1") != "0"
-        self.tail_overlap = os.environ.get("ZERO_HIP_TAIL_OVERLAP", "1") != "0"
         # ("256x256n": the LDS-DMA pieces of a K step issued right behind the barrier instead of spread between the MFMA
         # groups -- same-box A/B of the whole step: 4.708 ms spread, 4.673 ms not, 4.80 ms for the round-2 grouping)
         wt = os.environ.get("ZERO_HIP_WGRAD_TILE", "256x256n" if self.group_all else "128x256").lower()
@@ -722,9 +721,6 @@ class TransformerCore(object):
         Q = [d_enc, e.mat("ge.p1", Ts, H)]
         cur = 0
         ready_e = []
-        # (see below: the tail of a single-rank step on two streams; needs distinct source / target tables and an encoder)
-        tail = self.group_all and self.tail_overlap and not self.use_side and NE > 0 and self.side is not None and \
-            self.src_emb != self.tgt_emb and self.src_emb != self.soft_emb and self.group_wgrad and e.gemm_impl == 0
         for l in reversed(range(NE)):
             pre = "encoder/layer_%d" % l
             other = Q[cur ^ 1] if (Q[cur ^ 1] is not d_enc) else e.mat("ge.p0", Ts, H)
@@ -738,44 +734,12 @@ class TransformerCore(object):
             Q[cur ^ 1] = other
             cur ^= 1
             ready_e.append(pre)
-            if (not self.group_all and len(ready_e) >= self.group_layers) or (l == 0 and not tail):
+            if (not self.group_all and len(ready_e) >= self.group_layers) or l == 0:
                 self._flush_wgrads()
                 for key in ready_d + ready_e:      # (group_all: the decoder's keys were held back with its weight gradients)
                     self._side(lambda key=key: on_ready(key))
                 ready_d, ready_e = [], []
         dxs = Q[cur]
-        if tail:
-            # Single rank, everything deferred to here: the ONE weight-gradient launch (~0.5 ms, MFMA / LDS bound, one
-            # 512-thread workgroup per CU) runs on the main stream while a forked stream does what does not depend on
-            # it -- the grouped LayerNorm / bias reductions and the source-embedding gradient (HBM / latency bound, no
-            # LDS to speak of) -- in the CUs' spare wave slots and in the 60 %-full last round of tiles.  One fork and one
-            # join per step.  The shared bias is written by the source side here and accumulated into by the target side
-            # after the join (the other way round otherwise: the sum of two terms is the same either way).
-            main = torch.cuda.current_stream(e.device)
-            ev = torch.cuda.Event()
-            ev.record(main)
-            self.side.wait_event(ev)
-            with torch.cuda.stream(self.side):
-                if self._pending_colsums or self._pending_lnred:
-                    cs, ln = self._pending_colsums, self._pending_lnred
-                    self._pending_colsums, self._pending_lnred = [], []
-                    e.reductions_grouped(cs, ln)
-                e.embed_bwd_sorted(batch["src_sort"], dxs, st.g(self.src_emb), H, accumulate=False, drop_p=hp.dropout,
-                                   sid=9001)
-                e.colsum(dxs, st.g("bias"), skip_L=0, accumulate=False, drop_p=hp.dropout, sid=9001)
-                ev2 = torch.cuda.Event()
-                ev2.record(self.side)
-            self._flush_wgrads()                    # the grouped weight-gradient launch (+ deferred adds) on the main stream
-            main.wait_event(ev2)
-            for key in ready_d + ready_e:
-                on_ready(key)
-            e.embed_bwd_sorted(batch["tgt_sort"], dxt, st.g(self.tgt_emb), H,
-                               accumulate=(self.tgt_emb == self.soft_emb), drop_p=hp.dropout, sid=9002)
-            e.colsum(dxt, st.g("bias"), skip_L=Lt, accumulate=True, drop_p=hp.dropout, sid=9002)
-            tables_ready()
-            on_ready("bias")
-            on_ready(self.src_emb)
-            return
         if self.group_all:
             if ready_d:                            # a model without encoder layers
                 self._flush_wgrads()
