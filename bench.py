@@ -592,7 +592,7 @@ def main():
         # BASELINE configs[3] under the same clock: its own model / parameter store, after the training leg
         try:
             dargs = argparse.Namespace(**vars(args))
-            dargs.warmup = 2
+            dargs.warmup = max(args.warmup, 1)      # per lane, on the longest batches (untimed): buffers, pins, kernels, graph cache
             out["decode"] = decode_measure(dargs, rank, world)
         except Exception as exc:      # noqa: BLE001 -- the headline line must still be printed
             out["decode"] = {"error": repr(exc)}
