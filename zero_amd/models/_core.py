@@ -105,8 +105,6 @@ class TransformerCore(object):
         # T*V*4 bytes, which matters for larger batches / vocabularies)
         self.fused_ce = os.environ.get("ZERO_HIP_FUSED_CE", "0") != "0" and self.eng.lib.experiments
         self.logits_tile256 = os.environ.get("ZERO_HIP_LOGITS_256", "1") != "0"
-        # (256, 256): LDS-DMA pieces spread between the MFMA groups; (256, 256, 0): issued right behind the barrier
-        self.logits_tile = (256, 256, 0) if os.environ.get("ZERO_HIP_LOGITS_SPREAD", "1") == "0" else (256, 256)
         self._red_id = 0
         self.side = torch.cuda.Stream(self.eng.device) if self.eng.device.type == "cuda" else None
 
@@ -606,7 +604,7 @@ class TransformerCore(object):
                 # 223 us against 274-291 us for the 128x128 kernels on the 4096 x 32000 x 512 problem).  bf16 logits
                 # were measured and are slower (profiles/r03_negative_results.txt: a bf16 32x32 MFMA tile leaves
                 # as 64-byte half lines, +118 us on a GEMM that is not output-bound, for -16 us of cross entropy)
-                e.gemm_grouped([(feat, E, logits, Tt, self.V, self.H, None)], 0, 1, tile=self.logits_tile)
+                e.gemm_grouped([(feat, E, logits, Tt, self.V, self.H, None)], 0, 1, tile=(256, 256))
             else:
                 e.gemm(feat, E, logits, Tt, self.V, self.H, 0, 1)
             dlogits = e.mat("dlogits", Tt, self.Vpad) if need_grad else None
