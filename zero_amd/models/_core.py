@@ -106,7 +106,13 @@ class TransformerCore(object):
         self.fused_ce = os.environ.get("ZERO_HIP_FUSED_CE", "0") != "0" and self.eng.lib.experiments
         self.logits_tile256 = os.environ.get("ZERO_HIP_LOGITS_256", "1") != "0"
         self._red_id = 0
-        self.side = torch.cuda.Stream(self.eng.device) if self.eng.device.type == "cuda" else None
+        self._side_stream = None      # created on first use: every stream of the process takes a share of the hardware queues
+
+    @property
+    def side(self):
+        if self._side_stream is None and self.eng.device.type == "cuda":
+            self._side_stream = torch.cuda.Stream(self.eng.device)
+        return self._side_stream
 
     # ------------------------------------------------------------------ stream plumbing
     def _side(self, fn):
