@@ -8,15 +8,27 @@ Adam on ONE synthetic batch per GPU: B=64 sentences x (Ls=64 + Lt=64) tokens = 8
 tokens per GPU-step (BASELINE.json configs[1]), V=32000, H=512, F=2048, h=8,
 6+6 layers, bf16 MFMA compute / fp32 accumulate / fp32 master weights, dropouts 0.1 and label
 smoothing 0.1 as in the canonical recipe.  Weak scaling: every rank draws its own batch
-(seed 1234+rank).  Rank 0 prints ONE JSON line (contract in the task statement) with two
-extra objects:
+(seed 1234+rank).  With --gpus N and no launcher (WORLD_SIZE unset) bench.py starts its N ranks itself
+(torch.distributed.run on 127.0.0.1); under torchrun it goes straight on.  Rank 0 prints ONE JSON line
+(contract in the task statement) with these extra objects:
 
   roofline     -- the dominant kernel (the bf16 MFMA GEMM instance with the largest total
                   time), achieved = algorithmic FLOPs of its launches / their HIP-event time,
-                  measured in an instrumented eager pass right after the timed region;
+                  measured in an instrumented eager pass right after the timed region; `traffic` (HBM bytes
+                  per launch) and `mfma_busy` (MFMA-pipe utilisation) come from the newest committed counter
+                  summaries (profiles/*_pmc_traffic.json, *_pmc_mfma.json: separate rocprofv3 --pmc passes,
+                  stamped with their commit);
+  rccl         -- ranks, transport (zk_comm | torch.distributed:<backend>), bucket dtype, row-sparse tables,
+                  bytes per rank and step, the step time without the exchange and the exposed part of it;
+  decode       -- BASELINE configs[3] (transformer_aan, beam 4, 3000 synthetic sentences, eval batch 32) under
+                  the same clock: sentences/s, ms per decode step, launches per step, HBM roofline fraction,
+                  batches in flight, its own cpu_baseline (one rank only);
   cpu_baseline -- the oracle (oracle/ref_torch.py, unfused torch-CPU fp32 restatement of the
                   reference path: kind "port") timed on the host cores on a bounded sample of
-                  the same workload.  TF1 itself cannot run here.
+                  the same workload (3 warm-up + 10 timed steps when they fit 90 s).  TF1 itself cannot
+                  run here.
+
+Side measurements (never the headline): --sentences-per-gpu 256, --size big, --model ..., --mode decode.
 """
 
 import argparse
