@@ -189,6 +189,9 @@ class Cfg(object):
     # arithmetic and every accumulation stay fp32.  Lets the GPU tests assert a tight per-variable gradient
     # tolerance instead of the 12 % the pure-fp32 comparison needs.
     store_bf16 = False
+    # attribution aid (scripts/grad_noise_attribution.py): when not None, only the storage sites named here are rounded
+    # (weights, linear, probs, scores, attn_out, ln, embed, aan, logits); None = every site
+    store_sites = None
 
 
 def _bf16(x):
@@ -225,19 +228,23 @@ class _RoundBwd(torch.autograd.Function):
         return _bf16(g)
 
 
-def _st(x):
+def _on(site):
+    return Cfg.store_bf16 and (Cfg.store_sites is None or site in Cfg.store_sites)
+
+
+def _st(x, site="linear"):
     """activation stored as bf16 (value and its gradient)."""
-    return _RoundBoth.apply(x) if Cfg.store_bf16 else x
+    return _RoundBoth.apply(x) if _on(site) else x
 
 
-def _st_fwd(x):
+def _st_fwd(x, site="weights"):
     """value rounded (bf16 shadow weights, probabilities), gradient kept fp32."""
-    return _RoundFwd.apply(x) if Cfg.store_bf16 else x
+    return _RoundFwd.apply(x) if _on(site) else x
 
 
-def _st_bwd(x):
+def _st_bwd(x, site="scores"):
     """value kept fp32 (scores / logits live in registers or fp32), gradient stored bf16."""
-    return _RoundBwd.apply(x) if Cfg.store_bf16 else x
+    return _RoundBwd.apply(x) if _on(site) else x
 
 
 def dropout(x, p, training=True):
@@ -334,13 +341,13 @@ def dot_attention(query, memory, mem_mask, H, P, scope, num_heads, cache=None,
     if mem_mask is not None:
         logits = logits + mem_mask
     weights = torch.softmax(_st_bwd(logits), dim=-1)
-    dweights = _st_fwd(dropout(weights, drop, training))
+    dweights = _st_fwd(dropout(weights, drop, training), "probs")
     if use_rpr:
         r = rel_pos_embeddings(P, scope + "/rpr_values", q_len, k.shape[2], max_rel, r_lst)
         o = relative_attention_inner(dweights, v, r, False)
     else:
         o = torch.matmul(dweights, v)
-    o = _st(combine_heads(o))
+    o = _st(combine_heads(o), "attn_out")
     if fuse_mask is not None:
         v_q = linear(query, P, scope + "/v_map")        # shares v_map with the memory side
         if cache is not None and 'aan' in cache:
@@ -349,7 +356,7 @@ def dot_attention(query, memory, mem_mask, H, P, scope, num_heads, cache=None,
             aan_o = torch.matmul(fuse_mask, v_q)
         if cache is not None:
             cache['aan'] = v_q if 'aan' not in cache else v_q + cache['aan']
-        o = _st(o + aan_o)
+        o = _st(o + aan_o, "attn_out")
     o = linear(o, P, scope + "/o_map")
     return {'weights': weights, 'output': o, 'cache': cache}
 
@@ -360,7 +367,7 @@ def layer_norm(x, P, scope):
     offset = P[scope + "/layer_norm/offset"]
     mean = x.mean(-1, keepdim=True)
     var = ((x - mean) ** 2).mean(-1, keepdim=True)
-    return _st(scale * (x - mean) * torch.rsqrt(var + Cfg.eps) + offset)
+    return _st(scale * (x - mean) * torch.rsqrt(var + Cfg.eps) + offset, "ln")
 
 
 def residual_fn(x, y, drop=None, training=True):
@@ -461,7 +468,7 @@ def encoder(source, hp, P, model_name, training=True):
     x = _st_fwd(P[_emb_name(hp, "src")])[source] * (H ** 0.5)
     x = x + P["bias"]
     x = x + timing_signal(x.shape[1], x.shape[2], dt)
-    x = _st(dropout(x, hp.dropout, training))
+    x = _st(dropout(x, hp.dropout, training), "embed")
     rpr = model_name == "transformer_rpr"
     for l in range(hp.num_encoder_layer):
         pre = "encoder/layer_%d" % l
@@ -516,7 +523,7 @@ def decoder(target, state, hp, P, model_name, training=True):
             inputs = torch.zeros_like(inputs)
         mask = torch.ones_like(mask)
         inputs = inputs + timing_signal(1, inputs.shape[2], dt, time=state['time'])
-    x = _st(dropout(inputs, hp.dropout, training))
+    x = _st(dropout(inputs, hp.dropout, training), "embed")
     rpr = model_name == "transformer_rpr"
     aan = model_name == "transformer_aan"
     dstep = None if is_training else state['time']
@@ -537,12 +544,12 @@ def decoder(target, state, hp, P, model_name, training=True):
             continue
         if aan:
             assert [s.lower() for s in hp.strategies] == ["aan"]
-            y = _st(average_attention(x, mask, state, l, hp, is_training))
+            y = _st(average_attention(x, mask, state, l, hp, is_training), "aan")
             if hp.use_ffn:
                 y = ffn_layer(y, P, pre + "/average_attention", hp.relu_dropout, training)
             z = linear(torch.cat([x, y], dim=-1), P, pre + "/average_attention/z_project")
             i, f = torch.split(z, H, dim=-1)
-            y = _st(torch.sigmoid(i) * x + torch.sigmoid(f) * y)
+            y = _st(torch.sigmoid(i) * x + torch.sigmoid(f) * y, "aan")
             x = layer_norm(residual_fn(x, y, hp.residual_dropout, training), P, pre + "/average_attention")
         else:
             r = dot_attention(x, None, attention_bias(mask.shape[1], "causal").to(dt), H, P,
@@ -567,7 +574,7 @@ def decoder(target, state, hp, P, model_name, training=True):
     if 'dev_decode' in state:
         feature = x[:, -1, :]
     feature = feature.reshape(-1, hp.embed_size)
-    logits = _st_bwd(torch.matmul(feature, _st_fwd(P[_emb_name(hp, "softmax")]).t()))
+    logits = _st_bwd(torch.matmul(feature, _st_fwd(P[_emb_name(hp, "softmax")]).t()), "logits")
     logits32 = logits  # tf.cast(logits, tf.float32): the restatement already runs >= fp32
     if 'dev_decode' in state or not is_training:
         # loss tensors are built by the reference graph but never fetched on
