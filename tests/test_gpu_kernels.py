@@ -166,12 +166,14 @@ def test_gemm_grouped(ta, tb):
             assert rel_err(p[2].t, r) < 8e-3, (tile, p[3:6], rel_err(p[2].t, r))
 
 
-def test_gemm_grouped_256_tiles_with_bias_column_sums():
+@pytest.mark.parametrize("tile", [(256, 256), (256, 256, 0), (256, 256, "k32")])
+def test_gemm_grouped_256_tiles_with_bias_column_sums(tile):
     """Weight-gradient form (ta = 1, tb = 0: dW = X^T dY, fp32 out) on 256x256 tiles with the bias gradient
-    db = column sums of dY (func.py:16, 58-60) by MFMA beside the tm = 0 tiles: ragged M / N / K, several row tiles, a
-    problem without column sums in the same launch."""
+    db = column sums of dY (func.py:16, 58-60) by MFMA beside the tm = 0 tiles: ragged M / N / K (K tails of the 64-deep
+    two-stage ring and of the 32-deep four-stage ring), several row tiles, a problem without column sums in the launch."""
     e = eng()
-    shapes = [(512, 1536, 1000, True), (136, 520, 264, True), (600, 72, 4096, False), (256, 256, 64, True)]
+    shapes = [(512, 1536, 1000, True), (136, 520, 264, True), (600, 72, 4096, False), (256, 256, 64, True),
+              (264, 300, 40, True), (256, 512, 24, False)]
     probs, refs = [], []
     for i, (M, N, K, cs) in enumerate(shapes):
         X = rand_bf(K, M, seed=30 + i)
@@ -180,7 +182,7 @@ def test_gemm_grouped_256_tiles_with_bias_column_sums():
         db = torch.full((N,), 9.0, device="cuda") if cs else None
         probs.append((mat(X), mat(dY), mat(C), M, N, K, None, None, db))
         refs.append((X.float().t() @ dY.float(), dY.float().sum(0)))
-    e.gemm_grouped(probs, 1, 0, tile=(256, 256))
+    e.gemm_grouped(probs, 1, 0, tile=tile)
     torch.cuda.synchronize()
     for p, (r, rcs) in zip(probs, refs):
         assert rel_err(p[2].t, r) < 2e-3, (p[3:6], rel_err(p[2].t, r))

@@ -191,7 +191,118 @@ __device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* _
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (all-zero) pieces
 }
 
-template <bool TA, bool TB, bool SPREAD, bool CS = false>
+// The same 256 x 256 tile on a FOUR-stage ring of 32-deep K tiles (4 x 32 KiB = the same 128 KiB) for the weight-gradient
+// form (ta = 1, tb = 0: both operands stored [k][rows], so a stage is simply 32 k rows instead of 64).  Why: with two
+// 64-deep stages the LDS-DMA of K tile kt+1 has ONE compute step (~2048 MFMA cycles per SIMD, 0.85 us) to come back from
+// L2, and under load it takes longer -- the MFMA pipe of the one-launch weight-gradient group was 40 % busy
+// (profiles/r03_pmc_mfma.json), the waves parked at s_waitcnt.  Four stages keep three tiles (1.3 us of compute) in
+// flight behind counted vmcnt waits, at the price of twice the barriers.
+template <bool CS>
+__device__ __forceinline__ void gemm256_acc_k32(unsigned char* smem, const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                int lda, int ldb, int M, int N, int K, int m0, int n0, f32x16_t (&acc)[4][2],
+                                                bool cs_on, f32x16_t* acc_cs) {
+  constexpr int BM = 256, BN = 256, NS = 4, KT = 32, NW = 8, NWN = 4, WTM = 128, WTN = 64, TM = 4, TN = 2;
+  constexpr int STAGE = (BM + BN) * KT;                       // bf16 elements per ring stage
+  constexpr int PER_WAVE = BM * KT / 8 / NW, NINSTR = PER_WAVE / 64, CPR = BM / 8;   // (BM == BN)
+  constexpr int PER_STAGE = 2 * NINSTR;                       // LDS-DMA pieces per wave and stage
+  bf16_t* ring = reinterpret_cast<bf16_t*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int nk = (K + KT - 1) / KT;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  bf16x8_t ones;
+  if (CS) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc_cs[j][e] = 0.f;
+    typedef short v8s_ __attribute__((ext_vector_type(8)));
+    const v8s_ o = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};     // bf16 1.0
+    ones = __builtin_bit_cast(bf16x8_t, o);
+  }
+  // per-lane plan of the wave's pieces: running source pointer and k index inside the tile (K-tail predicate)
+  const bf16_t* curA[NINSTR]; const bf16_t* curB[NINSTR];
+  int kofs[NINSTR];
+#pragma unroll
+  for (int j = 0; j < NINSTR; ++j) {
+    const int P = wave * PER_WAVE + j * 64 + lane;
+    const int k = P / CPR, pos = P % CPR;
+    const int c = pos ^ swz_trans<BM>(k);
+    int ga = m0 + c * 8, gb = n0 + c * 8;
+    ga = ga < M ? ga : 0;
+    gb = gb < N ? gb : 0;
+    kofs[j] = k;
+    curA[j] = A + (size_t)k * lda + ga;
+    curB[j] = B + (size_t)k * ldb + gb;
+  }
+  const size_t stepA = (size_t)KT * lda, stepB = (size_t)KT * ldb;
+  const uint32_t ring_addr = lds_addr(ring);
+  auto issue = [&](int tt) {
+    const uint32_t st = ring_addr + (uint32_t)((tt % NS) * STAGE * 2);
+    const bool tail = tt * KT + KT > K;
+#pragma unroll
+    for (int j = 0; j < NINSTR; ++j) {
+      const bf16_t* g = curA[j];
+      if (tail) g = (tt * KT + kofs[j] < K) ? g : reinterpret_cast<const bf16_t*>(zk_zero_page);
+      glds16(g, st + (uint32_t)(wave * PER_WAVE + j * 64) * 16u);
+      curA[j] += stepA;
+    }
+#pragma unroll
+    for (int j = 0; j < NINSTR; ++j) {
+      const bf16_t* g = curB[j];
+      if (tail) g = (tt * KT + kofs[j] < K) ? g : reinterpret_cast<const bf16_t*>(zk_zero_page);
+      glds16(g, st + BM * KT * 2 + (uint32_t)(wave * PER_WAVE + j * 64) * 16u);
+      curB[j] += stepB;
+    }
+  };
+#pragma unroll
+  for (int s_ = 0; s_ < NS - 1; ++s_) issue(s_);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed once at most NS-2 later tiles of this wave are still in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PER_STAGE) : "memory");
+    __builtin_amdgcn_s_barrier();                          // ... for every wave, and everybody is done with tile kt-1
+    __builtin_amdgcn_sched_barrier(0);
+    issue(kt + NS - 1);                                    // refill the stage everybody finished reading
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16_t* sA = ring + (kt % NS) * STAGE;
+    const bf16_t* sB = sA + BM * KT;
+    bf16x8_t af[2][TM], bfr[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = load_frag<BM, true>(sA, wm * WTM + i * 32, 0, lane);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bfr[0][j] = load_frag<BN, true>(sB, wn * WTN + j * 32, 0, lane);
+#pragma unroll
+    for (int kk = 0; kk < KT / 16; ++kk) {
+      if (kk + 1 < KT / 16) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[(kk + 1) & 1][i] = load_frag<BM, true>(sA, wm * WTM + i * 32, kk + 1, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[(kk + 1) & 1][j] = load_frag<BN, true>(sB, wn * WTN + j * 32, kk + 1, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
+      if (CS && cs_on) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc_cs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bfr[kk & 1][j], acc_cs[j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (all-zero) pieces
+}
+
+template <bool TA, bool TB, bool SPREAD, bool CS = false, bool K32 = false>
 __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __restrict__ descs, int nprob) {
   constexpr int BM = 256, BN = 256, NS = 2, NWN = 4, WTM = 128, WTN = 64, TM = 4, TN = 2;
   constexpr int STAGE = (BM + BN) * 64;
@@ -220,7 +331,8 @@ __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __rest
     // fp32 tile + bias gradient: the waves of the first row of waves (wm = 0) of the tm = 0 tiles carry the column sums
     f32x16_t acc_cs[TN];
     const bool cs_on = d.colsum != nullptr && tm == 0 && wm == 0;
-    gemm256_acc<TA, TB, SPREAD, true>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, cs_on, acc_cs);
+    if (K32) gemm256_acc_k32<true>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, cs_on, acc_cs);
+    else gemm256_acc<TA, TB, SPREAD, true>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, cs_on, acc_cs);
     if (cs_on && lane < 32) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -228,6 +340,8 @@ __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __rest
         if (col < N) d.colsum[col] = acc_cs[j][0];
       }
     }
+  } else if (K32) {
+    gemm256_acc_k32<false>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, false, nullptr);
   } else {
     gemm256_acc<TA, TB, SPREAD>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc);
   }
@@ -519,10 +633,12 @@ int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int t
   ZK_CHECK_ARG(nprob >= 1 && total_tiles >= 1, "zk_gemm_grouped: empty group");
   // bit 8 of `tile` (256x256 tiles, ta = 1, tb = 0): some problem carries a column-sum output (GroupDesc.colsum)
   const bool cs = (tile & 256) != 0;
+  const bool k32 = (tile & 512) != 0;         // bit 9 (256x256, ta = 1, tb = 0): four-stage ring of 32-deep K tiles
   tile &= 255;
   ZK_CHECK_ARG(tile == 1 || tile == 4 || tile == 5 || tile == 6 || tile == 7 || tile == 8,
                "zk_gemm_grouped: tile must be 1 (128x128), 4 (64x64), 5 (256x128), 6 (128x256) or 7 / 8 (256x256)");
   ZK_CHECK_ARG(!cs || ((tile == 7 || tile == 8) && ta && !tb), "zk_gemm_grouped: column sums on 256x256 tiles need ta = 1, tb = 0");
+  ZK_CHECK_ARG(!k32 || ((tile == 7 || tile == 8) && ta && !tb), "zk_gemm_grouped: the 32-deep ring exists for ta = 1, tb = 0 on 256x256 tiles");
   const GroupDesc* d = (const GroupDesc*)descs;
   dim3 grid((unsigned)total_tiles);
   if (tile == 7 || tile == 8) {     // fp32 outputs without epilogue options only (checked on the host copy by the caller)
@@ -531,6 +647,8 @@ int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int t
     do {                                                                                                     \
       if (!ta && !tb) hipLaunchKernelGGL((k_gemm_grouped256<false, false, SP_>), grid, blk, 0, stream, d, nprob);   \
       else if (!ta && tb) hipLaunchKernelGGL((k_gemm_grouped256<false, true, SP_>), grid, blk, 0, stream, d, nprob); \
+      else if (ta && !tb && k32 && cs) hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, true, true>), grid, blk, 0, stream, d, nprob); \
+      else if (ta && !tb && k32) hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, false, true>), grid, blk, 0, stream, d, nprob); \
       else if (ta && !tb && cs) hipLaunchKernelGGL((k_gemm_grouped256<true, false, SP_, true>), grid, blk, 0, stream, d, nprob); \
       else if (ta && !tb) hipLaunchKernelGGL((k_gemm_grouped256<true, false, SP_>), grid, blk, 0, stream, d, nprob); \
       else hipLaunchKernelGGL((k_gemm_grouped256<true, true, SP_>), grid, blk, 0, stream, d, nprob);               \

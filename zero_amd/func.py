@@ -188,7 +188,8 @@ class Engine(object):
         problems = [tuple(p) + (None,) * (9 - len(p)) for p in problems]     # ..., residual, column-sum output
         # 128, 64, (256, 128), (128, 256), (256, 256) [fp32 outputs only] or (256, 256, 0) = the same without spreading
         # the LDS-DMA issue between the MFMA groups
-        spread = not (isinstance(tile, tuple) and len(tile) == 3 and not tile[2])
+        k32 = isinstance(tile, tuple) and len(tile) == 3 and tile[2] == "k32"     # 256x256: four stages of 32-deep K tiles
+        spread = not (isinstance(tile, tuple) and len(tile) == 3 and not tile[2]) and not k32
         bm, bn = (tile, tile) if isinstance(tile, int) else tile[:2]
         code = {(128, 128): 1, (64, 64): 4, (256, 128): 5, (128, 256): 6, (256, 256): 7 if spread else 8}[(bm, bn)]
         if (bm, bn) == (256, 256):
@@ -198,9 +199,12 @@ class Engine(object):
                        for _, _, c, _, _, _, bias, r, cs in problems)
             if any(p[8] is not None for p in problems):
                 code |= 256
+            if k32:
+                assert ta and not tb, "the 32-deep ring exists for the weight-gradient form (ta = 1, tb = 0)"
+                code |= 512
         elif any(p[8] is not None for p in problems):
             assert code in (5, 6) and not tb, "column sums ride on the producer waves of the wide tiles (tb = 0)"
-        key = (ta, tb, bm, bn, spread) + tuple((a.ptr, b.ptr, c.ptr, M, N, K, hip.ptr(bias) or 0, r.ptr if r is not None else 0,
+        key = (ta, tb, bm, bn, spread, k32) + tuple((a.ptr, b.ptr, c.ptr, M, N, K, hip.ptr(bias) or 0, r.ptr if r is not None else 0,
                                                 hip.ptr(cs) or 0) for a, b, c, M, N, K, bias, r, cs in problems)
         cache = self.__dict__.setdefault("_group_cache", {})
         ent = cache.get(key)

@@ -91,7 +91,7 @@ class TransformerCore(object):
         # groups -- same-box A/B of the whole step: 4.708 ms spread, 4.673 ms not, 4.80 ms for the round-2 grouping)
         wt = os.environ.get("ZERO_HIP_WGRAD_TILE", "256x256n" if self.group_all else "128x256").lower()
         self.wgrad_tile = {"128": 128, "128x128": 128, "256x128": (256, 128), "128x256": (128, 256),
-                           "256x256": (256, 256), "256x256n": (256, 256, 0)}[wt]
+                           "256x256": (256, 256), "256x256n": (256, 256, 0), "256x256k32": (256, 256, "k32")}[wt]
         self._pending_wgrads = []
         self._pending_colsums = []     # (dY Mat, bias-gradient view, private partial buffer)
         self._pending_lnred = []       # (partials, rows, H, dgamma, dbeta, dbias_prev)
