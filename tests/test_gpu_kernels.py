@@ -172,6 +172,8 @@ def test_gemm_grouped_256_tiles_with_bias_column_sums(tile):
     db = column sums of dY (func.py:16, 58-60) by MFMA beside the tm = 0 tiles: ragged M / N / K (K tails of the 64-deep
     two-stage ring and of the 32-deep four-stage ring), several row tiles, a problem without column sums in the launch."""
     e = eng()
+    if len(tile) == 3 and tile[2] == "k32" and not e.lib.experiments:
+        pytest.skip("the 32-deep four-stage ring is an experiment: `make EXPERIMENTS=1`")
     shapes = [(512, 1536, 1000, True), (136, 520, 264, True), (600, 72, 4096, False), (256, 256, 64, True),
               (264, 300, 40, True), (256, 512, 24, False)]
     probs, refs = [], []

@@ -191,6 +191,7 @@ __device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* _
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (all-zero) pieces
 }
 
+#ifdef ZK_EXPERIMENTS   // measured equal to the two-stage ring (profiles/r03_pmc_stall_split.txt): make EXPERIMENTS=1
 // The same 256 x 256 tile on a FOUR-stage ring of 32-deep K tiles (4 x 32 KiB = the same 128 KiB) for the weight-gradient
 // form (ta = 1, tb = 0: both operands stored [k][rows], so a stage is simply 32 k rows instead of 64).  Why: with two
 // 64-deep stages the LDS-DMA of K tile kt+1 has ONE compute step (~2048 MFMA cycles per SIMD, 0.85 us) to come back from
@@ -302,6 +303,8 @@ __device__ __forceinline__ void gemm256_acc_k32(unsigned char* smem, const bf16_
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (all-zero) pieces
 }
 
+#endif  // ZK_EXPERIMENTS
+
 template <bool TA, bool TB, bool SPREAD, bool CS = false, bool K32 = false>
 __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __restrict__ descs, int nprob) {
   constexpr int BM = 256, BN = 256, NS = 2, NWN = 4, WTM = 128, WTN = 64, TM = 4, TN = 2;
@@ -331,8 +334,11 @@ __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __rest
     // fp32 tile + bias gradient: the waves of the first row of waves (wm = 0) of the tm = 0 tiles carry the column sums
     f32x16_t acc_cs[TN];
     const bool cs_on = d.colsum != nullptr && tm == 0 && wm == 0;
+#ifdef ZK_EXPERIMENTS
     if (K32) gemm256_acc_k32<true>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, cs_on, acc_cs);
-    else gemm256_acc<TA, TB, SPREAD, true>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, cs_on, acc_cs);
+    else
+#endif
+    gemm256_acc<TA, TB, SPREAD, true>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, cs_on, acc_cs);
     if (cs_on && lane < 32) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -340,8 +346,10 @@ __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __rest
         if (col < N) d.colsum[col] = acc_cs[j][0];
       }
     }
+#ifdef ZK_EXPERIMENTS
   } else if (K32) {
     gemm256_acc_k32<false>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, false, nullptr);
+#endif
   } else {
     gemm256_acc<TA, TB, SPREAD>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc);
   }
@@ -639,16 +647,25 @@ int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int t
                "zk_gemm_grouped: tile must be 1 (128x128), 4 (64x64), 5 (256x128), 6 (128x256) or 7 / 8 (256x256)");
   ZK_CHECK_ARG(!cs || ((tile == 7 || tile == 8) && ta && !tb), "zk_gemm_grouped: column sums on 256x256 tiles need ta = 1, tb = 0");
   ZK_CHECK_ARG(!k32 || ((tile == 7 || tile == 8) && ta && !tb), "zk_gemm_grouped: the 32-deep ring exists for ta = 1, tb = 0 on 256x256 tiles");
+#ifndef ZK_EXPERIMENTS
+  ZK_CHECK_ARG(!k32, "zk_gemm_grouped: the 32-deep ring is an experiment (make EXPERIMENTS=1)");
+#endif
   const GroupDesc* d = (const GroupDesc*)descs;
   dim3 grid((unsigned)total_tiles);
   if (tile == 7 || tile == 8) {     // fp32 outputs without epilogue options only (checked on the host copy by the caller)
     const dim3 blk(512);
+#ifdef ZK_EXPERIMENTS
+#define ZK_G256_K32                                                                                                          \
+      else if (ta && !tb && k32 && cs) hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, true, true>), grid, blk, 0, stream, d, nprob); \
+      else if (ta && !tb && k32) hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, false, true>), grid, blk, 0, stream, d, nprob);
+#else
+#define ZK_G256_K32
+#endif
 #define ZK_G256(SP_)                                                                                         \
     do {                                                                                                     \
       if (!ta && !tb) hipLaunchKernelGGL((k_gemm_grouped256<false, false, SP_>), grid, blk, 0, stream, d, nprob);   \
       else if (!ta && tb) hipLaunchKernelGGL((k_gemm_grouped256<false, true, SP_>), grid, blk, 0, stream, d, nprob); \
-      else if (ta && !tb && k32 && cs) hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, true, true>), grid, blk, 0, stream, d, nprob); \
-      else if (ta && !tb && k32) hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, false, true>), grid, blk, 0, stream, d, nprob); \
+      ZK_G256_K32                                                                                          \
       else if (ta && !tb && cs) hipLaunchKernelGGL((k_gemm_grouped256<true, false, SP_, true>), grid, blk, 0, stream, d, nprob); \
       else if (ta && !tb) hipLaunchKernelGGL((k_gemm_grouped256<true, false, SP_>), grid, blk, 0, stream, d, nprob); \
       else hipLaunchKernelGGL((k_gemm_grouped256<true, true, SP_>), grid, blk, 0, stream, d, nprob);               \

@@ -201,6 +201,7 @@ class Engine(object):
                 code |= 256
             if k32:
                 assert ta and not tb, "the 32-deep ring exists for the weight-gradient form (ta = 1, tb = 0)"
+                assert self.lib.experiments, "the 32-deep ring is an experiment: make EXPERIMENTS=1"
                 code |= 512
         elif any(p[8] is not None for p in problems):
             assert code in (5, 6) and not tb, "column sums ride on the producer waves of the wide tiles (tb = 0)"
