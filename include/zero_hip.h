@@ -127,7 +127,11 @@ size_t zk_attn_bwd_workspace(int B, int nh, int Lq);
  * Table-gradient contract: WITH impl | 256 the call OVERWRITES drpr_k / drpr_v on every path (when the folded kernel
  * declines a shape -- alignment, ld % 8, Lq / Lk > 64, workspace -- the reference kernels run on tables the entry
  * point has cleared itself); WITHOUT the bit the reference kernels ADD to drpr_k / drpr_v with atomics and the
- * caller clears them beforehand. */
+ * caller clears them beforehand.
+ * impl | 512 (together with | 256): when the folded kernel runs, its per-(sentence, head) partials are LEFT in the
+ * workspace -- fp32 [B*nh][2][64][64] behind the B*nh*Lq floats of D, (2*max_rel+1)*64 leading elements of each slab
+ * valid -- and the call returns 1 instead of 0: the caller sums them (all attention layers of a step in one
+ * zk_reduce_grouped launch).  When it does not run the bit is ignored and 0 is returned. */
 size_t zk_attn_bwd_rpr_workspace(int B, int nh, int Lq);
 int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                 const float* lse, void* dq, void* dk, void* dv, float* drpr_k, float* drpr_v, int B, int nh,

@@ -636,6 +636,11 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
   // running (the folded kernel writes them; the reference kernels below accumulate with atomics, so they are cleared
   // first).  Without the bit the table gradients are accumulated into and the caller clears them.
   const bool overwrite_tables = (impl & 256) && drpr_k != nullptr && drpr_v != nullptr;
+  // impl | 512 (with | 256): the folded kernel's per-(sentence, head) table-gradient partials stay in the workspace
+  // (fp32 [B*nh][2][64][64] behind the B*nh*Lq floats of D) and the CALLER sums them -- e.g. all attention layers of a
+  // step in one grouped reduction launch instead of one launch per layer.  Only honoured when the folded kernel runs:
+  // the return value is 1 then (0: the tables were written here, as without the bit).
+  const bool defer_tables = (impl & 512) != 0;
   impl &= 255;
   if (fold) { a.rpr_k = nullptr; a.rpr_v = nullptr; }
   bool ok = attn_mfma_ok(a, ldo | lddo | lddq | lddk | lddv) &&
@@ -653,6 +658,7 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
     hipLaunchKernelGGL(k_attn_bwd_fused64<true>, dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
                        (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, part);
     ZK_LAUNCH_CHECK();
+    if (defer_tables) return 1;
     const int n = (2 * max_rel + 1) * AD;
     hipLaunchKernelGGL(k_rpr_part_reduce, dim3((n + 15) / 16, 2), dim3(256), 0, stream, (const float*)part, B * nh, n,
                        drpr_k, drpr_v);

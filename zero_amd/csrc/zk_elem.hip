@@ -423,6 +423,7 @@ __global__ void __launch_bounds__(256) k_colsum_grouped(const ColsumDesc* __rest
 struct ReduceDesc {
   const float* partials; float* out[3];
   int nblk, nq, H, block_start;
+  int bstride, qstride;       // element strides between blocks / quantities; 0 = packed (nq * H, H)
 };
 __global__ void __launch_bounds__(256) k_reduce_grouped(const ReduceDesc* __restrict__ descs, int nprob) {
   constexpr int NG = 256 / ZK_RED_COLS;
@@ -449,8 +450,8 @@ __global__ void __launch_bounds__(256) k_reduce_grouped(const ReduceDesc* __rest
   if (c < d.H) {
     // eight independent loads in flight per thread (the loop is a chain of ~0.5-us round trips otherwise); the
     // additions keep the order b = g, g + NG, ...
-    const float* src = d.partials + (size_t)q * d.H + c;
-    const size_t rs = (size_t)d.nq * d.H;
+    const float* src = d.partials + (size_t)q * (d.qstride ? d.qstride : d.H) + c;
+    const size_t rs = d.bstride ? (size_t)d.bstride : (size_t)d.nq * d.H;
     int b = g;
     for (; b + 7 * NG < d.nblk; b += 8 * NG) {
       float v[8];

@@ -42,7 +42,7 @@ class _ColsumDesc(ctypes.Structure):
 
 class _ReduceDesc(ctypes.Structure):
     _fields_ = [("partials", ctypes.c_void_p), ("out", ctypes.c_void_p * 3)] + \
-               [(n, ctypes.c_int) for n in ("nblk", "nq", "H", "block_start")]
+               [(n, ctypes.c_int) for n in ("nblk", "nq", "H", "block_start", "bstride", "qstride")]
 
 
 class Mat(object):
@@ -228,18 +228,21 @@ class Engine(object):
         dev, n, total = ent
         self.lib.call("zk_gemm_grouped", dev.data_ptr(), n, total, ta, tb, code, self.stream)
 
-    def reductions_grouped(self, colsums, ln_parts):
+    def reductions_grouped(self, colsums, ln_parts, rpr_parts=()):
         """colsums: [(Mat dY, out fp32 view, private fp32 partial buffer)];
-        ln_parts: [(partials buffer, rows, H, dgamma, dbeta, dbias_prev-or-None)].
+        ln_parts: [(partials buffer, rows, H, dgamma, dbeta, dbias_prev-or-None)];
+        rpr_parts: [(partials fp32 [slices][2][64*64] (device address), slices, n, d rpr_k, d rpr_v)] -- the table-gradient
+        partials the folded relative-position backward left behind (attn_bwd(defer_tables=...)).
         Two launches: column partial sums of every dY, then every final reduction."""
         key = tuple((a.ptr, o.data_ptr()) for a, o, _ in colsums) + \
-            tuple((w.data_ptr(), r) for w, r, _, _, _, _ in ln_parts)
+            tuple((w.data_ptr(), r) for w, r, _, _, _, _ in ln_parts) + \
+            tuple((pp, ns, n, dk.data_ptr()) for pp, ns, n, dk, _ in rpr_parts)
         cache = self.__dict__.setdefault("_red_cache", {})
         ent = cache.get(key)
         if ent is None:
             lib = self.lib
             cd = (_ColsumDesc * max(len(colsums), 1))()
-            rd = (_ReduceDesc * max(len(colsums) + len(ln_parts), 1))()
+            rd = (_ReduceDesc * max(len(colsums) + len(ln_parts) + len(rpr_parts), 1))()
             cstart = rstart = 0
             k = 0
             for i, (a, o, pw) in enumerate(colsums):
@@ -259,6 +262,13 @@ class Engine(object):
                 r.partials, r.nblk, r.nq, r.H, r.block_start = pw.data_ptr(), lib.raw("zk_ln_bwd_blocks")(rows), 3, H, rstart
                 r.out[0], r.out[1], r.out[2] = dg.data_ptr(), db.data_ptr(), hip.ptr(dbp)
                 rstart += 3 * ((H + RED_COLS - 1) // RED_COLS)
+                k += 1
+            for (pp, ns, n, dk, dv) in rpr_parts:
+                r = rd[k]
+                r.partials, r.nblk, r.nq, r.H, r.block_start = pp, ns, 2, n, rstart
+                r.bstride, r.qstride = 2 * 64 * 64, 64 * 64
+                r.out[0], r.out[1], r.out[2] = dk.data_ptr(), dv.data_ptr(), None
+                rstart += 2 * ((n + RED_COLS - 1) // RED_COLS)
                 k += 1
             cdev = torch.frombuffer(bytearray(bytes(cd)), dtype=torch.uint8).to(self.device)
             rdev = torch.frombuffer(bytearray(bytes(rd)), dtype=torch.uint8).to(self.device)
@@ -337,19 +347,33 @@ class Engine(object):
                                 None, out.cols_slice(h * d, (h + 1) * d)) for h in range(nh)], 0, 0, tile=64)
 
     def attn_bwd(self, q, k, v, out, dout, lse, dq, dk, dv, B, nh, Lq, Lk, d, kmask=None, causal=False,
-                 rpr_k=None, rpr_v=None, drpr_k=None, drpr_v=None, max_rel=0, drop_p=0.0, sid=0, impl=None):
+                 rpr_k=None, rpr_v=None, drpr_k=None, drpr_v=None, max_rel=0, drop_p=0.0, sid=0, impl=None,
+                 defer_tables=None):
         eff = self.attn_impl if impl is None else impl
         fold = self.rpr_fold and rpr_k is not None and drpr_k is not None and eff in (0, 2) and d == 64 and \
             Lq <= 64 and Lk <= 64 and 2 * max_rel + 1 <= 64 and rpr_k.shape[0] >= 2 * max_rel + 1
         if fold:
             # relative positions inside the single-tile backward kernel; table gradients are overwritten
-            ws = self.workspace(self.lib.query("zk_attn_bwd_rpr_workspace", B, nh, Lq))
-            self.lib.call(
-                "zk_attn_bwd", q.ptr, k.ptr, v.ptr, out.ptr, dout.ptr, lse.data_ptr(), dq.ptr, dk.ptr, dv.ptr,
-                hip.ptr(drpr_k), hip.ptr(drpr_v), B, nh, Lq, Lk, d, q.ld, k.ld, v.ld, out.ld, dout.ld, dq.ld,
-                dk.ld, dv.ld, hip.ptr(kmask), 1 if causal else 0, 0, float(d) ** -0.5, zdtype.inf(),
-                hip.ptr(rpr_k), hip.ptr(rpr_v), max_rel, float(drop_p), self.seed.data_ptr(), sid,
-                (0 if eff == 0 else 2) | 256, ws.data_ptr(), ws.numel(), None, None, None, None, 0, 0, self.stream)
+            nbytes = self.lib.query("zk_attn_bwd_rpr_workspace", B, nh, Lq)
+            if defer_tables is not None:
+                # defer_tables = (list, tag): the per-(sentence, head) partials of the table gradients stay in a buffer
+                # private to this attention and ONE grouped launch sums those of every layer (reductions_grouped)
+                pend, tag = defer_tables
+                ws = self.buf("g.%s.rprws" % tag, (nbytes,), torch.uint8)
+            else:
+                ws = self.workspace(nbytes)
+            self.lib.ncalls += 1
+            args = (q.ptr, k.ptr, v.ptr, out.ptr, dout.ptr, lse.data_ptr(), dq.ptr, dk.ptr, dv.ptr,
+                    hip.ptr(drpr_k), hip.ptr(drpr_v), B, nh, Lq, Lk, d, q.ld, k.ld, v.ld, out.ld, dout.ld, dq.ld,
+                    dk.ld, dv.ld, hip.ptr(kmask), 1 if causal else 0, 0, float(d) ** -0.5, zdtype.inf(),
+                    hip.ptr(rpr_k), hip.ptr(rpr_v), max_rel, float(drop_p), self.seed.data_ptr(), sid,
+                    (0 if eff == 0 else 2) | 256 | (512 if defer_tables is not None else 0), ws.data_ptr(), ws.numel(),
+                    None, None, None, None, 0, 0, self.stream)
+            rc = self.lib.raw("zk_attn_bwd")(*args)
+            if rc == 1:        # the folded kernel ran and left the partials: the caller's grouped reduction sums them
+                defer_tables[0].append((ws.data_ptr() + B * nh * Lq * 4, B * nh, (2 * max_rel + 1) * d, drpr_k, drpr_v))
+            elif rc != 0:
+                self.lib.call("zk_attn_bwd", *args)      # raises with the library's message
             return
         ws_bytes = self.lib.query("zk_attn_bwd_workspace", B, nh, Lq)
         ws = self.workspace(ws_bytes)

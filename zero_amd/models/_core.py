@@ -95,6 +95,7 @@ class TransformerCore(object):
         self._pending_wgrads = []
         self._pending_colsums = []     # (dY Mat, bias-gradient view, private partial buffer)
         self._pending_lnred = []       # (partials, rows, H, dgamma, dbeta, dbias_prev)
+        self._pending_rpr = []         # (partials address, slices, n, d rpr_k, d rpr_v): table gradients of the folded backward
         self._pending_adds = []        # (fp32 gradient view, fp32 temporary): dst += src after the flush
         self._mem_segs = []            # (dK or dV, W) pairs of the cross-attention memory side (see _finish_mem_grad)
         # encoder-output gradient by one K-segmented GEMM (needs the MFMA path: H a multiple of 64, aligned rows)
@@ -132,14 +133,20 @@ class TransformerCore(object):
             probs = self._pending_wgrads
             self._pending_wgrads = []
             self._side(lambda: self.eng.gemm_grouped(probs, 1, 0, tile=self.wgrad_tile))
-        if self._pending_colsums or self._pending_lnred:
-            cs, ln = self._pending_colsums, self._pending_lnred
-            self._pending_colsums, self._pending_lnred = [], []
-            self._side(lambda: self.eng.reductions_grouped(cs, ln))
+        if self._pending_colsums or self._pending_lnred or self._pending_rpr:
+            cs, ln, rp = self._pending_colsums, self._pending_lnred, self._pending_rpr
+            self._pending_colsums, self._pending_lnred, self._pending_rpr = [], [], []
+            self._side(lambda: self.eng.reductions_grouped(cs, ln, rp))
         if self._pending_adds:
             adds = self._pending_adds
             self._pending_adds = []
             self._side(lambda: [self._accumulate(dst, src) for dst, src in adds])
+
+    def _defer_rpr(self):
+        """Relative positions: the table-gradient partials of every attention layer summed by the grouped reduction
+        launch of the layer group (18 launches fewer per step; ZERO_HIP_RPR_DEFER=0: one reduction per attention)."""
+        return self.rpr and self.group_wgrad and self.eng.gemm_impl == 0 and \
+            os.environ.get("ZERO_HIP_RPR_DEFER", "1") != "0"
 
     def _use_kseg(self):
         return self.kseg_mem and self.H % 64 == 0 and self.eng.gemm_impl == 0
@@ -382,7 +389,8 @@ class TransformerCore(object):
                    rpr_k=rk, rpr_v=rv,
                    drpr_k=self.gb(p + "rpr_keys/embeddings") if self.rpr else None,
                    drpr_v=self.gb(p + "rpr_values/embeddings") if self.rpr else None,
-                   max_rel=hp.max_relative_position, drop_p=hp.attention_dropout, sid=sid0)
+                   max_rel=hp.max_relative_position, drop_p=hp.attention_dropout, sid=sid0,
+                   defer_tables=(self._pending_rpr, tag) if self._defer_rpr() else None)
         self._linear_bwd(x_in, dqkv, p + "qkv_map", dx=dx_out, residual=ds)
         return dx_out
 
@@ -409,7 +417,8 @@ class TransformerCore(object):
                    rpr_k=rk, rpr_v=rv,
                    drpr_k=self.gb(p + "rpr_keys/embeddings") if self.rpr else None,
                    drpr_v=self.gb(p + "rpr_values/embeddings") if self.rpr else None,
-                   max_rel=hp.max_relative_position, drop_p=hp.attention_dropout, sid=sid0)
+                   max_rel=hp.max_relative_position, drop_p=hp.attention_dropout, sid=sid0,
+                   defer_tables=(self._pending_rpr, tag) if self._defer_rpr() else None)
         self._linear_bwd(x_in, dq, p + "q_map", dx=dx_out, residual=ds)
         # memory side: the gradients of all decoder layers add up in d_mem.  Default: every layer only records its
         # (dK, W_k) / (dV, W_v) pair and ONE K-segmented GEMM sums them after the decoder (see _finish_mem_grad);
