@@ -131,7 +131,14 @@ size_t zk_attn_bwd_workspace(int B, int nh, int Lq);
  * impl | 512 (together with | 256): when the folded kernel runs, its per-(sentence, head) partials are LEFT in the
  * workspace -- fp32 [B*nh][2][64][64] behind the B*nh*Lq floats of D, (2*max_rel+1)*64 leading elements of each slab
  * valid -- and the call returns 1 instead of 0: the caller sums them (all attention layers of a step in one
- * zk_reduce_grouped launch).  When it does not run the bit is ignored and 0 is returned. */
+ * zk_reduce_grouped launch).  When it does not run the bit is ignored and 0 is returned.
+ * (oproj_dy, oproj_w) non-null: the gradient of the attention output is not read from `dout` (which may be null) but
+ * computed inside the single-tile kernel as dY . W_o[h*64 .. h*64+63, :]^T -- dY bf16 [B*Lq, oproj_lddy], W_o = the
+ * o_map weight [nh*64, oproj_ldw] row-major, oproj_n columns (a multiple of 128) -- i.e. the dgrad GEMM of the output
+ * projection (func.py:226-240 `o = linear(o, ..., scope="o_map")` differentiated) folded into the attention backward:
+ * one launch and one [B*Lq, nh*64] matrix in HBM less.  Only the single-tile kernel does it (Lq, Lk <= 64, d = 64, no
+ * decomposed rpr products): when the call would run any other kernel NOTHING is launched and 2 is returned, and the caller
+ * forms `dout` itself and calls again without the pair. */
 size_t zk_attn_bwd_rpr_workspace(int B, int nh, int Lq);
 int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                 const float* lse, void* dq, void* dk, void* dv, float* drpr_k, float* drpr_v, int B, int nh,
@@ -139,7 +146,8 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
                 int lddv, const float* kmask, int causal, int q_pos0, float scale, float mask_inf,
                 const void* rpr_k, const void* rpr_v, int max_rel, float drop_p, const uint64_t* seed,
                 uint32_t sid, int impl, void* workspace, size_t ws_bytes, const void* rpr_gq,
-                const void* rpr_gd, void* rpr_pb, void* rpr_dsb, int rpr_ldg, int rpr_nrp, zk_stream_t stream);
+                const void* rpr_gd, void* rpr_pb, void* rpr_dsb, int rpr_ldg, int rpr_nrp, const void* oproj_dy,
+                int oproj_lddy, const void* oproj_w, int oproj_ldw, int oproj_n, zk_stream_t stream);
 /* out[i] (+)= sum over s of in[s*stride + i], i < n  (fp32; head-wise partial table gradients of the
    decomposed rpr path) */
 int zk_sum_slices(float* out, const float* in, int nslices, size_t n, size_t stride, int accumulate,

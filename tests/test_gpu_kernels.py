@@ -290,6 +290,84 @@ def test_attention_dropout(impl):
     assert errs["out"] < 1.5e-2 and errs["dq"] < 2.5e-2 and errs["dk"] < 2.5e-2 and errs["dv"] < 2.5e-2, errs
 
 
+def _attn_bwd_oproj_pair(B, nh, Lq, Lk, H_out, use_mask, causal, rpr=False, drop=0.0, impl=2, seed=0):
+    """attention backward with the gradient of its output given (a) as the matrix dY . W_o^T formed by zk_gemm and
+    (b) as the (dY, W_o) pair -> (dq, dk, dv[, drk, drv]) of both."""
+    e = eng()
+    d = 64
+    H = nh * d
+    max_rel = 4
+    q = rand_bf(B * Lq, H, seed=seed + 1)
+    k = rand_bf(B * Lk, H, seed=seed + 2)
+    v = rand_bf(B * Lk, H, seed=seed + 3)
+    kmask = None
+    if use_mask:
+        kmask = torch.ones(B, Lk, device="cuda")
+        for b in range(1, B):
+            kmask[b, Lk - (b * 3) % max(Lk - 1, 1):] = 0
+        kmask[:, 0] = 1
+    rk = rand_bf(2 * max_rel + 1, d, scale=0.3, seed=seed + 4) if rpr else None
+    rv = rand_bf(2 * max_rel + 1, d, scale=0.3, seed=seed + 5) if rpr else None
+    out = torch.zeros(B * Lq, H, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B * nh * Lq, device="cuda")
+    e.set_seed(99)
+    e.attn_fwd(mat(q), mat(k), mat(v), mat(out), lse, B, nh, Lq, Lk, d, kmask=kmask, causal=causal, rpr_k=rk, rpr_v=rv,
+               max_rel=max_rel, drop_p=drop, sid=5, impl=impl)
+    dy = rand_bf(B * Lq, H_out, seed=seed + 9)
+    Wo = rand_bf(H, H_out, scale=0.05, seed=seed + 10)
+    res = []
+    for fused in (False, True):
+        dout = torch.full((B * Lq, H), float("nan"), dtype=torch.bfloat16, device="cuda")
+        if not fused:
+            e.gemm(mat(dy), mat(Wo), mat(dout), B * Lq, H, H_out, 0, 1)
+        dq = torch.zeros_like(q); dk = torch.zeros_like(k); dv = torch.zeros_like(v)
+        drk = torch.zeros(2 * max_rel + 1, d, device="cuda") if rpr else None
+        drv = torch.zeros(2 * max_rel + 1, d, device="cuda") if rpr else None
+        n0 = e.lib.ncalls
+        e.attn_bwd(mat(q), mat(k), mat(v), mat(out), mat(dout), lse, mat(dq), mat(dk), mat(dv), B, nh, Lq, Lk, d,
+                   kmask=kmask, causal=causal, rpr_k=rk, rpr_v=rv, drpr_k=drk, drpr_v=drv, max_rel=max_rel, drop_p=drop,
+                   sid=5, impl=impl, oproj=(mat(dy), mat(Wo)) if fused else None)
+        torch.cuda.synchronize()
+        res.append(dict(dq=dq, dk=dk, dv=dv, drk=drk, drv=drv, dout=dout, calls=e.lib.ncalls - n0))
+    return res
+
+
+OPROJ_CASES = [(2, 2, 64, 64, 128, False, False), (3, 8, 37, 53, 512, True, False), (2, 3, 50, 50, 384, False, True),
+               (2, 16, 64, 64, 1024, True, False), (1, 2, 1, 7, 128, True, False)]
+
+
+@pytest.mark.parametrize("case", OPROJ_CASES)
+@pytest.mark.parametrize("variant", ["plain", "dropout", "rpr"])
+def test_attention_backward_with_the_output_projection_folded_in(case, variant):
+    """zk_attn_bwd (oproj_dy, oproj_w): dO = dY . W_o^T computed per (sentence, head) inside the single-tile kernel must
+    give what the dgrad GEMM + the plain call give (same bf16 rounding of dO; fp32 summation order inside the
+    64 x 64 x n product differs between the two MFMA shapes, hence a tolerance instead of equality)."""
+    B, nh, Lq, Lk, n, um, causal = case
+    plain, fused = _attn_bwd_oproj_pair(B, nh, Lq, Lk, n, um, causal, rpr=variant == "rpr",
+                                        drop=0.2 if variant == "dropout" else 0.0)
+    assert torch.isnan(fused["dout"].float()).all(), "the fused call must not have formed dout"
+    assert fused["calls"] == 1, fused["calls"]
+    for key in ("dq", "dk", "dv") + (("drk", "drv") if variant == "rpr" else ()):
+        err = rel_err(fused[key], plain[key].float())
+        assert err < 4e-3, (key, err)
+        assert torch.isfinite(fused[key].float()).all()
+
+
+@pytest.mark.parametrize("why", ["long", "impl", "columns"])
+def test_attention_backward_forms_the_output_gradient_itself_when_the_fold_does_not_apply(why):
+    """return code 2 of zk_attn_bwd: nothing launched, func.attn_bwd runs the GEMM and calls again -> identical results"""
+    if why == "long":
+        plain, fused = _attn_bwd_oproj_pair(2, 2, 70, 130, 128, True, False)
+    elif why == "impl":
+        plain, fused = _attn_bwd_oproj_pair(2, 2, 64, 64, 128, True, False, impl=3)
+    else:
+        plain, fused = _attn_bwd_oproj_pair(2, 2, 64, 64, 192, True, False)      # n not a multiple of 128
+    assert fused["calls"] >= 3                      # declined call + GEMM + the plain call
+    assert torch.equal(fused["dout"], plain["dout"])
+    for key in ("dq", "dk", "dv"):
+        assert torch.equal(fused[key], plain[key]), key
+
+
 def test_attention_small_head_and_rpr():
     errs = _attn_case(1, 2, 2, 9, 11, 8, True, False)
     assert max(errs.values()) < 2.5e-2, errs

@@ -470,15 +470,19 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv_mfma(AttnArgs a, const bf1
 }
 
 // ---- backward, single tile (Lq <= 64 and Lk <= 64): grid (1, nh, B) -> dQ, dK, dV in ONE pass (attn_bwd_fused64_tile)
-template <bool RPR = false>
-__global__ void __launch_bounds__(256) k_attn_bwd_fused64(AttnArgs a, const bf16_t* __restrict__ o, int ldo,
-                                                          const bf16_t* __restrict__ dout, int lddo,
-                                                          const float* __restrict__ lse,
-                                                          bf16_t* __restrict__ dq, int lddq,
-                                                          bf16_t* __restrict__ dk, int lddk,
-                                                          bf16_t* __restrict__ dv, int lddv, float* __restrict__ rpr_part) {
+// (256, 2): two waves per SIMD = two workgroups per CU for the variants whose LDS allows it -- the OPROJ prologue keeps a
+// 512-column chunk of its operands in flight and would otherwise take 286 registers and halve the occupancy
+template <bool RPR = false, bool OPROJ = false>
+__global__ void __launch_bounds__(256, 2) k_attn_bwd_fused64(AttnArgs a, const bf16_t* __restrict__ o, int ldo,
+                                                             const bf16_t* __restrict__ dout, int lddo,
+                                                             const float* __restrict__ lse,
+                                                             bf16_t* __restrict__ dq, int lddq,
+                                                             bf16_t* __restrict__ dk, int lddk,
+                                                             bf16_t* __restrict__ dv, int lddv, float* __restrict__ rpr_part,
+                                                             AttnOProj op) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[RPR ? ATTN_BWD64_RPR_LDS_BYTES : ATTN_BWD64_LDS_BYTES];
-  attn_bwd_fused64_tile<RPR>(smem, a, o, ldo, dout, lddo, lse, dq, lddq, dk, lddk, dv, lddv, blockIdx.y, blockIdx.z, rpr_part);
+  attn_bwd_fused64_tile<RPR, OPROJ>(smem, a, o, ldo, dout, lddo, lse, dq, lddq, dk, lddk, dv, lddv, blockIdx.y, blockIdx.z,
+                                    rpr_part, op);
 }
 
 // sum of the per-(sentence, head) table-gradient partials of the folded relative-position backward:
@@ -612,8 +616,11 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
                 int causal, int q_pos0, float scale, float mask_inf, const void* rpr_k, const void* rpr_v,
                 int max_rel, float drop_p, const uint64_t* seed, uint32_t sid, int impl, void* workspace,
                 size_t ws_bytes, const void* rpr_gq, const void* rpr_gd, void* rpr_pb, void* rpr_dsb, int rpr_ldg,
-                int rpr_nrp, hipStream_t stream) {
+                int rpr_nrp, const void* oproj_dy, int oproj_lddy, const void* oproj_w, int oproj_ldw, int oproj_n,
+                hipStream_t stream) {
   ZK_CHECK_ARG((rpr_k == nullptr) == (rpr_v == nullptr), "zk_attn_bwd: rpr_k and rpr_v go together");
+  ZK_CHECK_ARG((oproj_dy == nullptr) == (oproj_w == nullptr), "zk_attn_bwd: oproj_dy and oproj_w go together");
+  ZK_CHECK_ARG(dout != nullptr || oproj_dy != nullptr, "zk_attn_bwd: dout or the (dY, W_o) pair it is the product of");
   ZK_CHECK_ARG(rpr_k == nullptr || rpr_gq != nullptr || (drpr_k != nullptr && drpr_v != nullptr),
                "zk_attn_bwd: rpr needs grad outputs");
   ZK_CHECK_ARG(rpr_gq == nullptr || (rpr_gd != nullptr && rpr_pb != nullptr && rpr_dsb != nullptr &&
@@ -648,6 +655,18 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
   if (fold) { a.rpr_k = (const bf16_t*)rpr_k; a.rpr_v = (const bf16_t*)rpr_v; }
   const bool folded = fold && ok && (impl == 0 || impl == 2) && Lq <= TQ && Lk <= TQ;
   if (fold && !folded) ok = false;
+  // (oproj_dy, oproj_w) given: dout = dY . W_o[h*64 .., :]^T is computed inside the single-tile kernel instead of read
+  // (the o_map dgrad GEMM of the caller disappears).  Only that kernel does it: when the call would run anything else,
+  // NOTHING is launched and the return value is 2 -- the caller then forms dout itself and calls again without the pair.
+  AttnOProj op = {(const bf16_t*)oproj_dy, oproj_lddy, (const bf16_t*)oproj_w, oproj_ldw, oproj_n};
+  if (oproj_dy != nullptr) {
+    const bool single = (impl == 0 || impl == 2) && ok && Lq <= TQ && Lk <= TQ && rpr_gq == nullptr && !zk_prog_active() &&
+                        (rpr_k == nullptr || folded);
+    const bool shape = oproj_n >= 128 && oproj_n % 128 == 0 && oproj_lddy % 8 == 0 && oproj_ldw % 8 == 0 &&
+                       oproj_lddy >= oproj_n && oproj_ldw >= oproj_n &&
+                       ((((uintptr_t)oproj_dy | (uintptr_t)oproj_w) & 15) == 0);
+    if (!single || !shape) return 2;
+  }
   ZK_CHECK_ARG(rpr_gq == nullptr || (ok && impl != 1), "zk_attn_bwd: decomposed rpr runs on the MFMA kernels only");
   ZK_CHECK_ARG(impl != 2 || ok, "zk_attn_bwd: MFMA kernel needs d=64, no rpr, ld%%8==0");
   ZK_CHECK_ARG(impl != 3 || ok, "zk_attn_bwd: MFMA kernels need d=64, no rpr, ld%%8==0");
@@ -655,8 +674,12 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
     if (zk_prog_active()) return zk_prog_reject("attention backward with relative positions");
     // table-gradient partials behind Dbuf in the workspace, summed over the B*nh (sentence, head) tiles afterwards
     float* part = (float*)workspace + (size_t)B * nh * Lq;
-    hipLaunchKernelGGL(k_attn_bwd_fused64<true>, dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
-                       (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, part);
+    if (oproj_dy != nullptr)
+      hipLaunchKernelGGL((k_attn_bwd_fused64<true, true>), dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
+                         (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, part, op);
+    else
+      hipLaunchKernelGGL((k_attn_bwd_fused64<true, false>), dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
+                         (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, part, op);
     ZK_LAUNCH_CHECK();
     if (defer_tables) return 1;
     const int n = (2 * max_rel + 1) * AD;
@@ -672,9 +695,14 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
                                      (bf16_t*)dk, lddk, (bf16_t*)dv, lddv);
   }
   if ((impl == 0 || impl == 2) && ok && Lq <= TQ && Lk <= TQ) {      // impl 3 forces the two-kernel form
-    hipLaunchKernelGGL(k_attn_bwd_fused64<false>, dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
-                       (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv,
-                       (float*)nullptr);
+    if (oproj_dy != nullptr)
+      hipLaunchKernelGGL((k_attn_bwd_fused64<false, true>), dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
+                         (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv,
+                         (float*)nullptr, op);
+    else
+      hipLaunchKernelGGL((k_attn_bwd_fused64<false, false>), dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
+                         (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv,
+                         (float*)nullptr, op);
     ZK_LAUNCH_CHECK();
     return 0;
   }

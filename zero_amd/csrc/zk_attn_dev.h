@@ -472,14 +472,21 @@ __device__ __forceinline__ void attn_fwd_tile(unsigned char* smem, const AttnArg
 // the caller) -- instead of four grouped-GEMM launches and two reductions around the kernel.  Six more bf16 tiles and
 // two fp32 tiles: one workgroup per CU.
 #define ATTN_BWD64_RPR_LDS_BYTES (ATTN_BWD64_LDS_BYTES + 6 * TQ * ALD * 2 + 2 * TQ * GLD * 4)
-template <bool RPR = false>
+// OPROJ: the gradient of the attention output is not read but COMPUTED here from the gradient of the output projection's
+// result: dO_h = dY . W_o[h*64 .. h*64+63, :]^T  (dY [rows, n], W_o [H, n] row-major, n = op.n a multiple of 128) -- the
+// 64 x 64 x n product of this (sentence, head) and nothing more, so the dgrad GEMM launch of o_map (and the dO matrix in HBM)
+// disappears.  W_o's 64 rows go through LDS in slabs of 128 columns (two of the tiles that are idle until the prologue ends,
+// double-buffered); the dY fragments of a wave's 16 rows come straight from global memory (no other wave needs them).
+struct AttnOProj { const bf16_t* dy; int lddy; const bf16_t* w; int ldw; int n; };
+template <bool RPR = false, bool OPROJ = false>
 __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const AttnArgs& a, const bf16_t* __restrict__ o, int ldo,
                                                       const bf16_t* __restrict__ dout, int lddo,
                                                       const float* __restrict__ lse,
                                                       bf16_t* __restrict__ dq, int lddq,
                                                       bf16_t* __restrict__ dk, int lddk,
                                                       bf16_t* __restrict__ dv, int lddv, int h, int b,
-                                                      float* __restrict__ rpr_part = nullptr) {
+                                                      float* __restrict__ rpr_part = nullptr,
+                                                      const AttnOProj op = AttnOProj()) {
   bf16_t* sQ = reinterpret_cast<bf16_t*>(smem);      // phase 2: dS   [query][key]
   bf16_t* sK = sQ + TQ * ALD;                          // phase 2: P^T  [key][query]
   bf16_t* sV = sK + TQ * ALD;                          // phase 2: dS^T [key][query]
@@ -508,14 +515,14 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
   DirectRegs rQ, rdO, rK, rV;
   TransRegs t0, t1;
   load_direct(rQ, qb, a.ldq, 0, a.Lq, tid);
-  load_direct(rdO, dob, lddo, 0, a.Lq, tid);
+  if (!OPROJ) load_direct(rdO, dob, lddo, 0, a.Lq, tid);
   load_direct(rK, kb, a.ldk, 0, a.Lk, tid);
   load_direct(rV, vb, a.ldv, 0, a.Lk, tid);
   if (tid < 128) {
     load_trans(t0, kb, a.ldk, 0, a.Lk, tid);
   } else {
     load_trans(t0, qb, a.ldq, 0, a.Lq, tid - 128);
-    load_trans(t1, dob, lddo, 0, a.Lq, tid - 128);
+    if (!OPROJ) load_trans(t1, dob, lddo, 0, a.Lq, tid - 128);
   }
   // D_i = sum_j P_ij dP_ij is taken from the P and dP this workgroup computes anyway (whole rows live in one tile),
   // not from rowsum(dO o O) over the stored bf16 O: no O / dO row loads, and sum_j dS_ij = 0 holds to fp32 rounding
@@ -530,15 +537,78 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
     const int j = nt * 16 + (lane & 15);
     kbias4[nt] = (a.kmask != nullptr && a.kmask[(size_t)b * a.ldmask + min(j, a.Lk - 1)] == 0.f) ? -a.mask_inf : 0.f;
   }
-  store_direct(sQ, rQ, tid);
-  store_direct(sdO, rdO, tid);
-  store_direct(sK, rK, tid);
-  store_direct(sV, rV, tid);
+  [[maybe_unused]] f32x4_t dOa[4];
+  if (OPROJ) {
+    // dO rows 16w .. 16w+15 of this head in slabs of 128 columns of dY / W_o.  Q, K, V go to their tiles first (their
+    // registers are needed); the four tiles of the second phase (dO, K^T, Q^T, dO^T) are idle until the product is done:
+    // slab s uses tiles 3 + 2(s&1), 4 + 2(s&1) (one barrier per slab).
+    store_direct(sQ, rQ, tid);
+    store_direct(sK, rK, tid);
+    store_direct(sV, rV, tid);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) dOa[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bf16_t* wrow = op.w + (size_t)h * AD * op.ldw;
+    const bf16_t* ap = op.dy + ((size_t)b * a.Lq + min(w * 16 + (lane & 15), a.Lq - 1)) * op.lddy + (lane >> 4) * 8;
+    // chunks of 512 columns with EVERY load of the chunk in flight before the first slab is multiplied (one slab of
+    // prefetch distance measured +7.4 us per launch: each slab then waits out most of a cold L2 / HBM latency)
+    for (int c0 = 0; c0 < op.n; c0 += 512) {
+      const int nsl = min(4, (op.n - c0) >> 7);
+      DirectRegs wr[8];
+      uint4 av[16];
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) {
+        if (sl < nsl) {
+          load_direct(wr[2 * sl], wrow + c0 + sl * 128, op.ldw, 0, AD, tid);
+          load_direct(wr[2 * sl + 1], wrow + c0 + sl * 128 + 64, op.ldw, 0, AD, tid);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) av[4 * sl + u] = zk_ld16<false>(ap + c0 + sl * 128 + u * 32);
+        }
+      }
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) {
+        if (sl < nsl) {
+          bf16_t* w0 = sdO + (sl & 1) * 2 * TQ * ALD;
+          bf16_t* w1 = w0 + TQ * ALD;
+          store_direct(w0, wr[2 * sl], tid);
+          store_direct(w1, wr[2 * sl + 1], tid);
+          __syncthreads();
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) {
+            dOa[nb] = mfma16(av[4 * sl + 0], frag(w0, nb * 16, 0, lane), dOa[nb]);
+            dOa[nb] = mfma16(av[4 * sl + 1], frag(w0, nb * 16, 1, lane), dOa[nb]);
+            dOa[nb] = mfma16(av[4 * sl + 2], frag(w1, nb * 16, 0, lane), dOa[nb]);
+            dOa[nb] = mfma16(av[4 * sl + 3], frag(w1, nb * 16, 1, lane), dOa[nb]);
+          }
+        }
+      }
+    }
+    __syncthreads();                     // the slabs are dead: the transposed tiles and dO may land
+  } else {
+    store_direct(sQ, rQ, tid);
+    store_direct(sdO, rdO, tid);
+    store_direct(sK, rK, tid);
+    store_direct(sV, rV, tid);
+  }
   if (tid < 128) {
     store_trans(sKt, t0, tid);
   } else {
     store_trans(sQt, t0, tid - 128);
-    store_trans(sdOt, t1, tid - 128);
+    if (!OPROJ) store_trans(sdOt, t1, tid - 128);
+  }
+  if (OPROJ) {
+    // dO (rounded to bf16 like the GEMM's output was) as [query][channel] and [phys channel][query]; rows >= Lq are 0
+    const int r0 = w * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const int c = nb * 16 + (lane & 15);
+      uint32_t hv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        hv[r] = (r0 + r < a.Lq) ? (uint32_t)f2bf(dOa[nb][r]) : 0u;
+        sdO[(r0 + r) * ALD + c] = (bf16_t)hv[r];
+      }
+      *reinterpret_cast<uint2*>(sdOt + ((c & 7) * 8 + (c >> 3)) * ALD + r0) = make_uint2(hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16));
+    }
   }
   if (dpart == 0) sL[dr] = (dr < a.Lq) ? lse_r : 0.f;
   if (RPR) {

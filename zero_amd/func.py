@@ -348,7 +348,23 @@ class Engine(object):
 
     def attn_bwd(self, q, k, v, out, dout, lse, dq, dk, dv, B, nh, Lq, Lk, d, kmask=None, causal=False,
                  rpr_k=None, rpr_v=None, drpr_k=None, drpr_v=None, max_rel=0, drop_p=0.0, sid=0, impl=None,
-                 defer_tables=None):
+                 defer_tables=None, oproj=None):
+        """oproj = (dY Mat, W_o Mat): `dout` is the product dY . W_o^T that has NOT been formed yet -- the single-tile
+        kernel computes its 64 x 64 piece per (sentence, head) itself; when another kernel would run (return code 2,
+        nothing launched) the product is formed here into `dout` and the call repeated without the pair."""
+        if oproj is not None:
+            dy, Wo = oproj
+            rc = self._attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, nh, Lq, Lk, d, kmask, causal, rpr_k, rpr_v,
+                                drpr_k, drpr_v, max_rel, drop_p, sid, impl, defer_tables,
+                                (dy.ptr, dy.ld, Wo.ptr, Wo.ld, Wo.cols))
+            if rc != 2:
+                return
+            self.gemm(dy, Wo, dout, dy.rows, Wo.rows, Wo.cols, 0, 1)
+        self._attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, nh, Lq, Lk, d, kmask, causal, rpr_k, rpr_v, drpr_k,
+                       drpr_v, max_rel, drop_p, sid, impl, defer_tables, (None, 0, None, 0, 0))
+
+    def _attn_bwd(self, q, k, v, out, dout, lse, dq, dk, dv, B, nh, Lq, Lk, d, kmask, causal, rpr_k, rpr_v, drpr_k,
+                  drpr_v, max_rel, drop_p, sid, impl, defer_tables, op):
         eff = self.attn_impl if impl is None else impl
         fold = self.rpr_fold and rpr_k is not None and drpr_k is not None and eff in (0, 2) and d == 64 and \
             Lq <= 64 and Lk <= 64 and 2 * max_rel + 1 <= 64 and rpr_k.shape[0] >= 2 * max_rel + 1
@@ -368,16 +384,31 @@ class Engine(object):
                     dk.ld, dv.ld, hip.ptr(kmask), 1 if causal else 0, 0, float(d) ** -0.5, zdtype.inf(),
                     hip.ptr(rpr_k), hip.ptr(rpr_v), max_rel, float(drop_p), self.seed.data_ptr(), sid,
                     (0 if eff == 0 else 2) | 256 | (512 if defer_tables is not None else 0), ws.data_ptr(), ws.numel(),
-                    None, None, None, None, 0, 0, self.stream)
+                    None, None, None, None, 0, 0) + tuple(op) + (self.stream,)
             rc = self.lib.raw("zk_attn_bwd")(*args)
             if rc == 1:        # the folded kernel ran and left the partials: the caller's grouped reduction sums them
                 defer_tables[0].append((ws.data_ptr() + B * nh * Lq * 4, B * nh, (2 * max_rel + 1) * d, drpr_k, drpr_v))
+            elif rc == 2 and op[0] is not None:
+                return 2
             elif rc != 0:
                 self.lib.call("zk_attn_bwd", *args)      # raises with the library's message
-            return
+            return 0
         ws_bytes = self.lib.query("zk_attn_bwd_workspace", B, nh, Lq)
         ws = self.workspace(ws_bytes)
         dec = self._rpr_mfma(impl, d, 0, rpr_k, (q.ld, k.ld, v.ld, out.ld, dout.ld, dq.ld, dk.ld, dv.ld), max_rel, bwd=True)
+        if op[0] is not None:
+            if dec or rpr_k is not None:
+                return 2           # decomposed products / reference kernels read dout
+            args = (q.ptr, k.ptr, v.ptr, out.ptr, dout.ptr, lse.data_ptr(), dq.ptr, dk.ptr, dv.ptr, None, None, B, nh, Lq,
+                    Lk, d, q.ld, k.ld, v.ld, out.ld, dout.ld, dq.ld, dk.ld, dv.ld, hip.ptr(kmask), 1 if causal else 0, 0,
+                    float(d) ** -0.5, zdtype.inf(), None, None, max_rel, float(drop_p), self.seed.data_ptr(), sid,
+                    self.attn_impl if impl is None else impl, ws.data_ptr(), ws.numel(), None, None, None, None, 0, 0) + \
+                tuple(op) + (self.stream,)
+            self.lib.ncalls += 1
+            rc = self.lib.raw("zk_attn_bwd")(*args)
+            if rc not in (0, 2):
+                self.lib.call("zk_attn_bwd", *args)      # raises with the library's message
+            return rc
         tabs = (None, None, None, None)
         ldg = nrp = 0
         if not dec and drpr_k is not None:
@@ -402,7 +433,7 @@ class Engine(object):
             dk.ld, dv.ld, hip.ptr(kmask), 1 if causal else 0, 0, float(d) ** -0.5, zdtype.inf(),
             hip.ptr(rpr_k), hip.ptr(rpr_v), max_rel, float(drop_p), self.seed.data_ptr(), sid,
             self.attn_impl if impl is None else impl, ws.data_ptr(), ws.numel(),
-            tabs[0], tabs[1], tabs[2], tabs[3], ldg, nrp, self.stream)
+            tabs[0], tabs[1], tabs[2], tabs[3], ldg, nrp, None, 0, None, 0, 0, self.stream)
         if dec:
             # dQ += dsb.Rk ; table gradients: per-head partials dsb_h^T Q_h and pb_h^T dO_h, summed over heads
             self.gemm_grouped([(sl(dsb, h, nrp), rk, sl(dq, h, d), T, d, nrp, None, sl(dq, h, d)) for h in heads],

@@ -106,6 +106,11 @@ class TransformerCore(object):
         # T*V*4 bytes, which matters for larger batches / vocabularies)
         self.fused_ce = os.environ.get("ZERO_HIP_FUSED_CE", "0") != "0" and self.eng.lib.experiments
         self.logits_tile256 = os.environ.get("ZERO_HIP_LOGITS_256", "1") != "0"
+        # the dgrad of the attention output projection inside the attention backward launch (zk_attn_bwd oproj_*): 18
+        # launches and 18 [T, H] matrices less per step, same-box A/B -0.02 to -0.05 ms (the 64 x 64 x H product per
+        # (sentence, head) costs the launch +7 us, the GEMM it replaces was 8-9 us).  Not with relative positions: that
+        # variant of the kernel runs one workgroup per CU and the longer prologue is not hidden (5.21 -> 5.24 ms).
+        self.attn_oproj = os.environ.get("ZERO_HIP_ATTN_OPROJ", "0" if self.rpr else "1") != "0"
         self._red_id = 0
         self._side_stream = None      # created on first use: every stream of the process takes a share of the hardware queues
 
@@ -378,7 +383,10 @@ class TransformerCore(object):
         ds, dy = self._ln_bwd(dx, scope, tag, p + "o_map/b_0", hp.residual_dropout, sid0 + 1, side)
         att = e.mat(tag + ".att", T, H)
         datt = e.mat("g.%s.datt" % tag, T, H)
-        self._linear_bwd(att, dy, p + "o_map", dx=datt, bias_grad=False)
+        # the dgrad of o_map runs INSIDE the attention backward (its 64 x 64 x H piece per sentence and head): only the
+        # weight gradient is recorded here
+        oproj = (dy, self.W(p + "o_map/W_0_0")) if self.attn_oproj else None
+        self._linear_bwd(att, dy, p + "o_map", dx=None if oproj else datt, bias_grad=False)
         qkv = e.mat(tag + ".qkv", T, 3 * H)
         dqkv = e.mat("g.%s.dqkv" % tag, T, 3 * H)
         rk = self.store.s(p + "rpr_keys/embeddings") if self.rpr else None
@@ -390,7 +398,7 @@ class TransformerCore(object):
                    drpr_k=self.gb(p + "rpr_keys/embeddings") if self.rpr else None,
                    drpr_v=self.gb(p + "rpr_values/embeddings") if self.rpr else None,
                    max_rel=hp.max_relative_position, drop_p=hp.attention_dropout, sid=sid0,
-                   defer_tables=(self._pending_rpr, tag) if self._defer_rpr() else None)
+                   defer_tables=(self._pending_rpr, tag) if self._defer_rpr() else None, oproj=oproj)
         self._linear_bwd(x_in, dqkv, p + "qkv_map", dx=dx_out, residual=ds)
         return dx_out
 
@@ -402,9 +410,11 @@ class TransformerCore(object):
         ds, dy = self._ln_bwd(dx, scope, tag, p + "o_map/b_0", hp.residual_dropout, sid0 + 1, side)
         att = e.mat(tag + ".att", T, H)
         datt = e.mat("g.%s.datt" % tag, T, H)
-        # merged attention: o_map saw att + averaged v_map(query); both terms get the same gradient
+        # merged attention: o_map saw att + averaged v_map(query); both terms get the same gradient (which the averaging's
+        # backward reads too: there the product is formed by the GEMM as before)
+        oproj = (dy, self.W(p + "o_map/W_0_0")) if self.attn_oproj and fuse_tmask is None else None
         self._linear_bwd(e.mat(tag + ".atts", T, H) if fuse_tmask is not None else att, dy, p + "o_map",
-                         dx=datt, bias_grad=False)
+                         dx=None if oproj else datt, bias_grad=False)
         q = e.mat(tag + ".q", T, H)
         kv = e.mat(tag + ".kv", mem.rows, 2 * H)
         dq = e.mat("g.%s.dq" % tag, T, H)
@@ -418,7 +428,7 @@ class TransformerCore(object):
                    drpr_k=self.gb(p + "rpr_keys/embeddings") if self.rpr else None,
                    drpr_v=self.gb(p + "rpr_values/embeddings") if self.rpr else None,
                    max_rel=hp.max_relative_position, drop_p=hp.attention_dropout, sid=sid0,
-                   defer_tables=(self._pending_rpr, tag) if self._defer_rpr() else None)
+                   defer_tables=(self._pending_rpr, tag) if self._defer_rpr() else None, oproj=oproj)
         self._linear_bwd(x_in, dq, p + "q_map", dx=dx_out, residual=ds)
         # memory side: the gradients of all decoder layers add up in d_mem.  Default: every layer only records its
         # (dK, W_k) / (dV, W_v) pair and ONE K-segmented GEMM sums them after the decoder (see _finish_mem_grad);
