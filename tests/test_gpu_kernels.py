@@ -968,6 +968,27 @@ def test_attention_rpr_on_mfma_kernels(case):
     assert max(errs[k] for k in ("dq", "dk", "dv", "drk", "drv")) < 3e-2, errs
 
 
+@pytest.mark.parametrize("case", [(2, 2, 64, 64, False, True, 0.0), (3, 8, 37, 53, True, False, 0.0), (2, 2, 20, 20, False, True, 0.2),
+                                  (4, 8, 64, 64, True, False, 0.1), (1, 1, 1, 1, False, False, 0.0)])
+def test_attention_rpr_backward_in_72kb_equals_the_resident_form(case):
+    """k_attn_bwd_rpr64 (tiles taking turns in 72 KB of LDS, two workgroups per CU) against k_attn_bwd_fused64<true>
+    (impl | 1024: every tile resident): the same MFMA sequences per output and the same bucket sums -> identical bits,
+    table gradients included."""
+    B, nh, Lq, Lk, um, causal, drop = case
+    e = eng()
+    res = []
+    for resident in (True, False):
+        old = e.rpr_bwd_resident
+        e.rpr_bwd_resident = resident
+        try:
+            plain, _ = _attn_bwd_oproj_pair(B, nh, Lq, Lk, 128, um, causal, rpr=True, drop=drop)
+        finally:
+            e.rpr_bwd_resident = old
+        res.append(plain)
+    for key in ("dq", "dk", "dv", "drk", "drv"):
+        assert torch.equal(res[0][key], res[1][key]), (key, rel_err(res[1][key], res[0][key].float()))
+
+
 def test_attention_rpr_mfma_forward_long_keys_and_dropout():
     # auto dispatch with several key / query tiles (two-kernel backward), then dropout on the fused one
     errs = _attn_case(0, 2, 2, 70, 130, 64, True, False, rpr=True)

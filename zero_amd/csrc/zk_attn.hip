@@ -485,6 +485,15 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_fused64(AttnArgs a, const b
                                     rpr_part, op);
 }
 
+// relative positions folded in, tiles taking turns in 72 KB of LDS: two workgroups per CU (attn_bwd_rpr64_tile)
+__global__ void __launch_bounds__(256, 2) k_attn_bwd_rpr64(AttnArgs a, const bf16_t* __restrict__ dout, int lddo,
+                                                           const float* __restrict__ lse, bf16_t* __restrict__ dq, int lddq,
+                                                           bf16_t* __restrict__ dk, int lddk, bf16_t* __restrict__ dv,
+                                                           int lddv, float* __restrict__ rpr_part) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[ATTN_BWD64_RPR2_LDS_BYTES];
+  attn_bwd_rpr64_tile(smem, a, dout, lddo, lse, dq, lddq, dk, lddk, dv, lddv, blockIdx.y, blockIdx.z, rpr_part);
+}
+
 // sum of the per-(sentence, head) table-gradient partials of the folded relative-position backward:
 // part fp32 [nslices][2][64][64] -> dk / dv fp32 [n] (n = (2*max_rel+1)*64 leading elements of each table slab).
 // Block = 16 columns x 16 slice groups: every thread adds nslices/16 values with all its loads in flight.
@@ -648,6 +657,9 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
   // step in one grouped reduction launch instead of one launch per layer.  Only honoured when the folded kernel runs:
   // the return value is 1 then (0: the tables were written here, as without the bit).
   const bool defer_tables = (impl & 512) != 0;
+  // impl | 1024 (with | 256): the folded kernel in its first form (every tile resident, 151 KB of LDS, one workgroup per
+  // CU) instead of the 72-KB form with two workgroups per CU -- kept for A/B runs and as the reference of the kernel tests
+  const bool resident_tiles = (impl & 1024) != 0;
   impl &= 255;
   if (fold) { a.rpr_k = nullptr; a.rpr_v = nullptr; }
   bool ok = attn_mfma_ok(a, ldo | lddo | lddq | lddk | lddv) &&
@@ -677,6 +689,9 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
     if (oproj_dy != nullptr)
       hipLaunchKernelGGL((k_attn_bwd_fused64<true, true>), dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
                          (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, part, op);
+    else if (!resident_tiles)
+      hipLaunchKernelGGL(k_attn_bwd_rpr64, dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)dout, lddo, lse,
+                         (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, part);
     else
       hipLaunchKernelGGL((k_attn_bwd_fused64<true, false>), dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
                          (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, part, op);

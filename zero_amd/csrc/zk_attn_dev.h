@@ -802,3 +802,266 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
   store_tile_rows(oV, dv + (size_t)b * a.Lk * lddv + h * AD, lddv, a.Lk, tid);
 }
 
+// ---- backward with relative positions, single tile, TWO workgroups per CU.
+// attn_bwd_fused64_tile<true> keeps every tile of both phases resident (151 KB: one four-wave workgroup per CU, 45 us per
+// launch against 17 for the plain kernel).  Here the tiles take turns in eight slots (+ the lse row: 72.3 KB):
+//   phase 1   T0 Q  T1 K  T2 V  T3 dO  T4 Rk  T5 Rv  T6-7 G (fp32 [64][GLD]: first Q.Rk^T for the scores, then -- same
+//             buffer, the rows are private to their wave -- dO.Rv^T for dP)
+//   phase 2a  T0 dS  T1 P^T  T2 dS^T  T3 K^T  T6 Q^T  T7 dO^T  T4 Rk^T   (the transposed operands wait in registers
+//             since the prologue)                                        -> dQ, dK, dV
+//   phase 2b  T2 dsb  T3 dsb^T  T5 pb^T (every wave writes -- values or zeros -- all rows / columns of its 16 queries)
+//                                                                        -> dQ += dsb.Rk, dRk = dsb^T Q, dRv = pb^T dO
+//   output    T0-3 the two fp32 table partials, T4-6 dQ, dK, dV as [row][channel] for 16-byte row stores
+// Same arithmetic as the resident form (same MFMA sequences per output, same bucket sums); the only difference is the
+// dropout multiplier of dP, applied from a kept-mask instead of being regenerated.
+#define ATTN_BWD64_RPR2_LDS_BYTES (8 * TQ * ALD * 2 + TQ * 4)
+__device__ __forceinline__ void attn_bwd_rpr64_tile(unsigned char* smem, const AttnArgs& a,
+                                                    const bf16_t* __restrict__ dout, int lddo,
+                                                    const float* __restrict__ lse,
+                                                    bf16_t* __restrict__ dq, int lddq,
+                                                    bf16_t* __restrict__ dk, int lddk,
+                                                    bf16_t* __restrict__ dv, int lddv, int h, int b,
+                                                    float* __restrict__ rpr_part) {
+  constexpr int TB = TQ * ALD;
+  bf16_t* T0 = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* T1 = T0 + TB; bf16_t* T2 = T1 + TB; bf16_t* T3 = T2 + TB;
+  bf16_t* T4 = T3 + TB; bf16_t* T5 = T4 + TB; bf16_t* T6 = T5 + TB; bf16_t* T7 = T6 + TB;
+  float* sG = reinterpret_cast<float*>(T6);            // [64][GLD] fp32 = 17408 B <= two tiles
+  float* sL = reinterpret_cast<float*>(T7 + TB);
+  static_assert(TQ * GLD * 4 <= 2 * TQ * ALD * 2, "G must fit two tiles");
+  static_assert(2 * TQ * GLD * 4 <= 4 * TQ * ALD * 2, "the two table partials must fit four tiles");
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bf16_t* qb = a.q + (size_t)b * a.bsq + h * AD;
+  const bf16_t* kb = a.k + (size_t)b * a.bsk + h * AD;
+  const bf16_t* vb = a.v + (size_t)b * a.bsv + h * AD;
+  const bf16_t* dob = dout + (size_t)b * a.Lq * lddo + h * AD;
+  const uint64_t seed = a.thr ? *a.seed : 0;
+  const int nrel = 2 * a.max_rel + 1;
+
+  // ---- prologue: every global load first
+  DirectRegs rQ, rdO, rK, rV, rRk, rRv;
+  TransRegs t0, t1;
+  load_direct(rQ, qb, a.ldq, 0, a.Lq, tid);
+  load_direct(rdO, dob, lddo, 0, a.Lq, tid);
+  load_direct(rK, kb, a.ldk, 0, a.Lk, tid);
+  load_direct(rV, vb, a.ldv, 0, a.Lk, tid);
+  load_direct(rRk, a.rpr_k, AD, 0, nrel, tid);
+  load_direct(rRv, a.rpr_v, AD, 0, nrel, tid);
+  if (tid < 128) {
+    load_trans(t0, kb, a.ldk, 0, a.Lk, tid);
+    load_trans(t1, a.rpr_k, AD, 0, nrel, tid);
+  } else {
+    load_trans(t0, qb, a.ldq, 0, a.Lq, tid - 128);
+    load_trans(t1, dob, lddo, 0, a.Lq, tid - 128);
+  }
+  const int dr = tid >> 2, dpart = tid & 3;
+  const float lse_r = lse[((size_t)b * a.nh + h) * a.Lq + min(dr, a.Lq - 1)];
+  float kbias4[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int j = nt * 16 + (lane & 15);
+    kbias4[nt] = (a.kmask != nullptr && a.kmask[(size_t)b * a.ldmask + min(j, a.Lk - 1)] == 0.f) ? -a.mask_inf : 0.f;
+  }
+  store_direct(T0, rQ, tid);
+  store_direct(T3, rdO, tid);
+  store_direct(T1, rK, tid);
+  store_direct(T2, rV, tid);
+  store_direct(T4, rRk, tid);
+  store_direct(T5, rRv, tid);
+  if (dpart == 0) sL[dr] = (dr < a.Lq) ? lse_r : 0.f;
+  __syncthreads();
+
+  // ---- phase 1: P and dS of query rows 16w .. 16w+15 against all 64 keys, kept in registers
+  const int rloc = w * 16 + (lane >> 4) * 4;
+  float pv[4][4], dsv[4][4];
+  {
+    float pu[4][4], Di[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t kept = 0;                                     // bit nt*4 + r: the element survived dropout
+    const uint4 q0 = frag(T0, w * 16, 0, lane), q1 = frag(T0, w * 16, 1, lane);
+    const uint4 g0 = frag(T3, w * 16, 0, lane), g1 = frag(T3, w * 16, 1, lane);
+    // G = Q.Rk^T rows of this wave's queries (read back by this wave only)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      f32x4_t ga = {0.f, 0.f, 0.f, 0.f};
+      ga = mfma16(q0, frag(T4, nt * 16, 0, lane), ga);
+      ga = mfma16(q1, frag(T4, nt * 16, 1, lane), ga);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sG[(rloc + r) * GLD + nt * 16 + (lane & 15)] = ga[r];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      f32x4_t sc4 = {0.f, 0.f, 0.f, 0.f};
+      sc4 = mfma16(q0, frag(T1, nt * 16, 0, lane), sc4);
+      sc4 = mfma16(q1, frag(T1, nt * 16, 1, lane), sc4);
+      const int j = nt * 16 + (lane & 15);
+      const bool kvalid = j < a.Lk;
+      const float kbias = kvalid ? kbias4[nt] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = rloc + r;
+        const bool live = kvalid && i < a.Lq;
+        float raw = sc4[r];
+        if (live) raw += sG[i * GLD + rel_index(a.q_pos0 + i, j, a.max_rel)];
+        float sc = raw * a.scale + kbias;
+        if (a.causal && j > a.q_pos0 + i) sc -= a.mask_inf;
+        const float p = live ? __expf(sc - sL[i]) : 0.f;
+        float ms = 1.f;
+        if (a.thr) {
+          const uint64_t idx = (((uint64_t)b * a.nh + h) * a.Lq + i) * a.Lk + j;
+          ms = zk_drop_scale(seed, a.sid, idx, a.thr, a.inv_keep);
+        }
+        if (ms != 0.f) kept |= 1u << (nt * 4 + r);
+        pv[nt][r] = p * ms;
+        pu[nt][r] = p;
+      }
+    }
+    // Gd = dO.Rv^T into the same rows of the same buffer
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      f32x4_t gb = {0.f, 0.f, 0.f, 0.f};
+      gb = mfma16(g0, frag(T5, nt * 16, 0, lane), gb);
+      gb = mfma16(g1, frag(T5, nt * 16, 1, lane), gb);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sG[(rloc + r) * GLD + nt * 16 + (lane & 15)] = gb[r];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    float dpv[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      f32x4_t dp = {0.f, 0.f, 0.f, 0.f};
+      dp = mfma16(g0, frag(T2, nt * 16, 0, lane), dp);
+      dp = mfma16(g1, frag(T2, nt * 16, 1, lane), dp);
+      const int j = nt * 16 + (lane & 15);
+      const bool kvalid = j < a.Lk;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = rloc + r;
+        float dpr = dp[r];
+        if (kvalid && i < a.Lq) dpr += sG[i * GLD + rel_index(a.q_pos0 + i, j, a.max_rel)];
+        const float ms = ((kept >> (nt * 4 + r)) & 1u) ? (a.thr ? a.inv_keep : 1.f) : 0.f;
+        dpv[nt][r] = dpr * ms;
+        Di[r] += pu[nt][r] * dpr * ms;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Di[r] = row16_sum(Di[r]);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dsv[nt][r] = pu[nt][r] * (dpv[nt][r] - Di[r]) * a.scale;
+  }
+  __syncthreads();                     // every wave is done with the operand tiles, the tables and G
+  bf16_t* sdS = T0; bf16_t* sPt = T1; bf16_t* sdSt = T2;
+  bf16_t* sKt = T3; bf16_t* sRkT = T4; bf16_t* sQt = T6; bf16_t* sdOt = T7;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int j = nt * 16 + (lane & 15);
+    uint2 pp, dd;
+    pp.x = (uint32_t)f2bf(pv[nt][0]) | ((uint32_t)f2bf(pv[nt][1]) << 16);
+    pp.y = (uint32_t)f2bf(pv[nt][2]) | ((uint32_t)f2bf(pv[nt][3]) << 16);
+    dd.x = (uint32_t)f2bf(dsv[nt][0]) | ((uint32_t)f2bf(dsv[nt][1]) << 16);
+    dd.y = (uint32_t)f2bf(dsv[nt][2]) | ((uint32_t)f2bf(dsv[nt][3]) << 16);
+    *reinterpret_cast<uint2*>(sPt + j * ALD + rloc) = pp;
+    *reinterpret_cast<uint2*>(sdSt + j * ALD + rloc) = dd;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sdS[(rloc + r) * ALD + j] = f2bf(dsv[nt][r]);
+  }
+  if (tid < 128) {
+    store_trans(sKt, t0, tid);
+    store_trans(sRkT, t1, tid);
+  } else {
+    store_trans(sQt, t0, tid - 128);
+    store_trans(sdOt, t1, tid - 128);
+  }
+  __syncthreads();
+  // ---- phase 2a: wave w -> dQ rows 16w.. (queries) and dK / dV rows 16w.. (keys)
+  f32x4_t dQ[4], dK[4], dV[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    dQ[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    dK[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    dV[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const uint4 da = frag(sdS, w * 16, kk, lane);
+    const uint4 pa = frag(sPt, w * 16, kk, lane);
+    const uint4 dt = frag(sdSt, w * 16, kk, lane);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      dQ[nb] = mfma16(da, frag(sKt, nb * 16, kk, lane), dQ[nb]);
+      dV[nb] = mfma16(pa, frag(sdOt, nb * 16, kk, lane), dV[nb]);
+      dK[nb] = mfma16(dt, frag(sQt, nb * 16, kk, lane), dK[nb]);
+    }
+  }
+  __syncthreads();                     // dS^T (T2) and K^T (T3) are dead
+  // ---- phase 2b: bucket sums of dS and P over the relative index, then the table terms
+  bf16_t* sSB = T2; bf16_t* sSBt = T3; bf16_t* sPBt = T5;
+  {
+    // this wave owns rows 16w.. of sSB and columns 16w.. of the two transposed tiles: zeros first, then the emitted buckets
+    // (LDS operations of one wave execute in order)
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int e = it * 64 + lane;                         // 128 pieces of 16 bytes
+      *reinterpret_cast<uint4*>(sSB + (w * 16 + (e >> 3)) * ALD + (e & 7) * 8) = z;
+      *reinterpret_cast<uint4*>(sSBt + (e >> 1) * ALD + w * 16 + (e & 1) * 8) = z;
+      *reinterpret_cast<uint4*>(sPBt + (e >> 1) * ALD + w * 16 + (e & 1) * 8) = z;
+    }
+  }
+  rpr_bucket_wave(a, nrel, 0, w, lane, [&](int row, int j) { return bf2f(sdS[row * ALD + j]); },
+                  [&](int row, int r, float v) { const bf16_t x = f2bf(v); sSB[row * ALD + r] = x; sSBt[r * ALD + row] = x; });
+  rpr_bucket_wave(a, nrel, 0, w, lane, [&](int row, int j) { return bf2f(sPt[j * ALD + row]); },
+                  [&](int row, int r, float v) { sPBt[r * ALD + row] = f2bf(v); });
+  __syncthreads();                     // the transposed bucket tiles are read across waves
+  f32x4_t tk[4], tv[4];                // rows r = 16w .. of dRk / dRv of this (sentence, head)
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) { tk[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; tv[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const uint4 sb = frag(sSB, w * 16, kk, lane);
+    const uint4 st = frag(sSBt, w * 16, kk, lane);
+    const uint4 pt = frag(sPBt, w * 16, kk, lane);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      dQ[nb] = mfma16(sb, frag(sRkT, nb * 16, kk, lane), dQ[nb]);
+      tk[nb] = mfma16(st, frag(sQt, nb * 16, kk, lane), tk[nb]);
+      tv[nb] = mfma16(pt, frag(sdOt, nb * 16, kk, lane), tv[nb]);
+    }
+  }
+  __syncthreads();                     // every tile is dead: outputs through LDS for 16-byte row stores
+  float* oTk = reinterpret_cast<float*>(T0);
+  float* oTv = oTk + TQ * GLD;
+  bf16_t* oQ = T4; bf16_t* oK = T5; bf16_t* oV = T6;
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int c = chan_of_phys(nb * 16 + (lane & 15));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = rloc + r;     // table row r for tk / tv, query row for dQ, key row for dK / dV
+      oTk[i * GLD + c] = tk[nb][r];
+      oTv[i * GLD + c] = tv[nb][r];
+      oQ[i * ALD + c] = f2bf(dQ[nb][r]);
+      oK[i * ALD + c] = f2bf(dK[nb][r]);
+      oV[i * ALD + c] = f2bf(dV[nb][r]);
+    }
+  }
+  __syncthreads();
+  float* pk = rpr_part + ((size_t)b * a.nh + h) * 2 * TQ * AD;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int e = it * 256 + tid, rr = e >> 4, c4 = (e & 15) * 4;
+    if (rr < nrel) {
+      *reinterpret_cast<float4*>(pk + rr * AD + c4) = *reinterpret_cast<const float4*>(oTk + rr * GLD + c4);
+      *reinterpret_cast<float4*>(pk + TQ * AD + rr * AD + c4) = *reinterpret_cast<const float4*>(oTv + rr * GLD + c4);
+    }
+  }
+  store_tile_rows(oQ, dq + (size_t)b * a.Lq * lddq + h * AD, lddq, a.Lq, tid);
+  store_tile_rows(oK, dk + (size_t)b * a.Lk * lddk + h * AD, lddk, a.Lk, tid);
+  store_tile_rows(oV, dv + (size_t)b * a.Lk * lddv + h * AD, lddv, a.Lk, tid);
+}

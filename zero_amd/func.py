@@ -106,6 +106,8 @@ class Engine(object):
         self.programs_enabled = os.environ.get("ZERO_HIP_PROGRAM", "0") != "0" and self.lib.experiments
         # relative positions folded into the attention forward tile (zk_attn_dev.h attn_fwd_tile<.., RPR>)
         self.rpr_fold = os.environ.get("ZERO_HIP_RPR_FOLD", "1") != "0"
+        # folded backward: 72 KB of LDS (two workgroups per CU) or every tile resident (151 KB, the first form)
+        self.rpr_bwd_resident = os.environ.get("ZERO_HIP_RPR_BWD", "") == "resident"
         self._prog_host = None
 
     # ---- plumbing -----------------------------------------------------------
@@ -383,7 +385,8 @@ class Engine(object):
                     hip.ptr(drpr_k), hip.ptr(drpr_v), B, nh, Lq, Lk, d, q.ld, k.ld, v.ld, out.ld, dout.ld, dq.ld,
                     dk.ld, dv.ld, hip.ptr(kmask), 1 if causal else 0, 0, float(d) ** -0.5, zdtype.inf(),
                     hip.ptr(rpr_k), hip.ptr(rpr_v), max_rel, float(drop_p), self.seed.data_ptr(), sid,
-                    (0 if eff == 0 else 2) | 256 | (512 if defer_tables is not None else 0), ws.data_ptr(), ws.numel(),
+                    (0 if eff == 0 else 2) | 256 | (512 if defer_tables is not None else 0) |
+                    (1024 if self.rpr_bwd_resident else 0), ws.data_ptr(), ws.numel(),
                     None, None, None, None, 0, 0) + tuple(op) + (self.stream,)
             rc = self.lib.raw("zk_attn_bwd")(*args)
             if rc == 1:        # the folded kernel ran and left the partials: the caller's grouped reduction sums them
