@@ -132,6 +132,8 @@ size_t zk_attn_bwd_workspace(int B, int nh, int Lq);
  * workspace -- fp32 [B*nh][2][64][64] behind the B*nh*Lq floats of D, (2*max_rel+1)*64 leading elements of each slab
  * valid -- and the call returns 1 instead of 0: the caller sums them (all attention layers of a step in one
  * zk_reduce_grouped launch).  When it does not run the bit is ignored and 0 is returned.
+ * impl | 1024 (together with | 256): the folded kernel in its first form -- every tile of both phases resident, 151 KB of
+ * LDS, one workgroup per CU -- instead of the 72-KB form (two workgroups per CU, identical results); for A/B runs and tests.
  * (oproj_dy, oproj_w) non-null: the gradient of the attention output is not read from `dout` (which may be null) but
  * computed inside the single-tile kernel as dY . W_o[h*64 .. h*64+63, :]^T -- dY bf16 [B*Lq, oproj_lddy], W_o = the
  * o_map weight [nh*64, oproj_ldw] row-major, oproj_n columns (a multiple of 128) -- i.e. the dgrad GEMM of the output
