@@ -122,7 +122,12 @@ class GemmProfiler(object):
             tf = lambda v: "true" if v else "false"
             bm_, bn_ = (tile, tile) if isinstance(tile, int) else tile[:2]
             if (bm_, bn_) == (256, 256):
-                name = "k_gemm_grouped256<%s, %s, %s>" % (tf(ta), tf(tb), tf(not (len(tile) == 3 and not tile[2])))
+                # <TA, TB, SPREAD, CS, K32> as zk_gemm_grouped instantiates it: CS = bias column sums ride along (a problem
+                # carries a colsum pointer), K32 = the 32-deep ring of the EXPERIMENTS build
+                k32 = len(tile) == 3 and tile[2] == "k32"
+                cs = bool(ta) and not tb and any(len(p) > 8 and p[8] is not None for p in problems)
+                spread = not k32 and not (len(tile) == 3 and not tile[2])
+                name = "k_gemm_grouped256<%s, %s, %s, %s, %s>" % (tf(ta), tf(tb), tf(spread), tf(cs), tf(k32))
             else:
                 name = "k_gemm_grouped<%d, %d, %d, %s, %s, %d>" % (bm_, bn_, 4 if bm_ == 64 else 3 if max(bm_, bn_) == 256 else 2,
                                                                   tf(ta), tf(tb), 4 if max(bm_, bn_) == 256 else 0)

@@ -71,13 +71,13 @@ def build(B, L=64, H=512, F=2048, V=32000, NE=6, ND=6, nh=8):
         b.gemm(c, 1, T, F, H)                            # ffn enlarge
         b.gemm(c, 1, T, H, F)                            # ffn output
         b.gemm(c, 1, T, H, 3 * H, extra_in=act)          # d qkv -> dx (+ residual)
-        b.gemm(c, 1, T, H, H)                            # d o_map
+        # (d o_map: inside the attention backward launch since round 3, see c5)
         b.gemm(c, 1, T, F, H, extra_in=T * F * 2.0)      # d ffn output (ReLU mask)
         b.gemm(c, 1, T, H, F, extra_in=act)              # d ffn enlarge (+ residual)
     for _ in range(ND):
         for (n_, k_) in ((3 * H, H), (H, H), (H, H), (H, H), (F, H), (H, F)):      # self qkv, o, cross q, o, ffn
             b.gemm(c, 1, T, n_, k_)
-        for (n_, k_, ex) in ((H, 3 * H, act), (H, H, 0), (H, H, act), (H, H, 0), (F, H, T * F * 2.0), (H, F, act)):
+        for (n_, k_, ex) in ((H, 3 * H, act), (H, H, act), (F, H, T * F * 2.0), (H, F, act)):     # d qkv, d q, d ffn x 2
             b.gemm(c, 1, T, n_, k_, extra_in=ex)
     # cross-attention K/V of all layers (one grouped launch), d(encoder output) (one K-segmented launch)
     c2 = "grouped K/V projections + K-segmented d(enc)"
@@ -90,8 +90,12 @@ def build(B, L=64, H=512, F=2048, V=32000, NE=6, ND=6, nh=8):
     wg_enc = NE * (H * 3 * H + H * H + 2 * H * F)
     wg_dec = ND * (H * 3 * H + 5 * H * H + 2 * H * F) + V * H
     params = wg_enc + wg_dec
-    # staged bytes per output element = (256 + 256) * K * 2 / (256 * 256); operands: every X / dY of the step + dlogits
-    b.add(c3, 1, 2.0 * params * T, params * 4.0 + 2 * 30 * act + T * V * 2.0, params / (256.0 * 256) * 512 * T * 2.0)
+    # staged bytes per output element = (256 + 256) * K * 2 / (256 * 256); operands: the X [T, in] and dY [T, out] of every
+    # weight, each read once (the X of the q / k / v problems of a layer are separate operands of separate problems)
+    enc_io = [(H, 3 * H), (H, H), (H, F), (F, H)]
+    dec_io = [(H, 3 * H), (H, H), (H, H), (H, 2 * H), (H, H), (H, F), (F, H)]
+    operands = (NE * sum(i + o for i, o in enc_io) + ND * sum(i + o for i, o in dec_io) + H + V) * T * 2.0
+    b.add(c3, 1, 2.0 * params * T, params * 4.0 + operands, params / (256.0 * 256) * 512 * T * 2.0)
     # ---- logits: forward GEMM (fp32 logits), dlogits x E
     c4 = "logits forward + dlogits x E"
     b.add(c4, 1, 2.0 * T * V * H, act + V * H * 2 + T * V * 4.0, (T // 256) * (V // 256) * 512 * H * 2.0)
@@ -100,7 +104,8 @@ def build(B, L=64, H=512, F=2048, V=32000, NE=6, ND=6, nh=8):
     c5 = "attention forward / backward (one (sentence, head) tile per workgroup)"
     n_att = NE + 2 * ND
     b.add(c5, n_att, 4.0 * B * L * L * H, 4 * act)
-    b.add(c5, n_att, 10.0 * B * L * L * H, 7 * act)
+    # backward: + the o_map dgrad of its (sentence, head): 2 T H H FLOPs, W_o once, per workgroup 64 x H of dY and of W_o staged
+    b.add(c5, n_att, 10.0 * B * L * L * H + 2.0 * T * H * H, 7 * act + H * H * 2.0, B * nh * 2 * 64 * H * 2.0)
     # ---- residual + LayerNorm
     c6 = "residual + LayerNorm forward / backward"
     n_ln = 2 * NE + 3 * ND
