@@ -443,6 +443,31 @@ def test_step_graphs_are_reused_across_batches_of_one_shape(model, monkeypatch):
         assert np.array_equal(a[..., :L], x[..., :L]) and np.array_equal(b, y) and c == z
 
 
+@pytest.mark.parametrize("model", ["transformer", "transformer_aan", "transformer_rpr"])
+def test_output_projection_dgrad_inside_the_attention_backward(model, monkeypatch):
+    """ZERO_HIP_ATTN_OPROJ=1 / 0: the o_map dgrad as the prologue of the attention backward launch or as a GEMM launch of
+    its own -- same loss (the forward is untouched), gradients equal up to the fp32 summation order inside the
+    64 x 64 x H product (bf16 flips of single dO elements), fewer entry-point calls."""
+    hp, Pn, src, tgt = _setup(model, seed=21)
+    g = registry.get_model(model)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("ZERO_HIP_ATTN_OPROJ", flag)
+        reset_cores()
+        core = get_core(hp, model, Pn)
+        n0 = core.eng.lib.ncalls
+        out = g.train_fn({"source": src, "target": tgt}, hp, initializer=Pn)
+        torch.cuda.synchronize()
+        res[flag] = (float(out["loss"].cpu()), out["store"].export("grad"), core.eng.lib.ncalls - n0)
+    assert res["0"][0] == res["1"][0]
+    n_att = hp.num_encoder_layer + (1 if model == "transformer_aan" else 2) * hp.num_decoder_layer
+    assert res["0"][2] - res["1"][2] == n_att, (res["0"][2], res["1"][2])
+    gmax = max(np.linalg.norm(v) for v in res["0"][1].values())
+    for k, ref in res["0"][1].items():
+        err = np.linalg.norm(res["1"][1][k] - ref) / max(np.linalg.norm(ref), 1e-3 * gmax)
+        assert err < 5e-3, (k, err)
+
+
 def test_transposed_decode_weights_follow_the_weight_version():
     """The transposed weight copies of the fused decode kernels are made by zk_transpose_bf16 once per weight version:
     reused across batches, refreshed after an optimiser update."""

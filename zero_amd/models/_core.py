@@ -108,11 +108,19 @@ class TransformerCore(object):
         self.logits_tile256 = os.environ.get("ZERO_HIP_LOGITS_256", "1") != "0"
         # the dgrad of the attention output projection inside the attention backward launch (zk_attn_bwd oproj_*): 18
         # launches and 18 [T, H] matrices less per step, same-box A/B -0.02 to -0.05 ms (the 64 x 64 x H product per
-        # (sentence, head) costs the launch +7 us, the GEMM it replaces was 8-9 us).  Not with relative positions: that
-        # variant of the kernel runs one workgroup per CU and the longer prologue is not hidden (5.21 -> 5.24 ms).
-        self.attn_oproj = os.environ.get("ZERO_HIP_ATTN_OPROJ", "0" if self.rpr else "1") != "0"
+        # (sentence, head) costs the launch +7 us, the GEMM it replaces was 8-9 us).  By rule (_use_oproj): only while the
+        # (sentence, head) workgroups fit the chip at once and H <= 512 -- with 2048 workgroups (256 sentences) or the big
+        # widths (H = 1024: two 512-column chunks per workgroup, 1024 workgroups) the GEMM launch is the cheaper place for
+        # the product (same-box: 12.39 vs 12.28 ms and 11.12 vs 11.01 ms).  Not with relative positions: the oproj variant
+        # of that kernel runs one workgroup per CU and the longer prologue is not hidden (5.21 -> 5.24 ms).
+        self.attn_oproj = os.environ.get("ZERO_HIP_ATTN_OPROJ", "auto").lower()
         self._red_id = 0
         self._side_stream = None      # created on first use: every stream of the process takes a share of the hardware queues
+
+    def _use_oproj(self, B):
+        if self.attn_oproj in ("0", "1"):
+            return self.attn_oproj == "1"
+        return (not self.rpr) and self.H <= 512 and B * self.nh <= 512
 
     @property
     def side(self):
@@ -385,7 +393,7 @@ class TransformerCore(object):
         datt = e.mat("g.%s.datt" % tag, T, H)
         # the dgrad of o_map runs INSIDE the attention backward (its 64 x 64 x H piece per sentence and head): only the
         # weight gradient is recorded here
-        oproj = (dy, self.W(p + "o_map/W_0_0")) if self.attn_oproj else None
+        oproj = (dy, self.W(p + "o_map/W_0_0")) if self._use_oproj(B) else None
         self._linear_bwd(att, dy, p + "o_map", dx=None if oproj else datt, bias_grad=False)
         qkv = e.mat(tag + ".qkv", T, 3 * H)
         dqkv = e.mat("g.%s.dqkv" % tag, T, 3 * H)
@@ -412,7 +420,7 @@ class TransformerCore(object):
         datt = e.mat("g.%s.datt" % tag, T, H)
         # merged attention: o_map saw att + averaged v_map(query); both terms get the same gradient (which the averaging's
         # backward reads too: there the product is formed by the GEMM as before)
-        oproj = (dy, self.W(p + "o_map/W_0_0")) if self.attn_oproj and fuse_tmask is None else None
+        oproj = (dy, self.W(p + "o_map/W_0_0")) if self._use_oproj(B) and fuse_tmask is None else None
         self._linear_bwd(e.mat(tag + ".atts", T, H) if fuse_tmask is not None else att, dy, p + "o_map",
                          dx=None if oproj else datt, bias_grad=False)
         q = e.mat(tag + ".q", T, H)
