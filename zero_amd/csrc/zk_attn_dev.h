@@ -88,9 +88,12 @@ __device__ __forceinline__ void rpr_bucket_wave(const AttnArgs& a, int nr, int i
     t1 = quad_sum(t1);
     if (q == 0 && i < a.Lq) { emit(row, 0, t0); if (m > 0) emit(row, 2 * m, t1); }
   }
-  // interior indices and padding
+  // interior indices and padding.  e / nr without the ~40-instruction integer division of a runtime divisor (nine
+  // iterations x two calls per kernel): (e * ceil(2^16 / nr)) >> 16 is exact for nr <= 64 and e < 1024
+  const int inv16 = (65536 + nr - 1) / nr;
   for (int e = lane; e < 16 * nr; e += 64) {
-    const int row = w * 16 + e / nr, r = e % nr;
+    const int qrow = (e * inv16) >> 16;
+    const int row = w * 16 + qrow, r = e - qrow * nr;
     const int i = i0 + row;
     if (i >= a.Lq || r == 0 || r == 2 * m) continue;
     float acc = 0.f;
