@@ -971,9 +971,10 @@ def test_attention_rpr_on_mfma_kernels(case):
 @pytest.mark.parametrize("case", [(2, 2, 64, 64, False, True, 0.0), (3, 8, 37, 53, True, False, 0.0), (2, 2, 20, 20, False, True, 0.2),
                                   (4, 8, 64, 64, True, False, 0.1), (1, 1, 1, 1, False, False, 0.0)])
 def test_attention_rpr_backward_in_72kb_equals_the_resident_form(case):
-    """k_attn_bwd_rpr64 (tiles taking turns in 72 KB of LDS, two workgroups per CU) against k_attn_bwd_fused64<true>
-    (impl | 1024: every tile resident): the same MFMA sequences per output and the same bucket sums -> identical bits,
-    table gradients included."""
+    """k_attn_bwd_rpr64 (tiles taking turns in 72 KB of LDS, two workgroups per CU, bucket sums from the registers of
+    phase 1) against k_attn_bwd_fused64<true> (impl | 1024: every tile resident, bucket sums by a second walk over the LDS
+    tiles): the same MFMA sequences per output on the same bf16 P / dS; only the fp32 order of the two clipped-tail sums
+    differs, i.e. a rare last-bit flip of a bf16 bucket -> gradients equal to ~1e-3, the untouched dK / dV bit for bit."""
     B, nh, Lq, Lk, um, causal, drop = case
     e = eng()
     res = []
@@ -985,8 +986,10 @@ def test_attention_rpr_backward_in_72kb_equals_the_resident_form(case):
         finally:
             e.rpr_bwd_resident = old
         res.append(plain)
-    for key in ("dq", "dk", "dv", "drk", "drv"):
+    for key in ("dk", "dv"):
         assert torch.equal(res[0][key], res[1][key]), (key, rel_err(res[1][key], res[0][key].float()))
+    for key in ("dq", "drk", "drv"):
+        assert rel_err(res[1][key], res[0][key].float()) < 2e-3, (key, rel_err(res[1][key], res[0][key].float()))
 
 
 def test_attention_rpr_mfma_forward_long_keys_and_dropout():

@@ -546,6 +546,12 @@ static bool attn_mfma_ok(const AttnArgs& a, int extra_ld_or) {
 }
 
 extern "C" int zk_zero(void* p, size_t bytes, hipStream_t stream);   // zk_elem.hip
+#ifdef ZK_ATTN_TRACE
+__device__ unsigned long long zk_attn_trace_buf[16];
+extern "C" int zk_attn_trace_read(unsigned long long* out16) {
+  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zk_attn_trace_buf), sizeof(unsigned long long) * 16);
+}
+#endif
 extern "C" {
 size_t zk_attn_bwd_rpr_workspace(int B, int nh, int Lq) {
   return (size_t)B * nh * Lq * sizeof(float) + (size_t)B * nh * 2 * TQ * AD * sizeof(float);

@@ -157,6 +157,18 @@ __device__ __forceinline__ float rpr_gather(const AttnArgs& a, const float* __re
 // =====================================================================================
 // MFMA kernels (d = 64)
 // =====================================================================================
+// make ATTNTRACE=1: workgroup (0, 0, 0) of the single-tile backward kernels stamps the constant 100 MHz clock at its phase
+// boundaries (scripts/attn_bwd_trace.py); nothing in the default build
+#ifdef ZK_ATTN_TRACE
+extern __device__ unsigned long long zk_attn_trace_buf[16];
+#define ZK_AT(i)                                                                                                     \
+  do {                                                                                                               \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)                                   \
+      zk_attn_trace_buf[i] = __builtin_amdgcn_s_memrealtime();                                                       \
+  } while (0)
+#else
+#define ZK_AT(i)
+#endif
 #define AD 64            // head dim
 #define ALD 72           // LDS row stride (bf16): 144 B rows -> conflict-free b128 fragment reads
 #define TQ 64            // query / key tile
@@ -401,6 +413,16 @@ __device__ __forceinline__ void attn_fwd_tile(unsigned char* smem, const AttnArg
     sum[r] = 1.f / sum[r];
   }
   // P (bf16, after dropout) -> sP rows owned by this wave
+  // RPR: PB[i][r] = the sum of P over the keys of relative index r, for this wave's rows, straight from these registers:
+  // an interior bucket 0 < r < 2m has exactly one key (the entry IS the bucket: a scattered 2-byte store), the two clipped
+  // tails are sums over the row (partials per lane, a 16-lane reduction, one store).  Rows beyond Lq and buckets beyond 2m
+  // stay zero: the wave clears its 16 x 64 slab first (LDS operations of one wave execute in order).  [A second walk over
+  // sP -- rpr_bucket_wave -- cost the backward 6 of its 18 us, profiles/r03_attn_bwd_phases_v1.txt.]
+  [[maybe_unused]] float tlo[4] = {0.f, 0.f, 0.f, 0.f}, thi[4] = {0.f, 0.f, 0.f, 0.f};
+  if (RPR) {
+    for (int e = lane; e < 16 * 8; e += 64)
+      *reinterpret_cast<uint4*>(sPB + (w * 16 + (e >> 3)) * ALD + (e & 7) * 8) = make_uint4(0u, 0u, 0u, 0u);
+  }
 #pragma unroll
   for (int t = 0; t < NKT * 4; ++t) {
     const int j = t * 16 + (lane & 15);
@@ -411,24 +433,33 @@ __device__ __forceinline__ void attn_fwd_tile(unsigned char* smem, const AttnArg
         const uint64_t idx = (((uint64_t)b * a.nh + h) * a.Lq + (rbase + r)) * a.Lk + j;
         p *= zk_drop_scale(seed, a.sid, idx, a.thr, a.inv_keep);
       }
-      sP[(w * 16 + (lane >> 4) * 4 + r) * PLD + j] = f2bf(p);
+      const bf16_t pb16 = f2bf(p);
+      const int il = w * 16 + (lane >> 4) * 4 + r;
+      sP[il * PLD + j] = pb16;
+      if (RPR) {
+        const float pr = (rbase + r < a.Lq && j < a.Lk) ? bf2f(pb16) : 0.f;
+        const int ri = rel_index(a.q_pos0 + rbase + r, j, a.max_rel);
+        if (ri == 0) tlo[r] += pr;
+        else if (ri == 2 * a.max_rel) thi[r] += pr;
+        else sPB[il * ALD + ri] = f2bf(pr);
+      }
+    }
+  }
+  if (RPR) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s0 = row16_sum(tlo[r]), s1 = row16_sum(thi[r]);
+      if ((lane & 15) == 0) {
+        const int il = w * 16 + (lane >> 4) * 4 + r;
+        sPB[il * ALD] = f2bf(s0);
+        if (a.max_rel > 0) sPB[il * ALD + 2 * a.max_rel] = f2bf(s1);
+      }
     }
   }
   if (a.pb != nullptr) {   // relative-position value term: bucket sums of this wave's own rows of P
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     rpr_bucket_rows(a, a.pb, b, h, i0, w, lane, [&](int row, int j) { return bf2f(sP[row * PLD + j]); });
-  }
-  if (RPR) {   // PB[i][r] for this wave's rows, r in [0, 64): interior indices pick one key, the two clipped tails sum
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    // rows beyond Lq and buckets beyond 2m are never emitted: clear this wave's 16 x 64 slab first
-    for (int e = lane; e < 16 * 8; e += 64)
-      *reinterpret_cast<uint4*>(sPB + (w * 16 + (e >> 3)) * ALD + (e & 7) * 8) = make_uint4(0u, 0u, 0u, 0u);
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    rpr_bucket_wave(a, 2 * a.max_rel + 1, i0, w, lane, [&](int row, int j) { return bf2f(sP[row * PLD + j]); },
-                    [&](int row, int r, float v) { sPB[row * ALD + r] = f2bf(v); });
   }
   // O = P V, V^T staged per key tile into sK
   f32x4_t O[4];
@@ -522,6 +553,7 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
   const uint64_t seed = a.thr ? *a.seed : 0;
 
   // every global load of the prologue first (tiles, the O / dO rows of D_i, lse, the key mask), then the LDS stores
+  ZK_AT(0);
   DirectRegs rQ, rdO, rK, rV;
   TransRegs t0, t1;
   load_direct(rQ, qb, a.ldq, 0, a.Lq, tid);
@@ -533,6 +565,35 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
   } else {
     load_trans(t0, qb, a.ldq, 0, a.Lq, tid - 128);
     if (!OPROJ) load_trans(t1, dob, lddo, 0, a.Lq, tid - 128);
+  }
+  // OPROJ: dO rows 16w .. 16w+15 of this head = dY rows x W_o[h*64 .., :]^T in slabs of 128 columns.  The loads of the first
+  // 512-column chunk are issued HERE, behind the tile loads and in front of everything that waits for a loaded value (the
+  // key-mask compare below waits for the whole queue: with the chunk issued behind it the product started one memory
+  // round trip late, ATTNTRACE).  Q, K, V go to their tiles before the first slab (their registers are needed); the four
+  // tiles of the second phase (dO, K^T, Q^T, dO^T) are idle until the product is done: slab s uses tiles 3 + 2(s&1),
+  // 4 + 2(s&1), one barrier per slab.
+  [[maybe_unused]] f32x4_t dOa[4];
+  [[maybe_unused]] DirectRegs wr[8];
+  [[maybe_unused]] uint4 av[16];
+  [[maybe_unused]] const bf16_t* wrow = OPROJ ? op.w + (size_t)h * AD * op.ldw : nullptr;
+  [[maybe_unused]] const bf16_t* ap =
+      OPROJ ? op.dy + ((size_t)b * a.Lq + min(w * 16 + (lane & 15), a.Lq - 1)) * op.lddy + (lane >> 4) * 8 : nullptr;
+  auto oproj_issue = [&](int c0) {
+    const int nsl = min(4, (op.n - c0) >> 7);
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      if (sl < nsl) {
+        load_direct(wr[2 * sl], wrow + c0 + sl * 128, op.ldw, 0, AD, tid);
+        load_direct(wr[2 * sl + 1], wrow + c0 + sl * 128 + 64, op.ldw, 0, AD, tid);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) av[4 * sl + u] = zk_ld16<false>(ap + c0 + sl * 128 + u * 32);
+      }
+    }
+  };
+  if (OPROJ) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) dOa[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    oproj_issue(0);
   }
   // D_i = sum_j P_ij dP_ij is taken from the P and dP this workgroup computes anyway (whole rows live in one tile),
   // not from rowsum(dO o O) over the stored bf16 O: no O / dO row loads, and sum_j dS_ij = 0 holds to fp32 rounding
@@ -547,32 +608,17 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
     const int j = nt * 16 + (lane & 15);
     kbias4[nt] = (a.kmask != nullptr && a.kmask[(size_t)b * a.ldmask + min(j, a.Lk - 1)] == 0.f) ? -a.mask_inf : 0.f;
   }
-  [[maybe_unused]] f32x4_t dOa[4];
   if (OPROJ) {
-    // dO rows 16w .. 16w+15 of this head in slabs of 128 columns of dY / W_o.  Q, K, V go to their tiles first (their
-    // registers are needed); the four tiles of the second phase (dO, K^T, Q^T, dO^T) are idle until the product is done:
-    // slab s uses tiles 3 + 2(s&1), 4 + 2(s&1) (one barrier per slab).
-    store_direct(sQ, rQ, tid);
-    store_direct(sK, rK, tid);
-    store_direct(sV, rV, tid);
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) dOa[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const bf16_t* wrow = op.w + (size_t)h * AD * op.ldw;
-    const bf16_t* ap = op.dy + ((size_t)b * a.Lq + min(w * 16 + (lane & 15), a.Lq - 1)) * op.lddy + (lane >> 4) * 8;
+    ZK_AT(1);
     // chunks of 512 columns with EVERY load of the chunk in flight before the first slab is multiplied (one slab of
     // prefetch distance measured +7.4 us per launch: each slab then waits out most of a cold L2 / HBM latency)
     for (int c0 = 0; c0 < op.n; c0 += 512) {
       const int nsl = min(4, (op.n - c0) >> 7);
-      DirectRegs wr[8];
-      uint4 av[16];
-#pragma unroll
-      for (int sl = 0; sl < 4; ++sl) {
-        if (sl < nsl) {
-          load_direct(wr[2 * sl], wrow + c0 + sl * 128, op.ldw, 0, AD, tid);
-          load_direct(wr[2 * sl + 1], wrow + c0 + sl * 128 + 64, op.ldw, 0, AD, tid);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) av[4 * sl + u] = zk_ld16<false>(ap + c0 + sl * 128 + u * 32);
-        }
+      if (c0 > 0) oproj_issue(c0);
+      else {
+        store_direct(sQ, rQ, tid);
+        store_direct(sK, rK, tid);
+        store_direct(sV, rV, tid);
       }
 #pragma unroll
       for (int sl = 0; sl < 4; ++sl) {
@@ -592,6 +638,7 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
         }
       }
     }
+    ZK_AT(2);
     __syncthreads();                     // the slabs are dead: the transposed tiles and dO may land
   } else {
     store_direct(sQ, rQ, tid);
@@ -621,6 +668,7 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
     }
   }
   if (dpart == 0) sL[dr] = (dr < a.Lq) ? lse_r : 0.f;
+  ZK_AT(3);
   if (RPR) {
     const int nrel = 2 * a.max_rel + 1;
     stage_direct(sRk, a.rpr_k, AD, 0, nrel, tid);
@@ -651,6 +699,7 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
     __builtin_amdgcn_wave_barrier();
   }
   // ---- phase 1: P and dS of query rows 16w .. 16w+15 against all 64 keys, kept in registers
+  ZK_AT(4);
   const int rloc = w * 16 + (lane >> 4) * 4;
   float pv[4][4], dsv[4][4];
   {
@@ -702,7 +751,9 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
 #pragma unroll
       for (int r = 0; r < 4; ++r) dsv[nt][r] = pu[nt][r] * (dpv[nt][r] - Di[r]) * a.scale;
   }
+  ZK_AT(5);
   __syncthreads();                     // every wave is done reading sQ / sK / sV / sdO
+  ZK_AT(6);
   bf16_t* sdS = sQ;
   bf16_t* sPt = sK;
   bf16_t* sdSt = sV;
@@ -732,6 +783,7 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
     rpr_bucket_rows(a, a.pb, b, h, 0, w, lane, [&](int row, int j) { return bf2f(sPt[j * ALD + row]); });
   }
   // ---- phase 2: wave w -> dQ rows 16w.. (queries) and dK / dV rows 16w.. (keys)
+  ZK_AT(7);
   f32x4_t dQ[4], dK[4], dV[4];
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
@@ -751,6 +803,7 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
       dK[nb] = mfma16(dt, frag(sQt, nb * 16, kk, lane), dK[nb]);
     }
   }
+  ZK_AT(8);
   if (RPR) {
     f32x4_t tk[4], tv[4];                // rows r = 16w .. of dRk / dRv of this (sentence, head)
 #pragma unroll
@@ -807,9 +860,11 @@ __device__ __forceinline__ void attn_bwd_fused64_tile(unsigned char* smem, const
     }
   }
   __syncthreads();
+  ZK_AT(9);
   store_tile_rows(oQ, dq + (size_t)b * a.Lq * lddq + h * AD, lddq, a.Lq, tid);
   store_tile_rows(oK, dk + (size_t)b * a.Lk * lddk + h * AD, lddk, a.Lk, tid);
   store_tile_rows(oV, dv + (size_t)b * a.Lk * lddv + h * AD, lddv, a.Lk, tid);
+  ZK_AT(10);
 }
 
 // ---- backward with relative positions, single tile, TWO workgroups per CU.
@@ -849,6 +904,7 @@ __device__ __forceinline__ void attn_bwd_rpr64_tile(unsigned char* smem, const A
   const int nrel = 2 * a.max_rel + 1;
 
   // ---- prologue: every global load first
+  ZK_AT(0);
   DirectRegs rQ, rdO, rK, rV, rRk, rRv;
   TransRegs t0, t1;
   load_direct(rQ, qb, a.ldq, 0, a.Lq, tid);
@@ -879,7 +935,9 @@ __device__ __forceinline__ void attn_bwd_rpr64_tile(unsigned char* smem, const A
   store_direct(T4, rRk, tid);
   store_direct(T5, rRv, tid);
   if (dpart == 0) sL[dr] = (dr < a.Lq) ? lse_r : 0.f;
+  ZK_AT(3);
   __syncthreads();
+  ZK_AT(4);
 
   // ---- phase 1: P and dS of query rows 16w .. 16w+15 against all 64 keys, kept in registers
   const int rloc = w * 16 + (lane >> 4) * 4;
@@ -965,9 +1023,12 @@ __device__ __forceinline__ void attn_bwd_rpr64_tile(unsigned char* smem, const A
 #pragma unroll
       for (int r = 0; r < 4; ++r) dsv[nt][r] = pu[nt][r] * (dpv[nt][r] - Di[r]) * a.scale;
   }
+  ZK_AT(5);
   __syncthreads();                     // every wave is done with the operand tiles, the tables and G
+  ZK_AT(6);
   bf16_t* sdS = T0; bf16_t* sPt = T1; bf16_t* sdSt = T2;
   bf16_t* sKt = T3; bf16_t* sRkT = T4; bf16_t* sQt = T6; bf16_t* sdOt = T7;
+  uint2 ppk[4], ddk[4];                 // this lane's 4 x 4 entries of P and dS as bf16 pairs: also the source of the bucket sums
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     const int j = nt * 16 + (lane & 15);
@@ -976,10 +1037,11 @@ __device__ __forceinline__ void attn_bwd_rpr64_tile(unsigned char* smem, const A
     pp.y = (uint32_t)f2bf(pv[nt][2]) | ((uint32_t)f2bf(pv[nt][3]) << 16);
     dd.x = (uint32_t)f2bf(dsv[nt][0]) | ((uint32_t)f2bf(dsv[nt][1]) << 16);
     dd.y = (uint32_t)f2bf(dsv[nt][2]) | ((uint32_t)f2bf(dsv[nt][3]) << 16);
+    ppk[nt] = pp; ddk[nt] = dd;
     *reinterpret_cast<uint2*>(sPt + j * ALD + rloc) = pp;
     *reinterpret_cast<uint2*>(sdSt + j * ALD + rloc) = dd;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sdS[(rloc + r) * ALD + j] = f2bf(dsv[nt][r]);
+    for (int r = 0; r < 4; ++r) sdS[(rloc + r) * ALD + j] = (bf16_t)((r & 1) ? ((r & 2 ? dd.y : dd.x) >> 16) : ((r & 2 ? dd.y : dd.x) & 0xffffu));
   }
   if (tid < 128) {
     store_trans(sKt, t0, tid);
@@ -989,6 +1051,7 @@ __device__ __forceinline__ void attn_bwd_rpr64_tile(unsigned char* smem, const A
     store_trans(sdOt, t1, tid - 128);
   }
   __syncthreads();
+  ZK_AT(7);
   // ---- phase 2a: wave w -> dQ rows 16w.. (queries) and dK / dV rows 16w.. (keys)
   f32x4_t dQ[4], dK[4], dV[4];
 #pragma unroll
@@ -1009,6 +1072,7 @@ __device__ __forceinline__ void attn_bwd_rpr64_tile(unsigned char* smem, const A
       dK[nb] = mfma16(dt, frag(sQt, nb * 16, kk, lane), dK[nb]);
     }
   }
+  ZK_AT(8);
   __syncthreads();                     // dS^T (T2) and K^T (T3) are dead
   // ---- phase 2b: bucket sums of dS and P over the relative index, then the table terms
   bf16_t* sSB = T2; bf16_t* sSBt = T3; bf16_t* sPBt = T5;
@@ -1024,10 +1088,44 @@ __device__ __forceinline__ void attn_bwd_rpr64_tile(unsigned char* smem, const A
       *reinterpret_cast<uint4*>(sPBt + (e >> 1) * ALD + w * 16 + (e & 1) * 8) = z;
     }
   }
-  rpr_bucket_wave(a, nrel, 0, w, lane, [&](int row, int j) { return bf2f(sdS[row * ALD + j]); },
-                  [&](int row, int r, float v) { const bf16_t x = f2bf(v); sSB[row * ALD + r] = x; sSBt[r * ALD + row] = x; });
-  rpr_bucket_wave(a, nrel, 0, w, lane, [&](int row, int j) { return bf2f(sPt[j * ALD + row]); },
-                  [&](int row, int r, float v) { sPBt[r * ALD + row] = f2bf(v); });
+  // Bucket sums over the relative index straight from the registers of phase 1 (the resident form walks the LDS tiles
+  // again: 6.2 of its 18 us, profiles/r03_attn_bwd_phases_v1.txt).  Entry (i, j) of this lane belongs to bucket
+  // r = clip(i - j, -m, m) + m: an interior bucket 0 < r < 2m has exactly ONE key, so the entry IS the bucket -- a scattered
+  // 2-byte store; the two clipped tails r = 0 (j >= i + m) and r = 2m (j <= i - m) are sums over the row: four partials per
+  // lane, a 16-lane reduction, one store.  Values are the bf16-rounded P / dS the products above used.
+  {
+    const int m = a.max_rel;
+    float tl_ds[4] = {0.f, 0.f, 0.f, 0.f}, th_ds[4] = {0.f, 0.f, 0.f, 0.f};
+    float tl_p[4] = {0.f, 0.f, 0.f, 0.f}, th_p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int j = nt * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = rloc + r;
+        const uint32_t dw = (r & 2) ? ddk[nt].y : ddk[nt].x, pw = (r & 2) ? ppk[nt].y : ppk[nt].x;
+        const bf16_t db = (bf16_t)((r & 1) ? (dw >> 16) : (dw & 0xffffu)), pb_ = (bf16_t)((r & 1) ? (pw >> 16) : (pw & 0xffffu));
+        const int ri = rel_index(a.q_pos0 + i, j, m);
+        if (ri == 0) { tl_ds[r] += bf2f(db); tl_p[r] += bf2f(pb_); }
+        else if (ri == 2 * m) { th_ds[r] += bf2f(db); th_p[r] += bf2f(pb_); }
+        else { sSB[i * ALD + ri] = db; sSBt[ri * ALD + i] = db; sPBt[ri * ALD + i] = pb_; }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a0 = row16_sum(tl_ds[r]), a1 = row16_sum(th_ds[r]), b0 = row16_sum(tl_p[r]), b1 = row16_sum(th_p[r]);
+      if ((lane & 15) == 0) {
+        const int i = rloc + r;
+        const bf16_t x0 = f2bf(a0), y0 = f2bf(b0);
+        sSB[i * ALD] = x0; sSBt[i] = x0; sPBt[i] = y0;
+        if (m > 0) {
+          const bf16_t x1 = f2bf(a1), y1 = f2bf(b1);
+          sSB[i * ALD + 2 * m] = x1; sSBt[2 * m * ALD + i] = x1; sPBt[2 * m * ALD + i] = y1;
+        }
+      }
+    }
+  }
+  ZK_AT(11);
   __syncthreads();                     // the transposed bucket tiles are read across waves
   f32x4_t tk[4], tv[4];                // rows r = 16w .. of dRk / dRv of this (sentence, head)
 #pragma unroll
@@ -1044,6 +1142,7 @@ __device__ __forceinline__ void attn_bwd_rpr64_tile(unsigned char* smem, const A
       tv[nb] = mfma16(pt, frag(sdOt, nb * 16, kk, lane), tv[nb]);
     }
   }
+  ZK_AT(12);
   __syncthreads();                     // every tile is dead: outputs through LDS for 16-byte row stores
   float* oTk = reinterpret_cast<float*>(T0);
   float* oTv = oTk + TQ * GLD;
@@ -1062,6 +1161,7 @@ __device__ __forceinline__ void attn_bwd_rpr64_tile(unsigned char* smem, const A
     }
   }
   __syncthreads();
+  ZK_AT(9);
   float* pk = rpr_part + ((size_t)b * a.nh + h) * 2 * TQ * AD;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
@@ -1074,4 +1174,5 @@ __device__ __forceinline__ void attn_bwd_rpr64_tile(unsigned char* smem, const A
   store_tile_rows(oQ, dq + (size_t)b * a.Lq * lddq + h * AD, lddq, a.Lq, tid);
   store_tile_rows(oK, dk + (size_t)b * a.Lk * lddk + h * AD, lddk, a.Lk, tid);
   store_tile_rows(oV, dv + (size_t)b * a.Lk * lddv + h * AD, lddv, a.Lk, tid);
+  ZK_AT(10);
 }
