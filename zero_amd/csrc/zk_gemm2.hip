@@ -324,7 +324,32 @@ __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __rest
   }
   const GroupDesc d = descs[p];
   const int local = t - d.tile_start;
-  const int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
+  // tile order inside a problem: blocks of 4 x 8 tiles, the blocks of one 8-tile column group one after the other.  An XCD
+  // runs 32 consecutive tiles at a time (its chunk of the launch is contiguous): a block keeps 4 A row blocks + 8 B column
+  // blocks = 3 MB at K = 512 in its 4-MB L2, and the next block reuses the 8 column blocks.  Row-major order made the
+  // logits forward (16 x 125 tiles) fetch the whole 33-MB softmax table once per row of tiles: FETCH_SIZE 543 MB against
+  // 37 MB of operands (profiles/r03_pmc_traffic.json), as much HBM traffic again as the 525 MB of logits it writes.
+  // Problems with fewer than 4 x 8 tiles (every weight gradient) keep the row-major order.
+  int tm, tn;
+  {
+    constexpr int GM = 4, GN = 8;
+    const int tiles_m = (d.M + BM - 1) / BM;
+    const int nbm = tiles_m / GM, nbn = d.tiles_n / GN;
+    const int full = nbm * nbn * GM * GN;
+    if (nbm == 0 || nbn == 0) {
+      tm = local / d.tiles_n; tn = local - tm * d.tiles_n;
+    } else if (local < full) {
+      const int blk = local / (GM * GN), within = local - blk * (GM * GN);
+      const int bn = blk / nbm, bm = blk - bn * nbm;
+      tm = bm * GM + within / GN; tn = bn * GN + within % GN;
+    } else {
+      // what the blocks leave: the right stripe (all rows, the last tiles_n % 8 columns), then the bottom stripe
+      int r = local - full;
+      const int wr = d.tiles_n - nbn * GN, right = wr * tiles_m;
+      if (r < right) { tm = r / wr; tn = nbn * GN + r - tm * wr; }
+      else { r -= right; const int wb = nbn * GN; tm = nbm * GM + r / wb; tn = r % wb; }
+    }
+  }
   const int m0 = tm * BM, n0 = tn * BN, M = d.M, N = d.N;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
