@@ -205,6 +205,20 @@ def pmc_traffic(kernel):
     return None, None, None
 
 
+def pmc_traffic_decode():
+    """HBM bytes per decode step from the newest committed summary of scripts/pmc_traffic_decode.sh
+    (profiles/*_pmc_traffic_decode.json); (None, None, None) without one."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_traffic_decode.json")), reverse=True):
+        try:
+            meta = json.load(open(f))
+            return meta["bytes_per_step"], os.path.basename(f), meta.get("commit")
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None, None
+
+
 def pmc_mfma(kernel):
     """MFMA-pipe utilisation of `kernel` from the newest committed counter summary (profiles/*_pmc_mfma.json,
     written by scripts/pmc_mfma.sh: one rocprofv3 --pmc pass with SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES and
@@ -383,7 +397,9 @@ def decode_measure(args, rank, world):
         "roofline": {"bound": "hbm", "kernel": "decode step (hipGraph of the whole step: cache reorder + decoder + logits "
                                                 "+ fused top-2K + search bookkeeping)",
                      "achieved": bytes_total / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
-                     "frac": bytes_total / dt / 8e12, "traffic": None,
+                     "frac": bytes_total / dt / 8e12, "traffic": pmc_traffic_decode()[0],
+                     "traffic_unit": "HBM bytes per decode step (FETCH_SIZE x2 + WRITE_SIZE of every kernel of the job, rocprofv3 PMC)",
+                     "traffic_source": pmc_traffic_decode()[1], "traffic_measured_at_commit": pmc_traffic_decode()[2],
                      "algorithmic_bytes_per_step": bytes_total / steps,
                      "note": "achieved = algorithmic bytes of every decode step / wall time of the whole job "
                              "(includes encoder passes and per-batch start-up)"},

@@ -27,7 +27,25 @@ for name in sorted(set(fetch) | set(write)):
     out[name] = {"launches": max(fn, wn),
                  "fetch_bytes_per_launch": 2.0 * 1024.0 * fk / max(fn, 1),
                  "write_bytes_per_launch": 1024.0 * wk / max(wn, 1)}
-import subprocess, datetime
+import datetime
+if "--decode" in sys.argv:
+    # the decode leg: everything the job launched, per decode step (k_beam_prepare runs once per step)
+    steps = max(out.get("k_beam_prepare", {}).get("launches", 0), 1)
+    tot_f = sum(v["fetch_bytes_per_launch"] * v["launches"] for v in out.values())
+    tot_w = sum(v["write_bytes_per_launch"] * v["launches"] for v in out.values())
+    try:
+        commit = open(".head_commit").read().strip()
+    except OSError:
+        commit = None
+    print(json.dumps({"commit": commit, "date": datetime.datetime.utcnow().strftime("%Y-%m-%d"),
+                      "note": "FETCH_SIZE KB x2 (gfx950 correction) + WRITE_SIZE KB x1 of EVERY kernel of bench.py --mode decode "
+                              "--sentences 320 --decode-streams 1 (encoder passes and start-up included), divided by the decode steps",
+                      "decode_steps": steps, "fetch_bytes_per_step": tot_f / steps, "write_bytes_per_step": tot_w / steps,
+                      "bytes_per_step": (tot_f + tot_w) / steps,
+                      "by_kernel_bytes_per_step": {k: (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] / steps
+                                                   for k, v in sorted(out.items(), key=lambda kv: -(kv[1]["fetch_bytes_per_launch"] + kv[1]["write_bytes_per_launch"]) * kv[1]["launches"])[:12]}},
+                     indent=1))
+    sys.exit(0)
 try:
     commit = open(".head_commit").read().strip()   # written by scripts/gpu.sh before the snapshot travels
 except OSError:
