@@ -228,6 +228,16 @@ __global__ void __launch_bounds__(256) k_add_ln_bwd(
 // lane), so 16 rows are in flight per block and the per-row latency chain (two wave reductions)
 // is overlapped 16 ways; column partials are reduced across the 16 waves through LDS, one
 // quantity at a time.
+// make ATTNTRACE=1: block 0 of the wide LayerNorm backward stamps the 100 MHz clock at its phase boundaries (scripts/ln_bwd_trace.py)
+#ifdef ZK_ATTN_TRACE
+__device__ unsigned long long zk_ln_trace_buf[8];
+extern "C" int zk_ln_trace_read(unsigned long long* out8) {
+  return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(zk_ln_trace_buf), sizeof(unsigned long long) * 8);
+}
+#define ZK_LT(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) zk_ln_trace_buf[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ZK_LT(i)
+#endif
 __global__ void __launch_bounds__(1024) k_add_ln_bwd_wide(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ s, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, bf16_t* __restrict__ dsum,
@@ -245,6 +255,7 @@ __global__ void __launch_bounds__(1024) k_add_ln_bwd_wide(
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[q][j] = 0.f;
   float gam[8];
+  ZK_LT(0);
 #pragma unroll
   for (int j = 0; j < 8; ++j) gam[j] = on ? gamma[c + j] : 0.f;
   for (int r = blockIdx.x * 16 + w; r < rows; r += gridDim.x * 16) {
@@ -265,8 +276,10 @@ __global__ void __launch_bounds__(1024) k_add_ln_bwd_wide(
         acc[1][j] += d[j];
       }
     }
+    ZK_LT(1);
     const float mg = wave_sum(sg) * invH;
     const float mgx = wave_sum(sgx) * invH;
+    ZK_LT(2);
     if (on) {
       float o[8], oy[8];
 #pragma unroll
@@ -292,11 +305,13 @@ __global__ void __launch_bounds__(1024) k_add_ln_bwd_wide(
     }
   }
   // the three column partials of the 16 waves through LDS in ONE pass (one barrier instead of six)
+  ZK_LT(3);
 #pragma unroll
   for (int q = 0; q < 3; ++q)
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[q][w][c + j] = acc[q][j];
   __syncthreads();
+  ZK_LT(4);
   for (int e = threadIdx.x; e < 3 * H; e += 1024) {
     const int q = e / H, col = e - q * H;
     float t = 0.f;
@@ -304,6 +319,7 @@ __global__ void __launch_bounds__(1024) k_add_ln_bwd_wide(
     for (int i = 0; i < 16; ++i) t += red[q][i][col];
     partials[((size_t)blockIdx.x * 3 + q) * H + col] = t;
   }
+  ZK_LT(5);
 }
 
 // out_q[c] = sum_b partials[b][q][c]   (q < nq; out pointers may be null)
