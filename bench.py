@@ -3,23 +3,30 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = forward + hand-written backward + (RCCL all-reduce when N>1) + global-norm +
-Adam on ONE synthetic batch per GPU: B=64 sentences x (Ls=64 + Lt=64) tokens = 8192 src+tgt
-tokens per GPU-step (BASELINE.json configs[1]), V=32000, H=512, F=2048, h=8,
-6+6 layers, bf16 MFMA compute / fp32 accumulate / fp32 master weights, dropouts 0.1 and label
-smoothing 0.1 as in the canonical recipe.  Weak scaling: every rank draws its own batch
-(seed 1234+rank).  With --gpus N and no launcher (WORLD_SIZE unset) bench.py starts its N ranks itself
+One "step" = what a user's training loop runs per batch (zero_amd.main.Trainer.step, the call of zero_amd.main.train):
+the batch's ids go host -> HBM through pinned staging slots, ONE launch derives what depends on the ids alone (masks,
+loss weights, the token rows grouped by embedding id), then forward + hand-written backward + (RCCL all-reduce when
+N>1) + global-norm + Adam.  The timed loop feeds a ROTATION of 8 distinct synthetic batches per GPU (seeds
+1234 + rank + 1000 i), each B=64 sentences x (Ls=64 + Lt=64) tokens = 8192 src+tgt tokens per GPU-step
+(BASELINE.json configs[1]), V=32000, H=512, F=2048, h=8, 6+6 layers, bf16 MFMA compute / fp32
+accumulate / fp32 master weights, dropouts 0.1 and label smoothing 0.1 as in the canonical recipe.  Weak scaling: every
+rank draws its own batches.  `static_batch_ms_per_step` in the same line is the old measurement (one pre-uploaded batch
+replayed: the device work alone); --static-batch makes it the headline of a SIDE measurement.  With --gpus N and no launcher (WORLD_SIZE unset) bench.py starts its N ranks itself
 (torch.distributed.run on 127.0.0.1); under torchrun it goes straight on.  Rank 0 prints ONE JSON line
 (contract in the task statement) with these extra objects:
 
-  roofline     -- the dominant kernel (the bf16 MFMA GEMM instance with the largest total
-                  time), achieved = algorithmic FLOPs of its launches / their HIP-event time,
-                  measured in an instrumented eager pass right after the timed region; `traffic` (HBM bytes
-                  per launch) and `mfma_busy` (MFMA-pipe utilisation) come from the newest committed counter
-                  summaries (profiles/*_pmc_traffic.json, *_pmc_mfma.json: separate rocprofv3 --pmc passes,
-                  stamped with their commit);
-  rccl         -- ranks, transport (zk_comm | torch.distributed:<backend>), bucket dtype, row-sparse tables,
-                  bytes per rank and step, the step time without the exchange and the exposed part of it;
+  roofline     -- the dominant kernel CLASS (the class with the largest time per step: splitting or merging template
+                  instances cannot move it), achieved = algorithmic FLOPs of its launches / their HIP-event time,
+                  measured in an instrumented eager pass right after the timed region; `by_class` holds every class
+                  (small-GEMM chain, big GEMMs, attention, LayerNorm, cross entropy, Adam, other) with launches,
+                  us per step, achieved TF or TB/s and the fraction of its bound; `worst_instance` / `by_kernel` the
+                  kernel instances; `traffic` (HBM bytes per launch) and `mfma_busy` (MFMA-pipe utilisation) come from
+                  the newest committed counter summaries (profiles/*_pmc_traffic.json, *_pmc_mfma.json: separate
+                  rocprofv3 --pmc passes, stamped with their commit);
+  rccl         -- ranks, distinct devices seen, and with N > 1 one short timed LEG per exchange mode in the same process
+                  group ({fp32, bf16} buckets x {torch.distributed, zk_comm} x {row-sparse, dense} source-embedding
+                  gradient): ms per step, bytes per rank, exposed ms; the headline is the fastest reference-exact
+                  (fp32) leg unless a bf16 leg wins by more than 3 %;
   decode       -- BASELINE configs[3] (transformer_aan, beam 4, 3000 synthetic sentences, eval batch 32) under
                   the same clock: sentences/s, ms per decode step, launches per step, HBM roofline fraction,
                   batches in flight, its own cpu_baseline (one rank only);
@@ -37,7 +44,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the HIP runtime initialises: see zero_amd/__init__.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the HIP runtime initialises: the decode leg runs 4 batches in flight (zero_amd/evalu.py decode_many)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -53,10 +60,14 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md chip t
 B, LS, LT, V = 64, 64, 64, 32000
 
 
-def synthetic_batch(rank, b=None):
-    """ids ~ U{3..V-1}, last column eos(2), no padding, seed 1234+rank."""
+ROTATION = 8     # distinct batches the timed loop cycles through
+
+
+def synthetic_batch(rank, b=None, i=0):
+    """ids ~ U{3..V-1}, last column eos(2), no padding, seed 1234 + rank + 1000 i (batch i of the
+    rank's rotation; i = 0 is the batch rounds 1-3 replayed)."""
     b = B if b is None else b
-    rng = np.random.default_rng(1234 + rank)
+    rng = np.random.default_rng(1234 + rank + 1000 * i)
     src = rng.integers(3, V, size=(b, LS), dtype=np.int64)
     tgt = rng.integers(3, V, size=(b, LT), dtype=np.int64)
     src[:, -1] = 2
@@ -88,14 +99,30 @@ def train_flops_per_step(hp, b=B, ls=LS, lt=LT, v=V):
     return 3.0 * (enc + dec + logits)
 
 
-class GemmProfiler(object):
-    """HIP-event timing of every GEMM launch of an eager step (events on the launch stream),
-    keyed by the kernel instance that runs (same names rocprofv3 --stats reports)."""
+HBM_PEAK_TBS = 8.0               # same guide: HBM3E peak
 
-    def __init__(self, engine):
-        self.eng = engine
-        self.records = []
-        self._gemm, self._grouped, self._kseg = engine.gemm, engine.gemm_grouped, engine.gemm_kseg
+# kernel classes of the step (roofline.by_class): name -> (bound, what it holds)
+CLASSES = (
+    ("small_gemm_chain", "mfma", "linear forward + dgrad on the 4096-row activations (k_gemm_dlds tiles), grouped K/V "
+                                 "projections, K-segmented d(encoder output)"),
+    ("big_gemms", "mfma", "all weight gradients (one grouped launch of 256x256 tiles), logits forward, dlogits x E"),
+    ("attention", "hbm", "attention forward / backward, one (sentence, head) tile per workgroup (backward incl. the "
+                         "folded o_map dgrad)"),
+    ("layernorm", "hbm", "residual + LayerNorm forward / backward"),
+    ("cross_entropy", "hbm", "label-smoothed cross entropy: fp32 logits in, bf16 dlogits out"),
+    ("adam", "hbm", "TF1 Adam + bf16 shadow refresh + norms, 30 B / parameter"),
+)
+
+
+class LaunchProfiler(object):
+    """HIP-event timing of the launches of an eager step (events on the launch stream).  GEMM launches are keyed by the
+    kernel instance that runs (same names rocprofv3 --stats reports); every wrapped launch is also booked to its
+    kernel CLASS with its algorithmic FLOPs and HBM bytes (roofline.by_class)."""
+
+    def __init__(self, engine, train_op=None):
+        self.eng, self.top = engine, train_op
+        self.records = []          # (class, kernel-or-None, flops, bytes, start, end)
+        self._saved = {}
 
     def _name(self, M, N, K, ta, tb, out_f32, plain):
         code = self.eng.lib.raw("zk_gemm_plan")(M, N, K, out_f32, plain)
@@ -107,18 +134,31 @@ class GemmProfiler(object):
             return "k_gemm_dlds<%d, %d, %d, %s, %s, 4, %d>" % (bm, bn, ns, tf(ta), tf(tb), (code >> 28) & 7)
         return "k_gemm_mfma<%d, %d, %s, %s>" % (bm, bn, tf(ta), tf(tb))
 
+    def _timed(self, cls, name, flops, nbytes, fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = fn()
+        e.record()
+        self.records.append((cls, name, float(flops), float(nbytes), s, e))
+        return out
+
     def __enter__(self):
-        def timed(A, Bm, C, M, N, K, ta, tb, **kw):
+        eng = self.eng
+        keep = self._saved
+        for k in ("gemm", "gemm_grouped", "gemm_kseg", "attn_fwd", "attn_bwd", "add_ln_fwd", "add_ln_bwd", "ce_fused"):
+            keep[k] = getattr(eng, k)
+        esz = lambda m: m.t.element_size()
+
+        def gemm(A, Bm, C, M, N, K, ta, tb, **kw):
             plain = not any(kw.get(k) is not None for k in ("bias", "residual")) and not kw.get("act") \
                 and not kw.get("drop_p")
             name = self._name(M, N, K, ta, tb, 1 if C.t.dtype == torch.float32 else 0, 1 if plain else 0)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            self._gemm(A, Bm, C, M, N, K, ta, tb, **kw)
-            e.record()
-            self.records.append((name, 2.0 * M * N * K, s, e))
+            cls = "big_gemms" if max(N, K) > 8192 else "small_gemm_chain"
+            nbytes = (M * K + K * N) * 2 + M * N * esz(C) + (M * N * 2 if kw.get("residual") is not None else 0) \
+                + (M * N * 2 if kw.get("aux") is not None else 0)
+            return self._timed(cls, name, 2.0 * M * N * K, nbytes, lambda: keep["gemm"](A, Bm, C, M, N, K, ta, tb, **kw))
 
-        def timed_grouped(problems, ta, tb, tile=128):
+        def gemm_grouped(problems, ta, tb, tile=128):
             tf = lambda v: "true" if v else "false"
             bm_, bn_ = (tile, tile) if isinstance(tile, int) else tile[:2]
             if (bm_, bn_) == (256, 256):
@@ -131,23 +171,58 @@ class GemmProfiler(object):
             else:
                 name = "k_gemm_grouped<%d, %d, %d, %s, %s, %d>" % (bm_, bn_, 4 if bm_ == 64 else 3 if max(bm_, bn_) == 256 else 2,
                                                                   tf(ta), tf(tb), 4 if max(bm_, bn_) == 256 else 0)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            self._grouped(problems, ta, tb, tile=tile)
-            e.record()
-            self.records.append((name, sum(2.0 * p[3] * p[4] * p[5] for p in problems), s, e))
-        def timed_kseg(segments, C, M, N, kseg, tb, residual=None):
+            cls = "big_gemms" if max(bm_, bn_) == 256 else "small_gemm_chain"
+            fl = sum(2.0 * p[3] * p[4] * p[5] for p in problems)
+            nbytes = sum((p[3] * p[5] + p[5] * p[4]) * 2 + p[3] * p[4] * esz(p[2]) for p in problems)
+            return self._timed(cls, name, fl, nbytes, lambda: keep["gemm_grouped"](problems, ta, tb, tile=tile))
+
+        def gemm_kseg(segments, C, M, N, kseg, tb, residual=None):
             name = "k_gemm_kseg<64, 64, 4, %s, 4>" % ("true" if tb else "false")
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            self._kseg(segments, C, M, N, kseg, tb, residual=residual)
-            e.record()
-            self.records.append((name, 2.0 * M * N * kseg * len(segments), s, e))
-        self.eng.gemm, self.eng.gemm_grouped, self.eng.gemm_kseg = timed, timed_grouped, timed_kseg
+            n = len(segments)
+            return self._timed("small_gemm_chain", name, 2.0 * M * N * kseg * n, n * (M * kseg + kseg * N) * 2 + M * N * 2,
+                               lambda: keep["gemm_kseg"](segments, C, M, N, kseg, tb, residual=residual))
+
+        def attn_fwd(q, k, v, out, lse, Bn, nh, Lq, Lk, d, **kw):
+            H = nh * d
+            return self._timed("attention", None, 4.0 * Bn * Lq * Lk * H, (2 * Bn * Lq + 2 * Bn * Lk) * H * 2,
+                               lambda: keep["attn_fwd"](q, k, v, out, lse, Bn, nh, Lq, Lk, d, **kw))
+
+        def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, Bn, nh, Lq, Lk, d, **kw):
+            H = nh * d
+            fl, by = 10.0 * Bn * Lq * Lk * H, (4 * Bn * Lq + 4 * Bn * Lk) * H * 2
+            if kw.get("oproj") is not None:        # the folded o_map dgrad: dY . W_o^T formed inside the launch
+                fl += 2.0 * Bn * Lq * H * H
+                by += H * H * 2
+            return self._timed("attention", None, fl, by,
+                               lambda: keep["attn_bwd"](q, k, v, out, dout, lse, dq, dk, dv, Bn, nh, Lq, Lk, d, **kw))
+
+        def add_ln_fwd(x, *a, **kw):
+            return self._timed("layernorm", None, 0.0, 4 * x.rows * x.cols * 2, lambda: keep["add_ln_fwd"](x, *a, **kw))
+
+        def add_ln_bwd(dout, *a, **kw):
+            return self._timed("layernorm", None, 0.0, 4 * dout.rows * dout.cols * 2,
+                               lambda: keep["add_ln_bwd"](dout, *a, **kw))
+
+        def ce_fused(logits, ids, w, ce, dlogits, rows, Vn, ls):
+            return self._timed("cross_entropy", None, 0.0, rows * logits.ld * (4 + (2 if dlogits is not None else 0)),
+                               lambda: keep["ce_fused"](logits, ids, w, ce, dlogits, rows, Vn, ls))
+        for k, fn in (("gemm", gemm), ("gemm_grouped", gemm_grouped), ("gemm_kseg", gemm_kseg), ("attn_fwd", attn_fwd),
+                      ("attn_bwd", attn_bwd), ("add_ln_fwd", add_ln_fwd), ("add_ln_bwd", add_ln_bwd), ("ce_fused", ce_fused)):
+            setattr(eng, k, fn)
+        if self.top is not None:
+            keep["launch_update"] = self.top.launch_update
+            numel = self.top.store.numel
+            self.top.launch_update = lambda *a, **kw: self._timed("adam", None, 0.0, 30.0 * numel,
+                                                                  lambda: keep["launch_update"](*a, **kw))
         return self
 
     def __exit__(self, *a):
-        self.eng.gemm, self.eng.gemm_grouped, self.eng.gemm_kseg = self._gemm, self._grouped, self._kseg
+        for k, fn in self._saved.items():
+            if k == "launch_update":
+                self.top.launch_update = fn
+            else:
+                setattr(self.eng, k, fn)
+        self._saved = {}
 
     def calibrate(self):
         """Cost of one event pair itself: brackets around 1 and around 33 one-thread kernels,
@@ -174,16 +249,30 @@ class GemmProfiler(object):
         b1, b33 = med(b[1]), med(b[33])
         return max(0.0, b1 - (b33 - b1) / 32.0)
 
-    def summary(self):
-        """{kernel: [flops, seconds, launches]}; seconds have the event-pair overhead removed."""
+    def _agg(self, keyfn):
         ovh = self.overhead_s()
         agg = {}
-        for key, fl, s, e in self.records:
-            d = agg.setdefault(key, [0.0, 0.0, 0])
-            d[0] += fl
-            d[1] += max(s.elapsed_time(e) * 1e-3 - ovh, 1e-7)
+        for rec in self.records:
+            key = keyfn(rec)
+            if key is None:
+                continue
+            d = agg.setdefault(key, [0.0, 0.0, 0, 0.0])
+            d[0] += rec[2]
+            d[1] += max(rec[4].elapsed_time(rec[5]) * 1e-3 - ovh, 1e-7)
             d[2] += 1
+            d[3] += rec[3]
         return agg
+
+    def summary(self):
+        """{GEMM kernel instance: [flops, seconds, launches, bytes]}; seconds have the event-pair overhead removed."""
+        return self._agg(lambda r: r[1])
+
+    def classes(self):
+        """{class: [flops, seconds, launches, bytes]}."""
+        return self._agg(lambda r: r[0])
+
+    def instances_of(self, cls):
+        return self._agg(lambda r: r[1] if r[0] == cls else None)
 
 
 def pmc_traffic(kernel):
@@ -473,6 +562,9 @@ def main():
                     help="training batch in sentences per GPU (default 64 = the metric's 4096+4096 tokens; other "
                          "values are SIDE measurements that separate kernel quality from 'problem too small for 256 CUs')")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode leg of the default line")
+    ap.add_argument("--static-batch", action="store_true",
+                    help="SIDE measurement: time the replay of ONE pre-uploaded batch (rounds 1-3's loop) instead of "
+                         "Trainer.step on rotating batches; the default line carries both")
     ap.add_argument("--decode-streams", type=int, default=0,
                     help="decode batches in flight at once (0 = ZERO_HIP_DECODE_STREAMS or its default)")
     args = ap.parse_args()
@@ -501,8 +593,7 @@ def main():
     hp.random_seed = 1234   # identical initial replicas on every rank
     tr = Trainer(hp)
     nb = args.sentences_per_gpu
-    src, tgt = synthetic_batch(rank, nb)
-    tr.prepare_static({"source": src, "target": tgt})
+    feats = [dict(zip(("source", "target"), synthetic_batch(rank, nb, i))) for i in range(ROTATION)]
     tr.core.eng.set_seed(1234 + rank)
     # one rank: the whole step is one hipGraph; several ranks: hipGraph segments between the
     # gradient-bucket hand-offs to RCCL (Trainer._step_segmented)
@@ -513,47 +604,146 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 2)):     # >= 2: eager sizing pass + graph capture
-        tr.step_static(use_graph)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = tr.step_static(use_graph)
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    def timed(step_fn, steps, warm):
+        """warm untimed steps, then EXACTLY `steps` steps between barrier + synchronize; max over ranks (seconds)."""
+        loss = None
+        for i in range(warm):
+            step_fn(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = step_fn(warm + i)
+        barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if world > 1:
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        return float(tmax.cpu()[0]), loss
+
+    def rotating(i):          # the loop a user runs: a NEW batch every step (upload + id prep + step)
+        return tr.step(feats[i % ROTATION], use_graph)
+
+    def static(i):            # one pre-uploaded batch replayed (rounds 1-3's measurement: the device work alone)
+        return tr.step_static(use_graph)
+
+    # ---- multi-GPU: one short timed leg per exchange mode, in this process group (VERDICT r03 item 4)
+    legs, chosen = [], None
     if world > 1:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax.cpu()[0])
+        import threading
+
+        def bail(name):
+            # a leg that does not come back (a collective of the optional direct transport waiting for a rank that never
+            # arrives) must not cost the run its line: print what was measured so far and leave
+            if rank == 0:
+                print(json.dumps(bench_line(chosen, legs, aborted=name)), flush=True)
+            os._exit(0)
+
+        def run_leg(dtype, direct, sparse, guard_s=None):
+            name = "%s/%s/%s" % (dtype, "zk_comm" if direct else "torch", "rows" if sparse else "dense")
+            timer = None
+            if guard_s:
+                timer = threading.Timer(guard_s, bail, args=(name,))
+                timer.daemon = True
+                timer.start()
+            try:
+                ok = parallel.select_transport(direct)
+                if direct and not ok:
+                    legs.append({"leg": name, "skipped": "the direct communicator did not come up on every rank"})
+                    return None
+                tr.reducer.configure(bucket_dtype=dtype, sparse=sparse)
+                dt, loss = timed(rotating, args.steps, 3)
+                leg = {"leg": name, "bucket_dtype": dtype, "transport": "zk_comm" if direct else
+                       "torch.distributed:%s" % torch.distributed.get_backend(), "sparse_rows_exchange": tr.reducer.sparse_keys(),
+                       "ms_per_step": dt / args.steps * 1e3, "bytes_per_rank_per_step": tr.reducer.bytes_last_step,
+                       "reference_exact": dtype == "fp32", "_dt": dt, "_loss": loss}
+                legs.append(leg)
+                return leg
+            finally:
+                if timer is not None:
+                    timer.cancel()
+
+    def bench_line(head, legs, aborted=None):
+        """The JSON object of the run so far (the multi-GPU watchdog prints it early if a later leg hangs)."""
+        dt = head["_dt"]
+        ms = dt / args.steps * 1e3
+        flops = train_flops_per_step(hp, b=nb)
+        out = {
+            "metric": "src+tgt tokens/sec training, Transformer-%s d=%d L=6" % (args.size, hp.hidden_size),
+            "value": world * nb * (LS + LT) * args.steps / dt, "unit": "src+tgt tokens/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"model_name": args.model,
+                       "workload": "Transformer-%s (d=%d, L=6+6, F=%d, h=%d, V=32000) training step, "
+                                   "B=%d x (src 64 + tgt 64) tokens per GPU, dropout %.2f, label_smooth 0.1, "
+                                   "fwd+bwd+allreduce+Adam%s%s" % (args.size, hp.hidden_size, hp.filter_size,
+                                                                   hp.num_heads, nb, args.dropout,
+                                                                   "" if nb == B else " [SIDE MEASUREMENT: not the metric's batch]",
+                                                                   " [SIDE MEASUREMENT: one static batch replayed]" if args.static_batch else ""),
+                       "global_batch_tokens": world * nb * (LS + LT), "parallelism": "dp%d" % world,
+                       "timed_loop": "one pre-uploaded batch replayed (Trainer.step_static)" if args.static_batch else
+                                     "Trainer.step(features) on a rotation of %d distinct batches per GPU: pinned async "
+                                     "id upload + device-side id prep (masks, loss weights, rows grouped by id) + step"
+                                     % ROTATION,
+                       "hip_graph": ("whole step" if world == 1 else "segments between all-reduce buckets") if use_graph else False},
+            "step_mfma_frac": flops / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12),
+        }
+        if legs:
+            out["rccl"] = {"ranks": world, "legs": [{k: v for k, v in l.items() if not k.startswith("_")} for l in legs],
+                           "headline_leg": head.get("leg"), "aborted_leg": aborted}
+        return out
+
+    if world == 1:
+        dt, loss = timed(static if args.static_batch else rotating, args.steps, max(args.warmup, 2))   # >= 2: eager sizing pass + capture
+        chosen = {"_dt": dt, "_loss": loss}
+    else:
+        # reference-exact first (fp32 buckets, torch.distributed = RCCL): the line exists before anything optional runs
+        chosen = run_leg("fp32", False, False)
+        run_leg("fp32", False, True)
+        run_leg("bf16", False, True)
+        run_leg("bf16", False, False)
+        if os.environ.get("ZERO_HIP_BENCH_DIRECT", "1") != "0":
+            run_leg("fp32", True, True, guard_s=120.0)
+            run_leg("bf16", True, True, guard_s=120.0)
+        done = [l for l in legs if "ms_per_step" in l]
+        best32 = min((l for l in done if l["reference_exact"]), key=lambda l: l["ms_per_step"])
+        best16 = min((l for l in done if not l["reference_exact"]), key=lambda l: l["ms_per_step"], default=None)
+        # headline = the fastest reference-exact (fp32) leg unless bf16 buckets win by more than 3 %
+        chosen = best16 if (best16 is not None and best16["ms_per_step"] < 0.97 * best32["ms_per_step"]) else best32
+        # leave the reducer in the chosen mode for what follows
+        parallel.select_transport(chosen["transport"] == "zk_comm")
+        tr.reducer.configure(bucket_dtype=chosen["bucket_dtype"], sparse=bool(chosen["sparse_rows_exchange"]))
+        for _ in range(2):
+            rotating(0)
+    dt, loss = chosen["_dt"], chosen["_loss"]
     loss_v = float(loss.cpu()[0])
     gnorm, pnorm, skipped = tr.train_op.stats()
     step_launches = getattr(tr.core.eng, "last_graph_nodes", None) if (use_graph and world == 1) else None
 
+    # ---- the other timed loop of the same line (one rank): static batch beside rotating batches
+    ms_other = None
+    if world == 1:
+        tr.prepare_static(feats[0])
+        d2, _ = timed(rotating if args.static_batch else static, args.steps, 2)
+        ms_other = d2 / args.steps * 1e3
+
     # ---- what the exchange costs: the same K steps with the gradient buckets NOT handed to RCCL (every rank updates
     # from its local gradients; the replicas drift apart, which is harmless after the timed region).  exposed =
-    # step time - this.  Runs the eager multi-rank path without collectives, so it is an upper bound of the one-rank step.
+    # step time - this.  Runs the multi-rank path without collectives, so it is an upper bound of the one-rank step.
     ms_nocomm = None
     if world > 1:
         tr.reducer.disabled = True
-        for _ in range(2):
-            tr.step_static(use_graph)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            tr.step_static(use_graph)
-        barrier()
-        tn = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(tn, op=torch.distributed.ReduceOp.MAX)
-        ms_nocomm = float(tn.cpu()[0]) / args.steps * 1e3
+        dn, _ = timed(rotating, args.steps, 2)
+        ms_nocomm = dn / args.steps * 1e3
         tr.reducer.disabled = False
 
-    # ---- roofline of the dominant kernel: instrumented eager pass (HIP events per launch).  Every
+    # ---- roofline: instrumented eager pass (HIP events per launch).  Every
     # rank runs it (the step contains collectives); only rank 0 reports.
     # Each pass is enqueued behind a 15 ms spin kernel on the launch stream, so the launches are
     # already queued when they run and the brackets do not contain the host launch latency.
     NPROF = 3
     eng = tr.core.eng
-    with GemmProfiler(eng) as prof:
+    tr.prepare_static(feats[0])
+    with LaunchProfiler(eng, tr.train_op) as prof:
         for _ in range(NPROF):
             torch.cuda.synchronize()
             eng.lib.call("zk_spin", 15000, eng.work_stream.cuda_stream)
@@ -563,63 +753,93 @@ def main():
             eng.lib.call("zk_spin", 15000, eng.work_stream.cuda_stream)   # long enough for the host to enqueue all of it
             prof.calibrate()
     agg = prof.summary()
+    cls_agg = prof.classes()
     barrier()
+    ranks_seen = None
+    if world > 1:
+        # which physical devices the ranks sit on (all-gather of the device UUIDs): SCALE shows N distinct GPUs
+        try:
+            me = str(torch.cuda.get_device_properties(local).uuid)
+        except Exception:      # noqa: BLE001
+            me = "%s:%d" % (os.uname().nodename, local)
+        seen = [None] * world
+        torch.distributed.all_gather_object(seen, me)
+        ranks_seen = {"distinct_devices": len(set(seen)), "device_uuids": seen}
     if rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()
         return
-    tokens = world * nb * (LS + LT) * args.steps
     ms = dt / args.steps * 1e3
     flops = train_flops_per_step(hp, b=nb)
-    out = {
-        "metric": "src+tgt tokens/sec training, Transformer-%s d=%d L=6" % (args.size, hp.hidden_size),
-        "value": tokens / dt, "unit": "src+tgt tokens/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"model_name": args.model,
-                   "workload": "Transformer-%s (d=%d, L=6+6, F=%d, h=%d, V=32000) training step, "
-                               "B=%d x (src 64 + tgt 64) tokens per GPU, dropout %.2f, label_smooth 0.1, "
-                               "fwd+bwd+allreduce+Adam%s" % (args.size, hp.hidden_size, hp.filter_size,
-                                                             hp.num_heads, nb, args.dropout,
-                                                             "" if nb == B else " [SIDE MEASUREMENT: not the metric's batch]"),
-                   "global_batch_tokens": world * nb * (LS + LT), "parallelism": "dp%d" % world,
-                   "hip_graph": ("whole step" if world == 1 else "segments between all-reduce buckets") if use_graph else False},
-        "loss": loss_v, "gnorm": gnorm, "update_skipped": skipped,
-        "step_mfma_frac": flops / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12),
-        "launches_per_step": step_launches,
-    }
+    out = bench_line(chosen, legs)
+    out.update({"loss": loss_v, "gnorm": gnorm, "update_skipped": skipped, "launches_per_step": step_launches})
+    if ms_other is not None:
+        out["static_batch_ms_per_step" if not args.static_batch else "rotating_batches_ms_per_step"] = ms_other
+        rot, sta = (ms, ms_other) if not args.static_batch else (ms_other, ms)
+        out["feed_overhead_frac"] = rot / sta - 1.0          # what the per-batch upload + id prep add to the replayed step
     tp = parallel.transport()
-    out["rccl"] = {"ranks": world,
-                   "transport": None if world == 1 else ("zk_comm" if tp is not None else "torch.distributed:%s"
-                                                         % torch.distributed.get_backend()),
-                   "bucket_dtype": tr.reducer.bucket_dtype_name() if world > 1 else None,
-                   "sparse_rows_exchange": tr.reducer.sparse_keys() if world > 1 else None,
-                   "bytes_per_rank_per_step": tr.reducer.bytes_last_step if world > 1 else 0,
-                   "ms_per_step_without_exchange": ms_nocomm,
-                   "exposed_allreduce_ms": (ms - ms_nocomm) if ms_nocomm is not None else 0.0}
-    # the dominant kernel = the kernel instance with the largest TOTAL time per step (the rule rocprofv3 --stats
-    # ranks by: profiles/*_rocprof_kernel_stats_*.txt); the runner-up is printed beside it because the two
-    # leading GEMM instances are within a few per cent of each other
-    ranked = sorted(agg, key=lambda k: -agg[k][1])
-    key = ranked[0]
+    rc = out.setdefault("rccl", {"ranks": world, "legs": [], "headline_leg": None, "aborted_leg": None})
+    rc.update({"transport": None if world == 1 else ("zk_comm" if tp is not None else "torch.distributed:%s"
+                                                     % torch.distributed.get_backend()),
+               "bucket_dtype": tr.reducer.bucket_dtype_name() if world > 1 else None,
+               "sparse_rows_exchange": tr.reducer.sparse_keys() if world > 1 else None,
+               "bytes_per_rank_per_step": chosen.get("bytes_per_rank_per_step", 0) if world > 1 else 0,
+               "ms_per_step_without_exchange": ms_nocomm,
+               "exposed_allreduce_ms": (ms - ms_nocomm) if ms_nocomm is not None else 0.0,
+               "ranks_seen": ranks_seen})
+    for leg in rc["legs"]:
+        if ms_nocomm is not None and "ms_per_step" in leg:
+            leg["exposed_ms"] = leg["ms_per_step"] - ms_nocomm
+    # ---- kernel classes (roofline.by_class): the headline is the class with the largest time per step, so that it cannot
+    # move by splitting or merging template instances; `other` = the step minus every booked class (embeddings, masks /
+    # id prep, loss, column / LayerNorm-parameter reductions, zero fill, and the gaps between graph nodes)
+    by_class, booked_us = {}, 0.0
+    for cname, bound, what in CLASSES:
+        if cname not in cls_agg:
+            continue
+        fl, sec, cnt, by = cls_agg[cname]
+        us = sec / NPROF * 1e6
+        booked_us += us
+        ent = {"bound": bound, "launches_per_step": cnt // NPROF, "us_per_step": us, "what": what}
+        if bound == "mfma":
+            ent.update({"achieved": fl / sec / 1e12, "unit": "TFLOP/s", "peak": MFMA_BF16_PEAK_TFLOPS,
+                        "frac": fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, "gflop_per_step": fl / NPROF / 1e9})
+        else:
+            ent.update({"achieved": by / sec / 1e12, "unit": "TB/s", "peak": HBM_PEAK_TBS,
+                        "frac": by / sec / 1e12 / HBM_PEAK_TBS, "algorithmic_mb_per_step": by / NPROF / 1e6})
+            if fl:
+                ent["tflops"] = fl / sec / 1e12
+        by_class[cname] = ent
+    by_class["other"] = {"bound": "latency", "us_per_step": max(ms * 1e3 - booked_us, 0.0),
+                         "what": "step time minus the booked classes: embeddings, id prep, loss, column / LayerNorm-"
+                                 "parameter reductions, zero fill, gaps between graph nodes"}
+    top_cls = max((c for c in by_class if c != "other"), key=lambda c: by_class[c]["us_per_step"])
+    inst = prof.instances_of(top_cls)
+    # worst instance of the dominant class = the one with the largest total time
+    ranked = sorted(inst, key=lambda k: -inst[k][1]) if inst else []
+    ranked_all = sorted(agg, key=lambda k: -agg[k][1])
+    key = ranked[0] if ranked else (ranked_all[0] if ranked_all else None)
     traffic, traffic_src, traffic_commit = pmc_traffic(key)
     mfma_busy, mfma_src, mfma_commit = pmc_mfma(key)
-    fl, sec, cnt = agg[key]
+    top = by_class[top_cls]
     tot_fl = sum(v[0] for v in agg.values())
     tot_s = sum(v[1] for v in agg.values())
     out["roofline"] = {
-        "bound": "mfma", "kernel": key, "achieved": fl / sec / 1e12,
-        "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-        "traffic": traffic, "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC)",
+        "bound": top["bound"], "class": top_cls, "kernel": "%s: %s" % (top_cls, top["what"]),
+        "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+        "total_us_per_step": top["us_per_step"], "launches_per_step": top["launches_per_step"],
+        "worst_instance": ({"kernel": key, "frac": agg[key][0] / agg[key][1] / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                            "tflops": agg[key][0] / agg[key][1] / 1e12,
+                            "total_us_per_step": agg[key][1] / NPROF * 1e6, "launches_per_step": agg[key][2] // NPROF,
+                            "avg_launch_us": agg[key][1] / agg[key][2] * 1e6,
+                            "flop_per_launch": agg[key][0] / agg[key][2]} if key in agg else None),
+        "traffic": traffic, "traffic_unit": "bytes/launch of worst_instance (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC)",
         "traffic_source": traffic_src, "traffic_measured_at_commit": traffic_commit,
         "mfma_busy": mfma_busy, "mfma_busy_source": mfma_src, "mfma_busy_measured_at_commit": mfma_commit,
         "step_frac": flops / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12),
-        "runner_up": ({"kernel": ranked[1], "frac": agg[ranked[1]][0] / agg[ranked[1]][1] / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                       "total_us_per_step": agg[ranked[1]][1] / NPROF * 1e6} if len(ranked) > 1 else None),
-        "total_us_per_step": sec / NPROF * 1e6,
-        "event_pair_overhead_us": prof.overhead_s() * 1e6, "launches_per_step": cnt // NPROF, "avg_launch_us": sec / cnt * 1e6,
-        "flop_per_launch": fl / cnt,
+        "event_pair_overhead_us": prof.overhead_s() * 1e6,
         "all_gemm_achieved": tot_fl / tot_s / 1e12, "all_gemm_ms_per_step": tot_s / NPROF * 1e3,
+        "by_class": by_class,
         "by_kernel": {k: {"launches_per_step": v[2] // NPROF, "avg_us": v[1] / v[2] * 1e6,
                           "tflops": v[0] / v[1] / 1e12} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])},
     }

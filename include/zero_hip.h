@@ -221,6 +221,20 @@ int zk_target_stats(const int* ids, float* mask, float* w, int B, int L, float l
 int zk_loss_reduce(const float* ce, const int* ids, float* per_sample, float* loss, int B, int L,
                    zk_stream_t stream);
 int zk_make_mask(const int* ids, float* mask, int n, zk_stream_t stream);
+/* Everything the training step derives from the ids alone, in ONE launch at the head of the (captured) step
+ * (zk_prep.hip): what TensorFlow does on the device for the reference -- the grouping of the token rows by id inside the
+ * gradient of tf.nn.embedding_lookup (tf.IndexedSlices / unsorted_segment_sum, main.py:28), the padding masks
+ * (func.py:372-387) and the loss weights (transformer.py:198-211).
+ *   src_ids int32 [B, Ls], tgt_ids int32 [B, Lt] (NULL: source side only);
+ *   *_rows [B*L], *_seg [B*L + 1], *_uid [B*L], *_n [1]: the inputs of zk_embed_bwd_sorted -- token rows sorted by
+ *   (id, row), i.e. the stable grouping; target side: row (b, t) carries id[b, t-1], rows with t = 0 none
+ *   (transformer.py:99-113).  A NULL *_rows pointer skips that side's sort;
+ *   smask [B, Ls], tmask / tw [B, Lt] fp32 (each optional): as zk_make_mask / zk_target_stats;
+ *   scratch: zk_batch_prep_workspace(B*Ls) + zk_batch_prep_workspace(B*Lt) bytes (0 up to 16384 rows per side). */
+size_t zk_batch_prep_workspace(int rows);
+int zk_batch_prep(const int* src_ids, const int* tgt_ids, int B, int Ls, int Lt, int* src_rows, int* src_seg,
+                  int* src_uid, int* src_n, int* tgt_rows, int* tgt_seg, int* tgt_uid, int* tgt_n, float* smask,
+                  float* tmask, float* tw, float loss_scale, void* scratch, size_t scratch_bytes, zk_stream_t stream);
 int zk_all_equal(const int* ids, int n, int value, int* flag, zk_stream_t stream);
 
 /* ---- transformer_aan.py:92-117,165-192 average attention network (train-time scan + gate) */

@@ -43,3 +43,44 @@ def perturb(Pn, rng):
         if k.endswith("scale"):
             Pn[k] = (1 + rng.normal(0, 0.1, Pn[k].shape)).astype(Pn[k].dtype)
     return Pn
+
+
+def host_sort_arrays(ids, shift):
+    """The checker of zk_batch_prep's grouping (numpy, stable): token rows grouped by embedding id.  shift: row (b, t)
+    carries id[b, t-1]; rows with t == 0 have no embedding.  Returns (rows_sorted, seg, uid)."""
+    ids = np.asarray(ids)
+    B, L = ids.shape
+    flat = ids.reshape(-1)
+    rows = np.arange(B * L, dtype=np.int64)
+    if shift:
+        rows = rows[rows % L != 0]
+        tok = flat[rows - 1]
+    else:
+        tok = flat
+    order = np.argsort(tok, kind="stable")
+    rows_sorted, tok_sorted = rows[order], tok[order]
+    uid, first = np.unique(tok_sorted, return_index=True)
+    seg = np.concatenate([first, [len(tok_sorted)]])
+    return rows_sorted.astype(np.int32), seg.astype(np.int32), uid.astype(np.int32)
+
+
+def device_sort_arrays(eng, name, ids, shift):
+    """zk_batch_prep on one side (GPU tests): the dict zk_embed_bwd_sorted takes.  A shifted side goes in as the target
+    of a one-column dummy source."""
+    import torch
+    from zero_amd.models._core import TransformerCore
+    import types
+    ids = np.asarray(ids)
+    B, L = ids.shape
+    fake = types.SimpleNamespace(eng=eng)
+    dev = eng.buf("t.ids." + name, (B, L), torch.int32)
+    dev.copy_(torch.from_numpy(ids.astype(np.int32)))
+    srt = TransformerCore._sort_buffers(fake, name, B * L)
+    if shift:
+        dummy = eng.buf("t.ids.dummy", (B, 1), torch.int32)
+        dummy.fill_(1)
+        batch = {"B": B, "Ls": 1, "Lt": L, "src": dummy, "tgt": dev, "tgt_sort": srt}
+    else:
+        batch = {"B": B, "Ls": L, "src": dev, "src_sort": srt}
+    eng.batch_prep(batch)
+    return srt

@@ -58,7 +58,10 @@ def beam_hp():
     return hp
 
 
-def beam_sources(n=64, seed=1234):
+BEAM_SENTENCES = 256      # full-size beam fixture (round 4: 256 sentences = 8 eval batches; 64 before)
+
+
+def beam_sources(n=BEAM_SENTENCES, seed=1234):
     """SURVEY.md 8(d) decode input: lengths ~ clipped Normal(28, 14) in [4, 100] + eos, length-sorted, padded."""
     rng = np.random.default_rng(seed)
     lens = np.clip(np.rint(rng.normal(28, 14, n)), 4, 100).astype(int)

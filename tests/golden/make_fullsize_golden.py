@@ -12,7 +12,8 @@ these sizes, so its outputs are committed here and the `-m gpu` tests compare ag
   enc12_synth_seed1234.npz BASELINE configs[4], the part the reference has code for: the same model with
                            num_encoder_layer=12 (transformer.py:35-69)
   big_synth_seed1234.npz   BASELINE configs[2] widths: d=1024, F=4096, h=16, 6+6 layers
-  aan_base_beam.npz        BASELINE configs[3] subset: transformer_aan, d=512, 64 sentences, beam 1 and 4
+  aan_base_beam.npz        BASELINE configs[3] subset: transformer_aan, d=512, 256 sentences, beam 1 and 4, by the fp32
+                           oracle and by the oracle under the bf16 storage model (keys bf16_*)
 
 Parameters are NOT stored (77-242 M floats): both sides regenerate them from
 ``oracle.ref_torch.init_params(hp, model, seed)`` + ``tests.common.perturb`` (numpy Generator streams are
@@ -37,7 +38,7 @@ sys.path.insert(0, ROOT)
 from oracle import ref_torch as rt  # noqa: E402
 from tests.common import perturb  # noqa: E402
 from tests.fullsize import (fullsize_hp, fullsize_batch, fullsize_params, param_probe, SLICES,  # noqa: E402
-                            beam_hp, beam_sources)
+                            beam_hp, beam_sources, BEAM_SENTENCES)
 
 
 def train_fixture(name, **kw):
@@ -68,45 +69,55 @@ def train_fixture(name, **kw):
 
 
 def beam_fixture():
+    """256 sentences (round 4; 64 before), each decoded by the fp32 oracle AND by the oracle under the bf16 storage
+    model (Cfg.store_bf16: the tensors the HIP path keeps as bf16 rounded at the same points).  The second run is what
+    turns a greedy miss from "explained" (a near-tie of the fp32 oracle) into "reproduced": at the step where the HIP
+    search leaves the fp32 oracle's path, tests/test_gpu_fullsize.py checks whether the bf16-storage oracle makes the
+    same choice as the HIP path, or whether the gap is inside the two oracles' own disagreement at that step."""
     hp = beam_hp()
     model = hp.model_name
     Pn = fullsize_params(hp, model)
     P = rt.to_torch(Pn)
-    src = beam_sources()
+    src = beam_sources(BEAM_SENTENCES)
     out = {"param_probe": param_probe(Pn), "source": src}
     enc, dec = rt.infer_fn(hp, P, model)
-    for K in (1, 4):
-        hp.beam_size = K
-        t0 = time.time()
-        seqs, scores, traces = [], [], []
-        for i in range(0, src.shape[0], 32):
-            hp.search_trace = []
-            r = rt.beam_search({"source": torch.tensor(src[i:i + 32])}, enc, dec, hp)
-            seqs.append(np.asarray(r["seq"])); scores.append(np.asarray(r["score"]))
-            traces.append(hp.search_trace)
-            hp.search_trace = None
-        # per-step candidate tables of the oracle: the 2K candidates search.py:172-176 keeps + the runner-up (scores
-        # fp32, flat index beam * V + token), [steps, sentences, 2K+1], steps past a batch's end are NaN / -1.
-        # tests/test_gpu_fullsize.py uses them to measure the score gap at the step where the HIP search first
-        # leaves the oracle's path.
-        T = max(len(t) for t in traces)
-        W = 2 * K + 1
-        tsc = np.full((T, src.shape[0], W), np.nan, dtype=np.float32)
-        tix = np.full((T, src.shape[0], W), -1, dtype=np.int32)
-        for bi, tr in enumerate(traces):
-            for t, (a, b) in enumerate(tr):
-                tsc[t, bi * 32:bi * 32 + a.shape[0], :a.shape[1]] = a
-                tix[t, bi * 32:bi * 32 + a.shape[0], :a.shape[1]] = b
-        out["trace_scores_k%d" % K] = tsc
-        out["trace_idx_k%d" % K] = tix
-        L = max(s.shape[-1] for s in seqs)
-        seqs = [np.pad(s, [(0, 0)] * (s.ndim - 1) + [(0, L - s.shape[-1])]) for s in seqs]
-        out["seqs_k%d" % K] = np.concatenate(seqs, 0).astype(np.int32)
-        out["scores_k%d" % K] = np.concatenate(scores, 0).astype(np.float32)
-        # margin between the best two candidates is what decides whether bf16 can flip a token: keep the
-        # best-hypothesis score gap to the runner-up for the report
-        print("beam %d: %s (%.0f s)" % (K, out["seqs_k%d" % K].shape, time.time() - t0), flush=True)
+    for prefix, flag in (("", False), ("bf16_", True)):
+        for K in (1, 4):
+            hp.beam_size = K
+            t0 = time.time()
+            seqs, scores, traces = [], [], []
+            for i in range(0, src.shape[0], 32):
+                hp.search_trace = []
+                rt.Cfg.store_bf16 = flag
+                try:
+                    r = rt.beam_search({"source": torch.tensor(src[i:i + 32])}, enc, dec, hp)
+                finally:
+                    rt.Cfg.store_bf16 = False
+                seqs.append(np.asarray(r["seq"])); scores.append(np.asarray(r["score"]))
+                traces.append(hp.search_trace)
+                hp.search_trace = None
+            # per-step candidate tables of the oracle: the 2K candidates search.py:172-176 keeps + the runner-up (scores
+            # fp32, flat index beam * V + token), [steps, sentences, 2K+1], steps past a batch's end are NaN / -1.
+            # tests/test_gpu_fullsize.py uses them to measure the score gap at the step where the HIP search first
+            # leaves the oracle's path.
+            T = max(len(t) for t in traces)
+            W = 2 * K + 1
+            tsc = np.full((T, src.shape[0], W), np.nan, dtype=np.float32)
+            tix = np.full((T, src.shape[0], W), -1, dtype=np.int32)
+            for bi, tr in enumerate(traces):
+                for t, (a, b) in enumerate(tr):
+                    tsc[t, bi * 32:bi * 32 + a.shape[0], :a.shape[1]] = a
+                    tix[t, bi * 32:bi * 32 + a.shape[0], :a.shape[1]] = b
+            out[prefix + "trace_scores_k%d" % K] = tsc
+            out[prefix + "trace_idx_k%d" % K] = tix
+            L = max(s.shape[-1] for s in seqs)
+            seqs = [np.pad(s, [(0, 0)] * (s.ndim - 1) + [(0, L - s.shape[-1])]) for s in seqs]
+            out[prefix + "seqs_k%d" % K] = np.concatenate(seqs, 0).astype(np.int32)
+            out[prefix + "scores_k%d" % K] = np.concatenate(scores, 0).astype(np.float32)
+            print("%sbeam %d: %s (%.0f s)" % (prefix, K, out[prefix + "seqs_k%d" % K].shape, time.time() - t0), flush=True)
+            np.savez_compressed(os.path.join(HERE, "aan_base_beam.partial.npz"), **out)
     np.savez_compressed(os.path.join(HERE, "aan_base_beam.npz"), **out)
+    os.remove(os.path.join(HERE, "aan_base_beam.partial.npz"))
 
 
 if __name__ == "__main__":

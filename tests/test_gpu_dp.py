@@ -170,8 +170,26 @@ def test_bench_contract_with_two_ranks_on_one_gpu():
     assert out["value"] > 0 and np.isfinite(out["loss"]) and not out["update_skipped"]
     assert "roofline" in out and "cpu_baseline" not in out          # the CPU baseline is a 1-rank field
     assert out["rccl"]["ranks"] == 2 and out["rccl"]["transport"] == "torch.distributed:gloo"
-    assert out["rccl"]["bucket_dtype"] == "bf16" and out["rccl"]["sparse_rows_exchange"] == ["src_embedding"]
     assert out["rccl"]["ms_per_step_without_exchange"] > 0 and "exposed_allreduce_ms" in out["rccl"]
+    # one timed leg per exchange mode in the same process group; the reference-exact (fp32) legs first; the direct
+    # transport cannot come up with two ranks on one device and must be reported as skipped, not hang
+    legs = out["rccl"]["legs"]
+    names = [l["leg"] for l in legs]
+    assert names[:4] == ["fp32/torch/dense", "fp32/torch/rows", "bf16/torch/rows", "bf16/torch/dense"], names
+    assert all(l["ms_per_step"] > 0 and "exposed_ms" in l for l in legs[:4])
+    assert legs[1]["sparse_rows_exchange"] == ["src_embedding"] and legs[0]["sparse_rows_exchange"] == []
+    assert legs[1]["bytes_per_rank_per_step"] < legs[0]["bytes_per_rank_per_step"]
+    assert legs[2]["bytes_per_rank_per_step"] < legs[1]["bytes_per_rank_per_step"]
+    assert [l.get("skipped") is not None for l in legs[4:]] == [True, True], legs[4:]
+    assert out["rccl"]["headline_leg"] in names[:4] and out["rccl"]["aborted_leg"] is None
+    head = [l for l in legs if l["leg"] == out["rccl"]["headline_leg"]][0]
+    assert abs(head["ms_per_step"] - out["ms_per_step"]) < 1e-9
+    # fp32 unless bf16 wins by more than 3 %
+    best32 = min(l["ms_per_step"] for l in legs[:2])
+    assert head["reference_exact"] or head["ms_per_step"] < 0.97 * best32
+    assert out["rccl"]["bucket_dtype"] == head["bucket_dtype"]
+    assert out["rccl"]["ranks_seen"]["distinct_devices"] == 1 and len(out["rccl"]["ranks_seen"]["device_uuids"]) == 2
+    assert "Trainer.step" in out["config"]["timed_loop"]
 
 
 def test_bench_spawns_its_own_ranks_when_not_under_a_launcher():

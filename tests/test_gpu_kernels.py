@@ -430,8 +430,7 @@ def test_embed_bwd_sorted_long_runs_of_one_id(H):
     """A frequent id (the eos of every sentence) owns a long run of rows: runs of 1 .. 150 rows (more than the 64
     indices one coalesced load brings in, not a multiple of the 8-row batches), with dropout regenerated per element;
     the sums must equal the serial walk's (fp32, same order) -- checked against an index_add in float64."""
-    import types
-    from zero_amd.models._core import TransformerCore
+    from tests.common import device_sort_arrays
     e = eng()
     B, L, V = 30, 17, 40
     rng = np.random.default_rng(11)
@@ -440,8 +439,7 @@ def test_embed_bwd_sorted_long_runs_of_one_id(H):
     ids_np[:10, 3:] = 7                    # a run of 140
     ids_np[rng.random((B, L)) < 0.2] = 5   # and a scattered one
     dout = rand_bf(B * L, H, seed=7)
-    fake = types.SimpleNamespace(eng=e)
-    srt = TransformerCore._sort_arrays(fake, "runs%d" % H, ids_np, False)
+    srt = device_sort_arrays(e, "runs%d" % H, ids_np, False)
     dtab = torch.zeros(V, H, device="cuda")
     e.embed_bwd_sorted(srt, mat(dout), dtab, H, accumulate=False)
     torch.cuda.synchronize()
@@ -452,18 +450,16 @@ def test_embed_bwd_sorted_long_runs_of_one_id(H):
 
 
 def test_embed_bwd_sorted_and_bias_colsum():
-    # atomics-free table gradient (host-sorted rows) + shared-bias gradient with skipped rows
-    import types
-    from zero_amd.models._core import TransformerCore
+    # atomics-free table gradient (rows grouped by id on the device) + shared-bias gradient with skipped rows
+    from tests.common import device_sort_arrays
     e = eng()
     B, L, H, V = 4, 9, 64, 23
     rng = np.random.default_rng(3)
     ids_np = rng.integers(0, V, (B, L))
     ids = torch.tensor(ids_np, dtype=torch.int32, device="cuda")
     dout = rand_bf(B * L, H, seed=5)
-    fake = types.SimpleNamespace(eng=e)
     for shift in (False, True):
-        srt = TransformerCore._sort_arrays(fake, "t%d" % shift, ids_np, shift)
+        srt = device_sort_arrays(e, "t%d" % shift, ids_np, shift)
         for acc in (False, True):
             dtab = torch.full((V, H), 0.5 if acc else 0.0, device="cuda")
             e.embed_bwd_sorted(srt, mat(dout), dtab, H, accumulate=acc)
@@ -479,6 +475,42 @@ def test_embed_bwd_sorted_and_bias_colsum():
             assert rel_err(dtab, ref_t) < 1e-5
             ref_b = g.reshape(-1, H).sum(0) + (3.0 if acc else 0.0)
             assert rel_err(dbias, ref_b) < 1e-5
+
+
+@pytest.mark.parametrize("B,L,V", [(64, 64, 32000), (1, 1, 5), (3, 2, 7), (50, 100, 32000), (79, 63, 200),
+                                   (160, 128, 70000), (5, 1, 9)])
+def test_batch_prep_groups_rows_like_the_stable_host_sort(B, L, V):
+    """zk_batch_prep against numpy's stable argsort + unique (what rounds 1-3 computed on the host): rows, group
+    boundaries, ids and the group count must be IDENTICAL -- so that zk_embed_bwd_sorted adds the rows of an id in the
+    same order and the table gradient is bit-identical.  Sizes: the bench batch (4096 rows: keys in 32 KB of LDS),
+    5000 rows (the 128-KB instantiation), 20480 rows (keys in the global scratch), degenerate shapes; eos runs;
+    ids beyond 16 bits.  Also the masks / loss weights against zk_make_mask / zk_target_stats' definitions."""
+    from tests.common import host_sort_arrays, device_sort_arrays
+    e = eng()
+    rng = np.random.default_rng(B * 1000 + L)
+    ids = rng.integers(0, V, (B, L))
+    ids[:, -1] = 2
+    if L > 4:
+        ids[::3, L // 2:] = 0              # ragged rows: padding
+    for shift in (False, True):
+        srt = device_sort_arrays(e, "p%d" % shift, ids, shift)
+        torch.cuda.synchronize()
+        rows, seg, uid = host_sort_arrays(ids, shift)
+        n = int(srt["n"].cpu()[0])
+        assert n == len(uid)
+        assert np.array_equal(srt["uid"].cpu().numpy()[:n], uid)
+        assert np.array_equal(srt["seg"].cpu().numpy()[:n + 1], seg)
+        assert np.array_equal(srt["rows"].cpu().numpy()[:len(rows)], rows)
+    # masks and loss weights in the same launch
+    dev_s = e.buf("t.m.src", (B, L), torch.int32); dev_s.copy_(torch.from_numpy(ids.astype(np.int32)))
+    batch = {"B": B, "Ls": L, "Lt": L, "src": dev_s, "tgt": dev_s, "smask": e.buf("t.m.sm", (B, L), torch.float32),
+             "tmask": e.buf("t.m.tm", (B, L), torch.float32), "tw": e.buf("t.m.tw", (B, L), torch.float32), "tw_scale": 2.0}
+    e.batch_prep(batch)
+    torch.cuda.synchronize()
+    m = (ids != 0).astype(np.float32)
+    assert np.array_equal(batch["smask"].cpu().numpy(), m) and np.array_equal(batch["tmask"].cpu().numpy(), m)
+    w = 2.0 * m / (m.sum(1, keepdims=True) * B)
+    assert np.allclose(batch["tw"].cpu().numpy(), w, rtol=1e-6, atol=0)
 
 
 def test_timing_signal_closed_form():

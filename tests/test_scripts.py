@@ -31,7 +31,7 @@ def test_step_budget_enumerates_the_step():
     # operands of the one weight-gradient launch: every X [T, in] and dY [T, out] once + the fp32 gradients
     assert 1.45e9 < wg["hbm"] < 1.52e9 and abs(wg["flops"] - 495e9) < 2e9
     floor = sum(r["floor"] for r in rows.values())
-    assert 3.7e-3 < floor < 4.1e-3
+    assert 2.9e-3 < floor < 3.4e-3                            # with the measured 1.5-us kernel boundary as the fixed cost (5 us: 3.9 ms)
     for r in rows.values():                                  # a floor can never be below the fixed cost of its launches
         assert r["floor"] >= r["fixed"]
     # four times the batch: the floor must grow by less than 4x (launch floors amortised) and more than 2x

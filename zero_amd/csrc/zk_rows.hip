@@ -7,7 +7,8 @@
 // rank order.  All ranks therefore compute bit-identical tables; with fp32 payloads the result equals the dense sum
 // all-reduce up to fp32 summation order.
 //
-// Payload of one rank: [ids int32 x R][rows x R x H] with R a capacity agreed at start-up; unused slots carry id -1.
+// Payload of one rank: [ids int32 x R][rows x R x H] with R a capacity agreed at start-up; unused slots carry id -1;
+// a batch with more than R distinct ids poisons its payload with NaN (k_rows_pack) -- a loud, collective failure.
 // HBM-bound, R x H elements per launch (4096 x 512: 8 MB read, 4-8 MB written).
 #include "zk_common.h"
 
@@ -30,7 +31,13 @@ __global__ void __launch_bounds__(256) k_rows_pack(float* __restrict__ dtable, c
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  const int nu = min(*n_uniq_dev, R);
+  const int n_all = *n_uniq_dev;
+  const int nu = min(n_all, R);
+  // More distinct ids than slots: the rows beyond R cannot travel.  No rank can tell the others in time (they are
+  // already in, or about to enter, the all-gather), so the failure is made loud ON THE DEVICE: slot 0 carries NaN, every
+  // rank adds it into its table, the gradient norm is NaN on every rank and the loop stops at its NaN check
+  // (main.py:316-319) instead of training on a silently truncated gradient -- or hanging on a rank-local exception.
+  const bool overflow = n_all > R;
   for (int u = wave; u < R; u += nwaves) {
     const bool live = u < nu;
     const int id = live ? uid[u] : -1;
@@ -41,6 +48,7 @@ __global__ void __launch_bounds__(256) k_rows_pack(float* __restrict__ dtable, c
       if (live) {
         v = *reinterpret_cast<const float4*>(src + c);
         if (clear_rows) *reinterpret_cast<float4*>(src + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (overflow && u == 0) v.x = __uint_as_float(0x7fc00000u);
       }
       if (BF16)
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(rows) + (size_t)u * H + c) =

@@ -67,6 +67,20 @@ def decode_streams(default=4):
         return default
 
 
+_HWQ_WARNED = []
+
+
+def _warn_hw_queues(streams):
+    try:
+        q = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        return
+    if int(streams) > 1 and q < int(streams) + 2 and not _HWQ_WARNED:
+        _HWQ_WARNED.append(1)
+        log.warning("decode_many: %d batches in flight on GPU_MAX_HW_QUEUES=%d hardware queues -- lanes that share a "
+                    "queue serialise; export GPU_MAX_HW_QUEUES=8 before the first HIP call of the process", int(streams), q)
+
+
 def decode_many(items, work, streams=None, each_lane=False):
     """``[work(item) for item in items]`` with up to ``streams`` items in flight at once, each on its own execution
     lane (zero_amd.models._factory.lane: own HIP stream, scratch and cache buffers, captured step graphs; the variable
@@ -82,7 +96,15 @@ def decode_many(items, work, streams=None, each_lane=False):
     measurement); the results of lane 0 are returned.
 
     Host side: one worker thread per lane (ctypes calls and stream / event waits release the GIL; the Python work
-    per decode step is ~30 us against ~360 us of device time)."""
+    per decode step is ~30 us against ~360 us of device time).
+
+    Hardware queues: HIP maps the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4),
+    round-robin; two lanes that share a queue run one after the other again (4 lanes: 2740 sentences/s on 4 queues,
+    3340 on 8, profiles/r03_bench_decode_models.jsonl).  The runtime reads the variable once, at its first HIP call,
+    so it is the HOST PROGRAM's to set before that (``zero_amd.run`` and ``bench.py`` export GPU_MAX_HW_QUEUES=8 at
+    start-up unless the user chose a value); a library import must not change the process environment behind the
+    host's back, so this function only warns when it finds fewer queues than lanes + 2."""
+    _warn_hw_queues(decode_streams() if streams is None else streams)
     import threading
     streams = decode_streams() if streams is None else max(1, int(streams))
     if each_lane:

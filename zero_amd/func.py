@@ -153,6 +153,30 @@ class Engine(object):
     def set_seed(self, value):
         self.seed.fill_(int(value))
 
+    def h2d(self, dst, arr):
+        """Small host array -> device tensor `dst` (same element count) as an ASYNCHRONOUS copy on the current stream
+        through a ring of pinned staging slots (zero_amd/utils/queuer.py PinnedRing): the training loop never blocks on
+        an upload unless it runs more than a few steps ahead of the device."""
+        if getattr(self, "_pins", None) is None:
+            from zero_amd.utils.queuer import PinnedRing
+            self._pins = PinnedRing(self.device)
+        self._pins.put(dst, arr)
+
+    def batch_prep(self, batch):
+        """zk_batch_prep on an uploaded batch (TransformerCore.upload): masks, loss weights, rows grouped by id."""
+        B, Ls, Lt = batch["B"], batch["Ls"], batch.get("Lt", 0)
+        tgt = batch.get("tgt")
+        ss, ts = batch.get("src_sort"), batch.get("tgt_sort")
+        nbytes = (self.lib.query("zk_batch_prep_workspace", B * Ls) if ss else 0) + \
+            (self.lib.query("zk_batch_prep_workspace", B * Lt) if ts else 0)
+        ws = self.buf("prep.scratch", (nbytes,), torch.uint8) if nbytes else None
+        p = lambda d, k: d[k].data_ptr() if d else None
+        self.lib.call("zk_batch_prep", batch["src"].data_ptr(), hip.ptr(tgt), B, Ls, Lt,
+                      p(ss, "rows"), p(ss, "seg"), p(ss, "uid"), p(ss, "n"),
+                      p(ts, "rows"), p(ts, "seg"), p(ts, "uid"), p(ts, "n"),
+                      hip.ptr(batch.get("smask")), hip.ptr(batch.get("tmask")), hip.ptr(batch.get("tw")),
+                      float(batch.get("tw_scale", 1.0)), hip.ptr(ws), nbytes, self.stream)
+
     def zero(self, t):
         self.lib.call("zk_zero", t.data_ptr(), t.numel() * t.element_size(), self.stream)
 

@@ -179,8 +179,17 @@ class Trainer(object):
         if not use_graph or features["source"].shape[0] == 0 or self.core.use_side:
             return self.micro_step(features)
         if hp.update_cycle == 1:
-            self.prepare_static(features)
-            return self.step_static()
+            # upload (asynchronous copies through pinned slots + the id-dependent launch, TransformerCore.upload) and
+            # the captured step on ONE stream: no host wait and no cross-stream edge between them
+            eng = self.core.eng
+            cur = torch.cuda.current_stream(eng.device)
+            ws = eng.work_stream
+            ws.wait_stream(cur)
+            with torch.cuda.stream(ws):
+                self.prepare_static(features)
+                loss = self._step_static(True)
+            cur.wait_stream(ws)
+            return loss
         eng = self.core.eng
         cur = torch.cuda.current_stream(eng.device)
         ws = eng.work_stream

@@ -488,36 +488,46 @@ class TransformerCore(object):
 
     # ------------------------------------------------------------------ whole model
     def upload(self, source, target=None, trim=True):
-        """Host ids -> device int32 (after remove_invalid_seq).  Returns dict of
-        static device buffers + dims."""
+        """Host ids -> device int32 (after remove_invalid_seq) through pinned staging slots (asynchronous copies on the
+        current stream), then ONE launch (zk_batch_prep) for everything that depends on the ids alone: source mask,
+        target mask + loss weights and -- with a target -- the grouping of the token rows by embedding id that the
+        atomics-free embedding gradient reads (rounds 1-3 sorted on the host, two numpy sorts + ~10 blocking copies per
+        batch; the reference's TensorFlow does it on the device, main.py:28).  Returns dict of static device buffers +
+        dims."""
         e = self.eng
         src = np.asarray(source.cpu() if torch.is_tensor(source) else source)
         if trim:
             src = trim_columns(src)
         B, Ls = src.shape
         ids_s = e.buf("ids.src", (B, Ls), torch.int32)
-        ids_s.copy_(torch.from_numpy(src.astype(np.int32)), non_blocking=False)
+        e.h2d(ids_s, src)
         out = {"B": B, "Ls": Ls, "src": ids_s}
-        # quantities that depend on the ids alone are computed here, once per batch, instead of inside every (replayed)
-        # step: the source mask now, the target mask / loss weights below
-        if B > 0:
-            out["smask"] = e.buf("smask", (B, Ls), F32)
-            e.make_mask(ids_s, out["smask"], B * Ls)
-        if target is not None:
-            out["src_sort"] = self._sort_arrays("src", src, False)
+        ids_t, Lt = None, 0
         if target is not None:
             tgt = np.asarray(target.cpu() if torch.is_tensor(target) else target)
             if trim:
                 tgt = trim_columns(tgt)
             Lt = tgt.shape[1]
             ids_t = e.buf("ids.tgt", (B, Lt), torch.int32)
-            ids_t.copy_(torch.from_numpy(tgt.astype(np.int32)), non_blocking=False)
-            out.update({"Lt": Lt, "tgt": ids_t, "tgt_sort": self._sort_arrays("tgt", tgt, True)})
-            if B > 0:
+            e.h2d(ids_t, tgt)
+            out.update({"Lt": Lt, "tgt": ids_t, "src_sort": self._sort_buffers("src", B * Ls),
+                        "tgt_sort": self._sort_buffers("tgt", B * Lt)})
+        if B > 0:
+            out["smask"] = e.buf("smask", (B, Ls), F32)
+            if ids_t is not None:
                 out["tmask"], out["tw"] = e.buf("tmask", (B, Lt), F32), e.buf("tw", (B, Lt), F32)
                 out["tw_scale"] = float(self.hp.loss_scale)
-                e.target_stats(ids_t, out["tmask"], out["tw"], B, Lt, out["tw_scale"])
+            e.batch_prep(out)
         return out
+
+    def _sort_buffers(self, name, T):
+        """Device arrays zk_batch_prep fills for zk_embed_bwd_sorted: token rows grouped by embedding id (`rows`), group
+        boundaries (`seg`), the id of each group (`uid`), their number (`n`, a device int)."""
+        e = self.eng
+        return {"rows": e.buf("sort.%s.rows" % name, (T,), torch.int32),
+                "seg": e.buf("sort.%s.seg" % name, (T + 1,), torch.int32),
+                "uid": e.buf("sort.%s.uid" % name, (T,), torch.int32),
+                "n": e.buf("sort.%s.n" % name, (1,), torch.int32), "max_uniq": T}
 
     def lookup_tables(self):
         """[(variable, 'src_sort' | 'tgt_sort')]: embedding tables whose ONLY use is the lookup of one side's ids, so
@@ -530,33 +540,6 @@ class TransformerCore(object):
         if self.tgt_emb != self.soft_emb and self.tgt_emb != self.src_emb:
             out.append((self.tgt_emb, "tgt_sort"))
         return out
-
-    def _sort_arrays(self, name, ids, shift):
-        """Group the token rows by embedding id on the host (it owns the ids), for the atomics-free
-        embedding-gradient kernel.  shift: row (b,t) uses id[b,t-1]; rows with t==0 have no embedding."""
-        e = self.eng
-        B, L = ids.shape
-        T = B * L
-        flat = ids.reshape(-1)
-        rows = np.arange(T, dtype=np.int64)
-        if shift:
-            rows = rows[rows % L != 0]
-            tok = flat[rows - 1]
-        else:
-            tok = flat
-        order = np.argsort(tok, kind="stable")
-        rows_sorted, tok_sorted = rows[order], tok[order]
-        uid, first = np.unique(tok_sorted, return_index=True)
-        seg = np.concatenate([first, [len(tok_sorted)]])
-        d = {"rows": e.buf("sort.%s.rows" % name, (T,), torch.int32),
-             "seg": e.buf("sort.%s.seg" % name, (T + 1,), torch.int32),
-             "uid": e.buf("sort.%s.uid" % name, (T,), torch.int32),
-             "n": e.buf("sort.%s.n" % name, (1,), torch.int32), "max_uniq": T}
-        d["rows"][:len(rows_sorted)].copy_(torch.from_numpy(rows_sorted.astype(np.int32)))
-        d["seg"][:len(seg)].copy_(torch.from_numpy(seg.astype(np.int32)))
-        d["uid"][:len(uid)].copy_(torch.from_numpy(uid.astype(np.int32)))
-        d["n"].copy_(torch.tensor([len(uid)], dtype=torch.int32))
-        return d
 
     def encode(self, batch, train, save):
         """transformer.py:15-84."""

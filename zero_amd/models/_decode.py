@@ -96,8 +96,11 @@ def adopt_graphs(state, book, temperature, forbid_value, noise):
     import os
     core = state["_core"]
     e = core.eng
+    # (zk_dec_group(-1) = the rows-per-workgroup geometry in force: graphs captured with several batches in flight --
+    # 16 rows per workgroup -- must not be adopted by a single-stream decode, nor the reverse)
+    from zero_amd import hip as _hip
     key = (state["B"], state["K"], state["Ls"], state["Tmax"], book is not None, float(temperature),
-           float(forbid_value), bool(noise))
+           float(forbid_value), bool(noise), int(_hip.lib().raw("zk_dec_group")(-1)))
     state["_gkey"] = key
     if os.environ.get("ZERO_HIP_DECODE_GRAPH_CACHE", "1") == "0":
         return
@@ -445,10 +448,22 @@ def make_infer_fns(params, model_name):
             state["graphs"][parity] = "warm"
             body()
         elif g == "warm":
-            # capture: python-side ping-pong bookkeeping runs during capture exactly as in an eager call
-            state["graphs"][parity] = e.graph_capture(body)
+            # capture: python-side ping-pong bookkeeping runs during capture exactly as in an eager call.  A capture
+            # that fails (an allocation met it: a workspace grew, or another thread allocated -- ROCm 7 invalidates
+            # captures across threads) must not cost the evaluation, and the training run with it: undo the
+            # python-side flip and run this step eagerly; the next step of this parity tries again.
+            pp0 = state["_pp"]
+            try:
+                gexec = e.graph_capture(body)
+            except Exception:
+                torch.cuda.synchronize(e.device)
+                state["_pp"] = pp0
+                state.bind_caches()
+                body()
+                return
+            state["graphs"][parity] = gexec
             core._decode_step_launches = e.last_graph_nodes
-            e.graph_launch(state["graphs"][parity])
+            e.graph_launch(gexec)
         else:
             state["_pp"] = 1 - state["_pp"]           # replay: redo the python-side pointer flip
             state.bind_caches()

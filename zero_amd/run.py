@@ -162,6 +162,13 @@ def main(argv=None):
     ap.add_argument("--name", default="model")
     ap.add_argument("--mode", default="train")
     args = ap.parse_args(argv)
+    if "GPU_MAX_HW_QUEUES" not in os.environ:
+        # this module is the host PROGRAM (the counterpart of the reference's run.py), so the process environment is
+        # its to set, and it does so out loud: evaluation decodes several batches at once on execution lanes, one HIP
+        # stream each, and on the runtime's default of 4 hardware queues lanes that share a queue serialise
+        # (zero_amd/evalu.py decode_many).  Read by the HIP runtime at its first call -- nothing has touched it yet.
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+        print("zero_amd.run: GPU_MAX_HW_QUEUES=8 exported for this process (unset; see zero_amd/evalu.py decode_many)")
     params = setup(build_params(args.parameters, args.config))
     from zero_amd.main import Trainer, tower_infer_graph, tower_score_graph
     from zero_amd.models import model, load_all

@@ -37,10 +37,15 @@ def beam_search(features, encoding_fn, decoding_fn, params):
     the legacy default stream)."""
     if params.search_mode == "cache":
         from zero_amd.models._factory import get_core
-        eng = get_core(params, params.model_name).eng
-        cur = torch.cuda.current_stream(eng.device)
-        ws = eng.work_stream
-        ws.wait_stream(cur)
+        from zero_amd.models._decode import STARTUP_LOCK
+        # a lane's first batch builds its core (device allocations), its work stream and an event here: under the
+        # start-up lock, like every other allocation of a batch's start-up -- another lane may be inside a stream
+        # capture, which an allocation in this thread would invalidate (models/_decode.py)
+        with STARTUP_LOCK:
+            eng = get_core(params, params.model_name).eng
+            cur = torch.cuda.current_stream(eng.device)
+            ws = eng.work_stream
+            ws.wait_stream(cur)
         with torch.cuda.stream(ws):
             out = _beam_search(features, encoding_fn, decoding_fn, params)
         cur.wait_stream(ws)

@@ -32,10 +32,10 @@ class TrainOp(object):
         self.hyper = torch.zeros(12, dtype=torch.float32, device=dev)
         if getattr(params, "safe_nan", False) and getattr(params, "gnorm_upper_bound", 0.) > 0.:
             self.hyper[9] = float(params.gnorm_upper_bound)      # main.py:325-329: update skipped above it
-        self.hyper_host = torch.zeros(6, dtype=torch.float32).pin_memory() if dev.type == "cuda" \
-            else torch.zeros(6, dtype=torch.float32)
-        self.ema_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" \
-            else torch.zeros(1, dtype=torch.float32)
+        # per-step host scalars travel through pinned staging slots (a single pinned buffer rewritten every step raced
+        # with its own asynchronous copy once the host ran a few steps ahead of the device)
+        from zero_amd.utils.queuer import PinnedRing
+        self._pins = PinnedRing(dev)
         self.ema = None          # tf.train.ExponentialMovingAverage shadows (cycle.py:113-127), on demand
         self._backup = None
         if getattr(params, "ema_decay", -1.) > 0.:
@@ -83,14 +83,13 @@ class TrainOp(object):
         clip = hp.clip_grad_norm or None
         clip = float(clip) if isinstance(clip, float) else 0.0
         scale = 1.0 / (float(world) * float(hp.loss_scale) * float(self.count + 1))
-        h = self.hyper_host
-        h[0], h[1], h[2], h[3], h[4], h[5] = lr_t, hp.beta1, hp.beta2, hp.epsilon, scale, clip
-        self.hyper[:6].copy_(h, non_blocking=True)
+        import numpy as _np
+        self._pins.put(self.hyper[:6], _np.array([lr_t, hp.beta1, hp.beta2, hp.epsilon, scale, clip], dtype=_np.float32))
         if self.ema is not None:
             # num_updates = global_step after this update (ema.apply runs under train_op's control
             # dependency, cycle.py:116-118): d = min(decay, (1 + n) / (10 + n))
-            self.ema_host[0] = min(float(hp.ema_decay), (1.0 + t) / (10.0 + t))
-            self.hyper[8:9].copy_(self.ema_host, non_blocking=True)
+            self._pins.put(self.hyper[8:9], _np.array([min(float(hp.ema_decay), (1.0 + t) / (10.0 + t))],
+                                                      dtype=_np.float32))
         return scale
 
     def launch_update(self, scale, advance_seed=True):

@@ -164,75 +164,106 @@ def _all_ranks_ok(ok):
 
 
 def _transport_self_test(t):
-    """One small sum all-reduce and one all-gather through the direct communicator, checked against the values
-    every rank can compute locally (rank-dependent integers, exact in fp32 / bf16)."""
+    """One small sum all-reduce (fp32), one (bf16) and one all-gather through the direct communicator, checked against
+    values every rank can compute locally (rank-dependent integers, exact in fp32 / bf16).  EVERY rank issues all
+    three collectives whatever it saw in the earlier ones (a rank that returned early on a mismatch would leave the
+    others blocked in the next collective); the verdicts are combined afterwards."""
     r, w = t.rank, t.world
     dev = t.device
     x = torch.arange(1024, dtype=torch.float32, device=dev) % 7 + float(r)
     t.all_reduce(x).synchronize()
     want = (torch.arange(1024, dtype=torch.float32, device=dev) % 7) * w + float(w * (w - 1) // 2)
-    if not torch.equal(x, want):
-        return False
+    ok = bool(torch.equal(x, want))
     xb = torch.full((512,), float(r + 1), dtype=torch.bfloat16, device=dev)
     t.all_reduce(xb).synchronize()
-    if float(xb.float().max()) != float(w * (w + 1) // 2) or float(xb.float().min()) != float(w * (w + 1) // 2):
-        return False
+    ok = ok and float(xb.float().max()) == float(w * (w + 1) // 2) and float(xb.float().min()) == float(w * (w + 1) // 2)
     send = torch.full((256,), r, dtype=torch.int32, device=dev)
     recv = torch.empty(256 * w, dtype=torch.int32, device=dev)
     t.all_gather(send, recv).synchronize()
-    return bool(torch.equal(recv.view(w, 256)[:, 0].cpu(), torch.arange(w, dtype=torch.int32)))
+    return ok and bool(torch.equal(recv.view(w, 256)[:, 0].cpu(), torch.arange(w, dtype=torch.int32)))
+
+
+def _bring_up_direct(log):
+    """Collective attempt to create the direct communicator: (RcclComm or None, reason).  Order of the collectives is
+    the same on every rank whatever happens locally: availability AND -> id broadcast + ncclCommInitRank -> success AND
+    (before any collective of the new communicator) -> self-test (all three collectives on every rank) -> verdict AND."""
+    from zero_amd import hip
+    avail = bool(hip.lib().raw("zk_comm_available")())
+    if not _all_ranks_ok(avail):
+        return None, "librccl not loadable on every rank"
+    t, why = None, None
+    try:
+        t = RcclComm()
+    except Exception as exc:      # noqa: BLE001 -- never lose the job to the optional transport
+        why = repr(exc)
+    if not _all_ranks_ok(t is not None):
+        why = why or "another rank failed to create its communicator"
+    else:
+        try:
+            good = _transport_self_test(t)
+        except Exception as exc:  # noqa: BLE001
+            good, why = False, repr(exc)
+        if not _all_ranks_ok(good):
+            why = why or "self-test mismatch (here or on another rank)"
+    if why is not None and t is not None:
+        try:
+            t.close()
+        except Exception:         # noqa: BLE001
+            pass
+        t = None
+    return t, why
 
 
 def transport():
     """Which library call carries the gradient buckets.  Decided by rule, once per process, COLLECTIVELY:
 
-      ZERO_HIP_COMM=auto (default)  the C-ABI communicator (``zk_comm_*`` = RCCL on a side HIP stream of its own) when
+      ZERO_HIP_COMM=torch (default) ``torch.distributed`` (whose ``nccl`` backend IS RCCL on ROCm; the only choice for
+                                    gloo and for several ranks sharing one GPU).  The default until a multi-GPU run
+                                    has carried gradients over the direct transport: `bench.py --gpus N` times both
+                                    and prints them side by side (``rccl.legs``).
+      ZERO_HIP_COMM=auto            the C-ABI communicator (``zk_comm_*`` = RCCL on a side HIP stream of its own) when
                                     librccl is loadable, world > 1 and every rank owns its own GPU (torch.distributed
                                     backend ``nccl``); otherwise ``torch.distributed``
       ZERO_HIP_COMM=rccl            the same attempt, also with a single process
-      ZERO_HIP_COMM=torch           ``torch.distributed`` (whose ``nccl`` backend IS RCCL on ROCm; the only choice for
-                                    gloo and for several ranks sharing one GPU)
 
     After the local attempt (dlopen, ncclCommInitRank, a small all-reduce / all-gather self-test) the ranks
     all-reduce(MIN) their success flags over the torch.distributed group: the direct transport is used only if it came
     up on EVERY rank; otherwise every rank destroys its communicator and logs the fallback.  Both transports issue the
     same sum all-reduces / all-gathers of the same buffers."""
     if "t" not in _TRANSPORT:
-        import logging
-        log = logging.getLogger("zero_amd")
-        mode = os.environ.get("ZERO_HIP_COMM", "auto").lower()
-        world = world_size()
-        distinct = dist.is_initialized() and dist.get_backend() == "nccl" and os.environ.get("ZERO_SINGLE_DEVICE", "0") == "0"
-        want = torch.cuda.is_available() and ((mode == "auto" and world > 1 and distinct) or
-                                              (mode == "rccl" and (world == 1 or distinct)))
-        t, why = None, None
-        if want:
-            # step 1, before any collective of the attempt: is librccl loadable on EVERY rank?  (a rank that fails here
-            # must not leave the others waiting in the id broadcast)
-            from zero_amd import hip
-            avail = bool(hip.lib().raw("zk_comm_available")())
-            if not _all_ranks_ok(avail):
-                why = "librccl not loadable on every rank"
-            else:
-                try:
-                    t = RcclComm()
-                    if not _transport_self_test(t):
-                        why = "self-test mismatch"
-                except Exception as exc:      # noqa: BLE001 -- never lose the job to the optional transport
-                    why = repr(exc)
-                if not _all_ranks_ok(t is not None and why is None):
-                    why = why or "another rank failed to set it up"
-            if why is not None:
-                if t is not None:
-                    try:
-                        t.close()
-                    except Exception:     # noqa: BLE001
-                        pass
-                t = None
-                log.warning("direct RCCL transport (zk_comm) NOT used on rank %d: %s; every rank falls back to "
-                            "torch.distributed", rank(), why)
-        _TRANSPORT["t"] = t
-    return _TRANSPORT["t"]
+        mode = os.environ.get("ZERO_HIP_COMM", "torch").lower()
+        _TRANSPORT["t"] = _decide_transport(mode)
+    return _TRANSPORT["t"] if _TRANSPORT.get("use", True) else None
+
+
+def _decide_transport(mode):
+    import logging
+    log = logging.getLogger("zero_amd")
+    world = world_size()
+    distinct = dist.is_initialized() and dist.get_backend() == "nccl" and os.environ.get("ZERO_SINGLE_DEVICE", "0") == "0"
+    want = torch.cuda.is_available() and ((mode == "auto" and world > 1 and distinct) or
+                                          (mode == "rccl" and (world == 1 or distinct)))
+    if not want:
+        return None
+    t, why = _bring_up_direct(log)
+    if why is not None:
+        log.warning("direct RCCL transport (zk_comm) NOT used on rank %d: %s; every rank falls back to "
+                    "torch.distributed", rank(), why)
+    return t
+
+
+def select_transport(direct):
+    """Measurement aid (bench.py --gpus N): switch between the direct communicator and torch.distributed at run time.
+    COLLECTIVE: every rank must call it with the same argument at the same point.  direct=True brings the communicator
+    up on first use (collectively, with the self-test); returns whether the direct transport is now in use."""
+    if direct:
+        if _TRANSPORT.get("t") is None:
+            _TRANSPORT["t"] = _decide_transport("auto")
+        _TRANSPORT["use"] = True
+        return _TRANSPORT["t"] is not None
+    _TRANSPORT.setdefault("t", None)
+    _TRANSPORT["use"] = False
+    return False
 
 
 def barrier():
@@ -275,9 +306,10 @@ class GradientAllReduce(object):
     """Bucketed, overlapped exchange of ``store.grad`` between the data-parallel ranks.
 
     * dense buckets: sum all-reduce of contiguous ranges of the flat fp32 gradient buffer, handed over as the backward
-      finishes them.  ``bucket_dtype`` bf16 (default on GPUs; ``ZERO_HIP_BUCKET_DTYPE=fp32`` restores the fp32
-      exchange): the range is cast into a bf16 staging buffer, all-reduced there (half the bytes on xGMI) and cast back
-      into the fp32 gradient buffer before its Adam pass, which accumulates in fp32 as before.
+      finishes them.  ``bucket_dtype`` fp32 by default -- the reference's tower average is fp32
+      (utils/parallel.py:184-196); ``ZERO_HIP_BUCKET_DTYPE=bf16`` (opt-in): the range is cast into a bf16 staging
+      buffer, all-reduced there (half the bytes on xGMI) and cast back into the fp32 gradient buffer before its Adam
+      pass, which accumulates in fp32 as before.
     * row-sparse tables (``set_sparse``): an embedding table that is only ever looked up receives gradient rows for
       the <= T ids of the batch; the ranks all-gather their packed (ids, rows) payloads and every rank adds all N
       payloads into its zeroed table in rank order (utils/parallel.py:142-181: IndexedSlices concatenated across the
@@ -294,7 +326,10 @@ class GradientAllReduce(object):
         on_gpu = store.grad.is_cuda
         self.ops = ops if ops is not None else (HipBucketOps() if on_gpu else None)
         if bucket_dtype is None:
-            bucket_dtype = os.environ.get("ZERO_HIP_BUCKET_DTYPE", "bf16" if self.ops is not None else "fp32")
+            # fp32 = what the reference averages (utils/parallel.py:184-196) and the default; bf16 halves the bytes
+            # on xGMI and is opt-in until a multi-GPU run shows that the fp32 exchange is exposed (bench.py --gpus N
+            # times both: rccl.legs)
+            bucket_dtype = os.environ.get("ZERO_HIP_BUCKET_DTYPE", "fp32")
         if isinstance(bucket_dtype, str):
             bucket_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[bucket_dtype.lower()]
         if bucket_dtype == torch.bfloat16 and self.ops is None:
@@ -329,15 +364,37 @@ class GradientAllReduce(object):
             # a ring all-gather moves (N-1) x R rows per rank, a ring all-reduce of the dense table 2 (N-1)/N x V rows:
             # the payloads only pay while R < 2 V / N (same decision on every rank: it depends on the limits alone)
             return
-        if rows is not None and rows > R:
-            # every rank sizes its payload from the same batching limits; a batch beyond them cannot be exchanged
-            # row-sparsely and the other ranks cannot be told in time: fail loudly rather than drop gradient rows
-            raise ValueError("sparse exchange of %s: the batch has %d token rows, payload capacity is %d "
-                             "(set ZERO_HIP_SPARSE_EMBED=0 or raise token_size)" % (key, rows, R))
+        if rows is not None and rows > R and not getattr(self, "_warned_rows", False):
+            # The payload holds one slot per DISTINCT id, the batch has `rows` token rows: more rows than slots is fine
+            # as long as the ids repeat enough.  Whether they do is only known on the device (zk_batch_prep counts
+            # them), and a rank must not raise on its own -- the others would wait in the all-gather for ever.  So the
+            # decision is the device's: zk_rows_pack poisons its payload with NaN when the count exceeds the capacity,
+            # every rank adds the same NaN into its table, and every rank stops at its next NaN check (main.py:316-319).
+            import logging
+            logging.getLogger("zero_amd").warning(
+                "sparse exchange of %s: the batch has %d token rows, payload capacity is %d distinct ids; if the batch "
+                "touches more ids than that the gradient is poisoned with NaN on every rank (raise token_size or set "
+                "ZERO_HIP_SPARSE_EMBED=0)", key, rows, R)
+            self._warned_rows = True
         self._sparse[key] = {"table": table, "uid": uid, "n": n_dev, "R": R, "H": H, "V": V}
 
     def clear_sparse(self):
         self._sparse = {}
+
+    def configure(self, bucket_dtype=None, sparse=None):
+        """Measurement aid (bench.py --gpus N: one process group times several exchange modes).  COLLECTIVE in effect:
+        every rank must make the same change between two steps (nothing may be pending)."""
+        assert not self.pending and self._open is None, "exchange in flight"
+        if bucket_dtype is not None:
+            bucket_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[bucket_dtype] \
+                if isinstance(bucket_dtype, str) else bucket_dtype
+            if bucket_dtype == torch.bfloat16 and self.ops is None:
+                raise ValueError("bf16 gradient buckets need the device-side cast ops")
+            self.bucket_dtype = bucket_dtype
+        if sparse is not None:
+            self.sparse_enabled = bool(sparse) and self.ops is not None
+            if not self.sparse_enabled:
+                self._sparse = {}
 
     def _buf(self, key, kind, words, device):
         b = self._payload.get((key, kind))

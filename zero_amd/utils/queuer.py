@@ -105,6 +105,58 @@ class EnQueuer(object):
             w.join()
 
 
+class PinnedRing(object):
+    """Pinned staging slots for the small per-step uploads of the training loop (token ids, optimiser scalars): ``put``
+    copies a host array into the next slot and enqueues an ASYNCHRONOUS copy to its device tensor on the current
+    stream.  A slot is reused only after the copy that last read it has completed (one event per slot), so the host may
+    run up to ``slots`` uploads ahead of the device and blocks -- bounded run-ahead -- beyond that.  (Pageable
+    ``tensor.copy_`` uploads, which rounds 1-3 used, stall the host until the device has caught up: every step.)"""
+
+    def __init__(self, device, slots=8):
+        import torch
+        self._torch = torch
+        self.device = torch.device(device)
+        self._n = slots
+        self._events = [None] * slots
+        self._bufs = {}            # dtype -> pinned [slots, capacity]: every slot is allocated at once (an allocation
+        self._i = 0                # later on could meet another thread's stream capture, zero_amd/evalu.py lanes)
+
+    def _slot_view(self, i, dtype, n):
+        torch = self._torch
+        buf = self._bufs.get(dtype)
+        if buf is None or buf.shape[1] < n:
+            for ev in self._events:                   # the old buffers may still be read by copies in flight
+                if ev is not None:
+                    ev.synchronize()
+            cap = max(4096, 1 << (int(n) - 1).bit_length())
+            buf = torch.empty((self._n, cap), dtype=dtype).pin_memory()
+            self._bufs[dtype] = buf
+        return buf[i, :n]
+
+    def put(self, dst, arr):
+        torch = self._torch
+        src = torch.as_tensor(arr).reshape(-1)
+        flat = dst.reshape(-1)
+        n = src.numel()
+        assert flat.numel() == n, (flat.numel(), n)
+        if n == 0:
+            return
+        if self.device.type != "cuda":
+            flat.copy_(src)
+            return
+        i = self._i
+        self._i = (i + 1) % self._n
+        if self._events[i] is not None:
+            self._events[i].synchronize()             # the copy that last read this slot is done
+        view = self._slot_view(i, dst.dtype, n)
+        view.copy_(src)                               # host-side conversion (int64 ids -> int32) into pinned memory
+        flat.copy_(view, non_blocking=True)
+        ev = self._events[i]
+        if ev is None:
+            ev = self._events[i] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+
+
 class DeviceFeeder(object):
     """Double-buffered pinned H2D feed of ``{"src","tgt",...}`` batches (the role of TF1's
     feed_dict copy, main.py:287-294).  Yields ``(batch, device_batch)`` where ``device_batch``
