@@ -145,7 +145,8 @@ class LaunchProfiler(object):
     def __enter__(self):
         eng = self.eng
         keep = self._saved
-        for k in ("gemm", "gemm_grouped", "gemm_kseg", "attn_fwd", "attn_bwd", "add_ln_fwd", "add_ln_bwd", "ce_fused"):
+        for k in ("gemm", "gemm_grouped", "gemm_kseg", "attn_fwd", "attn_bwd", "add_ln_fwd", "add_ln_bwd", "ce_fused",
+                  "gemm_ln", "ln_fold", "add_ln_bwd_lazy"):      # (the last three: the EXPERIMENTS-only LayerNorm-free forward)
             keep[k] = getattr(eng, k)
         esz = lambda m: m.t.element_size()
 
@@ -203,11 +204,27 @@ class LaunchProfiler(object):
             return self._timed("layernorm", None, 0.0, 4 * dout.rows * dout.cols * 2,
                                lambda: keep["add_ln_bwd"](dout, *a, **kw))
 
+        def gemm_ln(A, Bm, C, M, N, K, bias, np_, **kw):
+            # the linear layers of the LayerNorm-free forward (zk_gemm_ln): same tile kernels, LayerNorm in the epilogue
+            name = self._name(M, N, K, 0, 0, 0, 0)
+            nbytes = (M * K + K * N) * 2 + M * N * 2 + (M * N * 2 if kw.get("residual") is not None else 0)
+            return self._timed("small_gemm_chain", name, 2.0 * M * N * K, nbytes,
+                               lambda: keep["gemm_ln"](A, Bm, C, M, N, K, bias, np_, **kw))
+
+        def ln_fold(problems):
+            nbytes = sum(p[0].numel() * 6 for p in problems)
+            return self._timed("layernorm", None, 0.0, nbytes, lambda: keep["ln_fold"](problems))
+
+        def add_ln_bwd_lazy(dout, *a, **kw):
+            return self._timed("layernorm", None, 0.0, 5 * dout.rows * dout.cols * 2,
+                               lambda: keep["add_ln_bwd_lazy"](dout, *a, **kw))
+
         def ce_fused(logits, ids, w, ce, dlogits, rows, Vn, ls):
             return self._timed("cross_entropy", None, 0.0, rows * logits.ld * (4 + (2 if dlogits is not None else 0)),
                                lambda: keep["ce_fused"](logits, ids, w, ce, dlogits, rows, Vn, ls))
         for k, fn in (("gemm", gemm), ("gemm_grouped", gemm_grouped), ("gemm_kseg", gemm_kseg), ("attn_fwd", attn_fwd),
-                      ("attn_bwd", attn_bwd), ("add_ln_fwd", add_ln_fwd), ("add_ln_bwd", add_ln_bwd), ("ce_fused", ce_fused)):
+                      ("attn_bwd", attn_bwd), ("add_ln_fwd", add_ln_fwd), ("add_ln_bwd", add_ln_bwd), ("ce_fused", ce_fused),
+                      ("gemm_ln", gemm_ln), ("ln_fold", ln_fold), ("add_ln_bwd_lazy", add_ln_bwd_lazy)):
             setattr(eng, k, fn)
         if self.top is not None:
             keep["launch_update"] = self.top.launch_update

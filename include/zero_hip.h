@@ -174,6 +174,33 @@ int zk_embed_bwd_sorted(const int* rows_sorted, const int* seg, const int* uid, 
                         int max_uniq, const void* dout, float* dtable, int H, float scale, int accumulate,
                         float drop_p, const uint64_t* seed, uint32_t sid, zk_stream_t stream);
 
+#ifdef ZK_EXPERIMENTS   /* measured: no gain over the LayerNorm launches (profiles/r04_negative_results.txt): make EXPERIMENTS=1 */
+/* ---- round 4: residual + LayerNorm WITHOUT a launch of its own (func.py:289-303, 321-324 in the post-LN order of
+ * transformer.py:57-58; the forward half of the 30 LayerNorm launches of a Transformer-base step).
+ *   zk_gemm_ln   forward linear (func.py:14-65; A [M,K] x B [K,N], bf16 out) with the LayerNorm around it folded into
+ *                the epilogue.  PRODUCER (stat_out != NULL): C = residual + dropout(A B + bias), the sub-layer's
+ *                un-normalised sum, and stat_out [M][N/64][2] = {sum, M2} of every (row, 64-column group) of the
+ *                stored values.  res_part != NULL: the residual operand is the previous sub-layer's un-normalised sum
+ *                and is normalised on the fly (res_part [M][np][2], res_gamma / res_beta [N]).  CONSUMER
+ *                (in_c != NULL): A is an un-normalised sum (statistics in_part [M][np][2], np = K/64), B the weight
+ *                with gamma folded in, in_c / bias the vectors of zk_ln_fold:
+ *                C = act(rstd (A B - mu in_c) + bias), then dropout.  act: 0 none, 1 ReLU.
+ *   zk_ln_fold   per step, from the fp32 masters: Wf = bf16(gamma_k W_kn), c_n = sum_k Wf_kn, d_n = sum_k beta_k W_kn
+ *                + b_n for every consumer weight; descs = DEVICE array of {W, gamma, beta, b, Wf, c, d pointers; int K, N,
+ *                block_start (running sum of N/64), pad} (64 bytes), total_blocks = that sum.
+ *   zk_add_ln_bwd_lazy   the backward of such a LayerNorm: statistics from `part`; y_out (optional) receives
+ *                LN(sum) as zk_add_ln_fwd would have written it -- the X operand of the consumer's weight gradient. */
+int zk_gemm_ln(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, const float* bias,
+               const void* residual, int ldr, int act, float drop_p, const uint64_t* seed, uint32_t sid, float* stat_out,
+               const float* in_part, const float* in_c, const float* res_part, const float* res_gamma,
+               const float* res_beta, int np, float eps, zk_stream_t stream);
+int zk_ln_fold(const void* descs, int nprob, int total_blocks, zk_stream_t stream);
+int zk_add_ln_bwd_lazy(const void* dout, const void* sum, const float* part, const float* gamma, const float* beta,
+                       void* y_out, void* dsum, void* dy, float* dgamma, float* dbeta, float* dbias_prev, int rows, int H,
+                       float eps, float drop_p, const uint64_t* seed, uint32_t sid, void* workspace, size_t ws_bytes,
+                       int defer_reduce, zk_stream_t stream);
+#endif /* ZK_EXPERIMENTS */
+
 /* ---- func.py:321-324 residual_fn + func.py:289-303 layer_norm (post-LN, eps inside
  * rsqrt): out = LN(x + dropout(y)).  sum_out/mean/rstd are saved for the backward.    */
 int zk_add_ln_fwd(const void* x, const void* y, const float* gamma, const float* beta, void* out,
@@ -230,11 +257,18 @@ int zk_make_mask(const int* ids, float* mask, int n, zk_stream_t stream);
  *   (id, row), i.e. the stable grouping; target side: row (b, t) carries id[b, t-1], rows with t = 0 none
  *   (transformer.py:99-113).  A NULL *_rows pointer skips that side's sort;
  *   smask [B, Ls], tmask / tw [B, Lt] fp32 (each optional): as zk_make_mask / zk_target_stats;
+ *   max_id: every id is below it (the larger vocabulary; 0 = unknown): lets the sort run on 32-bit keys (id << bits(rows)
+ *   | row) when they fit, ~3x faster than the 64-bit network;
  *   scratch: zk_batch_prep_workspace(B*Ls) + zk_batch_prep_workspace(B*Lt) bytes (0 up to 16384 rows per side). */
 size_t zk_batch_prep_workspace(int rows);
 int zk_batch_prep(const int* src_ids, const int* tgt_ids, int B, int Ls, int Lt, int* src_rows, int* src_seg,
                   int* src_uid, int* src_n, int* tgt_rows, int* tgt_seg, int* tgt_uid, int* tgt_n, float* smask,
-                  float* tmask, float* tw, float loss_scale, void* scratch, size_t scratch_bytes, zk_stream_t stream);
+                  float* tmask, float* tw, float loss_scale, int max_id, void* scratch, size_t scratch_bytes,
+                  zk_stream_t stream);
+/* Up to 16 small device-to-device copies in one launch (host arrays of device pointers / byte counts, 4-byte granularity):
+ * the id-dependent arrays of the next batch move from the staging buffers a side stream filled (upload + zk_batch_prep,
+ * overlapping the previous step) into the static buffers of the captured step. */
+int zk_copy_many(void* const* dsts, const void* const* srcs, const size_t* nbytes, int n, zk_stream_t stream);
 int zk_all_equal(const int* ids, int n, int value, int* flag, zk_stream_t stream);
 
 /* ---- transformer_aan.py:92-117,165-192 average attention network (train-time scan + gate) */

@@ -64,7 +64,7 @@ def host_sort_arrays(ids, shift):
     return rows_sorted.astype(np.int32), seg.astype(np.int32), uid.astype(np.int32)
 
 
-def device_sort_arrays(eng, name, ids, shift):
+def device_sort_arrays(eng, name, ids, shift, max_id=0):
     """zk_batch_prep on one side (GPU tests): the dict zk_embed_bwd_sorted takes.  A shifted side goes in as the target
     of a one-column dummy source."""
     import torch
@@ -79,8 +79,8 @@ def device_sort_arrays(eng, name, ids, shift):
     if shift:
         dummy = eng.buf("t.ids.dummy", (B, 1), torch.int32)
         dummy.fill_(1)
-        batch = {"B": B, "Ls": 1, "Lt": L, "src": dummy, "tgt": dev, "tgt_sort": srt}
+        batch = {"B": B, "Ls": 1, "Lt": L, "src": dummy, "tgt": dev, "tgt_sort": srt, "max_id": max_id}
     else:
-        batch = {"B": B, "Ls": L, "src": dev, "src_sort": srt}
+        batch = {"B": B, "Ls": L, "src": dev, "src_sort": srt, "max_id": max_id}
     eng.batch_prep(batch)
     return srt

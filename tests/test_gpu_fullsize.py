@@ -12,16 +12,21 @@ Tolerances:
   gradients       compared with the oracle run under the bf16 STORAGE model (Cfg.store_bf16: every tensor the
                   HIP path keeps as bf16 is rounded at the same point, arithmetic fp32), so that what is left is
                   accumulation order and the few roundings the model does not place identically:
-                  global norm within 1e-2, EVERY variable's gradient norm within 2e-2 (measured <= 0.8 %, also
+                  global norm within 1e-2, EVERY variable's gradient norm within 1.5e-2 (measured <= 1.1 %, also
                   for the variables whose gradient is 1e-4 of the largest), slices within SLICE_TOL relative L2;
                   against the pure fp32 oracle the global norm must stay within 3e-2;
-  beam search     no sharpening of the random model: >= 60 of the 64 best hypotheses token-exact over their
-                  whole length (~80 decode steps each; measured 62/64 and 63/64), >= 90 % agree on the first 8
+  beam search     no sharpening of the random model, 256 sentences (round 4; 64 before): >= 240 of the 256 best
+                  hypotheses token-exact over their whole length (~80 decode steps each), >= 90 % agree on the first 8
                   tokens, the scores of the token-exact ones within 0.3 absolute (length-normalised sums of
                   ~80 log-probabilities, around -85: 3.5e-3 relative), and EVERY non-exact hypothesis must leave the
-                  oracle's path at a step where the oracle's own score gap between the two candidates is below
-                  2e-3 |score| (a near-tie no two bf16 implementations order alike); the per-divergence margins are
-                  written to gpurun_out/fullsize_beam_k*.json (copied to profiles/r03_parity_fullsize_beam_k*.json).
+                  fp32 oracle's path at a step where (a) the oracle's own score gap between the two candidates is below
+                  2e-3 |score| AND (b) the miss is REPRODUCED or BRACKETED by the oracle itself run under the bf16
+                  storage model (fixture keys bf16_*: the same restatement with the tensors the HIP path keeps as bf16
+                  rounded at the same points): either the bf16-storage oracle puts the HIP path's candidate at that
+                  rank too, or the fp32 gap is no larger than the distance the two oracles' own scores moved apart at
+                  that step (the two restatements of the SAME algorithm disagree by more than what separates the
+                  candidates); the per-divergence margins are written to gpurun_out/fullsize_beam_k*.json (copied to
+                  profiles/r04_parity_fullsize_beam_k*.json).
 """
 import copy
 import json
@@ -51,7 +56,8 @@ REPORT = os.path.join(os.path.dirname(GOLD), "..", "gpurun_out")
 # ffn enlarge, fourth encoder layer's o_map) sit 17 / 26 sub-layers deep in the backward chain: measured 3.5 % / 2.4 %
 # with the 6-layer encoder, 7.2 % / 3.3 % behind the 12-layer encoder (its output already differs by bf16 noise).
 # Slices 1 / 2 (last decoder layer, target embedding) are at the start of it: 0.5 % / 0.1 %.
-SLICE_TOL = (1e-1, 2e-2, 2e-2, 1e-1, 1e-1)
+SLICE_TOL = (8e-2, 2e-2, 2e-2, 8e-2, 8e-2)      # round 4: 1e-1 -> 8e-2 (measured 3.0-6.6 %, attributed to the bf16 shadow
+                                                  # weights in profiles/r03_grad_noise_attribution.json)
 
 
 def _report(name, obj):
@@ -106,8 +112,8 @@ def _train_case(name, **kw):
     assert rep["per_sample_rel_max"] < 2e-3, rep
     assert abs(gnorm - rep["gnorm_bf16model"]) / rep["gnorm_bf16model"] < 1e-2, rep
     assert abs(gnorm - rep["gnorm_f32"]) / rep["gnorm_f32"] < 3e-2, rep
-    assert rep["var_norm_rel_max_large"] < 2e-2, rep
-    assert rep["var_norm_rel_max_small"] < 2e-2, rep
+    assert rep["var_norm_rel_max_large"] < 1.5e-2, rep       # round 4: 2e-2 -> 1.5e-2 (measured <= 1.1 %)
+    assert rep["var_norm_rel_max_small"] < 1.5e-2, rep
     for i, tol in enumerate(SLICE_TOL):
         if "slice%d_rel_vs_bf16" % i in rep:
             assert rep["slice%d_rel_vs_bf16" % i] < tol, rep
@@ -151,15 +157,56 @@ def _first_divergence(hip_trace, ref_scores, ref_idx, s_local, s_global, K):
             where = np.nonzero(r_idx == h_idx[j])[0]
             gap = float(r_sc[j] - r_sc[int(where[0])]) if len(where) else None
             return {"step": t, "rank": j, "oracle_flat_index": int(r_idx[j]), "hip_flat_index": int(h_idx[j]),
-                    "oracle_score": float(r_sc[j]), "oracle_gap": gap,
+                    "oracle_score": float(r_sc[j]), "oracle_gap": gap, "oracle_pos_of_hip_candidate": int(where[0]) if len(where) else None,
                     "hip_gap_seen": float(hip_trace[t][0][s_local][j] - hip_trace[t][0][s_local][min(j + 1, 2 * K - 1)]),
                     "tolerance": NEAR_TIE_REL * max(abs(float(r_sc[j])), 1.0)}
     return None
 
 
+def _bf16_oracle_view(fx, K, d, s_global):
+    """What the oracle under the bf16 STORAGE model did at the step where the HIP search left the fp32 oracle's path
+    (fixture keys bf16_trace_*).  Two facts, per divergence:
+      bf16_oracle_same_choice          the bf16-storage oracle -- still on the common path up to that step -- has the
+                                       HIP path's candidate at that rank: the miss is REPRODUCED by the checker itself;
+      inside_oracle_pair_disagreement  the fp32 oracle's gap between the two candidates is no larger than the largest
+                                       distance between the two oracles' scores of the SAME candidates at that step
+                                       (x 2: either candidate may move): the two restatements of one algorithm move
+                                       these scores by more than what separates them."""
+    if d.get("step") is None or d.get("oracle_gap") is None:
+        return {}
+    t, j = d["step"], d["rank"]
+    f_sc, f_ix = fx["trace_scores_k%d" % K][:, s_global], fx["trace_idx_k%d" % K][:, s_global]
+    b_sc, b_ix = fx["bf16_trace_scores_k%d" % K][:, s_global], fx["bf16_trace_idx_k%d" % K][:, s_global]
+    out = {}
+    if t >= b_ix.shape[0] or b_ix[t, 0] < 0:
+        return {"bf16_oracle_on_common_path": False}
+    # the bf16-storage oracle is on the common path while its KEPT candidates (the first 2K) of all earlier steps
+    # equal the fp32 oracle's
+    first_off = next((u for u in range(t) if not np.array_equal(f_ix[u, :2 * K], b_ix[u, :2 * K])), None)
+    common = first_off is None
+    out["bf16_oracle_on_common_path"] = bool(common)
+    if not common:
+        # the two oracles part on this very sentence BEFORE the HIP search does (which followed the fp32 oracle longer
+        # than the bf16-storage oracle did): their own disagreement on the sentence is the larger one
+        out["oracle_pair_parted_at_step"] = int(first_off)
+        out["inside_oracle_pair_disagreement"] = True
+        return out
+    out["bf16_oracle_flat_index"] = int(b_ix[t, j])
+    out["bf16_oracle_same_choice"] = bool(common and int(b_ix[t, j]) == d["hip_flat_index"])
+    # distance between the two oracles' scores of the candidates both list at step t
+    moved = 0.0
+    for a, ia in enumerate(f_ix[t]):
+        w = np.nonzero(b_ix[t] == ia)[0]
+        if ia >= 0 and len(w) and f_sc[t, a] > -1e30 and b_sc[t, int(w[0])] > -1e30:
+            moved = max(moved, abs(float(f_sc[t, a]) - float(b_sc[t, int(w[0])])))
+    out["oracle_pair_score_distance_at_step"] = moved
+    out["inside_oracle_pair_disagreement"] = bool(common and d["oracle_gap"] <= 2.0 * moved)
+    return out
+
+
 @pytest.mark.parametrize("K", [1, 4])
 def test_aan_beam_search_base_size(K):
-    """BASELINE configs[3] subset: transformer_aan, d=512, V=32000, 64 length-sorted sentences, eval batch 32.
+    """BASELINE configs[3] subset: transformer_aan, d=512, V=32000, 256 length-sorted sentences, eval batch 32.
     north_star: token-id exact greedy decode.  Every hypothesis that is NOT token-exact must be explained: the test
     finds the first step at which the HIP search's candidate table leaves the oracle's (fixture `trace_*`: the
     oracle's 2K kept candidates + the runner-up of every step) and requires the oracle's own score gap between the two
@@ -211,6 +258,7 @@ def test_aan_beam_search_base_size(K):
             for j in miss:
                 d = _first_divergence(trace, ref_tsc, ref_tix, j, i + j, K)
                 d = dict(d or {"step": None, "oracle_gap": None}, sentence=i + j)
+                d.update(_bf16_oracle_view(fx, K, d, i + j))
                 if d.get("oracle_gap") is not None and d.get("rank") == 0:
                     # where this gap stands among the best-vs-second gaps of ALL (sentence, step) pairs of the fixture
                     allgaps = (ref_tsc[:, :, 0] - ref_tsc[:, :, 1])[ref_tix[:, :, 0] >= 0]
@@ -231,11 +279,24 @@ def test_aan_beam_search_base_size(K):
            "oracle_top2_near_ties": near, "oracle_sentence_steps": int(valid.sum())}
     print(json.dumps(rep, sort_keys=True))
     _report("beam_k%d" % K, rep)
-    # measured on MI355X: 62/64 (beam 1) and 63/64 (beam 4) whole hypotheses token-exact; the others leave the
-    # oracle's path at a near-tie of this random model (no sharpening) and end with a different score
-    assert rep["token_exact_rate"] >= 60.0 / 64.0, rep
+    # how often the two oracles (fp32 / bf16 storage) disagree with EACH OTHER on whole hypotheses: the yardstick for
+    # "token-id exact" between two correct implementations that round at different points
+    o_hyp = decode_hypothesis(ref_seq, hp)
+    b_hyp = decode_hypothesis(fx["bf16_seqs_k%d" % K], hp)
+    rep["oracle_fp32_vs_bf16storage_token_exact"] = int(sum(list(a) == list(b) for a, b in zip(o_hyp, b_hyp)))
+    rep["reproduced_by_bf16_oracle"] = int(sum(bool(d.get("bf16_oracle_same_choice")) for d in divergences))
+    rep["bracketed_by_oracle_pair"] = int(sum(bool(d.get("inside_oracle_pair_disagreement")) for d in divergences))
+    print(json.dumps({k: rep[k] for k in ("oracle_fp32_vs_bf16storage_token_exact", "reproduced_by_bf16_oracle",
+                                          "bracketed_by_oracle_pair")}))
+    _report("beam_k%d" % K, rep)
+    # measured on MI355X (round 3, 64 sentences): 62/64 (beam 1) and 63/64 (beam 4) whole hypotheses token-exact; the
+    # others leave the oracle's path at a near-tie of this random model (no sharpening) and end with a different score.
+    # Floor kept proportional: 240 / 256.
+    assert rep["token_exact_rate"] >= 240.0 / 256.0, rep
     assert rep["first8_rate"] >= 0.9, rep
     assert dscore_same < 0.3, rep       # scores are sums of ~80 log-probabilities around -85: 0.3 = 3.5e-3 relative
     for d in divergences:
         assert d["step"] is not None and d["oracle_gap"] is not None, ("unexplained divergence", d)
         assert 0.0 <= d["oracle_gap"] < d["tolerance"], ("divergence at a gap that bf16 noise does not explain", d)
+        assert d.get("bf16_oracle_same_choice") or d.get("inside_oracle_pair_disagreement"), \
+            ("neither reproduced by the bf16-storage oracle nor inside the oracle pair's own disagreement", d)

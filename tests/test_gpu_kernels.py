@@ -492,8 +492,8 @@ def test_batch_prep_groups_rows_like_the_stable_host_sort(B, L, V):
     ids[:, -1] = 2
     if L > 4:
         ids[::3, L // 2:] = 0              # ragged rows: padding
-    for shift in (False, True):
-        srt = device_sort_arrays(e, "p%d" % shift, ids, shift)
+    for shift, max_id in ((False, 0), (True, 0), (False, V), (True, V)):      # max_id = V: 32-bit keys where they fit
+        srt = device_sort_arrays(e, "p%d" % shift, ids, shift, max_id)
         torch.cuda.synchronize()
         rows, seg, uid = host_sort_arrays(ids, shift)
         n = int(srt["n"].cpu()[0])

@@ -741,6 +741,38 @@ def test_many_shapes_many_replays_match_eager():
     assert not any(b for _, _, b in traces[True])
 
 
+def test_steps_on_rotating_batches_without_host_syncs_match_eager():
+    """Trainer.step as the training loop calls it: a NEW batch every step, the host never waiting for the device (the
+    next batch is uploaded and prepared -- zk_batch_prep -- on a side stream into a staging set while the previous step
+    runs, then committed by one copy launch).  12 steps over 5 different batches of one shape, no synchronisation in
+    between, against eager micro steps with a synchronisation after every step: same losses, same weights."""
+    from zero_amd.main import Trainer
+    hp, Pn, _, _ = _setup("transformer", H=128, F=256, lrate=0.5, warmup_steps=10)
+    feats = []
+    for i in range(5):
+        src, tgt = make_batch(np.random.default_rng(100 + i), 6, 12, 14, hp.src_vocab.size(), hp.tgt_vocab.size())
+        src[:, -1], tgt[:, -1] = 2, 2
+        feats.append({"source": src, "target": tgt})
+    runs = {}
+    for mode in ("eager", "pipelined"):
+        reset_cores()
+        tr = Trainer(hp, initializer=Pn)
+        held = []
+        for i in range(12):
+            if mode == "eager":
+                loss = tr.micro_step(feats[i % 5])
+                torch.cuda.synchronize()
+                held.append(loss.reshape(-1)[0].clone())
+            else:
+                loss = tr.step(feats[i % 5])
+                held.append(loss.reshape(-1)[0].clone())          # (device-side copy, enqueued behind the step)
+        torch.cuda.synchronize()
+        runs[mode] = ([float(x.cpu()) for x in held], tr.store.master.cpu().numpy().copy())
+    assert runs["eager"][0] == runs["pipelined"][0], (runs["eager"][0], runs["pipelined"][0])
+    assert np.array_equal(runs["eager"][1], runs["pipelined"][1])
+    assert len(set(runs["eager"][0])) > 5                          # the batches really differ
+
+
 def test_length_bucketing_leaves_losses_and_updates_unchanged(monkeypatch):
     """ZERO_HIP_PAD_LEN=8 (Trainer.prepare_static: both sides padded to a multiple of 8 so that token-sized batches
     fall into few graph-cache shapes): padded keys are masked, padded target positions follow the real ones and carry

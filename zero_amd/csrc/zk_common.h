@@ -149,6 +149,48 @@ __device__ __forceinline__ void wave_argbest(float& s, int& i, int& t, B better)
   t = __builtin_amdgcn_readlane(t, 63);
 }
 
+// ---------------------------------------------------------------- LayerNorm statistics as per-64-column partials (round 4)
+// (mu, rstd) of row `row` from its per-64-column partials {sum, M2}: Chan's combination, robust for |mean| >> sigma
+#define ZK_LN_MAXP 16
+__device__ __forceinline__ void zk_ln_row_stats(const float* __restrict__ part, int np, float invh, float eps, size_t row,
+                                                float& mu, float& rs) {
+  const float4* p = reinterpret_cast<const float4*>(part + row * (size_t)np * 2);
+  float4 v[ZK_LN_MAXP / 2];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < ZK_LN_MAXP / 2; ++i) {
+    if (2 * i < np) { v[i] = p[i]; s += v[i].x + v[i].z; }
+  }
+  mu = s * invh;
+  float m2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < ZK_LN_MAXP / 2; ++i) {
+    if (2 * i < np) {
+      const float d0 = v[i].x * (1.f / 64.f) - mu, d1 = v[i].z * (1.f / 64.f) - mu;
+      m2 += v[i].y + v[i].w + 64.f * (d0 * d0 + d1 * d1);
+    }
+  }
+  rs = rsqrtf(m2 * invh + eps);
+}
+// the same for a row the whole WAVE works on: lane i < np loads partial i (one coalesced load instead of np/2 wave-wide
+// broadcast loads, each of which costs the address path as much as a full row), two 16-lane DPP reductions
+__device__ __forceinline__ void zk_ln_row_stats_wave(const float* __restrict__ part, int np, float invh, float eps, size_t row,
+                                                     int lane, float& mu, float& rs) {
+  float2 p = make_float2(0.f, 0.f);
+  if (lane < np) p = *reinterpret_cast<const float2*>(part + (row * (size_t)np + lane) * 2);
+  const float tot = row16_sum(p.x);
+  mu = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tot))) * invh;
+  const float d = p.x * (1.f / 64.f) - mu;
+  const float m2 = row16_sum(lane < np ? p.y + 64.f * d * d : 0.f);
+  rs = rsqrtf(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m2))) * invh + eps);
+}
+// sum over the 8 consecutive lanes (aligned to 8) that hold one row's 64-column group; all 8 receive it
+__device__ __forceinline__ float zk_sum8(float v) {
+  v = quad_sum(v);
+  v += zk_dpp<ZK_DPP_HALF_MIRROR, 0xf>(0.f, v);
+  return v;
+}
+
 // sum over a block of NW waves; every thread gets the result. sm: >= NW floats.
 template <int NW>
 __device__ __forceinline__ float block_sum(float v, float* sm) {

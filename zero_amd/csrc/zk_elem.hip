@@ -136,7 +136,8 @@ __global__ void __launch_bounds__(256) k_add_ln_bwd(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ s, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, bf16_t* __restrict__ dsum,
     bf16_t* __restrict__ dy, float* __restrict__ partials, int rows, int H, uint32_t thr,
-    float inv_keep, const uint64_t* __restrict__ seedp, uint32_t sid) {
+    float inv_keep, const uint64_t* __restrict__ seedp, uint32_t sid, const float* __restrict__ part, int np, float eps,
+    const float* __restrict__ beta, bf16_t* __restrict__ y_out) {
   __shared__ float red[4][3][8 * 64];  // per wave, per quantity, one 512-column slab at a time
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
@@ -153,7 +154,9 @@ __global__ void __launch_bounds__(256) k_add_ln_bwd(
       for (int j = 0; j < 8; ++j) acc[q][i][j] = 0.f;
 
   for (int r = wave; r < rows; r += nwaves) {
-    const float mu = mean[r], rs = rstd[r];
+    float mu, rs;
+    if (part != nullptr) zk_ln_row_stats_wave(part, np, invH, eps, (size_t)r, lane, mu, rs);   // lazy LayerNorm: statistics left by the producing GEMM
+    else { mu = mean[r]; rs = rstd[r]; }
     float xh[MAXC][8], g[MAXC][8];
     float sg = 0.f, sgx = 0.f;
 #pragma unroll
@@ -163,6 +166,12 @@ __global__ void __launch_bounds__(256) k_add_ln_bwd(
         float d[8], sv[8];
         unpack8(*reinterpret_cast<const uint4*>(dout + (size_t)r * H + c), d);
         unpack8(*reinterpret_cast<const uint4*>(s + (size_t)r * H + c), sv);
+        if (y_out != nullptr) {     // the normalised rows the forward never wrote: operand of the deferred weight gradients
+          float yv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) yv[j] = gamma[c + j] * (sv[j] - mu) * rs + beta[c + j];
+          *reinterpret_cast<uint4*>(y_out + (size_t)r * H + c) = pack8(yv);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           xh[i][j] = (sv[j] - mu) * rs;
@@ -242,7 +251,8 @@ __global__ void __launch_bounds__(1024) k_add_ln_bwd_wide(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ s, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, bf16_t* __restrict__ dsum,
     bf16_t* __restrict__ dy, float* __restrict__ partials, int rows, int H, uint32_t thr,
-    float inv_keep, const uint64_t* __restrict__ seedp, uint32_t sid) {
+    float inv_keep, const uint64_t* __restrict__ seedp, uint32_t sid, const float* __restrict__ part, int np, float eps,
+    const float* __restrict__ beta, bf16_t* __restrict__ y_out) {
   __shared__ float red[3][16][512 + 8];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = lane * 8;
@@ -258,14 +268,32 @@ __global__ void __launch_bounds__(1024) k_add_ln_bwd_wide(
   ZK_LT(0);
 #pragma unroll
   for (int j = 0; j < 8; ++j) gam[j] = on ? gamma[c + j] : 0.f;
+  float bet[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bet[j] = (on && y_out != nullptr) ? beta[c + j] : 0.f;
   for (int r = blockIdx.x * 16 + w; r < rows; r += gridDim.x * 16) {
-    const float mu = mean[r], rs = rstd[r];
+    // the row's data is requested BEFORE the statistics are combined (the combination waits for its own loads: behind
+    // it, the two round trips would add up)
+    uint4 raw_d = make_uint4(0, 0, 0, 0), raw_s = make_uint4(0, 0, 0, 0);
+    if (on) {
+      raw_d = *reinterpret_cast<const uint4*>(dout + (size_t)r * H + c);
+      raw_s = *reinterpret_cast<const uint4*>(s + (size_t)r * H + c);
+    }
+    float mu, rs;
+    if (part != nullptr) zk_ln_row_stats_wave(part, np, invH, eps, (size_t)r, lane, mu, rs);   // lazy LayerNorm: statistics left by the producing GEMM
+    else { mu = mean[r]; rs = rstd[r]; }
     float xh[8], g[8], d[8];
     float sg = 0.f, sgx = 0.f;
     if (on) {
       float sv[8];
-      unpack8(*reinterpret_cast<const uint4*>(dout + (size_t)r * H + c), d);
-      unpack8(*reinterpret_cast<const uint4*>(s + (size_t)r * H + c), sv);
+      unpack8(raw_d, d);
+      unpack8(raw_s, sv);
+      if (y_out != nullptr) {       // the normalised rows the forward never wrote: operand of the deferred weight gradients
+        float yv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) yv[j] = gam[j] * (sv[j] - mu) * rs + bet[j];
+        *reinterpret_cast<uint4*>(y_out + (size_t)r * H + c) = pack8(yv);
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         xh[j] = (sv[j] - mu) * rs;
@@ -1333,10 +1361,11 @@ int zk_add_ln_bwd_reduce(const void* workspace, int rows, int H, float* dgamma, 
   return 0;
 }
 
-int zk_add_ln_bwd(const void* dout, const void* sum, const float* mean, const float* rstd,
-                  const float* gamma, void* dsum, void* dy, float* dgamma, float* dbeta, float* dbias_prev,
-                  int rows, int H, float drop_p, const uint64_t* seed, uint32_t sid, void* workspace,
-                  size_t ws_bytes, int defer_reduce, hipStream_t stream) {
+static int add_ln_bwd_launch(const void* dout, const void* sum, const float* mean, const float* rstd,
+                             const float* gamma, void* dsum, void* dy, float* dgamma, float* dbeta, float* dbias_prev,
+                             int rows, int H, float drop_p, const uint64_t* seed, uint32_t sid, void* workspace,
+                             size_t ws_bytes, int defer_reduce, const float* part, int np, float eps, const float* beta,
+                             void* y_out, hipStream_t stream) {
   ZK_CHECK_ARG(H % 8 == 0 && H <= MAXC_LIMIT * 512, "zk_add_ln_bwd: H=%d must be a multiple of 8 and <= %d", H,
                MAXC_LIMIT * 512);
   ZK_CHECK_ARG(ws_bytes >= zk_add_ln_bwd_workspace(rows, H), "zk_add_ln_bwd: workspace too small");
@@ -1349,11 +1378,11 @@ int zk_add_ln_bwd(const void* dout, const void* sum, const float* mean, const fl
 #define ZK_LN_BWD(NC)                                                                                     \
   hipLaunchKernelGGL(k_add_ln_bwd<NC>, dim3(g), dim3(256), 0, stream, (const bf16_t*)dout, (const bf16_t*)sum, \
                      mean, rstd, gamma, (bf16_t*)dsum, (bf16_t*)dy, (float*)workspace, rows, H, thr, ik,     \
-                     seed, sid)
+                     seed, sid, part, np, eps, beta, (bf16_t*)y_out)
   if (H <= 512 && g_tune[0])
     hipLaunchKernelGGL(k_add_ln_bwd_wide, dim3(g), dim3(1024), 0, stream, (const bf16_t*)dout, (const bf16_t*)sum,
                        mean, rstd, gamma, (bf16_t*)dsum, (bf16_t*)dy, (float*)workspace, rows, H, thr, ik, seed,
-                       sid);
+                       sid, part, np, eps, beta, (bf16_t*)y_out);
   else if (H <= 512) ZK_LN_BWD(1);
   else if (H <= 1024) ZK_LN_BWD(2);
   else ZK_LN_BWD(4);
@@ -1362,6 +1391,31 @@ int zk_add_ln_bwd(const void* dout, const void* sum, const float* mean, const fl
   if (defer_reduce) return 0;
   return zk_add_ln_bwd_reduce(workspace, rows, H, dgamma, dbeta, dbias_prev, stream);
 }
+
+int zk_add_ln_bwd(const void* dout, const void* sum, const float* mean, const float* rstd,
+                  const float* gamma, void* dsum, void* dy, float* dgamma, float* dbeta, float* dbias_prev,
+                  int rows, int H, float drop_p, const uint64_t* seed, uint32_t sid, void* workspace,
+                  size_t ws_bytes, int defer_reduce, hipStream_t stream) {
+  return add_ln_bwd_launch(dout, sum, mean, rstd, gamma, dsum, dy, dgamma, dbeta, dbias_prev, rows, H, drop_p, seed, sid,
+                           workspace, ws_bytes, defer_reduce, nullptr, 0, 0.f, nullptr, nullptr, stream);
+}
+
+#ifdef ZK_EXPERIMENTS   // the LayerNorm-free forward: measured, no gain (profiles/r04_negative_results.txt)
+// The backward of a LayerNorm the forward never launched (zk_gemm_ln): the row statistics come from the per-64-column
+// partials `part` [rows][H/64][2] the producing GEMM left beside the un-normalised sum, and y_out (optional) receives
+// LN(sum) = bf16(gamma (sum - mu) rstd + beta) -- the rows k_add_ln_fwd would have written, needed only now, as the X
+// operand of the deferred weight gradient of the layer that consumed them.
+int zk_add_ln_bwd_lazy(const void* dout, const void* sum, const float* part, const float* gamma, const float* beta,
+                       void* y_out, void* dsum, void* dy, float* dgamma, float* dbeta, float* dbias_prev, int rows, int H,
+                       float eps, float drop_p, const uint64_t* seed, uint32_t sid, void* workspace, size_t ws_bytes,
+                       int defer_reduce, hipStream_t stream) {
+  ZK_CHECK_ARG(part != nullptr && H % 128 == 0 && H / 64 <= ZK_LN_MAXP, "zk_add_ln_bwd_lazy: H=%d must be a multiple of 128 and <= %d",
+               H, ZK_LN_MAXP * 64);
+  ZK_CHECK_ARG(y_out == nullptr || beta != nullptr, "zk_add_ln_bwd_lazy: y_out needs beta");
+  return add_ln_bwd_launch(dout, sum, nullptr, nullptr, gamma, dsum, dy, dgamma, dbeta, dbias_prev, rows, H, drop_p, seed,
+                           sid, workspace, ws_bytes, defer_reduce, part, H / 64, eps, beta, y_out, stream);
+}
+#endif  // ZK_EXPERIMENTS
 
 size_t zk_colsum_workspace(int rows, int N) {
   int gy = (rows + 255) / 256;

@@ -15,6 +15,20 @@ struct GemmEpi {
   int act;                 // 0 none, 1 relu, 2 multiply by (aux>0)*aux_scale
   const bf16_t* aux; int ldaux; float aux_scale;
   uint32_t thr; float inv_keep; const uint64_t* seed; uint32_t sid;  // dropout on the output
+  // ---- round 4: residual + LayerNorm WITHOUT a launch of its own (func.py:289-303, 321-324; post-LN order of
+  // transformer.py:57-58).  The GEMM that produces a sub-layer's output adds the residual itself and leaves, beside the
+  // un-normalised sum s (bf16), the row statistics of s as per-64-column partials; every reader of LN(s) applies the
+  // normalisation where it reads (gen-2 tile kernels only, 16-byte epilogue, N % 64 == 0):
+  //   producer   ln_stat_out != null: {sum, M2} of the bf16-ROUNDED outputs of each (row, 64-column group) ->
+  //              ln_stat_out[(row * N/64 + group) * 2 ..]; res_after_drop: out = res + dropout(acc + bias);
+  //   lazy residual   res_part != null: `res` holds the previous sub-layer's un-normalised sum, the residual is
+  //              bf16(gamma (res - mu) rstd + beta) with (mu, rstd) combined from res_part [M][ln_np][2];
+  //   consumer   ln_c != null: A was an un-normalised sum and B the weight with gamma folded in (zk_ln_fold):
+  //              out = rstd_row (acc - mu_row ln_c[n]) + bias[n], bias = beta . W + b  (then act / dropout as usual).
+  float* ln_stat_out = nullptr;
+  const float* ln_in_part = nullptr; const float* ln_c = nullptr;
+  const float* res_part = nullptr; const float* res_gamma = nullptr; const float* res_beta = nullptr;
+  int ln_np = 0; int res_after_drop = 0; float ln_eps = 0.f; float ln_invh = 0.f;
 };
 
 __device__ __forceinline__ void epi_store(const GemmEpi& e, float v, int gm, int gn, int N, uint64_t seed) {

@@ -292,6 +292,8 @@ static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, 
 }
 
 int zk_gemm_dlds_pw(int bm, int bn);
+int zk_gemm_dlds_ln_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int bm, int bn,
+                             const GemmEpi& e, hipStream_t stream);
 int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
                           int bm, int bn, int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags,
                           hipStream_t stream);
@@ -407,6 +409,57 @@ int zk_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda,
   }
   return 0;
 }
+
+#ifdef ZK_EXPERIMENTS   // measured: no gain over the LayerNorm launches (profiles/r04_negative_results.txt): make EXPERIMENTS=1
+// Forward linear with the residual + LayerNorm of the sub-layer folded into GEMM epilogues (GemmEpi, round 4): no
+// LayerNorm launch.  C bf16 [M, ldc] = epilogue(A [M, K] x B [K, N]), ta = tb = 0, gen-2 tile kernels only.
+//   stat_out  != NULL  PRODUCER: C is the un-normalised sum  residual + dropout(A B + bias)  and stat_out [M][N/64][2]
+//                      receives {sum, M2} of each (row, 64-column group) of the stored bf16 values;
+//   res_part  != NULL  the residual operand is itself an un-normalised sum: residual <- bf16(LN(residual)) with the
+//                      statistics res_part [M][np][2] and res_gamma / res_beta [N];
+//   in_c      != NULL  CONSUMER: A is an un-normalised sum with statistics in_part [M][np][2] (np = K / 64), B the weight
+//                      with gamma folded in and in_c / bias the vectors zk_ln_fold made:
+//                      C = act(rstd (A B - mu in_c) + bias), then dropout.
+int zk_gemm_ln(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, const float* bias,
+               const void* residual, int ldr, int act, float drop_p, const uint64_t* seed, uint32_t sid, float* stat_out,
+               const float* in_part, const float* in_c, const float* res_part, const float* res_gamma,
+               const float* res_beta, int np, float eps, hipStream_t stream) {
+  ZK_CHECK_ARG(M >= 0 && N >= 1 && K >= 1, "zk_gemm_ln: bad dims");
+  ZK_CHECK_ARG(act == 0 || act == 1, "zk_gemm_ln: act=%d (0 none, 1 ReLU)", act);
+  ZK_CHECK_ARG(drop_p == 0.f || seed != nullptr, "zk_gemm_ln: dropout needs a seed pointer");
+  ZK_CHECK_ARG(N % 64 == 0 && ldc % 8 == 0 && (residual == nullptr || ldr % 8 == 0), "zk_gemm_ln: N=%d must be a multiple of 64, ldc / ldr of 8", N);
+  ZK_CHECK_ARG(np >= 2 && np <= ZK_LN_MAXP && np % 2 == 0, "zk_gemm_ln: np=%d partials per row (even, 2..%d)", np, ZK_LN_MAXP);
+  ZK_CHECK_ARG(stat_out == nullptr || N == np * 64, "zk_gemm_ln: a producer writes N/64 = np partials per row");
+  ZK_CHECK_ARG((in_c == nullptr) == (in_part == nullptr), "zk_gemm_ln: in_part and in_c come together");
+  ZK_CHECK_ARG(in_c == nullptr || (stat_out == nullptr && res_part == nullptr && residual == nullptr),
+               "zk_gemm_ln: a GEMM is a consumer or a producer, not both");
+  ZK_CHECK_ARG(in_c == nullptr || (K == np * 64 && bias != nullptr), "zk_gemm_ln: a consumer needs K = 64 np and the folded bias");
+  ZK_CHECK_ARG(res_part == nullptr || (residual != nullptr && res_gamma != nullptr && res_beta != nullptr && N == np * 64),
+               "zk_gemm_ln: a lazy residual needs the sum, gamma, beta and N = 64 np");
+  const uintptr_t al = (uintptr_t)C | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)stat_out | (uintptr_t)in_part |
+                       (uintptr_t)in_c | (uintptr_t)res_part | (uintptr_t)res_gamma | (uintptr_t)res_beta;
+  ZK_CHECK_ARG((al & 15) == 0, "zk_gemm_ln: operands must be 16-byte aligned");
+  ZK_CHECK_ARG(mfma_ok(A, B, M, N, K, lda, ldb, 0, 0), "zk_gemm_ln: shape/alignment not supported by the MFMA kernel "
+               "(M=%d N=%d K=%d lda=%d ldb=%d)", M, N, K, lda, ldb);
+  ZK_CHECK_ARG(!zk_prog_active(), "zk_gemm_ln cannot be part of a layer program");
+  if (M == 0) return 0;
+  GemmEpi e;
+  e.C = C; e.ldc = ldc; e.out_f32 = 0; e.alpha = 1.f; e.bias = bias;
+  e.res = (const bf16_t*)residual; e.ldr = ldr; e.act = act; e.aux = nullptr; e.ldaux = 0; e.aux_scale = 1.f;
+  e.thr = drop_p > 0.f ? zk_drop_threshold(drop_p) : 0;
+  e.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  e.seed = seed; e.sid = sid;
+  e.ln_stat_out = stat_out; e.ln_in_part = in_part; e.ln_c = in_c;
+  e.res_part = res_part; e.res_gamma = res_gamma; e.res_beta = res_beta;
+  e.ln_np = np; e.res_after_drop = 1; e.ln_eps = eps; e.ln_invh = 1.f / (float)(np * 64);
+  int bm, bn, splits;
+  pick_config(M, N, K, 0, &bm, &bn, &splits);
+  (void)splits;                 // never split: the epilogue needs the whole sum
+  if (bm > 128 || bn > 128) { bm = 128; bn = 128; }
+  return zk_gemm_dlds_ln_dispatch((const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, bm, bn, e, stream);
+}
+
+#endif  // ZK_EXPERIMENTS
 
 // Split-K product left as its partial sums: parts[z] (fp32 [M, N] each, z < splits, part z at parts + z*M*N) =
 // A[:, K_z] B[K_z, :] over the z-th K range; no epilogue and no reduction launch -- the consumer adds them in the

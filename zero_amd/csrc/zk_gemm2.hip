@@ -16,16 +16,16 @@
 //     loads/stores (bias, residual, ReLU, ReLU-backward mask, dropout fused as before).
 #include "zk_gemm2_dev.h"
 
-template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0>
+template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0, int LN = 0>
 __global__ void __launch_bounds__((NW + PW) * 64) k_gemm_dlds(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M,
                                                    int N, int K, int lda, int ldb, int kchunk,
                                                    float* __restrict__ slabs, TileSched ts, GemmEpi e, EpiVec ev) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[DldsCfg<BM, BN, NS>::LDS_BYTES];   // the ONLY LDS object
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DldsCfg<BM, BN, NS>::LDS_BYTES];   // the ring (LN: + 2 x BM float2 of row statistics)
   int tm_, tn_, z_;
   tile_of_block(ts, tm_, tn_, z_);
   const int kbeg = z_ * kchunk;
   const int kend = min(K, kbeg + kchunk);
-  gemm_tile<BM, BN, NS, TA, TB, NW, PW>(smem, A, B, M, N, lda, ldb, kbeg, kend, tm_ * BM, tn_ * BN,
+  gemm_tile<BM, BN, NS, TA, TB, NW, PW, false, false, LN>(smem, A, B, M, N, lda, ldb, kbeg, kend, tm_ * BM, tn_ * BN,
                                     slabs ? slabs + (size_t)z_ * M * N : nullptr, e, ev.vec_ok);
   __builtin_amdgcn_sched_barrier(0);
   ZK_E(4);
@@ -861,6 +861,41 @@ int zk_gemm_dlds_pw(int bm, int bn) {
   if (pw == 2) return (bm == bn && !deep128) ? 2 : 0;      // instantiated: 64x64 and 128x128 with ring depth 2
   return (pw == 4 || pw == 8) ? pw : 0;
 }
+
+#ifdef ZK_EXPERIMENTS   // the LayerNorm-free forward: measured, no gain (profiles/r04_negative_results.txt)
+// the lazy-LayerNorm forms (zk_gemm_ln; A [M,K] x B [K,N], no split-K): the tile kernels of the default dispatch with the
+// LN epilogue compiled in -- 64x64 and 128x128 with four producer waves, 128x64 / 64x128 without (tuning key 6 = 0x44)
+template <int BM, int BN, int NS, int PW>
+static int launch_dlds_ln(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, const GemmEpi& e,
+                          hipStream_t stream) {
+  // two instantiations per tile: the consumer form (LN = 1) and the producer forms (LN = 2) -- a GEMM is never both, and
+  // keeping them apart keeps the 128x128 consumer at two workgroups per CU (<= 128 VGPRs)
+  TileSched ts;
+  ts.tiles_m = (M + BM - 1) / BM;
+  ts.tiles_n = (N + BN - 1) / BN;
+  ts.n_major = ((long)N > (long)M) ? 1 : 0;
+  ts.xcd_remap = 1;
+  EpiVec ev;
+  ev.vec_ok = 1;                     // checked by zk_gemm_ln: 16-byte aligned operands, ldc / ldr multiples of 8
+  dim3 grid((unsigned)((long)ts.tiles_m * ts.tiles_n));
+  if (e.ln_c != nullptr)
+    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, false, false, 4, PW, 1>), grid, dim3((4 + PW) * 64), 0, stream, A, B, M, N,
+                       K, lda, ldb, K, (float*)nullptr, ts, e, ev);
+  else
+    hipLaunchKernelGGL((k_gemm_dlds<BM, BN, NS, false, false, 4, PW, 2>), grid, dim3((4 + PW) * 64), 0, stream, A, B, M, N,
+                       K, lda, ldb, K, (float*)nullptr, ts, e, ev);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+int zk_gemm_dlds_ln_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int bm, int bn,
+                             const GemmEpi& e, hipStream_t stream) {
+  if (bm == 128 && bn == 128) return launch_dlds_ln<128, 128, 2, 4>(A, B, M, N, K, lda, ldb, e, stream);
+  if (bm == 128 && bn == 64) return launch_dlds_ln<128, 64, 2, 0>(A, B, M, N, K, lda, ldb, e, stream);
+  if (bm == 64 && bn == 128) return launch_dlds_ln<64, 128, 2, 0>(A, B, M, N, K, lda, ldb, e, stream);
+  return launch_dlds_ln<64, 64, 4, 4>(A, B, M, N, K, lda, ldb, e, stream);
+}
+
+#endif  // ZK_EXPERIMENTS
 
 // entry used by zk_gemm (zk_gemm.hip)
 int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,

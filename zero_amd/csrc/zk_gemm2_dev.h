@@ -163,11 +163,16 @@ struct KSegDesc {
 // behind a workgroup barrier, ready for a row-wise epilogue.
 // FRESH: the A operand (activations) and the epilogue's residual / mask tensors were written by other CUs earlier in
 // the same launch (layer program) -> L1-bypassing loads; B (weights) always takes the ordinary path.
-template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0, bool KSEG = false, bool FRESH = false>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// HOOK: called once by the waves that run the epilogue's row loop (every wave without producer waves, the compute waves
+// with them) right after the first ring stages have been requested -- work that only needs global memory (the row
+// statistics of a lazy LayerNorm) rides behind the ring fill instead of adding a round trip of its own.
+template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0, bool KSEG = false, bool FRESH = false,
+          typename HOOK = NoHook>
 __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16_t* __restrict__ A,
                                                  const bf16_t* __restrict__ B, int M, int N, int lda, int ldb,
                                                  int kbeg, int kend, int m0, int n0, const KSegDesc* ks = nullptr,
-                                                 float* __restrict__ colsum = nullptr) {
+                                                 float* __restrict__ colsum = nullptr, HOOK hook = HOOK()) {
   constexpr int NWM = NW == 8 ? 4 : 2, NWN = NW / NWM;       // wave grid over the tile: 2x2, 2x1 or 4x2
   constexpr int WTM = BM / NWM, WTN = BN / NWN, TM = WTM / 32, TN = WTN / 32;
   constexpr int STAGE = DldsCfg<BM, BN, NS>::STAGE;
@@ -280,6 +285,7 @@ __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16
       if (!TB && colsum != nullptr && pcol < BN && n0 + pcol < N) colsum[n0 + pcol] = cs;
     } else {
       ZK_E(1);
+      hook();
       for (int kt = 0; kt < nk; ++kt) {
         [[maybe_unused]] const int tr_i = kt;
         ZK_T(0);
@@ -297,6 +303,8 @@ __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16
     for (int s = 0; s < NS - 1; ++s) issue(s);
     __builtin_amdgcn_sched_barrier(0);
     ZK_E(1);
+    hook();
+    __builtin_amdgcn_sched_barrier(0);
     for (int kt = 0; kt < nk; ++kt) {
       [[maybe_unused]] const int tr_i = kt;
       ZK_T(0);
@@ -338,7 +346,11 @@ __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16
 }
 
 // one BMxBN output tile over k in [kbeg, kend); slab != null: write the fp32 partial tile there
-template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0, bool KSEG = false, bool FRESH = false>
+// LN: the lazy-LayerNorm epilogue forms of GemmEpi (zk_gemm_ln) are compiled in (separate instantiations: the ordinary
+// kernels pay nothing for them).  The row statistics (mu, rstd) of the tile's BM rows -- combined from the per-64-column
+// partials -- are computed once, by the first BM threads, behind the ring fill, and wait in 2 x BM float2 of LDS.
+template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0, bool KSEG = false, bool FRESH = false,
+          int LN = 0>      // LN: 0 none, 1 consumer form (ln_c), 2 producer forms (ln_stat_out, res_part, res_after_drop)
 __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __restrict__ A,
                                           const bf16_t* __restrict__ B, int M, int N, int lda, int ldb, int kbeg,
                                           int kend, int m0, int n0, float* __restrict__ slab, const GemmEpi& e,
@@ -362,8 +374,16 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
   constexpr bool PRE = ITER <= 2;
   uint4 rres[ITER], raux[ITER];
   float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  [[maybe_unused]] float lcv[8], lgv[8], lbv[8];            // LN: this thread's 8 columns of ln_c / res_gamma / res_beta
   uint64_t seed = 0;
+  auto ld8 = [&](const float* p, float* o) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  };
   auto load_epi = [&]() {
+    if constexpr (LN == 1) { if (e.ln_c) ld8(e.ln_c + gn, lcv); }
+    if constexpr (LN == 2) { if (e.res_part) { ld8(e.res_gamma + gn, lgv); ld8(e.res_beta + gn, lbv); } }
     if (e.res) {
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
@@ -388,7 +408,21 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
     seed = e.thr ? *e.seed : 0;
     if (fast) load_epi();
   }
-  gemm_tile_to_lds<BM, BN, NS, TA, TB, NW, PW, KSEG, FRESH>(smem, A, B, M, N, lda, ldb, kbeg, kend, m0, n0, ks, colsum);
+  __shared__ float2 s_lnstat[LN ? BM : 1];     // (mu, rstd) of the tile's rows: of the A operand (LN = 1) / of the residual (LN = 2)
+  if constexpr (LN != 0) {
+    auto ln_rows = [&]() {
+      const float* part = LN == 1 ? e.ln_in_part : e.res_part;
+      if (tid < BM && part != nullptr) {
+        const size_t gr = (size_t)min(m0 + tid, M - 1);
+        float mu, rs;
+        zk_ln_row_stats(part, e.ln_np, e.ln_invh, e.ln_eps, gr, mu, rs);
+        s_lnstat[tid] = make_float2(mu, rs);
+      }
+    };
+    gemm_tile_to_lds<BM, BN, NS, TA, TB, NW, PW, KSEG, FRESH>(smem, A, B, M, N, lda, ldb, kbeg, kend, m0, n0, ks, colsum, ln_rows);
+  } else {
+    gemm_tile_to_lds<BM, BN, NS, TA, TB, NW, PW, KSEG, FRESH>(smem, A, B, M, N, lda, ldb, kbeg, kend, m0, n0, ks, colsum);
+  }
   const float* sC = reinterpret_cast<const float*>(smem);
   if (!(PRE && !FRESH)) seed = e.thr ? *e.seed : 0;
   if (fast) {
@@ -407,13 +441,26 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
       const int row = row0 + it * RSTEP;
       if (CH % NT != 0 && row >= BM) break;
       const int gm = m0 + row;
+      if (LN == 1 && e.ln_c) {       // consumer of a lazy LayerNorm: rstd (s . (gamma o W) - mu colsum(gamma o W)) + (beta . W + b)
+        const float2 st = s_lnstat[row];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[it][j] = v[it][j] * e.alpha + bv[j];
+        for (int j = 0; j < 8; ++j) v[it][j] = st.y * (v[it][j] * e.alpha - st.x * lcv[j]) + bv[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[it][j] = v[it][j] * e.alpha + bv[j];
+      }
+      [[maybe_unused]] float rv[8];
       if (e.res) {
-        float rv[8];
         unpack8(rres[it], rv);
+        if (LN == 2 && e.res_part) {   // the residual is LN(previous sum), formed as k_add_ln_fwd forms it and rounded as it stores it
+          const float2 st = s_lnstat[row];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[it][j] += rv[j];
+          for (int j = 0; j < 8; ++j) rv[j] = bf2f(f2bf(lgv[j] * (rv[j] - st.x) * st.y + lbv[j]));
+        }
+        if (!(LN == 2 && e.res_after_drop)) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[it][j] += rv[j];
+        }
       }
       if (e.act == 1) {
 #pragma unroll
@@ -428,6 +475,31 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           v[it][j] *= zk_drop_scale(seed, e.sid, (uint64_t)gm * N + gn + j, e.thr, e.inv_keep);
+      }
+      if constexpr (LN == 2) {
+        if (e.res && e.res_after_drop) {     // residual_fn: x + dropout(y) (func.py:321-324)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[it][j] += rv[j];
+        }
+        if (e.ln_stat_out) {
+          // statistics of the STORED (bf16) sum, as k_add_ln_fwd takes them: {sum, M2} of this row's 64-column group
+          const uint4 pk = pack8(v[it]);
+          float r8[8];
+          unpack8(pk, r8);
+          float s1 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s1 += r8[j];
+          s1 = zk_sum8(s1);
+          const float mt = s1 * (1.f / 64.f);
+          float s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float d = r8[j] - mt; s2 += d * d; }
+          s2 = zk_sum8(s2);
+          if ((tid & 7) == 0)
+            *reinterpret_cast<float2*>(e.ln_stat_out + ((size_t)gm * (N >> 6) + (gn >> 6)) * 2) = make_float2(s1, s2);
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)gm * e.ldc + gn) = pk;
+          continue;
+        }
       }
       if (e.out_f32) {
         // fp32 outputs are the large write-once tensors (weight gradients, logits): streaming stores, so that the
@@ -467,16 +539,33 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
     if (vec_ok && gn + 8 <= N) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] *= e.alpha;
+      if (LN == 1 && e.ln_c) {
+        const float2 st = s_lnstat[row];
+        float cv8[8];
+        ld8(e.ln_c + gn, cv8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = st.y * (v[j] - st.x * cv8[j]);
+      }
       if (e.bias) {
         const float4 a = *reinterpret_cast<const float4*>(e.bias + gn);
         const float4 b = *reinterpret_cast<const float4*>(e.bias + gn + 4);
         v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
       }
+      [[maybe_unused]] float rv[8];
       if (e.res) {
-        float rv[8];
         unpack8(zk_ld16<FRESH>(e.res + (size_t)gm * e.ldr + gn), rv);
+        if (LN == 2 && e.res_part) {
+          const float2 st = s_lnstat[row];
+          float g8[8], b8[8];
+          ld8(e.res_gamma + gn, g8);
+          ld8(e.res_beta + gn, b8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += rv[j];
+          for (int j = 0; j < 8; ++j) rv[j] = bf2f(f2bf(g8[j] * (rv[j] - st.x) * st.y + b8[j]));
+        }
+        if (!(LN == 2 && e.res_after_drop)) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += rv[j];
+        }
       }
       if (e.act == 1) {
 #pragma unroll
@@ -490,6 +579,31 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
       if (e.thr) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= zk_drop_scale(seed, e.sid, (uint64_t)gm * N + gn + j, e.thr, e.inv_keep);
+      }
+      if constexpr (LN == 2) {
+        if (e.res && e.res_after_drop) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += rv[j];
+        }
+        if (e.ln_stat_out) {
+          // (N % 64 == 0 and the 8 threads of a 64-column group are consecutive: the group is active as a whole)
+          const uint4 pk = pack8(v);
+          float r8[8];
+          unpack8(pk, r8);
+          float s1 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s1 += r8[j];
+          s1 = zk_sum8(s1);
+          const float mt = s1 * (1.f / 64.f);
+          float s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float d = r8[j] - mt; s2 += d * d; }
+          s2 = zk_sum8(s2);
+          if ((c & 7) == 0)
+            *reinterpret_cast<float2*>(e.ln_stat_out + ((size_t)gm * (N >> 6) + (gn >> 6)) * 2) = make_float2(s1, s2);
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)gm * e.ldc + gn) = pk;
+          continue;
+        }
       }
       if (e.out_f32) {
         float* d = reinterpret_cast<float*>(e.C) + (size_t)gm * e.ldc + gn;

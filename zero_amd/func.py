@@ -35,6 +35,12 @@ class _GroupDesc(ctypes.Structure):
 RED_COLS = 32      # columns per block of k_reduce_grouped (ZK_RED_COLS in zero_amd/csrc/zk_elem.hip)
 
 
+class _FoldDesc(ctypes.Structure):
+    """Mirror of ``struct FoldDesc`` (zero_amd/csrc/zk_prep.hip, include/zero_hip.h zk_ln_fold)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("W", "gamma", "beta", "b", "Wf", "c", "d")] + \
+               [(n, ctypes.c_int) for n in ("K", "N", "block_start", "pad")]
+
+
 class _ColsumDesc(ctypes.Structure):
     _fields_ = [("a", ctypes.c_void_p), ("partials", ctypes.c_void_p)] + \
                [(n, ctypes.c_int) for n in ("rows", "N", "lda", "gy", "block_start", "pad")]
@@ -162,6 +168,25 @@ class Engine(object):
             self._pins = PinnedRing(self.device)
         self._pins.put(dst, arr)
 
+    def copy_many(self, pairs):
+        """[(dst tensor, src tensor)] (same byte counts, multiples of 4): one launch (zk_copy_many)."""
+        pairs = [(d, s_) for d, s_ in pairs if d.numel()]
+        for i in range(0, len(pairs), 16):
+            chunk = pairs[i:i + 16]
+            n = len(chunk)
+            dsts = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in chunk])
+            srcs = (ctypes.c_void_p * n)(*[s_.data_ptr() for _, s_ in chunk])
+            sizes = (ctypes.c_size_t * n)(*[d.numel() * d.element_size() for d, _ in chunk])
+            assert all(d.numel() * d.element_size() == s_.numel() * s_.element_size() for d, s_ in chunk)
+            self.lib.call("zk_copy_many", dsts, srcs, sizes, n, self.stream)
+
+    @property
+    def upload_stream(self):
+        """Side stream on which Trainer.step uploads and prepares the NEXT batch while the previous step runs."""
+        if getattr(self, "_upload_stream", None) is None:
+            self._upload_stream = torch.cuda.Stream(self.device)
+        return self._upload_stream
+
     def batch_prep(self, batch):
         """zk_batch_prep on an uploaded batch (TransformerCore.upload): masks, loss weights, rows grouped by id."""
         B, Ls, Lt = batch["B"], batch["Ls"], batch.get("Lt", 0)
@@ -169,13 +194,13 @@ class Engine(object):
         ss, ts = batch.get("src_sort"), batch.get("tgt_sort")
         nbytes = (self.lib.query("zk_batch_prep_workspace", B * Ls) if ss else 0) + \
             (self.lib.query("zk_batch_prep_workspace", B * Lt) if ts else 0)
-        ws = self.buf("prep.scratch", (nbytes,), torch.uint8) if nbytes else None
+        ws = self.buf("prep.scratch" + batch.get("suffix", ""), (nbytes,), torch.uint8) if nbytes else None
         p = lambda d, k: d[k].data_ptr() if d else None
         self.lib.call("zk_batch_prep", batch["src"].data_ptr(), hip.ptr(tgt), B, Ls, Lt,
                       p(ss, "rows"), p(ss, "seg"), p(ss, "uid"), p(ss, "n"),
                       p(ts, "rows"), p(ts, "seg"), p(ts, "uid"), p(ts, "n"),
                       hip.ptr(batch.get("smask")), hip.ptr(batch.get("tmask")), hip.ptr(batch.get("tw")),
-                      float(batch.get("tw_scale", 1.0)), hip.ptr(ws), nbytes, self.stream)
+                      float(batch.get("tw_scale", 1.0)), int(batch.get("max_id", 0)), hip.ptr(ws), nbytes, self.stream)
 
     def zero(self, t):
         self.lib.call("zk_zero", t.data_ptr(), t.numel() * t.element_size(), self.stream)
@@ -193,6 +218,48 @@ class Engine(object):
             aux.ptr if aux is not None else None, aux.ld if aux is not None else 0, aux_scale,
             float(drop_p), self.seed.data_ptr(), sid,
             self.gemm_impl if impl is None else impl, ws.data_ptr(), ws.numel(), self.stream)
+
+    # ---- residual + LayerNorm folded into GEMM epilogues (zk_gemm_ln / zk_ln_fold / zk_add_ln_bwd_lazy) ----------------
+    def gemm_ln(self, A, B, C, M, N, K, bias, np_, residual=None, act=0, drop_p=0.0, sid=0, stat_out=None, in_part=None,
+                in_c=None, res_part=None, res_gamma=None, res_beta=None):
+        """zk_gemm_ln: producer (stat_out) / lazy residual (res_part, res_gamma, res_beta) / consumer (in_part, in_c)."""
+        self.lib.call("zk_gemm_ln", A.ptr, B.ptr, C.ptr, M, N, K, A.ld, B.ld, C.ld, hip.ptr(bias),
+                      residual.ptr if residual is not None else None, residual.ld if residual is not None else 0, act,
+                      float(drop_p), self.seed.data_ptr(), sid, hip.ptr(stat_out), hip.ptr(in_part), hip.ptr(in_c),
+                      hip.ptr(res_part), hip.ptr(res_gamma), hip.ptr(res_beta), int(np_), zdtype.epsilon(), self.stream)
+
+    def ln_fold(self, problems):
+        """One launch: for every (W fp32 master [K, N], gamma [K], beta [K], bias [N] or None, Wf Mat bf16, c, d) write
+        Wf = bf16(gamma o W), c = colsum(Wf), d = beta . W + bias.  The device descriptor table is cached."""
+        key = tuple((w.data_ptr(), g.data_ptr(), wf.ptr) for w, g, _, _, wf, _, _ in problems)
+        cache = self.__dict__.setdefault("_fold_cache", {})
+        ent = cache.get(key)
+        if ent is None:
+            arr = (_FoldDesc * len(problems))()
+            start = 0
+            for i, (w, g, bt, b, wf, c, d) in enumerate(problems):
+                K, N = w.shape
+                assert N % 64 == 0 and wf.ld == N
+                r = arr[i]
+                r.W, r.gamma, r.beta, r.b = w.data_ptr(), g.data_ptr(), bt.data_ptr(), hip.ptr(b) or 0
+                r.Wf, r.c, r.d = wf.ptr, c.data_ptr(), d.data_ptr()
+                r.K, r.N, r.block_start, r.pad = K, N, start, 0
+                start += N // 64
+            ent = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device), len(problems), start)
+            cache[key] = ent
+        dev, n, total = ent
+        self.lib.call("zk_ln_fold", dev.data_ptr(), n, total, self.stream)
+
+    def add_ln_bwd_lazy(self, dout, s, part, gamma, beta, y_out, dsum, dy, dgamma, dbeta, dbias_prev, drop_p=0.0, sid=0,
+                        private_ws=None):
+        ws_bytes = self.lib.query("zk_add_ln_bwd_workspace", dout.rows, dout.cols)
+        ws = private_ws if private_ws is not None else self.workspace(ws_bytes)
+        assert ws.numel() * ws.element_size() >= ws_bytes
+        self.lib.call("zk_add_ln_bwd_lazy", dout.ptr, s.ptr, part.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                      y_out.ptr if y_out is not None else None, dsum.ptr, dy.ptr if dy is not None else None,
+                      hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(dbias_prev), dout.rows, dout.cols, zdtype.epsilon(),
+                      float(drop_p), self.seed.data_ptr(), sid, ws.data_ptr(), ws.numel() * ws.element_size(),
+                      1 if private_ws is not None else 0, self.stream)
 
     def gemm_kseg(self, segments, C, M, N, kseg, tb, residual=None):
         """C = sum over (A_s, B_s) in segments of A_s @ B_s (B_s transposed when tb) in one launch

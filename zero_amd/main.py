@@ -178,9 +178,40 @@ class Trainer(object):
         hp = self.params
         if not use_graph or features["source"].shape[0] == 0 or self.core.use_side:
             return self.micro_step(features)
+        if hp.update_cycle == 1 and self.pad_len == 1:
+            # The batch is uploaded (asynchronous copies through pinned slots) and prepared (zk_batch_prep: masks, loss
+            # weights, token rows grouped by embedding id) on a SIDE stream into one of two staging sets -- in the steady
+            # state, where the host runs ahead of the device, that happens while the PREVIOUS step is still running --
+            # and the captured step then starts with one small copy launch (commit) instead of waiting for a ~60-us
+            # single-workgroup sort.  The step itself is unchanged; one graph per batch shape as before.
+            eng = self.core.eng
+            cur = torch.cuda.current_stream(eng.device)
+            ws, up = eng.work_stream, eng.upload_stream
+            slot = self._stage_slot = 1 - getattr(self, "_stage_slot", 1)
+            evs = self.__dict__.setdefault("_commit_events", [None, None])
+            if evs[slot] is not None:
+                up.wait_event(evs[slot])            # the commit that last read this staging set is done
+            self.lr.step(self.global_step)
+            self.train_op.count = 0
+            with torch.cuda.stream(up):
+                staged = self.core.upload(features["source"], features["target"], suffix=".stg%d" % slot)
+                # the step's host scalars (lr_t, ...) travel the same way: no copy of their own between two step graphs
+                hstage = eng.buf("hyper.stg%d" % slot, (12,), torch.float32)
+                scale = self.train_op.set_hyper(self.lr.get_lr(), parallel.world_size(), dst=hstage)
+                ev_up = torch.cuda.Event()
+                ev_up.record(up)
+            ws.wait_stream(cur)
+            ws.wait_event(ev_up)
+            with torch.cuda.stream(ws):
+                self.batch = self.core.commit(staged, extra=self.train_op.hyper_pairs(hstage))
+                if evs[slot] is None:
+                    evs[slot] = torch.cuda.Event()
+                evs[slot].record(ws)
+                self._declare_sparse(self.batch)
+                loss = self._step_static(True, scale=scale)
+            cur.wait_stream(ws)
+            return loss
         if hp.update_cycle == 1:
-            # upload (asynchronous copies through pinned slots + the id-dependent launch, TransformerCore.upload) and
-            # the captured step on ONE stream: no host wait and no cross-stream edge between them
             eng = self.core.eng
             cur = torch.cuda.current_stream(eng.device)
             ws = eng.work_stream
@@ -470,15 +501,17 @@ class Trainer(object):
                 if h[0] in ("graph", "update") and not isinstance(h[1], str):
                     eng.lib.call("zk_graph_destroy", h[1])
 
-    def _step_static(self, use_graph):
+    def _step_static(self, use_graph, scale=None):
+        """scale: the caller has already staged this step's host scalars (Trainer.step: side stream + commit launch)."""
         hp = self.params
         assert hp.update_cycle == 1, "captured step supports update_cycle == 1"
         world = parallel.world_size()
         eng = self.core.eng
         self._check_graph_cache()
-        self.lr.step(self.global_step)
-        self.train_op.count = 0
-        scale = self.train_op.set_hyper(self.lr.get_lr(), world)
+        if scale is None:
+            self.lr.step(self.global_step)
+            self.train_op.count = 0
+            scale = self.train_op.set_hyper(self.lr.get_lr(), world)
         if world == 1 and use_graph and not self.force_segmented:
             key = (self.batch["B"], self.batch["Ls"], self.batch["Lt"])
             g = self._graphs.pop(key, None)
@@ -488,7 +521,7 @@ class Trainer(object):
                 # first use of a shape runs eagerly once (sizes every scratch buffer), then
                 # the same launch sequence is captured
                 self._graphs[key] = "warm"
-                return self._step_static(False)
+                return self._step_static(False, scale=scale)
             if g == "warm":
                 def body():
                     self._train_and_update(scale)

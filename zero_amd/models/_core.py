@@ -37,6 +37,16 @@ def trim_columns(ids):
     return np.ascontiguousarray(ids[:, keep])
 
 
+class LazyLN(object):
+    """LN(s) that no kernel has written (round 4): the un-normalised sum ``s`` a producer GEMM left (zk_gemm_ln), its
+    per-64-column row statistics ``part`` and the LayerNorm scope whose gamma / beta apply.  Readers normalise where they
+    read: the consumer GEMM algebraically, the next residual on the fly, the backward from the same statistics."""
+    __slots__ = ("s", "part", "scope", "tag", "rows")
+
+    def __init__(self, s, part, scope, tag):
+        self.s, self.part, self.scope, self.tag, self.rows = s, part, scope, tag, s.rows
+
+
 class TransformerCore(object):
     def __init__(self, params, model_name, store=None, device=None):
         self.hp = params
@@ -116,6 +126,59 @@ class TransformerCore(object):
         self.attn_oproj = os.environ.get("ZERO_HIP_ATTN_OPROJ", "auto").lower()
         self._red_id = 0
         self._side_stream = None      # created on first use: every stream of the process takes a share of the hardware queues
+        # Residual + LayerNorm without a launch of its own in the TRAINING forward (round 4, VERDICT r03 item 1b): the
+        # o_map / ffn-output GEMM adds the residual and leaves the un-normalised sum + row statistics (zk_gemm_ln), the
+        # next linear reads the sum against gamma-folded weights (zk_ln_fold, one launch per step), the next residual
+        # normalises on the fly, and the LayerNorm backward -- which runs anyway -- writes the normalised rows for the
+        # deferred weight gradients.  28 of the 30 LayerNorm-forward launches of a Transformer-base step go (the two that
+        # end the encoder / decoder stacks keep their launch: their outputs feed grouped / 256-tile GEMMs).
+        # MEASURED (profiles/r04_negative_results.txt): parity holds at the BASELINE sizes, the step does NOT get
+        # faster (+0.03 to +0.09 ms) -- what the 28 launches did has to be done somewhere: the producer epilogues cost
+        # +2 us each, the LayerNorm backward +5..7 us for the normalised rows it now writes, the fold launch 42 us.  So it
+        # is an experiment: only in a `make EXPERIMENTS=1` library, only with ZERO_HIP_LAZY_LN=1.
+        self.lazy_ln_mode = os.environ.get("ZERO_HIP_LAZY_LN", "0").lower() if self.eng.lib.experiments else "0"
+        self._lazy = False            # set per forward()
+        self._lazy_tags = {}          # tag -> LazyLN of this step's forward (read by the backward)
+
+    def _use_lazy_ln(self, train, save):
+        if self.lazy_ln_mode != "1" or not (train and save):
+            return False
+        ok = self.group_all and self.group_wgrad and self.eng.gemm_impl == 0 and not self.use_side and \
+            not self.aan and not self.fuse and self.H % 128 == 0 and self.H // 64 <= 16 and self.F % 64 == 0 and \
+            not self.eng.programs_enabled
+        if self.lazy_ln_mode == "1" and not ok:
+            raise hip.ZeroHipError("ZERO_HIP_LAZY_LN=1: the LayerNorm-free forward needs one rank (all weight gradients in "
+                                   "one deferred launch), the plain / rpr Transformer and H a multiple of 128 (<= 1024)")
+        return ok
+
+    def _lazy_pairs(self):
+        """[(linear scope, LayerNorm scope)]: every linear layer of the training forward whose input is the output of a
+        LayerNorm that is not materialised -- the weights zk_ln_fold prepares at the head of the step."""
+        hp, out = self.hp, []
+        for l in range(hp.num_encoder_layer):
+            pre = "encoder/layer_%d" % l
+            if l > 0:
+                out.append((pre + "/self_attention/dot_attention/qkv_map", "encoder/layer_%d/feed_forward" % (l - 1)))
+            out.append((pre + "/feed_forward/ffn_layer/enlarge", pre + "/self_attention"))
+        for l in range(hp.num_decoder_layer):
+            pre = "decoder/layer_%d" % l
+            if l > 0:
+                out.append((pre + "/self_attention/dot_attention/qkv_map", "decoder/layer_%d/feed_forward" % (l - 1)))
+            out.append((pre + "/%s/dot_attention/q_map" % self.cross, pre + "/self_attention"))
+            out.append((pre + "/feed_forward/ffn_layer/enlarge", pre + "/" + self.cross))
+        return out
+
+    def _fold_weights(self):
+        """zk_ln_fold for every pair of _lazy_pairs(): ONE launch at the head of the step (the fp32 masters changed in
+        the previous update)."""
+        e, st = self.eng, self.store
+        probs = []
+        for lin, ln in self._lazy_pairs():
+            W = st.w(lin + "/W_0_0")
+            K, N = W.shape
+            probs.append((W, st.w(ln + "/layer_norm/scale"), st.w(ln + "/layer_norm/offset"), st.w(lin + "/b_0"),
+                          e.mat("fold.W." + lin, K, N), e.buf("fold.c." + lin, (N,), F32), e.buf("fold.d." + lin, (N,), F32)))
+        e.ln_fold(probs)
 
     def _use_oproj(self, B):
         if self.attn_oproj in ("0", "1"):
@@ -200,7 +263,15 @@ class TransformerCore(object):
         return self.store.g(name)
 
     def _linear(self, x, scope, out, act=0, drop_p=0.0, sid=0):
-        """y = x @ W + b  (func.py:14-65)."""
+        """y = x @ W + b  (func.py:14-65).  x a LazyLN: y = LN(s) @ W + b from the un-normalised sum, the gamma-folded
+        weight and the row statistics (zk_gemm_ln consumer form)."""
+        if isinstance(x, LazyLN):
+            e = self.eng
+            K, N = self.store.pshape[scope + "/W_0_0"]
+            e.gemm_ln(x.s, e.mat("fold.W." + scope, K, N), out, x.rows, N, K, e.buf("fold.d." + scope, (N,), F32),
+                      self.H // 64, act=act, drop_p=drop_p, sid=sid, in_part=x.part,
+                      in_c=e.buf("fold.c." + scope, (N,), F32))
+            return
         Wm = self.W(scope + "/W_0_0")
         self.eng.gemm(x, Wm, out, x.rows, Wm.cols, Wm.rows, 0, 0, bias=self.b(scope + "/b_0"), act=act,
                       drop_p=drop_p, sid=sid)
@@ -243,6 +314,36 @@ class TransformerCore(object):
                           aux_scale=aux_scale)
 
     # ------------------------------------------------------------------ sub-layers (forward)
+    def _out_ln(self, a, lin, x, scope, tag, save, drop_p, sid, last=False):
+        """The tail of a sub-layer: LN(x + dropout(a @ W + b)) (func.py:321-324, 289-303; transformer.py:57-58).
+        Default: the GEMM, then the residual + LayerNorm launch.  With the LayerNorm-free forward (self._lazy) the GEMM
+        adds the residual itself -- normalising it on the fly when x is a LazyLN -- and leaves the un-normalised sum with
+        its row statistics; nothing normalises it here unless it ends a stack (last)."""
+        e, H = self.eng, self.H
+        T = a.rows
+        if not self._lazy:
+            y = e.mat("tmp.y%d" % T, T, H)
+            self._linear(a, lin, y)
+            return self._ln_fwd(x, y, scope, tag, save, drop_p, sid)
+        Wm = self.W(lin + "/W_0_0")
+        s = e.mat(tag + ".s", T, H)
+        part = e.buf(tag + ".part", (T, H // 64, 2), F32)
+        lazy_res = isinstance(x, LazyLN)
+        e.gemm_ln(a, Wm, s, T, H, Wm.rows, self.b(lin + "/b_0"), H // 64, residual=x.s if lazy_res else x,
+                  drop_p=drop_p, sid=sid, stat_out=part, res_part=x.part if lazy_res else None,
+                  res_gamma=self.b(x.scope + "/layer_norm/scale") if lazy_res else None,
+                  res_beta=self.b(x.scope + "/layer_norm/offset") if lazy_res else None)
+        if not last:
+            out = LazyLN(s, part, scope, tag)
+            self._lazy_tags[tag] = out
+            return out
+        # end of a stack: the normalised rows feed grouped / 256-tile GEMMs -> one LayerNorm launch over the stored sum
+        # (its own statistics; the backward of this sub-layer is the ordinary one)
+        out = e.mat(tag + ".o", T, H)
+        e.add_ln_fwd(s, None, self.b(scope + "/layer_norm/scale"), self.b(scope + "/layer_norm/offset"), out, None,
+                     e.buf(tag + ".mean", (T,), F32), e.buf(tag + ".rstd", (T,), F32), 0.0, sid)
+        return out
+
     def _ln_fwd(self, x, y, scope, tag, save, drop_p, sid):
         T, H = x.rows, self.H
         e = self.eng
@@ -271,9 +372,7 @@ class TransformerCore(object):
         e.attn_fwd(qkv.cols_slice(0, H), qkv.cols_slice(H, 2 * H), qkv.cols_slice(2 * H, 3 * H), att, lse, B,
                    self.nh, L, L, self.d, kmask=kmask, causal=causal, rpr_k=rk, rpr_v=rv,
                    max_rel=hp.max_relative_position, drop_p=hp.attention_dropout if train else 0.0, sid=sid0)
-        y = e.mat("tmp.y%d" % T, T, H)
-        self._linear(att, p + "o_map", y)
-        return self._ln_fwd(x, y, scope, tag, save, hp.residual_dropout if train else 0.0, sid0 + 1)
+        return self._out_ln(att, p + "o_map", x, scope, tag, save, hp.residual_dropout if train else 0.0, sid0 + 1)
 
     def _cross_kv_grouped(self, mem, n_layers):
         """k_map / v_map of EVERY decoder layer read only the encoder output (func.py:206-216): one
@@ -313,19 +412,16 @@ class TransformerCore(object):
             atts = e.mat(tag + ".atts", x.rows, H)
             e.cumavg_add_fwd(vq, fuse_tmask, att, atts, B, Lq, H)
             att = atts
-        y = e.mat("tmp.y%d" % x.rows, x.rows, H)
-        self._linear(att, p + "o_map", y)
-        return self._ln_fwd(x, y, scope, tag, save, hp.residual_dropout if train else 0.0, sid0 + 1)
+        return self._out_ln(att, p + "o_map", x, scope, tag, save, hp.residual_dropout if train else 0.0, sid0 + 1)
 
-    def _ffn_fwd(self, x, scope, tag, save, sid0, train):
+    def _ffn_fwd(self, x, scope, tag, save, sid0, train, last=False):
         e, H, F = self.eng, self.H, self.F
         hp = self.hp
         p = scope + "/ffn_layer/"
         h = e.mat(tag + ".h", x.rows, F)
         self._linear(x, p + "enlarge", h, act=1, drop_p=hp.relu_dropout if train else 0.0, sid=sid0)
-        y = e.mat("tmp.y%d" % x.rows, x.rows, H)
-        self._linear(h, p + "output", y)
-        return self._ln_fwd(x, y, scope, tag, save, hp.residual_dropout if train else 0.0, sid0 + 1)
+        return self._out_ln(h, p + "output", x, scope, tag, save, hp.residual_dropout if train else 0.0, sid0 + 1,
+                            last=last)
 
     def _aan_fwd(self, x, B, L, scope, tag, tmask, save, sid0, train):
         e, H = self.eng, self.H
@@ -356,7 +452,16 @@ class TransformerCore(object):
         dy = e.mat("g.%s.dy" % tag, T, H) if drop_p > 0.0 else None
         dgam, dbet = self.gb(scope + "/layer_norm/scale"), self.gb(scope + "/layer_norm/offset")
         dbp = self.gb(prev_bias) if prev_bias is not None else None
-        if self.group_wgrad and e.gemm_impl == 0:
+        lz = self._lazy_tags.get(tag)
+        if lz is not None:
+            # the LayerNorm the forward never launched: statistics from the producer GEMM's partials; the normalised rows
+            # (X operand of the consumer's deferred weight gradient) are written here, by the launch that runs anyway
+            nbytes = e.lib.query("zk_add_ln_bwd_workspace", T, H)
+            pws = e.buf("g.%s.lnws" % tag, (nbytes // 4,), F32)
+            e.add_ln_bwd_lazy(dx, lz.s, lz.part, self.b(scope + "/layer_norm/scale"), self.b(scope + "/layer_norm/offset"),
+                              e.mat(tag + ".o", T, H), ds, dy, dgam, dbet, dbp, drop_p, sid, private_ws=pws)
+            self._pending_lnred.append((pws, T, H, dgam, dbet, dbp))
+        elif self.group_wgrad and e.gemm_impl == 0:
             # per-block partial sums go to a buffer private to this sub-layer; the column reduction
             # joins the grouped reduction launch of this layer group
             nbytes = e.lib.query("zk_add_ln_bwd_workspace", T, H)
@@ -487,37 +592,70 @@ class TransformerCore(object):
         return dx_out
 
     # ------------------------------------------------------------------ whole model
-    def upload(self, source, target=None, trim=True):
+    def upload(self, source, target=None, trim=True, suffix=""):
         """Host ids -> device int32 (after remove_invalid_seq) through pinned staging slots (asynchronous copies on the
         current stream), then ONE launch (zk_batch_prep) for everything that depends on the ids alone: source mask,
         target mask + loss weights and -- with a target -- the grouping of the token rows by embedding id that the
         atomics-free embedding gradient reads (rounds 1-3 sorted on the host, two numpy sorts + ~10 blocking copies per
         batch; the reference's TensorFlow does it on the device, main.py:28).  Returns dict of static device buffers +
-        dims."""
+        dims.  suffix: write a second, STAGING set of the same buffers (Trainer.step prepares the next batch on a side
+        stream while the previous step still reads the static set; commit() moves it over)."""
         e = self.eng
         src = np.asarray(source.cpu() if torch.is_tensor(source) else source)
         if trim:
             src = trim_columns(src)
         B, Ls = src.shape
-        ids_s = e.buf("ids.src", (B, Ls), torch.int32)
+        ids_s = e.buf("ids.src" + suffix, (B, Ls), torch.int32)
         e.h2d(ids_s, src)
-        out = {"B": B, "Ls": Ls, "src": ids_s}
+        out = {"B": B, "Ls": Ls, "src": ids_s, "suffix": suffix,
+               "max_id": max(self.hp.src_vocab.size(), self.hp.tgt_vocab.size())}
         ids_t, Lt = None, 0
         if target is not None:
             tgt = np.asarray(target.cpu() if torch.is_tensor(target) else target)
             if trim:
                 tgt = trim_columns(tgt)
             Lt = tgt.shape[1]
-            ids_t = e.buf("ids.tgt", (B, Lt), torch.int32)
+            ids_t = e.buf("ids.tgt" + suffix, (B, Lt), torch.int32)
             e.h2d(ids_t, tgt)
-            out.update({"Lt": Lt, "tgt": ids_t, "src_sort": self._sort_buffers("src", B * Ls),
-                        "tgt_sort": self._sort_buffers("tgt", B * Lt)})
+            out.update({"Lt": Lt, "tgt": ids_t, "src_sort": self._sort_buffers("src" + suffix, B * Ls),
+                        "tgt_sort": self._sort_buffers("tgt" + suffix, B * Lt)})
         if B > 0:
-            out["smask"] = e.buf("smask", (B, Ls), F32)
+            out["smask"] = e.buf("smask" + suffix, (B, Ls), F32)
             if ids_t is not None:
-                out["tmask"], out["tw"] = e.buf("tmask", (B, Lt), F32), e.buf("tw", (B, Lt), F32)
+                out["tmask"], out["tw"] = e.buf("tmask" + suffix, (B, Lt), F32), e.buf("tw" + suffix, (B, Lt), F32)
                 out["tw_scale"] = float(self.hp.loss_scale)
             e.batch_prep(out)
+        return out
+
+    def commit(self, staged, extra=()):
+        """Move a batch that upload(..., suffix=...) prepared in staging buffers into the static buffers the captured
+        step reads: one launch (zk_copy_many) on the current stream.  extra: more (dst, src) pairs for the same launch
+        (the step's host scalars).  Returns the batch dict over the static buffers."""
+        e = self.eng
+        B, Ls, Lt = staged["B"], staged["Ls"], staged.get("Lt", 0)
+        out = {"B": B, "Ls": Ls, "suffix": ""}
+        pairs = []
+
+        def take(key, name, shape, dt):
+            dst = e.buf(name, shape, dt)
+            pairs.append((dst, staged[key]))
+            out[key] = dst
+        take("src", "ids.src", (B, Ls), torch.int32)
+        if "tgt" in staged:
+            out["Lt"] = Lt
+            take("tgt", "ids.tgt", (B, Lt), torch.int32)
+            for side, T in (("src", B * Ls), ("tgt", B * Lt)):
+                d = self._sort_buffers(side, T)
+                for k in ("rows", "seg", "uid", "n"):
+                    pairs.append((d[k], staged[side + "_sort"][k]))
+                out[side + "_sort"] = d
+        if "smask" in staged:
+            take("smask", "smask", (B, Ls), F32)
+        if "tmask" in staged:
+            take("tmask", "tmask", (B, Lt), F32)
+            take("tw", "tw", (B, Lt), F32)
+            out["tw_scale"] = staged["tw_scale"]
+        e.copy_many(pairs + list(extra))
         return out
 
     def _sort_buffers(self, name, T):
@@ -558,7 +696,8 @@ class TransformerCore(object):
                 pre = "encoder/layer_%d" % l
                 x = self._self_attn_fwd(x, B, Ls, pre + "/self_attention", "e%d.sa" % l, smask, False, save,
                                         100 * l + 1, train)
-                x = self._ffn_fwd(x, pre + "/feed_forward", "e%d.ff" % l, save, 100 * l + 11, train)
+                x = self._ffn_fwd(x, pre + "/feed_forward", "e%d.ff" % l, save, 100 * l + 11, train,
+                                  last=(l == hp.num_encoder_layer - 1))
             return x
         # the layer stack is sentence-local all the way down: one persistent launch (zk_layer.hip) when every op of
         # it can be recorded (plain dot-product attention on the MFMA tiles), ordinary launches otherwise
@@ -596,7 +735,8 @@ class TransformerCore(object):
                 self._join_side()
             x = self._cross_attn_fwd(x, enc, B, Lt, Ls, pre + "/" + self.cross, "d%d.ca" % l, smask, save,
                                      sid + 11, train, kv_ready=group_kv, fuse_tmask=tmask if self.fuse else None)
-            x = self._ffn_fwd(x, pre + "/feed_forward", "d%d.ff" % l, save, sid + 21, train)
+            x = self._ffn_fwd(x, pre + "/feed_forward", "d%d.ff" % l, save, sid + 21, train,
+                              last=(l == hp.num_decoder_layer - 1))
         return x, tmask, w
 
     def loss_head(self, batch, feat, w, label_smooth, need_grad):
@@ -632,9 +772,14 @@ class TransformerCore(object):
 
     def forward(self, batch, train=False, save=False, label_smooth=None):
         ls = self.hp.label_smooth if label_smooth is None else label_smooth
+        self._lazy = self._use_lazy_ln(train, save)
+        self._lazy_tags = {}
+        if self._lazy:
+            self._fold_weights()
         enc, smask = self.encode(batch, train, save)
         feat, tmask, w = self.decode_train(batch, enc, smask, train, save)
         loss, per_sample, logits, dlogits = self.loss_head(batch, feat, w, ls, save)
+        self._lazy = False        # (encode() / decode_train() are also called directly by the decode path)
         self._ctx = (batch, enc, smask, feat, tmask, dlogits)
         return loss, per_sample, logits
 

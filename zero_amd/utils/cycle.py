@@ -75,8 +75,11 @@ class TrainOp(object):
         self.eng.lib.call("zk_axpby_f32", st.grad.data_ptr(), st.accum.data_ptr(), 1.0, 1.0, st.numel,
                           self.eng.stream)
 
-    def set_hyper(self, lr, world=1):
-        """Host-side scalars of this update (lr is fed per step: main.py:157,292)."""
+    def set_hyper(self, lr, world=1, dst=None):
+        """Host-side scalars of this update (lr is fed per step: main.py:157,292).  dst: a staging copy of ``hyper``
+        to fill instead (Trainer.step uploads the next step's scalars on its side stream; hyper_pairs() lists what the
+        commit launch then copies)."""
+        hyper = self.hyper if dst is None else dst
         hp = self.hp
         t = self.store.step + 1
         lr_t = lr * math.sqrt(1.0 - hp.beta2 ** t) / (1.0 - hp.beta1 ** t)
@@ -84,13 +87,20 @@ class TrainOp(object):
         clip = float(clip) if isinstance(clip, float) else 0.0
         scale = 1.0 / (float(world) * float(hp.loss_scale) * float(self.count + 1))
         import numpy as _np
-        self._pins.put(self.hyper[:6], _np.array([lr_t, hp.beta1, hp.beta2, hp.epsilon, scale, clip], dtype=_np.float32))
+        self._pins.put(hyper[:6], _np.array([lr_t, hp.beta1, hp.beta2, hp.epsilon, scale, clip], dtype=_np.float32))
         if self.ema is not None:
             # num_updates = global_step after this update (ema.apply runs under train_op's control
             # dependency, cycle.py:116-118): d = min(decay, (1 + n) / (10 + n))
-            self._pins.put(self.hyper[8:9], _np.array([min(float(hp.ema_decay), (1.0 + t) / (10.0 + t))],
+            self._pins.put(hyper[8:9], _np.array([min(float(hp.ema_decay), (1.0 + t) / (10.0 + t))],
                                                       dtype=_np.float32))
         return scale
+
+    def hyper_pairs(self, staged):
+        """(dst, src) copies that move staged host scalars into ``hyper`` ([6], [7], [9], [10] are the device's own)."""
+        pairs = [(self.hyper[:6], staged[:6])]
+        if self.ema is not None:
+            pairs.append((self.hyper[8:9], staged[8:9]))
+        return pairs
 
     def launch_update(self, scale, advance_seed=True):
         """Device side of train_op; graph-capturable (reads scalars from self.hyper).  Also advances the
