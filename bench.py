@@ -105,12 +105,14 @@ HBM_PEAK_TBS = 8.0               # same guide: HBM3E peak
 CLASSES = (
     ("small_gemm_chain", "mfma", "linear forward + dgrad on the 4096-row activations (k_gemm_dlds tiles), grouped K/V "
                                  "projections, K-segmented d(encoder output)"),
-    ("big_gemms", "mfma", "all weight gradients (one grouped launch of 256x256 tiles), logits forward, dlogits x E"),
+    ("big_gemms", "mfma", "all weight gradients (one grouped launch of 256x256 tiles; it also runs the Adam update of the "
+                          "weight matrices on its accumulators), logits forward, dlogits x E"),
     ("attention", "hbm", "attention forward / backward, one (sentence, head) tile per workgroup (backward incl. the "
                          "folded o_map dgrad)"),
     ("layernorm", "hbm", "residual + LayerNorm forward / backward"),
     ("cross_entropy", "hbm", "label-smoothed cross entropy: fp32 logits in, bf16 dlogits out"),
-    ("adam", "hbm", "TF1 Adam + bf16 shadow refresh + norms, 30 B / parameter"),
+    ("adam", "hbm", "TF1 Adam + bf16 shadow refresh + norms, 30 B / parameter, on what the weight-gradient launch did not "
+                    "update itself (embedding tables, biases, LayerNorm parameters)"),
 )
 
 
@@ -131,7 +133,8 @@ class LaunchProfiler(object):
         if gen == 2:
             ns = 4 if (bm, bn) == (64, 64) else 3 if max(bm, bn) == 256 else 2
             # ..., 4 compute waves, producer waves per workgroup
-            return "k_gemm_dlds<%d, %d, %d, %s, %s, 4, %d>" % (bm, bn, ns, tf(ta), tf(tb), (code >> 28) & 7)
+            # ..., lazy-LayerNorm epilogue form (0: none; the EXPERIMENTS-only zk_gemm_ln uses 1 / 2)
+            return "k_gemm_dlds<%d, %d, %d, %s, %s, 4, %d, 0>" % (bm, bn, ns, tf(ta), tf(tb), (code >> 28) & 7)
         return "k_gemm_mfma<%d, %d, %s, %s>" % (bm, bn, tf(ta), tf(tb))
 
     def _timed(self, cls, name, flops, nbytes, fn):
@@ -145,7 +148,8 @@ class LaunchProfiler(object):
     def __enter__(self):
         eng = self.eng
         keep = self._saved
-        for k in ("gemm", "gemm_grouped", "gemm_kseg", "attn_fwd", "attn_bwd", "add_ln_fwd", "add_ln_bwd", "ce_fused",
+        for k in ("gemm", "gemm_grouped", "gemm_grouped_update", "gemm_kseg", "attn_fwd", "attn_bwd", "add_ln_fwd",
+                  "add_ln_bwd", "ce_fused",
                   "gemm_ln", "ln_fold", "add_ln_bwd_lazy"):      # (the last three: the EXPERIMENTS-only LayerNorm-free forward)
             keep[k] = getattr(eng, k)
         esz = lambda m: m.t.element_size()
@@ -168,7 +172,8 @@ class LaunchProfiler(object):
                 k32 = len(tile) == 3 and tile[2] == "k32"
                 cs = bool(ta) and not tb and any(len(p) > 8 and p[8] is not None for p in problems)
                 spread = not k32 and not (len(tile) == 3 and not tile[2])
-                name = "k_gemm_grouped256<%s, %s, %s, %s, %s>" % (tf(ta), tf(tb), tf(spread), tf(cs), tf(k32))
+                # ..., UPD = the optimiser update inside the launch (gemm_grouped_update below)
+                name = "k_gemm_grouped256<%s, %s, %s, %s, %s, false>" % (tf(ta), tf(tb), tf(spread), tf(cs), tf(k32))
             else:
                 name = "k_gemm_grouped<%d, %d, %d, %s, %s, %d>" % (bm_, bn_, 4 if bm_ == 64 else 3 if max(bm_, bn_) == 256 else 2,
                                                                   tf(ta), tf(tb), 4 if max(bm_, bn_) == 256 else 0)
@@ -176,6 +181,21 @@ class LaunchProfiler(object):
             fl = sum(2.0 * p[3] * p[4] * p[5] for p in problems)
             nbytes = sum((p[3] * p[5] + p[5] * p[4]) * 2 + p[3] * p[4] * esz(p[2]) for p in problems)
             return self._timed(cls, name, fl, nbytes, lambda: keep["gemm_grouped"](problems, ta, tb, tile=tile))
+
+        def gemm_grouped_update(problems, upd):
+            # all weight gradients + the Adam update of the fusable weights in one launch: the update's 22 B per
+            # parameter (theta, m, v read + written, bf16 shadow written) replace the 4 B of the gradient store
+            fl = sum(2.0 * p[3] * p[4] * p[5] for p in problems)
+            out = keep["gemm_grouped_update"](problems, upd)
+            self.fused_numel = sum(hi - lo for lo, hi in out[0])
+            return out
+
+        def gemm_grouped_update_timed(problems, upd):
+            fused = sum(p[3] * p[4] for p in problems if len(p) > 9 and p[9])
+            nbytes = sum((p[3] * p[5] + p[5] * p[4]) * 2 + p[3] * p[4] * 4 for p in problems) + 18.0 * fused
+            return self._timed("big_gemms", "k_gemm_grouped256<true, false, false, true, false, true>",
+                               sum(2.0 * p[3] * p[4] * p[5] for p in problems), nbytes,
+                               lambda: gemm_grouped_update(problems, upd))
 
         def gemm_kseg(segments, C, M, N, kseg, tb, residual=None):
             name = "k_gemm_kseg<64, 64, 4, %s, 4>" % ("true" if tb else "false")
@@ -222,14 +242,17 @@ class LaunchProfiler(object):
         def ce_fused(logits, ids, w, ce, dlogits, rows, Vn, ls):
             return self._timed("cross_entropy", None, 0.0, rows * logits.ld * (4 + (2 if dlogits is not None else 0)),
                                lambda: keep["ce_fused"](logits, ids, w, ce, dlogits, rows, Vn, ls))
-        for k, fn in (("gemm", gemm), ("gemm_grouped", gemm_grouped), ("gemm_kseg", gemm_kseg), ("attn_fwd", attn_fwd),
+        for k, fn in (("gemm", gemm), ("gemm_grouped", gemm_grouped), ("gemm_grouped_update", gemm_grouped_update_timed),
+                      ("gemm_kseg", gemm_kseg), ("attn_fwd", attn_fwd),
                       ("attn_bwd", attn_bwd), ("add_ln_fwd", add_ln_fwd), ("add_ln_bwd", add_ln_bwd), ("ce_fused", ce_fused),
                       ("gemm_ln", gemm_ln), ("ln_fold", ln_fold), ("add_ln_bwd_lazy", add_ln_bwd_lazy)):
             setattr(eng, k, fn)
         if self.top is not None:
             keep["launch_update"] = self.top.launch_update
             numel = self.top.store.numel
-            self.top.launch_update = lambda *a, **kw: self._timed("adam", None, 0.0, 30.0 * numel,
+            # (the parameters the weight-gradient launch updated itself are not this pass's traffic)
+            self.top.launch_update = lambda *a, **kw: self._timed("adam", None, 0.0,
+                                                                  30.0 * (numel - getattr(self, "fused_numel", 0)),
                                                                   lambda: keep["launch_update"](*a, **kw))
         return self
 
@@ -710,6 +733,8 @@ def main():
         return out
 
     if world == 1:
+        if args.static_batch:
+            tr.prepare_static(feats[0])
         dt, loss = timed(static if args.static_batch else rotating, args.steps, max(args.warmup, 2))   # >= 2: eager sizing pass + capture
         chosen = {"_dt": dt, "_loss": loss}
     else:

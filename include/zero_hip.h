@@ -306,6 +306,23 @@ size_t zk_adam_step_workspace(void);
 int zk_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n, float* hyper,
                  float* pnorm_out, uint64_t* seed, int norm_free, void* workspace, size_t ws_bytes,
                  zk_stream_t stream);
+#ifdef ZK_EXPERIMENTS   /* measured slower than gradient launch + Adam pass (profiles/r04_negative_results.txt): make EXPERIMENTS=1 */
+/* ---- round 4: the optimiser update of the weight matrices INSIDE the launch that makes their gradients
+ * (utils/cycle.py:94-101 norm-free form + main.py:178-181 TF1 Adam, fused into the autodiff mirror of func.py:14-65).
+ *   zk_gemm_grouped_update   the grouped weight-gradient launch of 256 x 256 tiles (as zk_gemm_grouped with ta = 1,
+ *       tb = 0, tile 8 | 256: bias column sums ride along); a descriptor with pad & 1 marks a problem whose output C is a
+ *       whole variable inside the flat gradient buffer `grad_base`: its tiles do not store the gradient but run Adam on
+ *       the accumulators against master / m / v / shadow at the same offset (hyper as zk_adam_step) and leave the wave's
+ *       {sum g^2, sum theta^2} in sq [total_tiles][8][2] (zeros from the other tiles).
+ *   zk_adam_step_segments    the norm-free update of everything else: segments [seg_lo[s], +len) of the flat buffers
+ *       (DEVICE int64 arrays, elements, multiples of 4, ascending; prefix = running lengths, prefix[0] = 0, total =
+ *       prefix[nseg]), then gradient / parameter norms over both parts (extra = sq above, n_extra = total_tiles * 8). */
+int zk_gemm_grouped_update(const void* descs, int nprob, int total_tiles, float* master, float* m, float* v, void* shadow,
+                           const float* grad_base, const float* hyper, float* sq, zk_stream_t stream);
+int zk_adam_step_segments(float* p, const float* g, float* m, float* v, void* shadow, const long* seg_lo, const long* prefix,
+                          int nseg, long total, float* hyper, float* pnorm_out, uint64_t* seed, const float* extra,
+                          int n_extra, void* workspace, size_t ws_bytes, zk_stream_t stream);
+#endif /* ZK_EXPERIMENTS */
 #ifdef ZK_EXPERIMENTS   /* Adam beside the encoder backward: 5.01 vs 4.94 ms (DESIGN 6b): make EXPERIMENTS=1 */
 /* the norm-free update in pieces: TF1 Adam on n elements writing its partial sums of squares into workspace slot
  * `slot` (< 16); zk_adam_finish sums nslots slots -> hyper[6] (+ flags), pnorm_out, seed += 1.  Lets the update of

@@ -1177,6 +1177,99 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
     if (threadIdx.x == 0) gsq[blockIdx.x] = gacc;
   }
 }
+#ifdef ZK_EXPERIMENTS
+// The norm-free update on a SUBSET of the flat buffers: nseg segments [lo_s, lo_s + len_s) (float4 units, ascending),
+// `prefix` their running lengths -- what is left when the weight matrices have been updated inside the launch that made
+// their gradients (k_gemm_grouped256<.., UPD>): the embedding tables and the vectors between the matrices.  The blocks
+// split the COMPACTED index space evenly (a split of the raw index space would leave the blocks that fall into the
+// skipped ranges idle and the others with all the traffic); a thread finds its segment by binary search in LDS, almost
+// always the segment of its previous element.  Same arithmetic as k_adam<true>.
+#define ZK_ADAM_MAXSEG 512
+__global__ void __launch_bounds__(256) k_adam_seg(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, bf16_t* __restrict__ shadow,
+                                                  const long* __restrict__ seg_lo, const long* __restrict__ prefix, int nseg,
+                                                  const float* __restrict__ hyper, float* __restrict__ psq,
+                                                  float* __restrict__ gsq, uint64_t* __restrict__ seed) {
+  __shared__ float sm_[8];
+  __shared__ long s_lo[ZK_ADAM_MAXSEG], s_pre[ZK_ADAM_MAXSEG + 1];
+  for (int i = threadIdx.x; i < nseg; i += 256) { s_lo[i] = seg_lo[i]; s_pre[i] = prefix[i]; }
+  if (threadIdx.x == 0) s_pre[nseg] = prefix[nseg];
+  __syncthreads();
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], f = hyper[4];
+  if (seed != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *seed += 1;
+  const long total = s_pre[nseg];
+  const long per_block = ((total + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+  const long cbeg = (long)blockIdx.x * per_block, cend = min(total, cbeg + per_block);
+  float pacc = 0.f, gacc = 0.f;
+  int sgm = 0;
+  for (long c0 = cbeg + threadIdx.x; c0 < cend; c0 += 2 * 256) {
+    float4 pp[2], gg[2], mm[2], vv[2];
+    long idx[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long c = c0 + u * 256;
+      idx[u] = -1;
+      if (c < cend) {
+        if (!(c >= s_pre[sgm] && c < s_pre[sgm + 1])) {
+          int lo = 0, hi = nseg - 1;
+          while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pre[mid] <= c) lo = mid; else hi = mid - 1; }
+          sgm = lo;
+        }
+        const long i = s_lo[sgm] + (c - s_pre[sgm]);
+        idx[u] = i;
+        pp[u] = reinterpret_cast<float4*>(p)[i];
+        const zk_f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const zk_f32x4*>(g) + i);
+        gg[u] = make_float4(t4.x, t4.y, t4.z, t4.w);
+        mm[u] = reinterpret_cast<float4*>(m)[i];
+        vv[u] = reinterpret_cast<float4*>(v)[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (idx[u] < 0) continue;
+      const long i = idx[u];
+      pacc += pp[u].x * pp[u].x + pp[u].y * pp[u].y + pp[u].z * pp[u].z + pp[u].w * pp[u].w;
+      float* P = &pp[u].x; const float* G = &gg[u].x; float* M = &mm[u].x; float* Vv = &vv[u].x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gj = G[j] * f;
+        gacc += gj * gj;
+        M[j] = b1 * M[j] + (1.f - b1) * gj;
+        Vv[j] = b2 * Vv[j] + (1.f - b2) * gj * gj;
+        P[j] -= lr * M[j] / (sqrtf(Vv[j]) + eps);
+      }
+      reinterpret_cast<float4*>(p)[i] = pp[u];
+      reinterpret_cast<float4*>(m)[i] = mm[u];
+      reinterpret_cast<float4*>(v)[i] = vv[u];
+      reinterpret_cast<uint2*>(shadow)[i] = make_uint2(pack2bf(P[0], P[1]), pack2bf(P[2], P[3]));
+    }
+  }
+  pacc = block_sum<4>(pacc, sm_);
+  if (threadIdx.x == 0) psq[blockIdx.x] = pacc;
+  gacc = block_sum<4>(gacc, sm_);
+  if (threadIdx.x == 0) gsq[blockIdx.x] = gacc;
+}
+// finish of the split update: the block partials of k_adam_seg + the wave partials {sum g^2, sum theta^2} the updating
+// weight-gradient launch left (extra [n_extra][2]), each summed in index order
+__global__ void __launch_bounds__(256) k_norm_final3(const float* __restrict__ psq, const float* __restrict__ gsq, int n,
+                                                     const float* __restrict__ extra, int n_extra,
+                                                     float* __restrict__ hyper, float* __restrict__ pnorm_out) {
+  __shared__ float sm[8];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) { a += gsq[i]; b += psq[i]; }
+  for (int i = threadIdx.x; i < n_extra; i += 256) { a += extra[2 * i]; b += extra[2 * i + 1]; }
+  a = block_sum<4>(a, sm);
+  b = block_sum<4>(b, sm);
+  if (threadIdx.x == 0) {
+    const float gn = sqrtf(a);
+    hyper[6] = gn;
+    const bool bad = !(gn == gn) || fabsf(gn) == INFINITY;
+    hyper[7] = bad ? 1.f : 0.f;
+    if (bad) hyper[10] += 1.f;
+    if (pnorm_out != nullptr) pnorm_out[0] = sqrtf(b);
+  }
+}
+#endif  // ZK_EXPERIMENTS
 // finishes k_adam<true>: gnorm = sqrt(sum gsq) -> hyper[6], the per-update flag hyper[7] and the sticky count
 // hyper[10] of non-finite norms; pnorm = sqrt(sum psq) -> pnorm_out.  One block.
 __global__ void __launch_bounds__(256) k_norm_final2(const float* __restrict__ psq, const float* __restrict__ gsq,
@@ -1336,7 +1429,7 @@ size_t zk_add_ln_bwd_workspace(int rows, int H) {
   return (size_t)g * 3 * H * sizeof(float);
 }
 
-int g_tune[12] = {1, 0, 0, 0, 0, 0, 0x44, 0, 0, 2, 512, 0};   // [0] wide LayerNorm backward kernel; [1] GEMM: legacy split-K rule (A/B)
+int g_tune[16] = {1, 0, 0, 0, 0, 0, 0x44, 0, 0, 2, 512, 0, 4 | (28 << 8), 0, 0, 0};   // [12]: phases | us << 8 of the updating weight-gradient launch   // [0] wide LayerNorm backward kernel; [1] GEMM: legacy split-K rule (A/B)
 static int ln_bwd_blocks(int rows) {
   int g = (rows + 15) / 16;
   if (g > 256) g = 256;
@@ -1346,7 +1439,7 @@ static int ln_bwd_blocks(int rows) {
 
 // tuning switches for A/B measurements (key 0: wide LayerNorm-backward kernel); returns the old value
 int zk_tune(int key, int value) {
-  if (key < 0 || key >= 12) return -1;
+  if (key < 0 || key >= 16) return -1;
   const int old = g_tune[key];
   g_tune[key] = value;
   return old;
@@ -1705,6 +1798,35 @@ int zk_adam_step(float* p, const float* g, float* m, float* v, void* shadow, siz
   ZK_LAUNCH_CHECK();
   return 0;
 }
+#ifdef ZK_EXPERIMENTS   // the update inside the weight-gradient launch: measured slower (profiles/r04_negative_results.txt)
+// The rest of a step's update when the weight matrices were updated inside the weight-gradient launch
+// (zk_gemm_grouped_update): TF1 Adam (norm-free form) on the nseg segments [seg_lo[s], seg_lo[s] + (prefix[s+1] -
+// prefix[s])) of the flat buffers -- DEVICE int64 arrays in ELEMENTS, multiples of 4, ascending, prefix[0] = 0 --, then the
+// norms over BOTH parts: extra [n_extra][2] are the wave partials of the fused launch.  seed (may be NULL) += 1.
+int zk_adam_step_segments(float* p, const float* g, float* m, float* v, void* shadow, const long* seg_lo, const long* prefix,
+                          int nseg, long total, float* hyper, float* pnorm_out, uint64_t* seed, const float* extra,
+                          int n_extra, void* workspace, size_t ws_bytes, hipStream_t stream) {
+  ZK_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)shadow) & 15) == 0,
+               "zk_adam_step_segments: buffers must be 16-byte aligned");
+  ZK_CHECK_ARG(ws_bytes >= zk_adam_step_workspace(), "zk_adam_step_segments: workspace too small");
+  ZK_CHECK_ARG(hyper != nullptr && shadow != nullptr && nseg >= 1 && nseg <= ZK_ADAM_MAXSEG && total >= 0 && total % 4 == 0 &&
+               seg_lo != nullptr && prefix != nullptr && (n_extra == 0 || extra != nullptr),
+               "zk_adam_step_segments: bad arguments (nseg=%d, at most %d)", nseg, ZK_ADAM_MAXSEG);
+  float* psq = (float*)workspace;
+  float* gsq = psq + 2048;
+  int gb = g_tune[10] > 0 && g_tune[10] <= 2048 ? g_tune[10] : 512;
+  const long n4 = total / 4;
+  if (n4 < (long)gb * 256) gb = (int)((n4 + 255) / 256);
+  if (gb < 1) gb = 1;
+  hipLaunchKernelGGL(k_adam_seg, dim3(gb), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, seg_lo, prefix, nseg, hyper,
+                     psq, gsq, seed);
+  ZK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_norm_final3, dim3(1), dim3(256), 0, stream, (const float*)psq, (const float*)gsq, gb, extra, n_extra,
+                     hyper, pnorm_out);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+#endif  // ZK_EXPERIMENTS
 #ifdef ZK_EXPERIMENTS   // Adam beside the encoder backward (5.01 vs 4.94 ms): make EXPERIMENTS=1
 // The norm-free update in pieces (utils/parallel.py buckets; with ONE rank: the decoder-side parameters are updated
 // on a side stream while the encoder backward is still running).  zk_adam_range: TF1 Adam + shadow refresh on n

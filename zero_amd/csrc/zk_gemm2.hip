@@ -305,8 +305,23 @@ __device__ __forceinline__ void gemm256_acc_k32(unsigned char* smem, const bf16_
 
 #endif  // ZK_EXPERIMENTS
 
-template <bool TA, bool TB, bool SPREAD, bool CS = false, bool K32 = false>
-__global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __restrict__ descs, int nprob) {
+// UPD (round 4): the optimiser update of a weight INSIDE the launch that produces its gradient.  A tile of a problem whose
+// descriptor carries pad_ & 1 does not store its fp32 gradient tile; every lane runs TF1 Adam (cycle.py:94-101 with
+// clip_grad_norm = 0.0: the norm-free update; main.py:178-181) on the elements it holds in its accumulators -- reads
+// theta, m, v, writes theta, m, v and the bf16 shadow, at the gradient's offset inside the flat buffers -- and leaves its
+// wave's sums of squares (scaled gradient, parameters before the update) in `sq` for the norm the step reports.  The
+// gradient never travels to HBM and back (8 B per parameter) and the HBM-bound update of the weights (22 B per
+// parameter) runs under the MFMA / LDS-bound K loops of the other workgroups instead of in a pass of its own.
+struct UpdArgs {
+  float* master; float* m; float* v; bf16_t* shadow;   // flat buffers (zero_amd/variables.py)
+  const float* grad_base;                              // the flat gradient buffer the descriptors' C pointers point into
+  const float* hyper;                                  // [0] lr_t [1] beta1 [2] beta2 [3] eps [4] gradient scale
+  float* sq;                                           // [tiles][8 waves][2]: sum g^2, sum theta^2 per wave (zeros for other tiles)
+  int stagger;                                         // phases | us per phase << 8 (0: all workgroups start together)
+};
+
+template <bool TA, bool TB, bool SPREAD, bool CS = false, bool K32 = false, bool UPD = false>
+__global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __restrict__ descs, int nprob, UpdArgs ua) {
   constexpr int BM = 256, BN = 256, NS = 2, NWN = 4, WTM = 128, WTN = 64, TM = 4, TN = 2;
   constexpr int STAGE = (BM + BN) * 64;
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE * 2];   // the ONLY LDS object (128 KiB)
@@ -324,6 +339,19 @@ __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __rest
   }
   const GroupDesc d = descs[p];
   const int local = t - d.tile_start;
+  if constexpr (UPD) {
+    // Every tile ends with ~1.7 MB of optimiser traffic.  Workgroups that start together finish their K loops together
+    // and then all pull on HBM at once (measured: 794 us for the launch, the K loops idle meanwhile, against 500 us
+    // without the update).  The first wave of workgroups therefore starts in PHASES a fraction of a K loop apart
+    // (tuning key 12: phases | delay in us per phase << 8): later workgroups inherit the phase of the CU they land on, so
+    // that some CUs stream their update while the others multiply.
+    const int phases = ua.stagger & 255, step_us = ua.stagger >> 8;
+    if (phases > 1 && bid < 256) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+      const unsigned long long wait = (unsigned long long)((bid >> 3) % phases) * step_us * 100ull;
+      while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   // tile order inside a problem: blocks of 4 x 8 tiles, the blocks of one 8-tile column group one after the other.  An XCD
   // runs 32 consecutive tiles at a time (its chunk of the launch is contiguous): a block keeps 4 A row blocks + 8 B column
   // blocks = 3 MB at K = 512 in its 4-MB L2, and the next block reuses the 8 column blocks.  Row-major order made the
@@ -379,6 +407,60 @@ __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __rest
     gemm256_acc<TA, TB, SPREAD>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc);
   }
   float* C = reinterpret_cast<float*>(d.C);
+  if constexpr (UPD) {
+    float gacc = 0.f, pacc = 0.f;
+    if (d.pad_ & 1) {
+      const size_t off = (size_t)(reinterpret_cast<const float*>(d.C) - ua.grad_base);
+      float* __restrict__ P = ua.master + off;
+      float* __restrict__ Mo = ua.m + off;
+      float* __restrict__ Vo = ua.v + off;
+      bf16_t* __restrict__ S = ua.shadow + off;
+      const float lr = ua.hyper[0], b1 = ua.hyper[1], b2 = ua.hyper[2], eps = ua.hyper[3], gs = ua.hyper[4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = n0 + wn * WTN + j * 32 + (lane & 31);
+          // 24 loads (half a 32 x 32 piece) are requested before the first is used
+#pragma unroll
+          for (int eh = 0; eh < 16; eh += 8) {
+            float pv[8], mv[8], vv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int e = eh + q;
+              const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+              const bool ok = row < M && col < N;
+              const size_t idx = (size_t)row * d.ldc + col;
+              pv[q] = ok ? P[idx] : 0.f;
+              mv[q] = ok ? Mo[idx] : 0.f;
+              vv[q] = ok ? Vo[idx] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int e = eh + q;
+              const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+              if (row < M && col < N) {
+                const size_t idx = (size_t)row * d.ldc + col;
+                // the arithmetic of k_adam<GSQ = true> (zk_elem.hip), element for element
+                const float gj = acc[i][j][e] * gs;
+                gacc += gj * gj;
+                pacc += pv[q] * pv[q];
+                const float mn = b1 * mv[q] + (1.f - b1) * gj;
+                const float vn = b2 * vv[q] + (1.f - b2) * gj * gj;
+                const float pn = pv[q] - lr * mn / (sqrtf(vn) + eps);
+                P[idx] = pn; Mo[idx] = mn; Vo[idx] = vn;
+                S[idx] = f2bf(pn);
+              }
+            }
+          }
+        }
+    }
+    // the wave's sums of squares (zeros from the tiles that store a gradient): fixed slots, summed in a fixed order later
+    gacc = wave_sum(gacc);
+    pacc = wave_sum(pacc);
+    if (lane == 0) { ua.sq[((size_t)t * 8 + wave) * 2] = gacc; ua.sq[((size_t)t * 8 + wave) * 2 + 1] = pacc; }
+    if (d.pad_ & 1) return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -681,19 +763,19 @@ int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int t
     const dim3 blk(512);
 #ifdef ZK_EXPERIMENTS
 #define ZK_G256_K32                                                                                                          \
-      else if (ta && !tb && k32 && cs) hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, true, true>), grid, blk, 0, stream, d, nprob); \
-      else if (ta && !tb && k32) hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, false, true>), grid, blk, 0, stream, d, nprob);
+      else if (ta && !tb && k32 && cs) hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, true, true>), grid, blk, 0, stream, d, nprob, UpdArgs()); \
+      else if (ta && !tb && k32) hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, false, true>), grid, blk, 0, stream, d, nprob, UpdArgs());
 #else
 #define ZK_G256_K32
 #endif
 #define ZK_G256(SP_)                                                                                         \
     do {                                                                                                     \
-      if (!ta && !tb) hipLaunchKernelGGL((k_gemm_grouped256<false, false, SP_>), grid, blk, 0, stream, d, nprob);   \
-      else if (!ta && tb) hipLaunchKernelGGL((k_gemm_grouped256<false, true, SP_>), grid, blk, 0, stream, d, nprob); \
+      if (!ta && !tb) hipLaunchKernelGGL((k_gemm_grouped256<false, false, SP_>), grid, blk, 0, stream, d, nprob, UpdArgs());   \
+      else if (!ta && tb) hipLaunchKernelGGL((k_gemm_grouped256<false, true, SP_>), grid, blk, 0, stream, d, nprob, UpdArgs()); \
       ZK_G256_K32                                                                                          \
-      else if (ta && !tb && cs) hipLaunchKernelGGL((k_gemm_grouped256<true, false, SP_, true>), grid, blk, 0, stream, d, nprob); \
-      else if (ta && !tb) hipLaunchKernelGGL((k_gemm_grouped256<true, false, SP_>), grid, blk, 0, stream, d, nprob); \
-      else hipLaunchKernelGGL((k_gemm_grouped256<true, true, SP_>), grid, blk, 0, stream, d, nprob);               \
+      else if (ta && !tb && cs) hipLaunchKernelGGL((k_gemm_grouped256<true, false, SP_, true>), grid, blk, 0, stream, d, nprob, UpdArgs()); \
+      else if (ta && !tb) hipLaunchKernelGGL((k_gemm_grouped256<true, false, SP_>), grid, blk, 0, stream, d, nprob, UpdArgs()); \
+      else hipLaunchKernelGGL((k_gemm_grouped256<true, true, SP_>), grid, blk, 0, stream, d, nprob, UpdArgs());               \
     } while (0)
     if (tile == 7) ZK_G256(true); else ZK_G256(false);
 #undef ZK_G256
@@ -720,6 +802,24 @@ int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int t
   ZK_LAUNCH_CHECK();
   return 0;
 }
+#ifdef ZK_EXPERIMENTS   // the update inside the weight-gradient launch: measured slower (profiles/r04_negative_results.txt)
+// Every weight gradient of the step AND the update of the weights it belongs to, in one launch (UpdArgs above): the grouped
+// weight-gradient launch of 256 x 256 tiles (ta = 1, tb = 0, bias column sums riding along) whose descriptors carry
+// pad_ & 1 for the problems whose output is a whole variable of the flat buffers -- those tiles run TF1 Adam on their
+// accumulators instead of storing them.  sq: fp32 [total_tiles * 16], written by every tile.
+int zk_gemm_grouped_update(const void* descs, int nprob, int total_tiles, float* master, float* m, float* v, void* shadow,
+                           const float* grad_base, const float* hyper, float* sq, hipStream_t stream) {
+  ZK_CHECK_ARG(nprob >= 1 && total_tiles >= 1, "zk_gemm_grouped_update: empty group");
+  ZK_CHECK_ARG(master && m && v && shadow && grad_base && hyper && sq, "zk_gemm_grouped_update: null pointer");
+  UpdArgs ua;
+  ua.master = master; ua.m = m; ua.v = v; ua.shadow = (bf16_t*)shadow; ua.grad_base = grad_base; ua.hyper = hyper; ua.sq = sq;
+  ua.stagger = g_tune[12];         // tuning key 12 (default 4 phases, 28 us apart)
+  hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, true, false, true>), dim3((unsigned)total_tiles), dim3(512), 0,
+                     stream, (const GroupDesc*)descs, nprob, ua);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+#endif  // ZK_EXPERIMENTS
 // C bf16 [M, ldc] = sum_s A_s [M, kseg] (lda) x B_s (+ residual bf16 [M, ldr], may alias C).
 //   tb = 1: B_s is [N, ldb] with K contiguous (dgrad through W stored [in, out]);  tb = 0: B_s is [kseg, ldb].
 // a_segs / b_segs: HOST arrays of nseg (<= 16) device pointers; kseg a multiple of 64; 16-byte aligned operands,

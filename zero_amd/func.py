@@ -321,6 +321,44 @@ class Engine(object):
         dev, n, total = ent
         self.lib.call("zk_gemm_grouped", dev.data_ptr(), n, total, ta, tb, code, self.stream)
 
+    def gemm_grouped_update(self, problems, upd):
+        """zk_gemm_grouped_update: every weight gradient of the step in one launch of 256 x 256 tiles (ta = 1, tb = 0, bias
+        column sums riding along), and for the problems marked fusable (10th element of the tuple) the TF1 Adam update of
+        the variable inside the same launch -- their gradient is never stored.  upd: dict(master, m, v, shadow, grad,
+        hyper) of flat tensors.  Returns (ranges [(lo, hi)] of the flat buffers that were updated, sq tensor, n_extra)."""
+        problems = [tuple(p) + (None,) * (10 - len(p)) for p in problems]
+        grad = upd["grad"]
+        g0, g1 = grad.data_ptr(), grad.data_ptr() + grad.numel() * 4
+        key = ("upd",) + tuple((a.ptr, b.ptr, c.ptr, M, N, K, hip.ptr(cs) or 0, bool(fz))
+                               for a, b, c, M, N, K, _, _, cs, fz in problems)
+        cache = self.__dict__.setdefault("_group_cache", {})
+        ent = cache.get(key)
+        if ent is None:
+            arr = (_GroupDesc * len(problems))()
+            start, ranges = 0, []
+            for i, (a, b, c, M, N, K, bias, res, cs, fz) in enumerate(problems):
+                assert bias is None and res is None and c.t.dtype == torch.float32
+                tn = (N + 255) // 256
+                d = arr[i]
+                d.A, d.B, d.C, d.bias, d.res, d.ldr = a.ptr, b.ptr, c.ptr, 0, 0, 0
+                d.colsum = hip.ptr(cs) or 0
+                d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, a.ld, b.ld, c.ld
+                d.out_f32, d.tile_start, d.tiles_n = 1, start, tn
+                fuse = bool(fz) and c.ld == N and g0 <= c.ptr and c.ptr + M * N * 4 <= g1
+                d.pad = 1 if fuse else 0
+                if fuse:
+                    lo = (c.ptr - g0) // 4
+                    ranges.append((lo, lo + M * N))
+                start += ((M + 255) // 256) * tn
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            ent = (host.to(self.device), len(problems), start, tuple(sorted(ranges)))
+            cache[key] = ent
+        dev, n, total, ranges = ent
+        sq = self.buf("upd.sq", (total * 16,), torch.float32)
+        self.lib.call("zk_gemm_grouped_update", dev.data_ptr(), n, total, upd["master"].data_ptr(), upd["m"].data_ptr(),
+                      upd["v"].data_ptr(), upd["shadow"].data_ptr(), g0, upd["hyper"].data_ptr(), sq.data_ptr(), self.stream)
+        return ranges, sq, total * 8
+
     def reductions_grouped(self, colsums, ln_parts, rpr_parts=()):
         """colsums: [(Mat dY, out fp32 view, private fp32 partial buffer)];
         ln_parts: [(partials buffer, rows, H, dgamma, dbeta, dbias_prev-or-None)];

@@ -84,6 +84,10 @@ class Trainer(object):
         self.overlap_adam = _os.environ.get("ZERO_HIP_OVERLAP_ADAM", "0") != "0" and self.core.eng.lib.experiments
         self._adam_stream = None
         self._empty_ids = None
+        # the update of the weight matrices inside the weight-gradient launch (zk_gemm_grouped_update; _can_fuse_update):
+        # MEASURED SLOWER (profiles/r04_negative_results.txt: the launch 500 -> 794 us for 255 us less in the Adam pass)
+        # -> an experiment: `make EXPERIMENTS=1` library + ZERO_HIP_FUSED_UPDATE=1
+        self.fuse_update = _os.environ.get("ZERO_HIP_FUSED_UPDATE", "0") == "1" and self.core.eng.lib.experiments
         self.reseed()
 
     # -- row-sparse exchange of lookup-table gradients (utils/parallel.py:142-181) -----------------
@@ -129,6 +133,13 @@ class Trainer(object):
         micro = (self.global_step * max(1, int(hp.update_cycle)) + self.cycle_counter) & 0xFFFFFFFF
         self.core.eng.set_seed((hi << 32) | micro)
 
+    def _can_fuse_update(self):
+        """One rank, no accumulation, an update that does not look at the global norm (cycle.py:98-101 with the recipe's
+        clip_grad_norm = 0.0 and no safe_nan), all weight gradients in the backward's single deferred launch."""
+        return self.fuse_update and parallel.world_size() == 1 and not self.force_segmented and \
+            self.params.update_cycle == 1 and self.train_op.can_update_by_range() and self.core.group_all and \
+            not self.overlap_adam and not self.core.use_side
+
     def rollback_skipped_update(self):
         """main.py:320-332 (safe_nan): a skipped update does not run train_op, so global_step, Adam's t and the
         learning-rate schedule do not advance."""
@@ -152,7 +163,23 @@ class Trainer(object):
             if "B" not in features and features["source"].shape[0] > 0:
                 features = self.core.upload(features["source"], features["target"])
             self._declare_sparse(features if "B" in features else None)
-        loss, _ = tower_train_graph(features, self.graph, hp, self.reducer if overlap else None)
+        fuse = last and hp.update_cycle == 1 and self._can_fuse_update()
+        if fuse:
+            # the weight-gradient launch runs the update of the weights itself: the scalars of this update first
+            self.train_op.count = 0
+            scale = self.train_op.set_hyper(self.lr.get_lr(), world)
+            self.core.fused_update = self.train_op.fused_ctx()
+        self.core.fused_info = None
+        try:
+            loss, _ = tower_train_graph(features, self.graph, hp, self.reducer if overlap else None)
+        finally:
+            self.core.fused_update = None
+        if fuse:
+            self.train_op.launch_update(scale, fused=self.core.fused_info)
+            self.store.step += 1
+            self.cycle_counter = 0
+            self.global_step += 1
+            return loss
         if not last:
             self.train_op.collect()
             self.cycle_counter += 1
@@ -392,8 +419,13 @@ class Trainer(object):
         (zk_adam_range slots -> zk_adam_finish).  Same arithmetic per element as the single launch."""
         hp, top, core = self.params, self.train_op, self.core
         if not (self.overlap_adam and top.can_update_by_range() and not core.use_side):
-            self.graph.train_fn(self.batch, hp)
-            top.launch_update(scale)
+            core.fused_update = top.fused_ctx() if self._can_fuse_update() else None
+            core.fused_info = None
+            try:
+                self.graph.train_fn(self.batch, hp)
+            finally:
+                core.fused_update = None
+            top.launch_update(scale, fused=core.fused_info)
             return
         eng = core.eng
         main = torch.cuda.current_stream(eng.device)

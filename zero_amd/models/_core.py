@@ -137,6 +137,12 @@ class TransformerCore(object):
         # +2 us each, the LayerNorm backward +5..7 us for the normalised rows it now writes, the fold launch 42 us.  So it
         # is an experiment: only in a `make EXPERIMENTS=1` library, only with ZERO_HIP_LAZY_LN=1.
         self.lazy_ln_mode = os.environ.get("ZERO_HIP_LAZY_LN", "0").lower() if self.eng.lib.experiments else "0"
+        # The update of the weight matrices inside the weight-gradient launch (round 4; zk_gemm_grouped_update): set by the
+        # Trainer for a step whose update is norm-free, single-rank and unaccumulated; the backward's one grouped launch
+        # then runs TF1 Adam on its accumulators for every weight it can (see _flush_wgrads) and `fused_info` tells the
+        # optimiser what is left to do.
+        self.fused_update = None      # dict(master, m, v, shadow, grad, hyper) or None
+        self.fused_info = None        # (ranges, sq, n_extra) of the last backward, or None
         self._lazy = False            # set per forward()
         self._lazy_tags = {}          # tag -> LazyLN of this step's forward (read by the backward)
 
@@ -208,7 +214,12 @@ class TransformerCore(object):
         if self._pending_wgrads:
             probs = self._pending_wgrads
             self._pending_wgrads = []
-            self._side(lambda: self.eng.gemm_grouped(probs, 1, 0, tile=self.wgrad_tile))
+            if self.fused_update is not None and self.group_all and self.wgrad_tile == (256, 256, 0) and \
+                    not self.use_side and self.eng.gemm_impl == 0 and self.fused_info is None and \
+                    not self._pending_adds:      # (a variable used twice gets a second contribution AFTER this launch)
+                self.fused_info = self.eng.gemm_grouped_update(probs, self.fused_update)
+            else:
+                self._side(lambda: self.eng.gemm_grouped([p[:9] for p in probs], 1, 0, tile=self.wgrad_tile))
         if self._pending_colsums or self._pending_lnred or self._pending_rpr:
             cs, ln, rp = self._pending_colsums, self._pending_lnred, self._pending_rpr
             self._pending_colsums, self._pending_lnred, self._pending_rpr = [], [], []
@@ -295,7 +306,9 @@ class TransformerCore(object):
         # (256x256 tiles: by two extra MFMAs per eight on the fragments the tm = 0 tiles hold anyway)
         fold_cs = bias_grad and isinstance(self.wgrad_tile, tuple) and os.environ.get("ZERO_HIP_FOLD_COLSUM", "1") != "0"
         if self.group_wgrad and self.eng.gemm_impl == 0:
-            self._pending_wgrads.append((x, dy, gW, Wm.rows, Wm.cols, x.rows, None, None, gb if fold_cs else None))
+            # (10th element: the variable's gradient is complete with this product -> its update may run in the launch)
+            self._pending_wgrads.append((x, dy, gW, Wm.rows, Wm.cols, x.rows, None, None, gb if fold_cs else None,
+                                         not accumulate and not adds))
             if bias_grad and not fold_cs:
                 gy = self.eng.lib.raw("zk_colsum_rowchunks")(dy.rows)
                 pw = self.eng.buf("g.cs%d" % len(self._pending_colsums) + scope, (gy * dy.cols,), F32)
@@ -794,6 +807,7 @@ class TransformerCore(object):
         batch, enc, smask, feat, tmask, dlogits = self._ctx
         B, Ls, Lt = batch["B"], batch["Ls"], batch["Lt"]
         Ts, Tt = B * Ls, B * Lt
+        self.fused_info = None
         if dlogits is None:      # fused cross entropy: recompute the logits tiles, write d(loss)/d(logits)
             lse, w, ls = self._ce_ctx
             dlogits = e.mat("dlogits", Tt, self.Vpad)
@@ -813,7 +827,9 @@ class TransformerCore(object):
         e.gemm(dlogits, E, P[cur], Tt, H, self.Vpad, 0, 0)
         gE = self.gW(self.soft_emb)
         if self.group_wgrad and e.gemm_impl == 0:
-            self._pending_wgrads.append((dlogits, feat, gE, self.Vpad, H, Tt, None))
+            # (the table's gradient is complete here only if no embedding lookup adds rows to it afterwards)
+            self._pending_wgrads.append((dlogits, feat, gE, self.Vpad, H, Tt, None, None, None,
+                                         self.soft_emb != self.tgt_emb and self.soft_emb != self.src_emb))
         else:
             self._side(lambda: e.gemm(dlogits, feat, gE, self.Vpad, H, Tt, 1, 0))
         d_enc = e.mat("g.denc", Ts, H)

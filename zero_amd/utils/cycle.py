@@ -102,12 +102,54 @@ class TrainOp(object):
             pairs.append((self.hyper[8:9], staged[8:9]))
         return pairs
 
-    def launch_update(self, scale, advance_seed=True):
+    def fused_ctx(self):
+        """What the weight-gradient launch needs to update weights itself (zk_gemm_grouped_update): the flat buffers and
+        the device scalars of THIS update -- set_hyper() must have run before the backward is issued."""
+        st = self.store
+        return {"master": st.master, "m": st.m, "v": st.v, "shadow": st.shadow, "grad": st.grad, "hyper": self.hyper}
+
+    def _segments(self, ranges):
+        """Device tables (seg_lo, prefix, nseg, total) of what the fused launch did NOT update: the complement of
+        `ranges` in [0, numel), in elements (every variable starts on a 64-element boundary)."""
+        cache = self.__dict__.setdefault("_seg_cache", {})
+        ent = cache.get(ranges)
+        if ent is None:
+            lo, segs = 0, []
+            for a, b in ranges:
+                if a > lo:
+                    segs.append((lo, a - lo))
+                lo = max(lo, b)
+            if self.store.numel > lo:
+                segs.append((lo, self.store.numel - lo))
+            assert all(x % 4 == 0 and n % 4 == 0 for x, n in segs)
+            prefix = [0]
+            for _, n in segs:
+                prefix.append(prefix[-1] + n // 4)
+            dev = self.store.device
+            ent = (torch.tensor([x // 4 for x, _ in segs] or [0], dtype=torch.int64, device=dev),
+                   torch.tensor(prefix, dtype=torch.int64, device=dev), len(segs), prefix[-1] * 4)
+            cache[ranges] = ent
+        return ent
+
+    def launch_update(self, scale, advance_seed=True, fused=None):
         """Device side of train_op; graph-capturable (reads scalars from self.hyper).  Also advances the
         dropout step seed (same launch).  When the update does not depend on the global norm (no clipping,
         no safe_nan -- cycle.py:98-101 with the recipe's clip_grad_norm = 0.0) the gradient norm is only
-        reported, and it is accumulated inside the Adam pass instead of a pass of its own."""
+        reported, and it is accumulated inside the Adam pass instead of a pass of its own.
+        fused = (ranges, sq, n_extra) from TransformerCore.fused_info: those ranges of the flat buffers were updated
+        inside the weight-gradient launch; this call updates the rest and finishes the norms over both parts."""
         st, lib, s = self.store, self.eng.lib, self.eng.stream
+        if fused is not None and fused[0]:
+            ranges, sq, n_extra = fused
+            seg_lo, prefix, nseg, total = self._segments(ranges)
+            if nseg:
+                lib.call("zk_adam_step_segments", st.master.data_ptr(), st.grad.data_ptr(), st.m.data_ptr(), st.v.data_ptr(),
+                         st.shadow.data_ptr(), seg_lo.data_ptr(), prefix.data_ptr(), nseg, total, self.hyper.data_ptr(),
+                         self.pnorm.data_ptr(), self.eng.seed.data_ptr() if advance_seed else None, sq.data_ptr(),
+                         n_extra, self._ws.data_ptr(), self._ws.numel(), s)
+                if self.ema is not None:
+                    lib.call("zk_ema", self.ema.data_ptr(), st.master.data_ptr(), self.hyper.data_ptr(), st.numel, s)
+                return
         norm_free = self.can_update_by_range()
         if not norm_free:
             lib.call("zk_l2norm", st.grad.data_ptr(), st.numel, scale, self.hyper.data_ptr() + 6 * 4,
