@@ -535,6 +535,18 @@ def decode_measure(args, rank, world):
     }
     from zero_amd.models._factory import get_core
     out["launches_per_step"] = getattr(get_core(hp, model), "_decode_step_launches", None)
+    # the latency of ONE batch's decode step: the same batches one after the other on one lane --
+    # a bounded sample (every 8th batch), untimed warm-up on the longest of them first.  `ms_per_step` above is wall time
+    # per step with `batches_in_flight` batches overlapping; this is what a single batch waits for a step.
+    sample = batches[::8]
+    decode_many(sample[-1:], work, 1)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    single_steps = sum(decode_many(sample, work, 1))
+    torch.cuda.synchronize()
+    out["single_batch_ms_per_step"] = (time.perf_counter() - t1) / max(single_steps, 1) * 1e3
+    out["single_batch_sample"] = "%d of the %d batches, one after the other on one lane, %d decode steps" % (
+        len(sample), len(batches), single_steps)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_decode_baseline(hp, model, batches)
     return out

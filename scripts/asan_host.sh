@@ -5,10 +5,10 @@
 # ASan runtime into python and runs the `not gpu` tests that load the library.  Log: profiles/rNN_asan_host.log.
 set -u
 cd "$(dirname "$0")/.."
-OUT=${1:-profiles/r02_asan_host.log}
+OUT=${1:-profiles/r04_asan_host.log}
 B=/tmp/zk_asan; rm -rf $B; mkdir -p $B
 HIPCC=/opt/rocm/bin/hipcc
-for f in zk_elem zk_gemm zk_gemm2 zk_attn zk_decode zk_probe zk_comm zk_layer zk_decfuse; do
+for f in zk_elem zk_gemm zk_gemm2 zk_attn zk_decode zk_probe zk_comm zk_decfuse zk_rows zk_prep; do
   $HIPCC --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-value -Xarch_host -fsanitize=address \
      -Xarch_host -fno-omit-frame-pointer -c zero_amd/csrc/$f.hip -o $B/$f.o || exit 1 &
 done
@@ -20,7 +20,16 @@ RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
   echo "# ASan runtime: $RT"
   echo "# library: $B/libzero_hip.so (host code instrumented), $(date -u +%F)"
   ZERO_HIP_LIB=$B/libzero_hip.so LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=0 \
-    python -m pytest tests/test_abi.py tests/test_host_logic.py tests/test_host_rows.py tests/test_data.py -m "not gpu" -q -p no:cacheprovider 2>&1 | tail -15
+    python -m pytest tests/test_abi.py tests/test_host_logic.py tests/test_host_rows.py tests/test_data.py tests/test_scripts.py -m "not gpu" -q -p no:cacheprovider 2>&1 | tail -15
   echo "# exit code: ${PIPESTATUS[0]}"
+  if python -c "import torch,sys; sys.exit(0 if torch.cuda.is_available() else 1)" 2>/dev/null; then
+    # round 4, on the GPU box: the multi-threaded host C of the decode lanes (zk_beam_dev_run from four host threads, the
+    # start-up lock, graph adoption) and the step's new host paths (zk_batch_prep / zk_copy_many argument handling)
+    echo "# GPU box: decode lanes + rotating-batch steps with the instrumented host code"
+    ZERO_HIP_LIB=$B/libzero_hip.so LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:protect_shadow_gap=0 \
+      timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q -p no:cacheprovider \
+        -k "batches_in_flight or step_graphs_are_reused or rotating_batches or device_resident_search" 2>&1 | tail -8
+    echo "# exit code: ${PIPESTATUS[0]}"
+  fi
 } > $OUT 2>&1
 tail -5 $OUT

@@ -29,4 +29,31 @@ for model in ("transformer", "transformer_aan"):
     seqs, scores = tower_infer_graph({"source": src}, registry.get_model(model), hp)
     out[model]["beam_crc"] = zlib.crc32(np.ascontiguousarray(seqs).tobytes())
     out[model]["beam_scores_crc"] = zlib.crc32(np.ascontiguousarray(scores).tobytes())
+    # round 4: the loop a user runs -- Trainer.step on ROTATING batches (next batch uploaded and prepared on a side stream
+    # into a staging set, one commit launch, captured step) with no host synchronisation in between
+    feats = []
+    for i in range(4):
+        s_, t_ = make_batch(np.random.default_rng(40 + i), 8, 12, 11, hp.src_vocab.size(), hp.tgt_vocab.size())
+        s_[:, -1], t_[:, -1] = 2, 2
+        feats.append({"source": s_, "target": t_})
+    held = [tr.step(feats[i % 4]).reshape(-1)[0].clone() for i in range(10)]
+    torch.cuda.synchronize()
+    out[model]["rotating_losses"] = [float(x.cpu()).hex() for x in held]
+    out[model]["rotating_weights_crc"] = zlib.crc32(tr.store.master.cpu().numpy().tobytes())
+    # round 4: four decode batches in flight on execution lanes (evalu.decode_many; zk_beam_dev_run called from four host
+    # threads, start-ups serialised by a lock, replays free)
+    import copy, threading
+    from zero_amd.evalu import decode_many
+    from zero_amd.search import beam_search
+    hpd = copy.copy(hp); hpd.search_mode = "cache"
+    tl = threading.local()
+
+    def work(s_):
+        if not hasattr(tl, "fns"):
+            tl.fns = registry.get_model(model).infer_fn(hpd)
+        r = beam_search({"source": s_}, tl.fns[0], tl.fns[1], hpd)
+        return zlib.crc32(np.ascontiguousarray(r["seq"]).tobytes()), zlib.crc32(np.ascontiguousarray(r["score"]).tobytes()), r["steps"]
+    srcs = [make_batch(np.random.default_rng(60 + i), 3 + i % 4, 6 + 2 * i, 5, hp.src_vocab.size(), hp.tgt_vocab.size())[0]
+            for i in range(12)]
+    out[model]["lanes4"] = decode_many(srcs, work, streams=4)
 print(json.dumps(out, indent=1, sort_keys=True))

@@ -111,9 +111,9 @@ class Engine(object):
         # layer program (zk_layer.hip): an experiment, only present in a `make EXPERIMENTS=1` library
         self.programs_enabled = os.environ.get("ZERO_HIP_PROGRAM", "0") != "0" and self.lib.experiments
         # relative positions folded into the attention forward tile (zk_attn_dev.h attn_fwd_tile<.., RPR>)
-        self.rpr_fold = os.environ.get("ZERO_HIP_RPR_FOLD", "1") != "0"
+        self.rpr_fold = True           # (an attribute, not a switch: the kernel tests flip it to reach the decomposed form)
         # folded backward: 72 KB of LDS (two workgroups per CU) or every tile resident (151 KB, the first form)
-        self.rpr_bwd_resident = os.environ.get("ZERO_HIP_RPR_BWD", "") == "resident"
+        self.rpr_bwd_resident = False  # (the kernel test of the 72-KB form compares it with this, the first, form)
         self._prog_host = None
 
     # ---- plumbing -----------------------------------------------------------
@@ -574,8 +574,7 @@ class Engine(object):
             # walk all T rows alone (64 K steps, 24 us on 16 workgroups); cutting the rows into KS slices (every (head,
             # slice) its own tile, zk_sum_slices adds the nh * KS partials) was measured and is SLOWER in the step
             # (same box: KS = 1 6.37 ms, 4 6.41, 8 6.64), so KS = 1 stays the default
-            KS = int(os.environ.get("ZERO_HIP_RPR_KSPLIT", "1"))
-            KS = KS if T % (KS * 64) == 0 else 1
+            KS = 1
             Tk = T // KS
             part = self.mat("rpr.part", 2 * nh * KS * nrp, d, torch.float32)
             rows = lambda i: Mat(part.t, nrp, d, d, i * nrp * d)

@@ -83,7 +83,7 @@ class TransformerCore(object):
         self.use_side = os.environ.get("ZERO_HIP_SIDE_STREAM", "0") != "0" and self.eng.lib.experiments
         # weight-gradient GEMMs are deferred and launched as ONE grouped grid per `group_layers`
         # layers (each is far too small to fill 256 CUs on its own)
-        self.group_wgrad = os.environ.get("ZERO_HIP_GROUP_WGRAD", "1") != "0"
+        self.group_wgrad = True
         # tile of the grouped weight-gradient launch: 128x256 (four waves with a 128x64 register tile each + four
         # producer waves, scripts/gemm_big_bench.py: 780 -> 856 TF on the decoder side incl. the logits problem)
         # one group per side of the model with a single rank (fewest launches); smaller groups with
@@ -96,12 +96,14 @@ class TransformerCore(object):
         # per MFLOP against 11.7 for 128x256).  The coarse tile needs the big group: 922 tiles on 256 CUs = 3.6 rounds,
         # while the encoder's 288 tiles alone would be 1.1 -- which is why the 256x256 tile lost inside the per-side
         # groups of round 2.  The bias gradients ride along as column sums by MFMA (gemm256_acc<.., CS>).
-        self.group_all = (not _multi) and os.environ.get("ZERO_HIP_GROUP_ALL", "1") != "0"
+        self.group_all = not _multi
         # ("256x256n": the LDS-DMA pieces of a K step issued right behind the barrier instead of spread between the MFMA
         # groups -- same-box A/B of the whole step: 4.708 ms spread, 4.673 ms not, 4.80 ms for the round-2 grouping)
-        wt = os.environ.get("ZERO_HIP_WGRAD_TILE", "256x256n" if self.group_all else "128x256").lower()
-        self.wgrad_tile = {"128": 128, "128x128": 128, "256x128": (256, 128), "128x256": (128, 256),
-                           "256x256": (256, 256), "256x256n": (256, 256, 0), "256x256k32": (256, 256, "k32")}[wt]
+        # (round 4: the measured-and-lost alternatives -- per-side groups, the spread DMA issue, 128x128 -- lost their
+        # switches; the 32-deep ring of the EXPERIMENTS build is selected with ZERO_HIP_WGRAD_TILE=256x256k32 there)
+        self.wgrad_tile = (256, 256, 0) if self.group_all else (128, 256)
+        if self.eng.lib.experiments and os.environ.get("ZERO_HIP_WGRAD_TILE", "").lower() == "256x256k32":
+            self.wgrad_tile = (256, 256, "k32")
         self._pending_wgrads = []
         self._pending_colsums = []     # (dY Mat, bias-gradient view, private partial buffer)
         self._pending_lnred = []       # (partials, rows, H, dgamma, dbeta, dbias_prev)
@@ -109,13 +111,13 @@ class TransformerCore(object):
         self._pending_adds = []        # (fp32 gradient view, fp32 temporary): dst += src after the flush
         self._mem_segs = []            # (dK or dV, W) pairs of the cross-attention memory side (see _finish_mem_grad)
         # encoder-output gradient by one K-segmented GEMM (needs the MFMA path: H a multiple of 64, aligned rows)
-        self.kseg_mem = os.environ.get("ZERO_HIP_KSEG_MEM", "1") != "0"
+        self.kseg_mem = True
         # fused logits + cross entropy (no [T, V] fp32 logits in HBM, recompute in the backward): measured
         # 224 + 8 us forward and 287 us backward against 291 + 208 us for GEMM + k_ce_fused -- the second
         # pass over the 137-GFLOP GEMM costs what the saved 1 GB of traffic buys, so it is opt-in (it frees
         # T*V*4 bytes, which matters for larger batches / vocabularies)
         self.fused_ce = os.environ.get("ZERO_HIP_FUSED_CE", "0") != "0" and self.eng.lib.experiments
-        self.logits_tile256 = os.environ.get("ZERO_HIP_LOGITS_256", "1") != "0"
+        self.logits_tile256 = True
         # the dgrad of the attention output projection inside the attention backward launch (zk_attn_bwd oproj_*): 18
         # launches and 18 [T, H] matrices less per step, same-box A/B -0.02 to -0.05 ms (the 64 x 64 x H product per
         # (sentence, head) costs the launch +7 us, the GEMM it replaces was 8-9 us).  By rule (_use_oproj): only while the
@@ -231,9 +233,8 @@ class TransformerCore(object):
 
     def _defer_rpr(self):
         """Relative positions: the table-gradient partials of every attention layer summed by the grouped reduction
-        launch of the layer group (18 launches fewer per step; ZERO_HIP_RPR_DEFER=0: one reduction per attention)."""
-        return self.rpr and self.group_wgrad and self.eng.gemm_impl == 0 and \
-            os.environ.get("ZERO_HIP_RPR_DEFER", "1") != "0"
+        launch of the layer group (18 launches fewer per step than one reduction per attention)."""
+        return self.rpr and self.group_wgrad and self.eng.gemm_impl == 0
 
     def _use_kseg(self):
         return self.kseg_mem and self.H % 64 == 0 and self.eng.gemm_impl == 0
@@ -304,7 +305,7 @@ class TransformerCore(object):
         # bias gradient = column sums of dY: on the wide (producer-wave) tiles the producers of the weight-gradient GEMM
         # compute them from the dY tiles they stage anyway (no separate pass over dY)
         # (256x256 tiles: by two extra MFMAs per eight on the fragments the tm = 0 tiles hold anyway)
-        fold_cs = bias_grad and isinstance(self.wgrad_tile, tuple) and os.environ.get("ZERO_HIP_FOLD_COLSUM", "1") != "0"
+        fold_cs = bias_grad and isinstance(self.wgrad_tile, tuple)
         if self.group_wgrad and self.eng.gemm_impl == 0:
             # (10th element: the variable's gradient is complete with this product -> its update may run in the launch)
             self._pending_wgrads.append((x, dy, gW, Wm.rows, Wm.cols, x.rows, None, None, gb if fold_cs else None,

@@ -150,8 +150,7 @@ class lanes_mode(object):
     fastest with one sentence (4 beam rows) per workgroup: 256 workgroups of 121 KB LDS, i.e. the whole chip, 12.7 us
     against 16.5 us with 16 rows per workgroup.  With several batches in flight that launch is the one kernel of a step
     the lanes cannot overlap (it owns every CU's LDS); at 16 rows per workgroup it covers a quarter of the chip and the
-    lanes' launches run side by side (measured: 4 lanes 1.5-1.6 k -> 1.9-2.2 k sentences/s).  ZERO_HIP_DEC_GROUP=n
-    pins the value (0 = the single-batch default)."""
+    lanes' launches run side by side (measured: 4 lanes 1.5-1.6 k -> 1.9-2.2 k sentences/s)."""
 
     def __init__(self, n):
         self.n = int(n)
@@ -159,8 +158,7 @@ class lanes_mode(object):
     def __enter__(self):
         import os
         from zero_amd import hip
-        env = os.environ.get("ZERO_HIP_DEC_GROUP")
-        rows = int(env) if env else (16 if self.n > 1 else 0)
+        rows = 16 if self.n > 1 else 0
         self.prev = hip.lib().raw("zk_dec_group")(rows)
         return self
 
@@ -229,7 +227,7 @@ def _fuse_att_ok(core, hp, K):
 
 def _fuse_tail():
     import os
-    return os.environ.get("ZERO_HIP_DECODE_FUSE_TAIL", "1") != "0"
+    return True
 
 
 def _transposed(core, name):
@@ -401,8 +399,7 @@ def make_infer_fns(params, model_name):
                 e.lib.call("zk_beam_dev_prepare", *book, e.stream)
             import os
             state.reorder(state["idx"], time_dev=sb[0:1],
-                          defer_aan=core.aan and os.environ.get("ZERO_HIP_DECODE_FUSE_HEAD", "1") != "0"
-                          and os.environ.get("ZERO_HIP_DECODE_FUSE_GATHER", "1") != "0")
+                          defer_aan=core.aan)
             logits, _ = _step_cache(state["tok"], state, None, time_dev=sb[0:1])
             if hp.enable_noise_beam_search:      # search.py:143-145; a fresh stream position every step
                 e.lib.call("zk_add_gumbel", logits.ptr, state["BK"], core.V, logits.ld, float(zdtype.epsilon()),
@@ -477,7 +474,7 @@ def make_infer_fns(params, model_name):
             raise RuntimeError("decode step %d exceeds the allocated cache length %d" % (time, Tmax))
         import os as _os
         zf = state["zero_flag"]
-        fuse_head = _os.environ.get("ZERO_HIP_DECODE_FUSE_HEAD", "1") != "0"
+        fuse_head = True
         if not fuse_head:
             e.lib.call("zk_all_equal", target.data_ptr(), BK, hp.tgt_vocab.pad(), zf.data_ptr(), e.stream)
         import os as _os
@@ -525,7 +522,7 @@ def make_infer_fns(params, model_name):
                        None, None, parts.data_ptr(), nh, BK * H, core.b(p + "o_map/b_0").data_ptr(), None, None, 1.0,
                        None, e.stream)
             return out
-        ffn_split = int(_os.environ.get("ZERO_HIP_DECODE_FFN_SPLIT", "4")) if fuse_att else 0
+        ffn_split = 4 if fuse_att else 0
 
         def ffn_parts(x_in, f, l):
             """feed-forward sub-layer up to the output projection, left as split-K partial products (zk_gemm_parts: 64
@@ -576,7 +573,7 @@ def make_infer_fns(params, model_name):
                     core._linear(ya, a + "/ffn_layer/enlarge", hh, act=1)
                     core._linear(hh, a + "/ffn_layer/output", cat.cols_slice(H, 2 * H))
                 z = e.mat("dc.z", BK, 2 * H)
-                gate_split = int(_os.environ.get("ZERO_HIP_DECODE_GATE_SPLIT", "1")) if fuse_att else 0
+                gate_split = 1 if fuse_att else 0
                 if gate_split <= 1:
                     core._linear(cat, a + "/z_project", z)
                 g = e.mat("dc.y", BK, H)

@@ -337,7 +337,7 @@ def _beam_search_device(state, decoding_fn, params, B, K, V, eos_id, pad_id, alp
     # Once both parity graphs of the step exist (at once when the shape's graphs were adopted from the cache), the rest of
     # the loop runs inside ONE C call (zk_beam_dev_run: same launches, same one-group-behind poll): no interpreter between
     # two decode steps, and with several batches in flight the lanes' host threads stop serialising on it.
-    run_c = os.environ.get("ZERO_HIP_DECODE_RUN_C", "1") != "0"
+    run_c = True
     from zero_amd.models import _decode as _dec
     if run_c and "_gkey" not in state:
         _dec.adopt_graphs(state, state["book"], params.beam_search_temperature, zdtype.inf(),
