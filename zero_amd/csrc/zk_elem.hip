@@ -1841,17 +1841,20 @@ int zk_adam_range(float* p, const float* g, float* m, float* v, void* shadow, si
   ZK_CHECK_ARG(slot >= 0 && slot < 16 && ws_bytes >= zk_adam_range_workspace() && hyper != nullptr,
                "zk_adam_range: slot %d / workspace", slot);
   float* psq = (float*)workspace + (size_t)slot * 4096;
-  hipLaunchKernelGGL(k_adam<true>, dim3(2048), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n, hyper, psq,
+  // tuning key 13: blocks of a piece (default 2048).  A piece that runs BESIDE a latency-bound chain can be given few
+  // blocks so that it trickles along on a fraction of the HBM bandwidth and of the wave slots (round-4 probe).
+  const int nb = g_tune[13] > 0 && g_tune[13] <= 2048 ? g_tune[13] : 2048;
+  hipLaunchKernelGGL(k_adam<true>, dim3(nb), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n, hyper, psq,
                      psq + 2048, (uint64_t*)nullptr);
   ZK_LAUNCH_CHECK();
   return 0;
 }
 __global__ void __launch_bounds__(256) k_adam_finish(const float* __restrict__ ws, int nslots, float* __restrict__ hyper,
-                                                     float* __restrict__ pnorm_out, uint64_t* __restrict__ seed) {
+                                                     float* __restrict__ pnorm_out, uint64_t* __restrict__ seed, int nb) {
   __shared__ float sm[8];
   float a = 0.f, b = 0.f;
   for (int s = 0; s < nslots; ++s)
-    for (int i = threadIdx.x; i < 2048; i += 256) { b += ws[s * 4096 + i]; a += ws[s * 4096 + 2048 + i]; }
+    for (int i = threadIdx.x; i < nb; i += 256) { b += ws[s * 4096 + i]; a += ws[s * 4096 + 2048 + i]; }
   a = block_sum<4>(a, sm);
   b = block_sum<4>(b, sm);
   if (threadIdx.x == 0) {
@@ -1868,7 +1871,8 @@ int zk_adam_finish(float* hyper, float* pnorm_out, uint64_t* seed, int nslots, c
                    hipStream_t stream) {
   ZK_CHECK_ARG(hyper != nullptr && nslots >= 1 && nslots <= 16 && ws_bytes >= zk_adam_range_workspace(),
                "zk_adam_finish: nslots %d / workspace", nslots);
-  hipLaunchKernelGGL(k_adam_finish, dim3(1), dim3(256), 0, stream, (const float*)workspace, nslots, hyper, pnorm_out, seed);
+  hipLaunchKernelGGL(k_adam_finish, dim3(1), dim3(256), 0, stream, (const float*)workspace, nslots, hyper, pnorm_out, seed,
+                     g_tune[13] > 0 && g_tune[13] <= 2048 ? g_tune[13] : 2048);
   ZK_LAUNCH_CHECK();
   return 0;
 }
