@@ -536,10 +536,10 @@ def decode_measure(args, rank, world):
     from zero_amd.models._factory import get_core
     out["launches_per_step"] = getattr(get_core(hp, model), "_decode_step_launches", None)
     # the latency of ONE batch's decode step: the same batches one after the other on one lane --
-    # a bounded sample (every 8th batch), untimed warm-up on the longest of them first.  `ms_per_step` above is wall time
+    # a bounded sample (every 8th batch), run once untimed first (buffers, step graphs of these shapes).  `ms_per_step` above is wall time
     # per step with `batches_in_flight` batches overlapping; this is what a single batch waits for a step.
     sample = batches[::8]
-    decode_many(sample[-1:], work, 1)
+    decode_many(sample, work, 1)          # untimed: this lane's buffers and the step graphs of the sample's shapes
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     single_steps = sum(decode_many(sample, work, 1))
@@ -769,7 +769,7 @@ def main():
         for _ in range(2):
             rotating(0)
     dt, loss = chosen["_dt"], chosen["_loss"]
-    loss_v = float(loss.cpu()[0])
+    loss_v = float(loss.reshape(-1)[0].cpu())
     gnorm, pnorm, skipped = tr.train_op.stats()
     step_launches = getattr(tr.core.eng, "last_graph_nodes", None) if (use_graph and world == 1) else None
 
