@@ -497,13 +497,17 @@ int zk_ln_decode(const void* x, void* ybuf, const float* gamma, const float* bet
  * dimension contiguous, row strides ldwq / ldwo) so that a matrix-core fragment is one 16-byte load.
  * d = 64 per head, H = nh * 64 a power of two in 128 .. 2048.  Cross: keys / values of sentence b at k + b*bsk + j*ldk
  * (func.py:206-216 mk / mv), kmask [B, ldmask] (1 = valid) or NULL.  Values are rounded to bf16 where the launch-per-op
- * path stores bf16. */
+ * path stores bf16.
+ * Relative positions (modules/rpr.py:10-75 with last = 1; round 4): rpr_k / rpr_v bf16 [2 max_rel + 1, 64] or NULL
+ * (max_rel <= 31).  The query sits at position pos (*pos_dev when given; self-attention: its time step): key j adds
+ * q . rpr_k[clip(pos - j) + max_rel] to its score and P_j rpr_v[clip(pos - j) + max_rel] to the context. */
 int zk_dec_cross(const void* x, void* ybuf, const float* gamma, const float* beta, void* xout, int H, float eps,
                  const void* z, const void* cat_in, const float* parts, int nparts, long part_stride, const float* bias,
                  float* cache, void* cat_out, float inv_count, const int* time_dev, const void* wqt, int ldwq,
                  const float* bq, const void* k, const void* v, int ldk, int ldv, long bsk, long bsv, const float* kmask,
                  int ldmask, const void* wot, int ldwo, float* out_parts, int B, int R, int nh, int Lk, float scale,
-                 float mask_inf, zk_stream_t stream);
+                 float mask_inf, const void* rpr_k, const void* rpr_v, int max_rel, int pos, const int* pos_dev,
+                 zk_stream_t stream);
 /* Beam rows per workgroup of zk_dec_cross / zk_dec_self (1 .. 16; 0 = built-in default); returns the previous setting.
  * A measurement knob (scripts/dec_attn_trace.py): results do not depend on it. */
 int zk_dec_group(int n);
@@ -514,12 +518,14 @@ int zk_dec_self(const void* x, void* ybuf, const float* gamma, const float* beta
                 const void* z, const void* cat_in, const float* parts, int nparts, long part_stride, const float* bias,
                 float* cache, void* cat_out, float inv_count, const int* ln_time_dev, const void* wqkvt, int ldw,
                 const float* bqkv, void* kcache, void* vcache, int Tmax, int time, const int* time_dev, const void* wot,
-                int ldwo, float* out_parts, int B, int R, int nh, float scale, zk_stream_t stream);
+                int ldwo, float* out_parts, int B, int R, int nh, float scale, const void* rpr_k, const void* rpr_v,
+                int max_rel, zk_stream_t stream);
 int zk_aan_decode(const void* x, float* cache, void* cat, int rows, int H, float inv_count, const int* time_dev,
                   zk_stream_t stream);
 /* dynamic LDS bytes a zk_dec_cross / zk_dec_self workgroup needs for hidden size H and Lk keys (a CU has 160 KiB):
- * lets the caller choose the launch-per-op path for shapes that do not fit, before the batch starts decoding */
-size_t zk_dec_attn_lds(int H, int Lk);
+ * lets the caller choose the launch-per-op path for shapes that do not fit, before the batch starts decoding.
+ * max_rel < 0: without relative-position tables. */
+size_t zk_dec_attn_lds(int H, int Lk, int max_rel);
 /* Decoder input of one decode position in one launch (transformer.py:88-119; was zk_all_equal + zk_embed_fwd +
  * zk_aan_decode): every fed id == pad_id (first step) -> zero embedding, else table[id] * scale + bias; + timing[pos];
  * cache / cat != NULL: the first layer's average-attention update (transformer_aan.py:110-112).  *pos_dev overrides

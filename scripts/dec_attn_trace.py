@@ -39,12 +39,12 @@ pro = (x.data_ptr(), None, gamma.data_ptr(), beta.data_ptr(), xout.data_ptr(), H
 def launch():
     if self_mode:
         lib.call("zk_dec_self", *pro, wqt.data_ptr(), H + PW, bq.data_ptr(), kc.data_ptr(), vc.data_ptr(), Tmax, 40, None,
-                 wot.data_ptr(), H + PW, parts.data_ptr(), B, R, nh, 0.125, st)
+                 wot.data_ptr(), H + PW, parts.data_ptr(), B, R, nh, 0.125, None, None, 0, st)
     else:
         LD = 2 * H + PKV
         lib.call("zk_dec_cross", *pro, wqt.data_ptr(), H + PW, bq.data_ptr(), kv.data_ptr(), kv.data_ptr() + H * 2, LD,
                  LD, Ls * LD, Ls * LD, mask.data_ptr(), Ls, wot.data_ptr(), H + PW, parts.data_ptr(), B, R, nh, Ls,
-                 0.125, 1e9, st)
+                 0.125, 1e9, None, None, 0, 0, None, st)
 
 
 lib.raw("zk_dec_group")(int(os.environ.get("GROUP", "0")))

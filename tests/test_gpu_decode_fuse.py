@@ -35,14 +35,18 @@ def _model(model, size, seed, K):
     return hp, Pn, src
 
 
-@pytest.mark.parametrize("model", ["transformer", "transformer_aan"])
+@pytest.mark.parametrize("model", ["transformer", "transformer_aan", "transformer_rpr"])
 @pytest.mark.parametrize("size,K", [("small", 1), ("small", 4), ("base", 4), ("base", 2), ("base", 8), ("wide", 4)])
 def test_step_logits_fused_vs_per_op(model, size, K, monkeypatch):
-    """Four consecutive eager decode steps (time = 0 .. 3, caches carried) on both paths: logits compared."""
+    """Consecutive eager decode steps (time = 0 .. 3, caches carried; with relative positions 0 .. 7, i.e. past the
+    clipping distance max_relative_position = 4 of the test model, in both directions of the cross attention) on both
+    paths: logits compared.  transformer_rpr (round 4): the relative-position terms of modules/rpr.py:10-75 run inside
+    the fused launch instead of the launch-per-op attention."""
     hp, Pn, src = _model(model, size, 21, K)
     V = hp.tgt_vocab.size()
     rng = np.random.default_rng(5)
-    toks = [rng.integers(3, V, size=(src.shape[0] * K,)).astype(np.int32) for _ in range(4)]
+    nsteps = 8 if model == "transformer_rpr" else 4
+    toks = [rng.integers(3, V, size=(src.shape[0] * K,)).astype(np.int32) for _ in range(nsteps)]
     outs = {}
     for fuse in ("0", "1"):
         monkeypatch.setenv("ZERO_HIP_DECODE_FUSE_ATT", fuse)
@@ -58,7 +62,7 @@ def test_step_logits_fused_vs_per_op(model, size, K, monkeypatch):
             # same beams kept on both paths: identity reorder (exercises the ping-pong halves)
             state.reorder(torch.arange(src.shape[0] * K, dtype=torch.int32, device=core.eng.device))
         outs[fuse] = steps
-    for t in range(4):
+    for t in range(nsteps):
         a, b = outs["0"][t], outs["1"][t]
         scale = np.abs(a).max()
         err = np.abs(a - b).max() / scale
@@ -68,7 +72,7 @@ def test_step_logits_fused_vs_per_op(model, size, K, monkeypatch):
         assert (a.argmax(1) == b.argmax(1)).mean() >= 0.95
 
 
-@pytest.mark.parametrize("model", ["transformer", "transformer_aan"])
+@pytest.mark.parametrize("model", ["transformer", "transformer_aan", "transformer_rpr"])
 @pytest.mark.parametrize("size,K", [("small", 4), ("base", 4), ("base", 1)])
 def test_beam_search_fused_vs_per_op(model, size, K, monkeypatch):
     """Whole searches (device-resident bookkeeping, replayed step graphs): same hypotheses, scores within 2e-2."""
@@ -115,4 +119,4 @@ def test_dec_cross_argument_checks():
     with pytest.raises(hip.ZeroHipError, match="power of two"):
         lib.call("zk_dec_cross", x.data_ptr(), None, None, None, None, 192, 1e-6, None, None, None, 0, 0, None, None, None,
                  1.0, None, w.data_ptr(), 192, f.data_ptr(), x.data_ptr(), x.data_ptr(), 192, 192, 192 * 4,
-                 192 * 4, None, 0, w.data_ptr(), 192, f.data_ptr(), 2, 4, 3, 4, 0.125, 1e9, st)
+                 192 * 4, None, 0, w.data_ptr(), 192, f.data_ptr(), 2, 4, 3, 4, 0.125, 1e9, None, None, 0, 0, None, st)

@@ -58,8 +58,14 @@ struct DecAttnArgs {
   float* part;                                   // [nh][B*R][H]
   int B, R, nh, Lk;                              // Lk: cross = source length; self = cache capacity
   float scale, mask_inf;
-  const int* time_dev; int time;                 // self: this step's slot (the device value wins)
+  const int* time_dev; int time;                 // self: this step's slot (the device value wins); cross with relative
+                                                 // positions: the query's position
   int gr;                                        // beam rows per workgroup (<= 16)
+  // relative positions (modules/rpr.py:10-75 at Lq = 1; round 4: folded into this launch, transformer_rpr's decode step
+  // no longer takes the launch-per-op path): tables bf16 [2 max_rel + 1][64] (shared by the heads) or NULL.  Key j of a
+  // query at position t reads row clip(t - j, -max_rel, max_rel) + max_rel: the scores get q . Rk[row], the context
+  // sum_j P_j Rv[row].
+  const bf16_t* rpr_k; const bf16_t* rpr_v; int max_rel;
 };
 
 // 512 threads = 8 waves; one workgroup = (16 consecutive beam rows, head h).  MAXC = ceil(H / 512).
@@ -71,7 +77,8 @@ __global__ void __launch_bounds__(512) k_dec_attn(DecAttnArgs a) {
   const int h = blockIdx.x % a.nh, row0 = (blockIdx.x / a.nh) * a.gr;
   const int H = a.pro.H, R = a.R, rows = a.B * a.R;
   const int NR = min(a.gr, rows - row0);                 // valid rows of this group
-  const int t = SELF ? (a.time_dev != nullptr ? *a.time_dev : a.time) : 0;
+  const bool rpr = a.rpr_k != nullptr;
+  const int t = (SELF || rpr) ? (a.time_dev != nullptr ? *a.time_dev : a.time) : 0;
   const int Lk = SELF ? min(a.Lk, t + 1) : a.Lk;
   const int LkPad = (a.Lk + 3) & ~3;
   const int XLD = H + 8;
@@ -85,6 +92,13 @@ __global__ void __launch_bounds__(512) k_dec_attn(DecAttnArgs a) {
   float* sVc = sKc + 1024;
   float* sS = sVc + 1024;                               // [16][LkPad]
   bf16_t* sCb = reinterpret_cast<bf16_t*>(sS + 16 * LkPad);   // [16][72]
+  float* sRk = reinterpret_cast<float*>(sCb + 16 * 72);       // relative positions: [2 max_rel + 1][64] fp32, keys ...
+  float* sRv = sRk + (2 * a.max_rel + 1) * 64;                // ... and values (only with tables: dec_attn_lds)
+  auto rel_row = [&](int j) {                                 // modules/rpr.py:66-75: clip(i - j) + max_rel
+    int dlt = t - j;
+    dlt = dlt < -a.max_rel ? -a.max_rel : (dlt > a.max_rel ? a.max_rel : dlt);
+    return (dlt + a.max_rel) * 64;
+  };
   // keys / values of row r (cross: of its sentence)
   auto kbase = [&](int r) { return a.k + (size_t)(SELF ? row0 + r : (row0 + r) / R) * a.bsk + h * 64; };
   auto vbase = [&](int r) { return a.v + (size_t)(SELF ? row0 + r : (row0 + r) / R) * a.bsv + h * 64; };
@@ -186,6 +200,10 @@ __global__ void __launch_bounds__(512) k_dec_attn(DecAttnArgs a) {
       const int c = (i * 64 + lane) * 8;
       if (c < H && w + 8 * n < NR) *reinterpret_cast<uint4*>(sXb + (w + 8 * n) * XLD + c) = xr[n][i];
     }
+  if (rpr) {
+    const int n = (2 * a.max_rel + 1) * 64;
+    for (int e = tid; e < n; e += 512) { sRk[e] = bf2f(a.rpr_k[e]); sRv[e] = bf2f(a.rpr_v[e]); }
+  }
   ZK_DT(11);
   __syncthreads();
 
@@ -269,6 +287,10 @@ __global__ void __launch_bounds__(512) k_dec_attn(DecAttnArgs a) {
     } else {
       for (int i = 0; i < 64; ++i) dot += sQ[r * 64 + i] * sKc[r * 64 + i];
     }
+    if (rpr) {
+      const float* rk = sRk + rel_row(j);
+      for (int i = 0; i < 64; ++i) dot += sQ[r * 64 + i] * rk[i];
+    }
     sS[r * LkPad + j] = dot * a.scale + ((!SELF && km_r == 0.f) ? -a.mask_inf : 0.f);
   }
   __syncthreads();
@@ -314,6 +336,11 @@ __global__ void __launch_bounds__(512) k_dec_attn(DecAttnArgs a) {
             for (int i = 0; i < 8; ++i) vf[i] = sVc[cr * 64 + ccg * 8 + i];
           }
           const float pr = sS[cr * LkPad + j];
+          if (rpr) {
+            const float* rv = sRv + rel_row(j) + ccg * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vf[i] += rv[i];
+          }
 #pragma unroll
           for (int i = 0; i < 8; ++i) acc[i] += pr * vf[i];
         }
@@ -348,17 +375,19 @@ __global__ void __launch_bounds__(512) k_dec_attn(DecAttnArgs a) {
   ZK_DT(7);
 }
 
-static size_t dec_attn_lds(int H, int Lk) {
-  return 2 * 16 * (size_t)(H + 8) + sizeof(float) * (3 * 8 * 256 + 3 * 1024 + 16 * (size_t)((Lk + 3) & ~3)) + 2 * 16 * 72;
+static size_t dec_attn_lds(int H, int Lk, int max_rel = -1) {
+  return 2 * 16 * (size_t)(H + 8) + sizeof(float) * (3 * 8 * 256 + 3 * 1024 + 16 * (size_t)((Lk + 3) & ~3)) + 2 * 16 * 72 +
+         (max_rel >= 0 ? sizeof(float) * 2 * (size_t)(2 * max_rel + 1) * 64 : 0);
 }
 
 // LDS bytes one workgroup of zk_dec_cross / zk_dec_self needs for (H, Lk): the host asks BEFORE it commits a decode batch
 // to the fused path (a shape over the 160 KiB of a CU takes the launch-per-op path instead of failing mid-decode)
-extern "C" size_t zk_dec_attn_lds(int H, int Lk) { return dec_attn_lds(H, Lk); }
+// max_rel < 0: no relative-position tables
+extern "C" size_t zk_dec_attn_lds(int H, int Lk, int max_rel) { return dec_attn_lds(H, Lk, max_rel); }
 
 template <bool SELF, int MAXC>
 static int launch_dec_attn(const DecAttnArgs& a, hipStream_t stream) {
-  const size_t lds = dec_attn_lds(a.pro.H, a.Lk);
+  const size_t lds = dec_attn_lds(a.pro.H, a.Lk, a.rpr_k != nullptr ? a.max_rel : -1);
   ZK_CHECK_ARG(lds <= 160 * 1024, "zk_dec_attn: %zu bytes of LDS needed (H=%d, Lk=%d)", lds, a.pro.H, a.Lk);
   auto kern = k_dec_attn<SELF, MAXC>;
   if (lds > 64 * 1024) {
@@ -436,7 +465,8 @@ int zk_dec_cross(const void* x, void* ybuf, const float* gamma, const float* bet
                  float* cache, void* cat_out, float inv_count, const int* time_dev, const void* wqt, int ldwq,
                  const float* bq, const void* k, const void* v, int ldk, int ldv, long bsk, long bsv, const float* kmask,
                  int ldmask, const void* wot, int ldwo, float* out_parts, int B, int R, int nh, int Lk, float scale,
-                 float mask_inf, hipStream_t stream) {
+                 float mask_inf, const void* rpr_k, const void* rpr_v, int max_rel, int pos, const int* pos_dev,
+                 hipStream_t stream) {
   DecAttnArgs a{};
   a.pro = LnDecArgs{(const bf16_t*)x, (bf16_t*)ybuf, gamma, beta, (bf16_t*)xout, B * R, H, eps, (const bf16_t*)z,
                     (const bf16_t*)cat_in, parts, nparts, part_stride, bias, cache, (bf16_t*)cat_out, inv_count, time_dev};
@@ -449,6 +479,10 @@ int zk_dec_cross(const void* x, void* ybuf, const float* gamma, const float* bet
   a.kmask = kmask; a.ldmask = ldmask;
   a.wot = (const bf16_t*)wot; a.ldwo = ldwo; a.part = out_parts;
   a.B = B; a.R = R; a.nh = nh; a.Lk = Lk; a.scale = scale; a.mask_inf = mask_inf;
+  ZK_CHECK_ARG((rpr_k == nullptr) == (rpr_v == nullptr) && (rpr_k == nullptr || (max_rel >= 0 && max_rel <= 31)),
+               "zk_dec_cross: relative positions need both tables and 0 <= max_rel <= 31");
+  a.rpr_k = (const bf16_t*)rpr_k; a.rpr_v = (const bf16_t*)rpr_v; a.max_rel = rpr_k ? max_rel : 0;
+  a.time = pos; a.time_dev = rpr_k ? pos_dev : nullptr;
   a.gr = dec_group_rows(R);
   return dispatch_dec_attn<false>(a, stream);
 }
@@ -460,7 +494,8 @@ int zk_dec_self(const void* x, void* ybuf, const float* gamma, const float* beta
                 const void* z, const void* cat_in, const float* parts, int nparts, long part_stride, const float* bias,
                 float* cache, void* cat_out, float inv_count, const int* ln_time_dev, const void* wqkvt, int ldw,
                 const float* bqkv, void* kcache, void* vcache, int Tmax, int time, const int* time_dev, const void* wot,
-                int ldwo, float* out_parts, int B, int R, int nh, float scale, hipStream_t stream) {
+                int ldwo, float* out_parts, int B, int R, int nh, float scale, const void* rpr_k, const void* rpr_v,
+                int max_rel, hipStream_t stream) {
   DecAttnArgs a{};
   a.pro = LnDecArgs{(const bf16_t*)x, (bf16_t*)ybuf, gamma, beta, (bf16_t*)xout, B * R, H, eps, (const bf16_t*)z,
                     (const bf16_t*)cat_in, parts, nparts, part_stride, bias, cache, (bf16_t*)cat_out, inv_count,
@@ -477,6 +512,9 @@ int zk_dec_self(const void* x, void* ybuf, const float* gamma, const float* beta
   a.wot = (const bf16_t*)wot; a.ldwo = ldwo; a.part = out_parts;
   a.B = B; a.R = R; a.nh = nh; a.Lk = Tmax; a.scale = scale; a.mask_inf = 0.f;
   a.time_dev = time_dev; a.time = time;
+  ZK_CHECK_ARG((rpr_k == nullptr) == (rpr_v == nullptr) && (rpr_k == nullptr || (max_rel >= 0 && max_rel <= 31)),
+               "zk_dec_self: relative positions need both tables and 0 <= max_rel <= 31");
+  a.rpr_k = (const bf16_t*)rpr_k; a.rpr_v = (const bf16_t*)rpr_v; a.max_rel = rpr_k ? max_rel : 0;
   a.gr = dec_group_rows(R);
   return dispatch_dec_attn<true>(a, stream);
 }

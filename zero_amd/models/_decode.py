@@ -221,7 +221,8 @@ def _fuse_att_ok(core, hp, K):
     """The attention sub-layers of a cached decode step as one launch per (sentence, head) (zk_dec_cross / zk_dec_self)."""
     import os
     return (os.environ.get("ZERO_HIP_DECODE_FUSE_ATT", "1") != "0" and core.d == 64
-            and core.H in (128, 256, 512, 1024, 2048) and not core.rpr and not core.fuse
+            and core.H in (128, 256, 512, 1024, 2048) and not core.fuse
+            and (not core.rpr or hp.max_relative_position <= 31)
             and (not core.aan or os.environ.get("ZERO_HIP_DECODE_FUSE_LN", "1") != "0") and not hp.use_ffn)
 
 
@@ -326,7 +327,8 @@ def make_infer_fns(params, model_name):
         # and the whole workgroup state must fit the 160 KiB of a CU: otherwise 'wt' stays empty and the step takes the
         # launch-per-op path (_cross_unfused) instead of failing mid-decode
         if _fuse_att_ok(core, hp, K) and max(Ls, max_steps) <= 1024 and \
-                e.lib.query("zk_dec_attn_lds", H, max(Ls, max_steps)) <= 160 * 1024:
+                e.lib.query("zk_dec_attn_lds", H, max(Ls, max_steps),
+                            hp.max_relative_position if core.rpr else -1) <= 160 * 1024:
             for l in range(nl):
                 blocks = [(core.cross, ("q_map", "o_map"))]
                 if not core.aan:
@@ -498,13 +500,21 @@ def make_infer_fns(params, model_name):
             return dict(gamma=core.b(scope + "/layer_norm/scale").data_ptr(),
                         beta=core.b(scope + "/layer_norm/offset").data_ptr())
 
+        def rpr_tabs(p):
+            """(rpr_k, rpr_v, max_rel) of the attention scope p: relative positions inside the fused launch (round 4)."""
+            if not core.rpr:
+                return (None, None, 0)
+            return (core.store.s(p + "rpr_keys/embeddings").data_ptr(), core.store.s(p + "rpr_values/embeddings").data_ptr(),
+                    hp.max_relative_position)
+
         def dec_cross(x_in, pro, p, lay, parts):
             la = ln_args(pro) or (x_in.ptr, None, None, None, None, H, eps, None, None, None, 0, 0, None, None, None,
                                   1.0, None)
             Wq, Wo = state["wt"][p + "q_map/W_0_0"], state["wt"][p + "o_map/W_0_0"]
             e.lib.call("zk_dec_cross", *la, Wq.ptr, Wq.ld, core.b(p + "q_map/b_0").data_ptr(), lay["mk"].ptr,
                        lay["mv"].ptr, lay["mk"].ld, lay["mv"].ld, Ls * 2 * H, Ls * 2 * H, state["mask"].data_ptr(), Ls,
-                       Wo.ptr, Wo.ld, parts.data_ptr(), B, K, nh, Ls, float(d) ** -0.5, zdtype.inf(), e.stream)
+                       Wo.ptr, Wo.ld, parts.data_ptr(), B, K, nh, Ls, float(d) ** -0.5, zdtype.inf(),
+                       *(rpr_tabs(p) + (0 if time_dev is not None else time, tdev)), e.stream)
 
         def dec_self(x_in, pro, p, lay, parts):
             la = ln_args(pro) or (x_in.ptr, None, None, None, None, H, eps, None, None, None, 0, 0, None, None, None,
@@ -512,7 +522,7 @@ def make_infer_fns(params, model_name):
             Wq, Wo = state["wt"][p + "qkv_map/W_0_0"], state["wt"][p + "o_map/W_0_0"]
             e.lib.call("zk_dec_self", *la, Wq.ptr, Wq.ld, core.b(p + "qkv_map/b_0").data_ptr(), lay["k"].data_ptr(),
                        lay["v"].data_ptr(), Tmax, 0 if time_dev is not None else time, tdev, Wo.ptr, Wo.ld,
-                       parts.data_ptr(), B, K, nh, float(d) ** -0.5, e.stream)
+                       parts.data_ptr(), B, K, nh, float(d) ** -0.5, *rpr_tabs(p), e.stream)
 
         def ln_parts(x_in, scope, p, parts, tag):
             """x = LayerNorm(x_in + bf16(sum of the nh partial output projections + o_map bias))"""
