@@ -249,3 +249,23 @@ def test_decode_many_order_lanes_and_errors():
         pass
     else:
         raise AssertionError("the worker's exception was swallowed")
+
+
+def test_pinned_ring_cpu_path_and_bench_rotation():
+    """utils/queuer.PinnedRing off the GPU is a plain copy (int64 ids -> int32); bench.py's rotation of synthetic batches:
+    eight distinct batches per rank, batch 0 = the batch rounds 1-3 replayed, ranks draw different ones."""
+    import numpy as np
+    import torch
+    from zero_amd.utils.queuer import PinnedRing
+    ring = PinnedRing("cpu")
+    dst = torch.zeros(3, 4, dtype=torch.int32)
+    for i in range(20):                         # more puts than slots
+        ring.put(dst, np.arange(12, dtype=np.int64).reshape(3, 4) + i)
+        assert dst[2, 3].item() == 11 + i
+    import bench
+    b = [bench.synthetic_batch(0, None, i) for i in range(bench.ROTATION)]
+    assert len({x[0].tobytes() for x in b}) == bench.ROTATION and all(x[0].shape == (64, 64) for x in b)
+    rng = np.random.default_rng(1234)
+    assert np.array_equal(b[0][0][:, :-1], rng.integers(3, 32000, size=(64, 64), dtype=np.int64)[:, :-1])
+    assert not np.array_equal(bench.synthetic_batch(1, None, 0)[0], b[0][0])
+    assert all((x[0][:, -1] == 2).all() and (x[1][:, -1] == 2).all() for x in b)

@@ -197,3 +197,65 @@ def test_transport_rule_without_gpu_is_torch_distributed():
     parallel._TRANSPORT.clear()
     assert parallel.transport() is None     # no GPU / no process group: torch.distributed (or nothing) carries the buckets
     parallel._TRANSPORT.clear()
+
+
+# ---------------------------------------------------------------------------------------------
+# round 4: run-time reconfiguration (bench.py --gpus N times one leg per exchange mode in ONE process group), the
+# transport selector, and the payload-capacity rule that must not raise on one rank
+# ---------------------------------------------------------------------------------------------
+def test_reducer_defaults_and_runtime_configuration():
+    hp = make_hp("transformer", H=16, F=32, heads=2, layers=1, Vs=13, Vt=11)
+    store = VariableStore(hp, "transformer", "cpu")
+    red = parallel.GradientAllReduce(store, ops=TorchBucketOps())
+    assert red.bucket_dtype_name() == "fp32"                      # the reference averages fp32 (utils/parallel.py:184-196)
+    red.configure(bucket_dtype="bf16", sparse=True)
+    assert red.bucket_dtype_name() == "bf16" and red.sparse_enabled
+    red.configure(bucket_dtype="fp32", sparse=False)
+    assert red.bucket_dtype_name() == "fp32" and not red.sparse_enabled and red.sparse_keys() == []
+    bare = parallel.GradientAllReduce(store)                      # no device-side cast ops on CPU
+    with pytest.raises(ValueError):
+        bare.configure(bucket_dtype="bf16")
+
+
+def test_select_transport_is_collective_safe_without_gpus():
+    parallel._TRANSPORT.clear()
+    assert parallel.select_transport(True) is False               # no GPU / one process: the direct communicator is never tried
+    assert parallel.transport() is None
+    assert parallel.select_transport(False) is False and parallel.transport() is None
+    parallel._TRANSPORT.clear()
+    assert os.environ.get("ZERO_HIP_COMM", "torch") == "torch"    # default: torch.distributed (whose nccl backend is RCCL)
+
+
+def _overflow_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    parallel.init_distributed("gloo")
+    hp = make_hp("transformer", H=16, F=32, heads=2, layers=1, Vs=41, Vt=11)
+    store = VariableStore(hp, "transformer", "cpu")
+    red = parallel.GradientAllReduce(store, ops=TorchBucketOps())
+    red.sparse_enabled = True
+    uid = torch.zeros(32, dtype=torch.int32)
+    # rank 1's batch has MORE token rows than the payload has slots: no exception (the others would wait in the all-gather
+    # for ever); the decision is the device's (zk_rows_pack poisons the payload when the DISTINCT ids exceed the capacity)
+    try:
+        red.set_sparse("src_embedding", store.g("src_embedding"), uid, torch.tensor([3], dtype=torch.int32), 8,
+                       rows=8 if rank == 0 else 30)
+        ok = red.sparse_keys() == ["src_embedding"]
+    except Exception:       # noqa: BLE001
+        ok = False
+    dist.barrier()
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_payload_capacity_never_raises_on_one_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overflow_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
