@@ -51,6 +51,20 @@ size_t zk_gemm_workspace_split(int M, int N, int splits);
  * (func.py:327-338 ffn_layer "output" at 128 rows: 64 workgroups instead of 16). */
 int zk_gemm_parts(const void* A, const void* B, float* parts, int M, int N, int K, int lda, int ldb, int ta, int tb,
                   int splits, int* nparts_out, zk_stream_t stream);
+/* The tail of a post-LN sub-layer in ONE launch: s = residual + dropout(bf16(A B + bias)); y = LayerNorm(s)
+ * (func.py:321-324 residual_fn + func.py:289-303 layer_norm in the order of transformer.py:57-58; replaces zk_gemm followed by
+ * zk_add_ln_fwd).  A [M, lda] x B [K, ldb] (no transposition), N % 64 == 0, N <= 1024.  The N/64 workgroups holding a block
+ * of rows exchange the {sum, M2} of their 64 columns through `slots` (zk_gemm_add_ln_workspace bytes, zero-filled once,
+ * shared by all calls on a stream) and normalise their own columns.  s_out (bf16 [M, N]), mean, rstd (fp32 [M]): what
+ * zk_add_ln_bwd reads, may be null.  `epoch`: device word advanced by zk_ln_epoch_bump once per forward pass (start it at
+ * 0 and bump before the first use); `site` in 1..255 differs between the calls of one pass.  *err (device int, may be
+ * null) is set to 1 if a workgroup gave up waiting for a peer. */
+size_t zk_gemm_add_ln_workspace(int rows, int N);
+int zk_ln_epoch_bump(uint32_t* epoch, zk_stream_t stream);
+int zk_gemm_add_ln(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias,
+                   const void* residual, int ldr, float drop_p, const uint64_t* seed, uint32_t sid, const float* gamma,
+                   const float* beta, float eps, void* s_out, void* y, float* mean, float* rstd, void* slots,
+                   size_t slots_bytes, const uint32_t* epoch, uint32_t site, int* err, zk_stream_t stream);
 int zk_gemm_plan(int M, int N, int K, int out_f32, int plain);  /* gen | (bm/8)<<8 | (bn/8)<<16 | splits<<24 | producer waves<<28 chosen by impl=0 */
 int zk_gemm_set_generation(int gen);   /* 1 = register-staged kernel, 2 = LDS-DMA ring kernel (default) */
 /* K-segmented GEMM: C bf16 [M, ldc] = sum_s A_s [M, kseg] x B_s (+ bf16 residual, may alias C) in ONE launch --

@@ -1,0 +1,136 @@
+"""The tail of a post-LN sub-layer in one launch (round 4: zk_gemm_add_ln; func.py:321-324 residual_fn, func.py:289-303
+layer_norm, transformer.py:57-58): the workgroups of a block of rows exchange the statistics of their 64 columns and
+normalise them in the epilogue.  Checked against the two launches it replaces (zk_gemm, zk_add_ln_fwd) on the kernels,
+under repetition (the exchange slots are reused by every call), and on the whole training step."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.util_gpu import eng, rand_bf, mat, rel_err  # noqa: E402
+
+F32 = torch.float32
+
+
+def _two_launches(e, A, W, b, R, gam, bet, drop, sid):
+    M, N = A.shape[0], W.shape[1]
+    y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    out, s = torch.empty_like(y), torch.empty_like(y)
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    e.gemm(mat(A), mat(W), mat(y), M, N, A.shape[1], 0, 0, bias=b)
+    e.add_ln_fwd(mat(R), mat(y), gam, bet, mat(out), mat(s), mean, rstd, drop, sid)
+    return out, s, mean, rstd
+
+
+def _one_launch(e, A, W, b, R, gam, bet, drop, sid, save=True):
+    M, N = A.shape[0], W.shape[1]
+    out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    s = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda") if save else None
+    mean = torch.empty(M, device="cuda") if save else None
+    rstd = torch.empty(M, device="cuda") if save else None
+    e.gemm_add_ln(mat(A), mat(W), M, N, A.shape[1], b, mat(R), gam, bet, mat(out), mat(s) if save else None, mean, rstd,
+                  drop, sid)
+    return out, s, mean, rstd
+
+
+def _ulp_close(a, b):
+    """bf16 tensors equal up to one unit in the last place of the larger magnitude (the statistics differ in their last
+    fp32 bits: Chan's combination of eight partials against two passes over the row)."""
+    a, b = a.float(), b.float()
+    tol = torch.maximum(a.abs(), b.abs()) * 2.0 ** -7 + 1e-6
+    return bool(((a - b).abs() <= tol).all())
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 512), (4096, 512, 2048), (66, 512, 512), (700, 512, 512), (130, 512, 2048),
+                                   (1000, 1024, 1024), (257, 128, 512), (64, 64, 64), (5, 512, 512)])
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+def test_one_launch_against_gemm_then_layernorm(M, N, K, drop):
+    """Interior and ragged row counts, both tile shapes (64x64 for K = 512, 128x64 for the long K), one to sixteen
+    workgroups per row block: the stored sum is the two-launch sum bit for bit (same rounding of the product, same
+    dropout mask), y agrees to the last bf16 bit of the statistics, mean / rstd to fp32 rounding."""
+    e = eng()
+    e.set_seed(5)
+    A, W = rand_bf(M, K, seed=1, scale=0.5), rand_bf(K, N, seed=2, scale=0.05)
+    R = rand_bf(M, N, seed=3)
+    g = torch.Generator().manual_seed(4)
+    b = (torch.randn(N, generator=g) * 0.1).cuda()
+    gam = (1.0 + 0.2 * torch.randn(N, generator=g)).cuda()
+    bet = (0.1 * torch.randn(N, generator=g)).cuda()
+    ref = _two_launches(e, A, W, b, R, gam, bet, drop, 11)
+    e.ln_epoch_bump()
+    got = _one_launch(e, A, W, b, R, gam, bet, drop, 11)
+    torch.cuda.synchronize()
+    assert e.sync_ln_errors() == 0
+    assert torch.equal(got[1], ref[1])
+    assert _ulp_close(got[0], ref[0]) and rel_err(got[0], ref[0]) < 2e-3
+    assert torch.allclose(got[2], ref[2], rtol=1e-5, atol=1e-6) and torch.allclose(got[3], ref[3], rtol=1e-5, atol=0)
+    # without the outputs the backward reads
+    e.ln_epoch_bump()
+    lean = _one_launch(e, A, W, b, R, gam, bet, drop, 11, save=False)
+    torch.cuda.synchronize()
+    assert torch.equal(lean[0], got[0])
+
+
+def test_repeated_launches_reuse_the_slots():
+    """Several hundred launches back to back on the same slots, different inputs and sites, the epoch advancing every 30
+    launches as it does in a training step (30 sub-layers): every one of them must see this launch's partials, never an
+    earlier launch's.  Two alternating inputs: a stale slot would show up as the other input's statistics."""
+    e = eng()
+    M, N, K = 4096, 512, 512
+    W = rand_bf(K, N, seed=2, scale=0.05)
+    gam, bet = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
+    ins = [(rand_bf(M, K, seed=10 + i, scale=0.5 * (1 + 3 * i)), rand_bf(M, N, seed=20 + i, scale=1.0 + 2 * i)) for i in range(2)]
+    want = []
+    for A, R in ins:
+        e.ln_epoch_bump()
+        want.append(_one_launch(e, A, W, None, R, gam, bet, 0.0, 0)[0].clone())
+    torch.cuda.synchronize()
+    assert not torch.equal(want[0], want[1])
+    out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    bad = 0
+    for it in range(360):
+        if it % 30 == 0:
+            e.ln_epoch_bump()
+        A, R = ins[it % 2]
+        e.gemm_add_ln(mat(A), mat(W), M, N, K, None, mat(R), gam, bet, mat(out))
+        if it % 7 == 0 or it > 340:
+            torch.cuda.synchronize()
+            bad += int(not torch.equal(out, want[it % 2]))
+    torch.cuda.synchronize()
+    assert bad == 0 and e.sync_ln_errors() == 0
+
+
+@pytest.mark.parametrize("model", ["transformer", "transformer_rpr"])
+def test_training_steps_with_the_layernorm_inside_the_launch(model, monkeypatch):
+    """Trainer with ZERO_HIP_SYNC_LN on / off: the same losses and weights after five steps up to the last-bit difference
+    of the statistics; captured replay == eager bit for bit with it on (the epoch word lives on the device)."""
+    from tests.common import make_hp, make_batch, perturb
+    from oracle import ref_torch as rt
+    from zero_amd.main import Trainer
+    from zero_amd.models._factory import reset_cores
+    from zero_amd.variables import reset_stores
+    hp = make_hp(model, H=128, F=256, lrate=0.02, warmup_steps=10, dropout=0.1, residual_dropout=0.1)
+    rng = np.random.default_rng(3)
+    src, tgt = make_batch(rng, 6, 11, 13, hp.src_vocab.size(), hp.tgt_vocab.size())
+    Pn = perturb(rt.init_params(hp, model, seed=8), rng)
+    out = {}
+    for sync in ("1", "0"):
+        monkeypatch.setenv("ZERO_HIP_SYNC_LN", sync)
+        for use_graph in (False, True):
+            reset_cores(); reset_stores()
+            tr = Trainer(hp, initializer=Pn)
+            assert tr.core.sync_ln_mode == (sync == "1")
+            tr.prepare_static({"source": src, "target": tgt})
+            tr.core.eng.set_seed(11)
+            losses = [float(tr.step_static(use_graph).cpu()[0]) for _ in range(5)]
+            torch.cuda.synchronize()
+            assert tr.core.eng.sync_ln_errors() == 0
+            out[(sync, use_graph)] = (losses, tr.store.master.cpu().numpy().copy())
+    a, b = out[("1", False)], out[("1", True)]
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    on, off = out[("1", True)], out[("0", True)]
+    assert np.allclose(on[0], off[0], rtol=2e-3, atol=0), (on[0], off[0])
+    assert np.linalg.norm(on[1] - off[1]) <= 2e-3 * np.linalg.norm(off[1])

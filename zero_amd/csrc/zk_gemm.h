@@ -29,6 +29,24 @@ struct GemmEpi {
   const float* ln_in_part = nullptr; const float* ln_c = nullptr;
   const float* res_part = nullptr; const float* res_gamma = nullptr; const float* res_beta = nullptr;
   int ln_np = 0; int res_after_drop = 0; float ln_eps = 0.f; float ln_invh = 0.f;
+  // ---- residual + LayerNorm INSIDE the producing launch (zk_gemm_add_ln; gemm_tile<.., LN = 3>): the N/64 workgroups
+  // that hold one block of rows exchange their per-64-column {sum, M2} through `sy_slots` ([rows][N/64] x 16 bytes:
+  // {sum, tag, M2, tag}, agent-scope 8-byte atomics, each half validated by its own tag) and every one of them
+  // normalises its own 64 columns: C = s = res + dropout(bf16(acc + bias)) (may be null), sy_y = LN(s),
+  // sy_mean / sy_rstd (may be null) by the tn = 0 tile.  tag = (*sy_epoch << 8) | sy_site: *sy_epoch is bumped once
+  // per forward pass (zk_ln_epoch_bump), the site differs between the launches of one pass, so a slot left by an
+  // earlier launch never validates.  *sy_err is set if a peer's partial did not arrive within the spin budget.
+  unsigned long long* sy_slots = nullptr; const uint32_t* sy_epoch = nullptr; uint32_t sy_site = 0;
+  const float* sy_gamma = nullptr; const float* sy_beta = nullptr; bf16_t* sy_y = nullptr; int sy_ldy = 0;
+  float* sy_mean = nullptr; float* sy_rstd = nullptr; int* sy_err = nullptr; int sy_local = 0;
+  // ---- the BACKWARD of a residual + LayerNorm inside the dgrad launch that produces its input gradient (zk_gemm_ln_bwd;
+  // gemm_tile<.., LN = 4>): dout = bf16(acc + res) is the gradient of the normalised rows (never stored); with the saved
+  // sum sy_s, its statistics sy_mean_in / sy_rstd_in and sy_gamma:  g = dout gamma, xh = (s - mu) rstd,
+  // ds = rstd (g - mean(g) - xh mean(g xh)) -> sy_y (bf16), dy = bf16(ds) dropmask -> sy_dy (null without dropout),
+  // column partials {sum dout xh, sum dout, sum dy} over the tile's rows -> sy_part [tiles_m][3][N].  The two row means
+  // are exchanged between the row block's workgroups exactly as the forward's {sum, M2} (same slots, epoch and sites).
+  const bf16_t* sy_s = nullptr; int sy_lds = 0; const float* sy_mean_in = nullptr; const float* sy_rstd_in = nullptr;
+  bf16_t* sy_dy = nullptr; float* sy_part = nullptr;
 };
 
 __device__ __forceinline__ void epi_store(const GemmEpi& e, float v, int gm, int gn, int N, uint64_t seed) {

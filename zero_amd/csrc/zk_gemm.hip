@@ -294,6 +294,8 @@ static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, 
 int zk_gemm_dlds_pw(int bm, int bn);
 int zk_gemm_dlds_ln_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int bm, int bn,
                              const GemmEpi& e, hipStream_t stream);
+int zk_gemm_dlds_sync_ln_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int bm,
+                                  const GemmEpi& e, hipStream_t stream);
 int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
                           int bm, int bn, int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags,
                           hipStream_t stream);
@@ -460,6 +462,61 @@ int zk_gemm_ln(const void* A, const void* B, void* C, int M, int N, int K, int l
 }
 
 #endif  // ZK_EXPERIMENTS
+
+// The tail of a post-LN sub-layer in ONE launch (func.py:321-324 residual_fn, func.py:289-303 layer_norm, the order of
+// transformer.py:57-58):   s = residual + dropout(bf16(A B + bias));   y = LN(s) = gamma (s - mu) rstd + beta.
+// The N/64 workgroups that hold one block of rows exchange the {sum, M2} of their 64 columns through `slots`
+// (zk_gemm_add_ln_workspace(rows, N) bytes, zero-filled once, shared by every call on the stream) and each normalises its
+// own columns -- the LayerNorm launch, its read of the product and of the residual, and a kernel boundary disappear.
+// s_out / mean / rstd (what the backward reads) may be null.  `epoch` is a device word that zk_ln_epoch_bump advances
+// once per forward pass; `site` (1..255) must differ between the calls of one pass that share `slots`.  *err (device
+// int, may be null) becomes 1 if a workgroup gave up waiting (tens of milliseconds; never observed).
+// Same values as zk_gemm followed by zk_add_ln_fwd up to the last bit of the statistics (Chan's combination of the
+// per-64-column partials instead of two passes over the row).
+size_t zk_gemm_add_ln_workspace(int rows, int N) { return (size_t)((rows + 127) / 128 * 128) * (size_t)(N / 64) * 16; }
+
+__global__ void k_ln_epoch_bump(uint32_t* epoch) { if (threadIdx.x == 0) { const uint32_t v = *epoch + 1; *epoch = (v & 0xffffffu) ? v : 1; } }
+int zk_ln_epoch_bump(uint32_t* epoch, hipStream_t stream) {
+  ZK_CHECK_ARG(epoch != nullptr, "zk_ln_epoch_bump: null epoch word");
+  hipLaunchKernelGGL(k_ln_epoch_bump, dim3(1), dim3(64), 0, stream, epoch);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int zk_gemm_add_ln(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias,
+                   const void* residual, int ldr, float drop_p, const uint64_t* seed, uint32_t sid, const float* gamma,
+                   const float* beta, float eps, void* s_out, void* y, float* mean, float* rstd, void* slots,
+                   size_t slots_bytes, const uint32_t* epoch, uint32_t site, int* err, hipStream_t stream) {
+  ZK_CHECK_ARG(M >= 0 && N >= 64 && K >= 1, "zk_gemm_add_ln: bad dims");
+  ZK_CHECK_ARG(N % 64 == 0 && N / 64 <= 16, "zk_gemm_add_ln: N=%d must be a multiple of 64 and <= 1024", N);
+  ZK_CHECK_ARG(residual != nullptr && ldr % 8 == 0 && gamma != nullptr && beta != nullptr && y != nullptr,
+               "zk_gemm_add_ln: residual (row stride a multiple of 8), gamma, beta and y are required");
+  ZK_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "zk_gemm_add_ln: mean / rstd must both be given");
+  ZK_CHECK_ARG(drop_p == 0.f || seed != nullptr, "zk_gemm_add_ln: dropout needs a seed pointer");
+  ZK_CHECK_ARG(slots != nullptr && epoch != nullptr && site >= 1 && site <= 255, "zk_gemm_add_ln: slots, epoch and a site in 1..255 are required");
+  ZK_CHECK_ARG(slots_bytes >= zk_gemm_add_ln_workspace(M, N), "zk_gemm_add_ln: slots too small (zk_gemm_add_ln_workspace)");
+  const uintptr_t al = (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)s_out |
+                       (uintptr_t)y | (uintptr_t)slots;
+  ZK_CHECK_ARG((al & 15) == 0, "zk_gemm_add_ln: operands must be 16-byte aligned");
+  ZK_CHECK_ARG(mfma_ok(A, B, M, N, K, lda, ldb, 0, 0), "zk_gemm_add_ln: shape/alignment not supported by the MFMA kernel "
+               "(M=%d N=%d K=%d lda=%d ldb=%d)", M, N, K, lda, ldb);
+  ZK_CHECK_ARG(!zk_prog_active(), "zk_gemm_add_ln cannot be part of a layer program");
+  if (M == 0) return 0;
+  GemmEpi e;
+  e.C = s_out; e.ldc = N; e.out_f32 = 0; e.alpha = 1.f; e.bias = bias;
+  e.res = (const bf16_t*)residual; e.ldr = ldr; e.act = 0; e.aux = nullptr; e.ldaux = 0; e.aux_scale = 1.f;
+  e.thr = drop_p > 0.f ? zk_drop_threshold(drop_p) : 0;
+  e.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  e.seed = seed; e.sid = sid;
+  e.ln_eps = eps; e.ln_invh = 1.f / (float)N;
+  e.sy_slots = (unsigned long long*)slots; e.sy_epoch = epoch; e.sy_site = site;
+  e.sy_gamma = gamma; e.sy_beta = beta; e.sy_y = (bf16_t*)y; e.sy_ldy = N;
+  e.sy_mean = mean; e.sy_rstd = rstd; e.sy_err = err;
+  int bm, bn, splits;
+  pick_config(M, N, K, 0, &bm, &bn, &splits);
+  (void)splits; (void)bn;          // never split, always 64 columns: the epilogue needs the whole sum of a 64-column group
+  return zk_gemm_dlds_sync_ln_dispatch((const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, bm >= 128 ? 128 : 64, e, stream);
+}
 
 // Split-K product left as its partial sums: parts[z] (fp32 [M, N] each, z < splits, part z at parts + z*M*N) =
 // A[:, K_z] B[K_z, :] over the z-th K range; no epilogue and no reduction launch -- the consumer adds them in the

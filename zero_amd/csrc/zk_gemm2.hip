@@ -997,6 +997,38 @@ int zk_gemm_dlds_ln_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int
 
 #endif  // ZK_EXPERIMENTS
 
+// residual + LayerNorm inside the producing launch (zk_gemm_add_ln; A [M,K] x B [K,N], no split-K): the two tiles the
+// default dispatch gives the sub-layer output products (64x64 with four producer waves; 128x64 for the long K of the
+// feed-forward output) with the LN = 3 epilogue.  Tile order: row-block major, so that the N/64 workgroups that wait for
+// each other are consecutive in the dispatch order (and, with the XCD remap, on one XCD whenever the grid is a multiple
+// of 64): a workgroup only ever waits for workgroups that are already resident or next in line.
+template <int BM, int NS, int PW>
+static int launch_dlds_sync_ln(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, const GemmEpi& e,
+                               hipStream_t stream) {
+  TileSched ts;
+  ts.tiles_m = (M + BM - 1) / BM;
+  ts.tiles_n = N / 64;
+  ts.n_major = 0;
+  ts.xcd_remap = 1;
+  EpiVec ev;
+  ev.vec_ok = 1;
+  const long nwg = (long)ts.tiles_m * ts.tiles_n;
+  dim3 grid((unsigned)nwg);
+  GemmEpi el = e;
+  // every XCD owns a contiguous range of nwg / 8 tiles: with that a multiple of the group size no group straddles two
+  // XCDs and the exchange stays in their L2 (tuning key 15 = 1: never assume it -- exchange through memory)
+  el.sy_local = (nwg % (8 * ts.tiles_n) == 0 && g_tune[15] == 0) ? 1 : 0;
+  hipLaunchKernelGGL((k_gemm_dlds<BM, 64, NS, false, false, 4, PW, 3>), grid, dim3((4 + PW) * 64), 0, stream, A, B, M, N, K,
+                     lda, ldb, K, (float*)nullptr, ts, el, ev);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+int zk_gemm_dlds_sync_ln_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int bm,
+                                  const GemmEpi& e, hipStream_t stream) {
+  if (bm == 128) return launch_dlds_sync_ln<128, 2, 0>(A, B, M, N, K, lda, ldb, e, stream);
+  return launch_dlds_sync_ln<64, 4, 4>(A, B, M, N, K, lda, ldb, e, stream);
+}
+
 // entry used by zk_gemm (zk_gemm.hip)
 int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
                           int bm, int bn, int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags,

@@ -350,7 +350,8 @@ __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16
 // kernels pay nothing for them).  The row statistics (mu, rstd) of the tile's BM rows -- combined from the per-64-column
 // partials -- are computed once, by the first BM threads, behind the ring fill, and wait in 2 x BM float2 of LDS.
 template <int BM, int BN, int NS, bool TA, bool TB, int NW = 4, int PW = 0, bool KSEG = false, bool FRESH = false,
-          int LN = 0>      // LN: 0 none, 1 consumer form (ln_c), 2 producer forms (ln_stat_out, res_part, res_after_drop)
+          int LN = 0>      // LN: 0 none, 1 consumer form (ln_c), 2 producer forms (ln_stat_out, res_part, res_after_drop),
+                           //     3 residual + LayerNorm in the launch (sy_*: the row's tiles exchange their statistics)
 __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __restrict__ A,
                                           const bf16_t* __restrict__ B, int M, int N, int lda, int ldb, int kbeg,
                                           int kend, int m0, int n0, float* __restrict__ slab, const GemmEpi& e,
@@ -366,7 +367,8 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
   static_assert(NT % CPRW == 0, "a thread's chunks must share their columns");
   constexpr int CH = BM * CPRW, ITER = (CH + NT - 1) / NT;
   constexpr int RSTEP = NT / CPRW;
-  const bool fast = slab == nullptr && vec_ok && m0 + BM <= M && n0 + BN <= N;
+  // (LN = 3: zk_gemm_add_ln has checked the 16-byte path and N % 64 == 0; rows past M are clamped for the loads)
+  const bool fast = LN >= 3 ? true : (slab == nullptr && vec_ok && m0 + BM <= M && n0 + BN <= N);
   const int cc = (tid % CPRW) * 8, gn = n0 + cc, row0 = tid / CPRW;
   // The epilogue's inputs (residual, ReLU mask, bias, dropout seed) do not depend on the product: on the small tiles,
   // where a launch is a chain of a few memory round trips, they are requested BEFORE the K loop instead of after it
@@ -375,6 +377,7 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
   uint4 rres[ITER], raux[ITER];
   float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   [[maybe_unused]] float lcv[8], lgv[8], lbv[8];            // LN: this thread's 8 columns of ln_c / res_gamma / res_beta
+  [[maybe_unused]] uint32_t sy_ep = 0;
   uint64_t seed = 0;
   auto ld8 = [&](const float* p, float* o) {
     const float4 a = *reinterpret_cast<const float4*>(p);
@@ -384,10 +387,23 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
   auto load_epi = [&]() {
     if constexpr (LN == 1) { if (e.ln_c) ld8(e.ln_c + gn, lcv); }
     if constexpr (LN == 2) { if (e.res_part) { ld8(e.res_gamma + gn, lgv); ld8(e.res_beta + gn, lbv); } }
+    if constexpr (LN == 3) { ld8(e.sy_gamma + gn, lgv); ld8(e.sy_beta + gn, lbv); sy_ep = *e.sy_epoch; }
+    if constexpr (LN == 4) {
+      ld8(e.sy_gamma + gn, lgv);
+      sy_ep = *e.sy_epoch;
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int gm = min(m0 + min(row0 + it * RSTEP, BM - 1), M - 1);
+        raux[it] = zk_ld16<FRESH>(e.sy_s + (size_t)gm * e.sy_lds + gn);
+        lbv[2 * it] = e.sy_mean_in[gm];
+        lbv[2 * it + 1] = e.sy_rstd_in[gm];
+      }
+    }
     if (e.res) {
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
-        const int gm = m0 + min(row0 + it * RSTEP, BM - 1);
+        int gm = m0 + min(row0 + it * RSTEP, BM - 1);
+        if constexpr (LN >= 3) gm = min(gm, M - 1);
         rres[it] = zk_ld16<FRESH>(e.res + (size_t)gm * e.ldr + gn);
       }
     }
@@ -425,6 +441,274 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
   }
   const float* sC = reinterpret_cast<const float*>(smem);
   if (!(PRE && !FRESH)) seed = e.thr ? *e.seed : 0;
+  if constexpr (LN >= 3) {
+    // residual + LayerNorm inside this launch (GemmEpi.sy_*): s = res + dropout(bf16(acc + bias)) exactly as the two
+    // launches form it (the product rounded to bf16 where it used to be stored, the same dropout index), the statistics
+    // of the STORED sum as {sum, M2} of this tile's 64 columns, published; then every thread fetches one peer's partial
+    // of its row (its own tile's comes back the same way), the eight lanes of a row combine them (Chan), and the row's 64
+    // columns are normalised from the registers they are still in.
+    static_assert(BN == 64 && CH % NT == 0, "the in-launch LayerNorm is instantiated for 64-column tiles");
+    if (!(PRE && !FRESH)) load_epi();
+    const int np = N >> 6, tn = n0 >> 6, j8 = tid & 7;
+    const uint32_t tag = (sy_ep << 8) | e.sy_site;
+    // sy_local (the row block's workgroups share an XCD: grid a multiple of 64 under the XCD remap): their L2 is the point
+    // of coherence -- ordinary stores (the L1 writes through), and polls by an atomic OR of zero, which executes in the L2
+    // whatever the L1 holds.  [Group-scope (sc0) loads may hit the CU's own L1, which still holds the line an earlier
+    // poll fetched: every launch ran into the spin budget.  Ordinary loads behind an L1 invalidation (buffer_inv sc1) are
+    // correct but the invalidations cost the CU's other workgroup its K loop: 61.6 us a launch.]  Otherwise agent-scope
+    // (sc1) stores and loads: through memory.
+    const bool local = e.sy_local != 0;
+    auto slot_st = [&](unsigned long long* p, unsigned long long v) {
+      if (local) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // one slot of a peer, valid once both halves carry this launch's tag.  plain_first (local): the line has not been
+    // touched by this CU in this launch, an ordinary load misses the L1 and is served by the L2
+    auto slot_wait = [&](unsigned long long* p, unsigned long long& a, unsigned long long& b, bool plain_first) {
+      int spins = 0;
+      if (local && plain_first) {
+        a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if ((uint32_t)(a >> 32) == tag && (uint32_t)(b >> 32) == tag) return;
+      }
+      for (;;) {
+        if (local) {
+          // (written out: the compiler turns an atomic OR of zero into a group-scope LOAD, which may hit the L1)
+          const unsigned long long z = 0;
+          asm volatile("global_atomic_or_x2 %0, %2, %3, off sc0\n\tglobal_atomic_or_x2 %1, %2, %3, off offset:8 sc0\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(a), "=&v"(b) : "v"(p), "v"(z) : "memory");
+        } else {
+          a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if ((uint32_t)(a >> 32) == tag && (uint32_t)(b >> 32) == tag) return;
+        if (++spins > (1 << 15)) {             // tens of milliseconds: a peer that never came (must not happen)
+          if (e.sy_err != nullptr) __hip_atomic_store(e.sy_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    };
+    if constexpr (LN == 3) {
+    float r8[ITER][8], own1[ITER], own2[ITER];
+    uint4 pk[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int row = row0 + it * RSTEP, gm = m0 + row;
+      const bool ok = gm < M;
+      float v[8];
+      {
+        const float4 a = *reinterpret_cast<const float4*>(sC + row * CLD + cc);
+        const float4 b = *reinterpret_cast<const float4*>(sC + row * CLD + cc + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v[j] * e.alpha + bv[j];
+      unpack8(pack8(v), v);
+      if (e.thr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= zk_drop_scale(seed, e.sid, (uint64_t)gm * N + gn + j, e.thr, e.inv_keep);
+      }
+      if (e.res) {
+        float rv[8];
+        unpack8(rres[it], rv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = rv[j] + v[j];
+      }
+      pk[it] = pack8(v);
+      unpack8(pk[it], r8[it]);
+      float s1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s1 += r8[it][j];
+      s1 = zk_sum8(s1);
+      const float mt = s1 * (1.f / 64.f);
+      float s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = r8[it][j] - mt; s2 += d * d; }
+      s2 = zk_sum8(s2);
+      own1[it] = s1; own2[it] = s2;
+      if (ok && j8 == 0) {       // published first: the peers are waiting for this, nobody for the sum below
+        unsigned long long* p = e.sy_slots + ((size_t)gm * np + tn) * 2;
+        slot_st(p, ((unsigned long long)tag << 32) | __float_as_uint(s1));
+        slot_st(p + 1, ((unsigned long long)tag << 32) | __float_as_uint(s2));
+      }
+    }
+    if (e.C != nullptr) {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int gm = m0 + row0 + it * RSTEP;
+        if (gm < M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)gm * e.ldc + gn) = pk[it];
+      }
+    }
+    // a few lanes watch ONE row's slots (the block's last row, one lane per peer) until every peer has published; only
+    // then does every thread fetch its own slots.  [All threads polling from the start: 30.7 us a launch against
+    // 13.9 + 7.0 for the two launches; a few lanes of every wave: 23.4 us; this: 20.0 us through memory.]
+    {
+      const int grep = min(m0 + BM, M) - 1;
+      if (tid < np && tid != tn) {
+        unsigned long long a, b;
+        slot_wait(e.sy_slots + ((size_t)grep * np + tid) * 2, a, b, false);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int row = row0 + it * RSTEP, gm = m0 + row;
+      const bool ok = gm < M;
+      float ps[2] = {0.f, 0.f}, pm[2] = {0.f, 0.f};
+      bool have[2] = {false, false};
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = j8 + 8 * u;
+        if (ok && q < np) {
+          if (q == tn) { ps[u] = own1[it]; pm[u] = own2[it]; }        // this tile's own partial never leaves the registers
+          else {
+            unsigned long long a, b;
+            slot_wait(e.sy_slots + ((size_t)gm * np + q) * 2, a, b, true);   // (a peer's other rows land within its store burst)
+            ps[u] = __uint_as_float((uint32_t)a);
+            pm[u] = __uint_as_float((uint32_t)b);
+          }
+          have[u] = true;
+        }
+      }
+      const float mu = zk_sum8(ps[0] + ps[1]) * e.ln_invh;
+      const float d0 = ps[0] * (1.f / 64.f) - mu, d1 = ps[1] * (1.f / 64.f) - mu;
+      const float m2 = zk_sum8((have[0] ? pm[0] + 64.f * d0 * d0 : 0.f) + (have[1] ? pm[1] + 64.f * d1 * d1 : 0.f));
+      const float rs = rsqrtf(m2 * e.ln_invh + e.ln_eps);
+      if (ok) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = lgv[j] * (r8[it][j] - mu) * rs + lbv[j];
+        *reinterpret_cast<uint4*>(e.sy_y + (size_t)gm * e.sy_ldy + gn) = pack8(o);
+        if (tn == 0 && j8 == 0 && e.sy_mean != nullptr) { e.sy_mean[gm] = mu; e.sy_rstd[gm] = rs; }
+      }
+    }
+    }
+    if constexpr (LN == 4) {
+      // backward of the residual + LayerNorm whose input gradient this product completes (GemmEpi.sy_s ..): see zk_gemm.h
+      static_assert(ITER <= 4, "lbv holds (mu, rstd) of at most four rows");
+      float* red = reinterpret_cast<float*>(smem);         // [3][BM][64] column-partial staging (the fp32 tile is consumed first)
+      float d[ITER][8], xh[ITER][8], g[ITER][8], own1[ITER], own2[ITER];
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int row = row0 + it * RSTEP, gm = m0 + row;
+        const bool ok = gm < M;
+        float v[8];
+        {
+          const float4 a = *reinterpret_cast<const float4*>(sC + row * CLD + cc);
+          const float4 b = *reinterpret_cast<const float4*>(sC + row * CLD + cc + 4);
+          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= e.alpha;
+        if (e.res) {
+          float rv[8];
+          unpack8(rres[it], rv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += rv[j];
+        }
+        unpack8(pack8(v), d[it]);                           // the gradient as the dgrad launch used to store it
+        float sv[8];
+        unpack8(raux[it], sv);
+        const float mu = lbv[2 * it], rs = lbv[2 * it + 1];
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (!ok) d[it][j] = 0.f;
+          xh[it][j] = (sv[j] - mu) * rs;
+          g[it][j] = d[it][j] * lgv[j];
+          sg += g[it][j];
+          sgx += g[it][j] * xh[it][j];
+        }
+        sg = zk_sum8(sg);
+        sgx = zk_sum8(sgx);
+        own1[it] = sg; own2[it] = sgx;
+        if (ok && j8 == 0) {
+          unsigned long long* p = e.sy_slots + ((size_t)gm * np + tn) * 2;
+          slot_st(p, ((unsigned long long)tag << 32) | __float_as_uint(sg));
+          slot_st(p + 1, ((unsigned long long)tag << 32) | __float_as_uint(sgx));
+        }
+      }
+      // the two column sums that need nothing from the peers, while they arrive
+      __syncthreads();                                      // every thread has taken its part of the fp32 tile
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int row = row0 + it * RSTEP;
+        float* r0 = red + row * 64 + cc;
+        float* r1 = red + (BM + row) * 64 + cc;
+        *reinterpret_cast<float4*>(r0) = make_float4(d[it][0] * xh[it][0], d[it][1] * xh[it][1], d[it][2] * xh[it][2], d[it][3] * xh[it][3]);
+        *reinterpret_cast<float4*>(r0 + 4) = make_float4(d[it][4] * xh[it][4], d[it][5] * xh[it][5], d[it][6] * xh[it][6], d[it][7] * xh[it][7]);
+        *reinterpret_cast<float4*>(r1) = make_float4(d[it][0], d[it][1], d[it][2], d[it][3]);
+        *reinterpret_cast<float4*>(r1 + 4) = make_float4(d[it][4], d[it][5], d[it][6], d[it][7]);
+      }
+      __syncthreads();
+      if (tid < 128) {
+        const int q = tid >> 6, col = tid & 63;
+        float t = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < BM; ++r) t += red[(q * BM + r) * 64 + col];
+        e.sy_part[((size_t)(m0 / BM) * 3 + q) * N + n0 + col] = t;
+      }
+      {
+        const int grep = min(m0 + BM, M) - 1;
+        if (tid < np && tid != tn) {
+          unsigned long long a, b;
+          slot_wait(e.sy_slots + ((size_t)grep * np + tid) * 2, a, b, false);
+        }
+        __syncthreads();
+      }
+      float* red2 = red + 2 * BM * 64;
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int row = row0 + it * RSTEP, gm = m0 + row;
+        const bool ok = gm < M;
+        float ps[2] = {0.f, 0.f}, pm[2] = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int q = j8 + 8 * u;
+          if (ok && q < np) {
+            if (q == tn) { ps[u] = own1[it]; pm[u] = own2[it]; }
+            else {
+              unsigned long long a, b;
+              slot_wait(e.sy_slots + ((size_t)gm * np + q) * 2, a, b, true);
+              ps[u] = __uint_as_float((uint32_t)a);
+              pm[u] = __uint_as_float((uint32_t)b);
+            }
+          }
+        }
+        const float mg = zk_sum8(ps[0] + ps[1]) * e.ln_invh;
+        const float mgx = zk_sum8(pm[0] + pm[1]) * e.ln_invh;
+        const float rs = lbv[2 * it + 1];
+        float o[8], oy[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rs * (g[it][j] - mg - xh[it][j] * mgx);
+        const uint4 po = pack8(o);
+        if (ok) *reinterpret_cast<uint4*>(e.sy_y + (size_t)gm * e.sy_ldy + gn) = po;
+        unpack8(po, o);                                     // dy derives from the stored (rounded) ds
+        if (e.thr) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) oy[j] = o[j] * zk_drop_scale(seed, e.sid, (uint64_t)gm * N + gn + j, e.thr, e.inv_keep);
+          const uint4 py = pack8(oy);
+          if (ok && e.sy_dy != nullptr) *reinterpret_cast<uint4*>(e.sy_dy + (size_t)gm * e.sy_ldy + gn) = py;
+          unpack8(py, oy);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) oy[j] = o[j];
+        }
+        float* r2 = red2 + row * 64 + cc;
+        *reinterpret_cast<float4*>(r2) = ok ? make_float4(oy[0], oy[1], oy[2], oy[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(r2 + 4) = ok ? make_float4(oy[4], oy[5], oy[6], oy[7]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      __syncthreads();
+      if (tid < 64) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < BM; ++r) t += red2[r * 64 + tid];
+        e.sy_part[((size_t)(m0 / BM) * 3 + 2) * N + n0 + tid] = t;
+      }
+    }
+    return;
+  }
   if (fast) {
     float v[ITER][8];
 #pragma unroll

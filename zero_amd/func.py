@@ -220,6 +220,51 @@ class Engine(object):
             self.gemm_impl if impl is None else impl, ws.data_ptr(), ws.numel(), self.stream)
 
     # ---- residual + LayerNorm folded into GEMM epilogues (zk_gemm_ln / zk_ln_fold / zk_add_ln_bwd_lazy) ----------------
+    # ---- residual + LayerNorm inside the producing GEMM launch (zk_gemm_add_ln)
+    def sync_ln_state(self, rows, N):
+        """(slots, meta) of the in-launch LayerNorm: the exchange slots of the row blocks' workgroups (zero-filled once,
+        shared by all calls of this engine: they run one after the other on its stream) and meta = int32 [4]: the epoch
+        word (ln_epoch_bump), the error word."""
+        need = self.lib.query("zk_gemm_add_ln_workspace", int(rows), int(N))
+        st = self.__dict__.get("_sync_ln")
+        if st is None or st[0].numel() < need:
+            if st is not None:
+                self.realloc_gen += 1          # captured graphs point at the old slots (see buf())
+            slots = torch.empty(max(int(need), 1 << 20), dtype=torch.uint8, device=self.device)
+            self.zero(slots)
+            meta = st[1] if st is not None else torch.empty(4, dtype=torch.int32, device=self.device)
+            if st is None:
+                self.zero(meta)
+            st = self._sync_ln = (slots, meta)
+        return st
+
+    def ln_epoch_bump(self):
+        """Once per forward pass (and whenever the sites of a pass run out): later zk_gemm_add_ln launches never take a
+        slot written before this for one of theirs."""
+        _, meta = self.sync_ln_state(1, 64)
+        self.lib.call("zk_ln_epoch_bump", meta.data_ptr(), self.stream)
+        self._sync_site = 0
+
+    def gemm_add_ln(self, A, B, M, N, K, bias, residual, gamma, beta, y, s_out=None, mean=None, rstd=None, drop_p=0.0,
+                    sid=0):
+        """y = LN(residual + dropout(A @ B + bias)) in one launch; s_out / mean / rstd: what add_ln_bwd reads."""
+        if self.__dict__.get("_sync_site", 255) >= 255:
+            self.ln_epoch_bump()
+        self._sync_site += 1
+        slots, meta = self.sync_ln_state(M, N)
+        self.lib.call("zk_gemm_add_ln", A.ptr, B.ptr, M, N, K, A.ld, B.ld, hip.ptr(bias), residual.ptr, residual.ld,
+                      float(drop_p), self.seed.data_ptr(), sid, gamma.data_ptr(), beta.data_ptr(), zdtype.epsilon(),
+                      s_out.ptr if s_out is not None else None, y.ptr, hip.ptr(mean), hip.ptr(rstd), slots.data_ptr(),
+                      slots.numel(), meta.data_ptr(), self._sync_site, meta.data_ptr() + 4, self.stream)
+
+    def sync_ln_errors(self):
+        """1 if a workgroup of some zk_gemm_add_ln launch ever gave up waiting for its peers (synchronises)."""
+        st = self.__dict__.get("_sync_ln")
+        if st is None:
+            return 0
+        torch.cuda.synchronize()
+        return int(st[1][1].item())
+
     def gemm_ln(self, A, B, C, M, N, K, bias, np_, residual=None, act=0, drop_p=0.0, sid=0, stat_out=None, in_part=None,
                 in_c=None, res_part=None, res_gamma=None, res_beta=None):
         """zk_gemm_ln: producer (stat_out) / lazy residual (res_part, res_gamma, res_beta) / consumer (in_part, in_c)."""

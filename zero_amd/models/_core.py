@@ -139,6 +139,8 @@ class TransformerCore(object):
         # +2 us each, the LayerNorm backward +5..7 us for the normalised rows it now writes, the fold launch 42 us.  So it
         # is an experiment: only in a `make EXPERIMENTS=1` library, only with ZERO_HIP_LAZY_LN=1.
         self.lazy_ln_mode = os.environ.get("ZERO_HIP_LAZY_LN", "0").lower() if self.eng.lib.experiments else "0"
+        self.sync_ln_mode = os.environ.get("ZERO_HIP_SYNC_LN", "1") != "0"
+        self._sync_ln = False
         # The update of the weight matrices inside the weight-gradient launch (round 4; zk_gemm_grouped_update): set by the
         # Trainer for a step whose update is norm-free, single-rank and unaccumulated; the backward's one grouped launch
         # then runs TF1 Adam on its accumulators for every weight it can (see _flush_wgrads) and `fused_info` tells the
@@ -336,6 +338,16 @@ class TransformerCore(object):
         e, H = self.eng, self.H
         T = a.rows
         if not self._lazy:
+            if self._sync_ln and not e.lib.recording:
+                # one launch: the workgroups of a block of rows exchange their LayerNorm partials (zk_gemm_add_ln)
+                Wm = self.W(lin + "/W_0_0")
+                out = e.mat(tag + ".o", T, H)
+                s = e.mat(tag + ".s", T, H) if save else None
+                mean = e.buf(tag + ".mean", (T,), F32) if save else None
+                rstd = e.buf(tag + ".rstd", (T,), F32) if save else None
+                e.gemm_add_ln(a, Wm, T, H, Wm.rows, self.b(lin + "/b_0"), x, self.b(scope + "/layer_norm/scale"),
+                              self.b(scope + "/layer_norm/offset"), out, s, mean, rstd, drop_p, sid)
+                return out
             y = e.mat("tmp.y%d" % T, T, H)
             self._linear(a, lin, y)
             return self._ln_fwd(x, y, scope, tag, save, drop_p, sid)
@@ -788,12 +800,18 @@ class TransformerCore(object):
         ls = self.hp.label_smooth if label_smooth is None else label_smooth
         self._lazy = self._use_lazy_ln(train, save)
         self._lazy_tags = {}
+        # residual + LayerNorm inside the sub-layer output GEMMs (ZERO_HIP_SYNC_LN=0: a launch of their own)
+        self._sync_ln = self.sync_ln_mode and not self._lazy and self.eng.gemm_impl == 0 and self.H % 64 == 0 and \
+            self.H <= 1024 and self.F % 64 == 0
+        if self._sync_ln:
+            self.eng.ln_epoch_bump()
         if self._lazy:
             self._fold_weights()
         enc, smask = self.encode(batch, train, save)
         feat, tmask, w = self.decode_train(batch, enc, smask, train, save)
         loss, per_sample, logits, dlogits = self.loss_head(batch, feat, w, ls, save)
         self._lazy = False        # (encode() / decode_train() are also called directly by the decode path)
+        self._sync_ln = False
         self._ctx = (batch, enc, smask, feat, tmask, dlogits)
         return loss, per_sample, logits
 
