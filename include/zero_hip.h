@@ -65,6 +65,16 @@ int zk_gemm_add_ln(const void* A, const void* B, int M, int N, int K, int lda, i
                    const void* residual, int ldr, float drop_p, const uint64_t* seed, uint32_t sid, const float* gamma,
                    const float* beta, float eps, void* s_out, void* y, float* mean, float* rstd, void* slots,
                    size_t slots_bytes, const uint32_t* epoch, uint32_t site, int* err, zk_stream_t stream);
+/* The backward of that tail inside the dgrad launch that completes its input gradient: dout = bf16(dY W^T + residual) is
+ * never stored; dsum = d(loss)/d(s) (bf16 [M, N]), dy_out = dsum x the dropout mask of (seed, sid) (null without dropout),
+ * partials (zk_gemm_ln_bwd_partials bytes: [ceil(M/64)][3][N]) = the per-row-block column sums {dout xhat, dout, dy} that
+ * zk_add_ln_bwd_reduce / zk_reduce_grouped finish with nblk = ceil(M/64).  dY [M, lda], W [N, ldb] (both K contiguous).
+ * Replaces zk_gemm(tb = 1, residual) + zk_add_ln_bwd(defer_reduce = 1); slots / epoch / site / err as for zk_gemm_add_ln. */
+size_t zk_gemm_ln_bwd_partials(int rows, int N);
+int zk_gemm_ln_bwd(const void* dY, const void* W, int M, int N, int K, int lda, int ldb, const void* residual, int ldr,
+                   const void* s, const float* mean, const float* rstd, const float* gamma, float drop_p,
+                   const uint64_t* seed, uint32_t sid, void* dsum, void* dy_out, float* partials, void* slots,
+                   size_t slots_bytes, const uint32_t* epoch, uint32_t site, int* err, zk_stream_t stream);
 int zk_gemm_plan(int M, int N, int K, int out_f32, int plain);  /* gen | (bm/8)<<8 | (bn/8)<<16 | splits<<24 | producer waves<<28 chosen by impl=0 */
 int zk_gemm_set_generation(int gen);   /* 1 = register-staged kernel, 2 = LDS-DMA ring kernel (default) */
 /* K-segmented GEMM: C bf16 [M, ldc] = sum_s A_s [M, kseg] x B_s (+ bf16 residual, may alias C) in ONE launch --

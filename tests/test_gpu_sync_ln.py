@@ -74,6 +74,53 @@ def test_one_launch_against_gemm_then_layernorm(M, N, K, drop):
     assert torch.equal(lean[0], got[0])
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 2048), (4096, 512, 512), (4096, 512, 1536), (66, 512, 512), (700, 512, 1536),
+                                   (1000, 1024, 1024), (257, 128, 512), (5, 512, 512)])
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+def test_backward_inside_the_dgrad_launch(M, N, K, drop):
+    """zk_gemm_ln_bwd against the two launches it replaces (zk_gemm with tb = 1 and a residual, zk_add_ln_bwd): ds and dy
+    to the last bf16 bit of the two row means (eight partial sums combined instead of one wave-wide sum), the three column
+    sums after their reduction to fp32 summation-order differences."""
+    e = eng()
+    e.set_seed(9)
+    dY, W = rand_bf(M, K, seed=1, scale=0.5), rand_bf(N, K, seed=2, scale=0.05)
+    R, S = rand_bf(M, N, seed=3, scale=0.3), rand_bf(M, N, seed=4)
+    g = torch.Generator().manual_seed(4)
+    gam = (1.0 + 0.2 * torch.randn(N, generator=g)).cuda()
+    mean = S.float().mean(1).contiguous()
+    rstd = (1.0 / torch.sqrt(S.float().var(1, unbiased=False) + 1e-8)).contiguous()
+    # reference: two launches + the reduction
+    dx = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    e.gemm(mat(dY), mat(W), mat(dx), M, N, K, 0, 1, residual=mat(R))
+    ds0, dy0 = torch.empty_like(dx), torch.empty_like(dx)
+    out0 = [torch.zeros(N, device="cuda") for _ in range(3)]
+    e.add_ln_bwd(mat(dx), mat(S), mean, rstd, gam, mat(ds0), mat(dy0) if drop else None, out0[0], out0[1], out0[2], drop, 17)
+    # one launch + the grouped reduction over its 64-row partials
+    ds1 = torch.full_like(dx, 7.0)
+    dy1 = torch.full_like(dx, 7.0)
+    nfl = e.lib.query("zk_gemm_ln_bwd_partials", M, N) // 4
+    part = torch.full((nfl,), 1e9, device="cuda")
+    out1 = [torch.zeros(N, device="cuda") for _ in range(3)]
+    e.ln_epoch_bump()
+    e.gemm_ln_bwd(mat(dY), mat(W), M, N, K, mat(R), mat(S), mean, rstd, gam, mat(ds1), mat(dy1) if drop else None, part, drop, 17)
+    e.reductions_grouped([], [(part, M, N, out1[0], out1[1], out1[2], True)])
+    torch.cuda.synchronize()
+    assert e.sync_ln_errors() == 0
+    assert rel_err(ds1, ds0) < 3e-3 and _ulp_close_abs(ds1, ds0)
+    if drop:
+        assert rel_err(dy1, dy0) < 3e-3
+        assert torch.equal(dy1 == 0, dy0 == 0) or float(((dy1 == 0) != (dy0 == 0)).float().mean()) < 1e-3   # the same mask
+    for a, b in zip(out1, out0):
+        assert rel_err(a, b) < 2e-3, rel_err(a, b)
+
+
+def _ulp_close_abs(a, b):
+    """ds is a difference of nearly equal terms: compare against the row scale instead of the element"""
+    a, b = a.float(), b.float()
+    scale = b.abs().amax(dim=1, keepdim=True) + 1e-12
+    return bool(((a - b).abs() <= scale * 2.0 ** -6).all())
+
+
 def test_repeated_launches_reuse_the_slots():
     """Several hundred launches back to back on the same slots, different inputs and sites, the epoch advancing every 30
     launches as it does in a training step (30 sub-layers): every one of them must see this launch's partials, never an
@@ -105,7 +152,7 @@ def test_repeated_launches_reuse_the_slots():
 
 @pytest.mark.parametrize("model", ["transformer", "transformer_rpr"])
 def test_training_steps_with_the_layernorm_inside_the_launch(model, monkeypatch):
-    """Trainer with ZERO_HIP_SYNC_LN on / off: the same losses and weights after five steps up to the last-bit difference
+    """Trainer with ZERO_HIP_SYNC_LN = 1 (forward and backward) / fwd / 0: the same losses and weights after five steps up to the last-bit difference
     of the statistics; captured replay == eager bit for bit with it on (the epoch word lives on the device)."""
     from tests.common import make_hp, make_batch, perturb
     from oracle import ref_torch as rt
@@ -117,12 +164,12 @@ def test_training_steps_with_the_layernorm_inside_the_launch(model, monkeypatch)
     src, tgt = make_batch(rng, 6, 11, 13, hp.src_vocab.size(), hp.tgt_vocab.size())
     Pn = perturb(rt.init_params(hp, model, seed=8), rng)
     out = {}
-    for sync in ("1", "0"):
+    for sync in ("1", "fwd", "0"):
         monkeypatch.setenv("ZERO_HIP_SYNC_LN", sync)
         for use_graph in (False, True):
             reset_cores(); reset_stores()
             tr = Trainer(hp, initializer=Pn)
-            assert tr.core.sync_ln_mode == (sync == "1")
+            assert tr.core.sync_ln_mode == (sync != "0") and tr.core.sync_ln_bwd == (sync != "fwd")
             tr.prepare_static({"source": src, "target": tgt})
             tr.core.eng.set_seed(11)
             losses = [float(tr.step_static(use_graph).cpu()[0]) for _ in range(5)]
@@ -131,6 +178,8 @@ def test_training_steps_with_the_layernorm_inside_the_launch(model, monkeypatch)
             out[(sync, use_graph)] = (losses, tr.store.master.cpu().numpy().copy())
     a, b = out[("1", False)], out[("1", True)]
     assert a[0] == b[0] and np.array_equal(a[1], b[1])
-    on, off = out[("1", True)], out[("0", True)]
-    assert np.allclose(on[0], off[0], rtol=2e-3, atol=0), (on[0], off[0])
-    assert np.linalg.norm(on[1] - off[1]) <= 2e-3 * np.linalg.norm(off[1])
+    off = out[("0", True)]
+    for mode in ("1", "fwd"):
+        on = out[(mode, True)]
+        assert np.allclose(on[0], off[0], rtol=2e-3, atol=0), (mode, on[0], off[0])
+        assert np.linalg.norm(on[1] - off[1]) <= 2e-3 * np.linalg.norm(off[1])

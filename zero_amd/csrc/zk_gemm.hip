@@ -296,6 +296,8 @@ int zk_gemm_dlds_ln_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int
                              const GemmEpi& e, hipStream_t stream);
 int zk_gemm_dlds_sync_ln_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int bm,
                                   const GemmEpi& e, hipStream_t stream);
+int zk_gemm_dlds_sync_ln_bwd_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb,
+                                      const GemmEpi& e, hipStream_t stream);
 int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
                           int bm, int bn, int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags,
                           hipStream_t stream);
@@ -516,6 +518,50 @@ int zk_gemm_add_ln(const void* A, const void* B, int M, int N, int K, int lda, i
   pick_config(M, N, K, 0, &bm, &bn, &splits);
   (void)splits; (void)bn;          // never split, always 64 columns: the epilogue needs the whole sum of a 64-column group
   return zk_gemm_dlds_sync_ln_dispatch((const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, bm >= 128 ? 128 : 64, e, stream);
+}
+
+// The backward of that tail inside the dgrad launch that completes its input gradient (autodiff of transformer.py:57-58
+// through func.py:289-303 / 321-324):   dout = bf16(dY W^T + residual)   [never stored]
+//   g = dout gamma, xh = (s - mean) rstd, ds = rstd (g - mean_row(g) - xh mean_row(g xh)) -> dsum (bf16)
+//   dy = bf16(ds) x dropout mask of (seed, sid) -> dy_out (null: no dropout, dy == ds)
+//   partials [ceil(M/64)][3][N] = column sums over each 64-row block of {dout xh, dout, dy}: the dgamma / dbeta /
+//   previous-bias partials zk_add_ln_bwd leaves for its reduction (nblk = ceil(M/64) here).
+// dY [M, lda] (K contiguous), W [N, ldb] (K contiguous: the forward weight of a layer with N inputs).  Replaces zk_gemm
+// (tb = 1, residual) followed by zk_add_ln_bwd(defer_reduce = 1); the exchange of the two row means between the N/64
+// workgroups of a row block uses the slots / epoch / site scheme of zk_gemm_add_ln.
+size_t zk_gemm_ln_bwd_partials(int rows, int N) { return (size_t)((rows + 63) / 64) * 3 * (size_t)N * sizeof(float); }
+
+int zk_gemm_ln_bwd(const void* dY, const void* W, int M, int N, int K, int lda, int ldb, const void* residual, int ldr,
+                   const void* s, const float* mean, const float* rstd, const float* gamma, float drop_p,
+                   const uint64_t* seed, uint32_t sid, void* dsum, void* dy_out, float* partials, void* slots,
+                   size_t slots_bytes, const uint32_t* epoch, uint32_t site, int* err, hipStream_t stream) {
+  ZK_CHECK_ARG(M >= 0 && N >= 64 && K >= 1, "zk_gemm_ln_bwd: bad dims");
+  ZK_CHECK_ARG(N % 64 == 0 && N / 64 <= 16, "zk_gemm_ln_bwd: N=%d must be a multiple of 64 and <= 1024", N);
+  ZK_CHECK_ARG(s != nullptr && mean != nullptr && rstd != nullptr && gamma != nullptr && dsum != nullptr && partials != nullptr,
+               "zk_gemm_ln_bwd: s, mean, rstd, gamma, dsum and partials are required");
+  ZK_CHECK_ARG(residual == nullptr || ldr % 8 == 0, "zk_gemm_ln_bwd: residual row stride must be a multiple of 8");
+  ZK_CHECK_ARG(drop_p == 0.f || (seed != nullptr && dy_out != nullptr), "zk_gemm_ln_bwd: dropout needs a seed pointer and dy_out");
+  ZK_CHECK_ARG(slots != nullptr && epoch != nullptr && site >= 1 && site <= 255, "zk_gemm_ln_bwd: slots, epoch and a site in 1..255 are required");
+  ZK_CHECK_ARG(slots_bytes >= zk_gemm_add_ln_workspace(M, N), "zk_gemm_ln_bwd: slots too small (zk_gemm_add_ln_workspace)");
+  const uintptr_t al = (uintptr_t)residual | (uintptr_t)s | (uintptr_t)gamma | (uintptr_t)dsum | (uintptr_t)dy_out |
+                       (uintptr_t)slots | (uintptr_t)partials;
+  ZK_CHECK_ARG((al & 15) == 0, "zk_gemm_ln_bwd: operands must be 16-byte aligned");
+  ZK_CHECK_ARG(mfma_ok(dY, W, M, N, K, lda, ldb, 0, 1), "zk_gemm_ln_bwd: shape/alignment not supported by the MFMA kernel "
+               "(M=%d N=%d K=%d lda=%d ldb=%d)", M, N, K, lda, ldb);
+  ZK_CHECK_ARG(!zk_prog_active(), "zk_gemm_ln_bwd cannot be part of a layer program");
+  if (M == 0) return 0;
+  GemmEpi e;
+  e.C = nullptr; e.ldc = N; e.out_f32 = 0; e.alpha = 1.f; e.bias = nullptr;
+  e.res = (const bf16_t*)residual; e.ldr = ldr; e.act = 0; e.aux = nullptr; e.ldaux = 0; e.aux_scale = 1.f;
+  e.thr = drop_p > 0.f ? zk_drop_threshold(drop_p) : 0;
+  e.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  e.seed = seed; e.sid = sid;
+  e.ln_invh = 1.f / (float)N;
+  e.sy_slots = (unsigned long long*)slots; e.sy_epoch = epoch; e.sy_site = site;
+  e.sy_gamma = gamma; e.sy_y = (bf16_t*)dsum; e.sy_ldy = N; e.sy_err = err;
+  e.sy_s = (const bf16_t*)s; e.sy_lds = N; e.sy_mean_in = mean; e.sy_rstd_in = rstd;
+  e.sy_dy = (bf16_t*)dy_out; e.sy_part = partials;
+  return zk_gemm_dlds_sync_ln_bwd_dispatch((const bf16_t*)dY, (const bf16_t*)W, M, N, K, lda, ldb, e, stream);
 }
 
 // Split-K product left as its partial sums: parts[z] (fp32 [M, N] each, z < splits, part z at parts + z*M*N) =

@@ -1029,6 +1029,25 @@ int zk_gemm_dlds_sync_ln_dispatch(const bf16_t* A, const bf16_t* B, int M, int N
   return launch_dlds_sync_ln<64, 4, 4>(A, B, M, N, K, lda, ldb, e, stream);
 }
 
+// the backward form (zk_gemm_ln_bwd): dgrad A [M,K] x B[N,K]^T on 64x64 tiles with the LN = 4 epilogue
+int zk_gemm_dlds_sync_ln_bwd_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb,
+                                      const GemmEpi& e, hipStream_t stream) {
+  TileSched ts;
+  ts.tiles_m = (M + 63) / 64;
+  ts.tiles_n = N / 64;
+  ts.n_major = 0;
+  ts.xcd_remap = 1;
+  EpiVec ev;
+  ev.vec_ok = 1;
+  const long nwg = (long)ts.tiles_m * ts.tiles_n;
+  GemmEpi el = e;
+  el.sy_local = (nwg % (8 * ts.tiles_n) == 0 && g_tune[15] == 0) ? 1 : 0;
+  hipLaunchKernelGGL((k_gemm_dlds<64, 64, 4, false, true, 4, 4, 4>), dim3((unsigned)nwg), dim3(512), 0, stream, A, B, M, N, K,
+                     lda, ldb, K, (float*)nullptr, ts, el, ev);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
 // entry used by zk_gemm (zk_gemm.hip)
 int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
                           int bm, int bn, int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags,

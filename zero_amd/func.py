@@ -257,6 +257,19 @@ class Engine(object):
                       s_out.ptr if s_out is not None else None, y.ptr, hip.ptr(mean), hip.ptr(rstd), slots.data_ptr(),
                       slots.numel(), meta.data_ptr(), self._sync_site, meta.data_ptr() + 4, self.stream)
 
+    def gemm_ln_bwd(self, dY, W, M, N, K, residual, s, mean, rstd, gamma, dsum, dy_out, partials, drop_p=0.0, sid=0):
+        """dgrad dY @ W^T (+ residual) and the backward of the residual + LayerNorm it feeds, in one launch."""
+        if self.__dict__.get("_sync_site", 255) >= 255:
+            self.ln_epoch_bump()
+        self._sync_site += 1
+        slots, meta = self.sync_ln_state(M, N)
+        assert partials.numel() * 4 >= self.lib.query("zk_gemm_ln_bwd_partials", M, N)
+        self.lib.call("zk_gemm_ln_bwd", dY.ptr, W.ptr, M, N, K, dY.ld, W.ld, residual.ptr if residual is not None else None,
+                      residual.ld if residual is not None else 0, s.ptr, mean.data_ptr(), rstd.data_ptr(),
+                      gamma.data_ptr(), float(drop_p), self.seed.data_ptr(), sid, dsum.ptr,
+                      dy_out.ptr if dy_out is not None else None, partials.data_ptr(), slots.data_ptr(), slots.numel(),
+                      meta.data_ptr(), self._sync_site, meta.data_ptr() + 4, self.stream)
+
     def sync_ln_errors(self):
         """1 if a workgroup of some zk_gemm_add_ln launch ever gave up waiting for its peers (synchronises)."""
         st = self.__dict__.get("_sync_ln")
@@ -406,12 +419,12 @@ class Engine(object):
 
     def reductions_grouped(self, colsums, ln_parts, rpr_parts=()):
         """colsums: [(Mat dY, out fp32 view, private fp32 partial buffer)];
-        ln_parts: [(partials buffer, rows, H, dgamma, dbeta, dbias_prev-or-None)];
+        ln_parts: [(partials buffer, rows, H, dgamma, dbeta, dbias_prev-or-None[, True: written by gemm_ln_bwd])];
         rpr_parts: [(partials fp32 [slices][2][64*64] (device address), slices, n, d rpr_k, d rpr_v)] -- the table-gradient
         partials the folded relative-position backward left behind (attn_bwd(defer_tables=...)).
         Two launches: column partial sums of every dY, then every final reduction."""
         key = tuple((a.ptr, o.data_ptr()) for a, o, _ in colsums) + \
-            tuple((w.data_ptr(), r) for w, r, _, _, _, _ in ln_parts) + \
+            tuple((lp[0].data_ptr(), lp[1], len(lp), lp[3].data_ptr()) for lp in ln_parts) + \
             tuple((pp, ns, n, dk.data_ptr()) for pp, ns, n, dk, _ in rpr_parts)
         cache = self.__dict__.setdefault("_red_cache", {})
         ent = cache.get(key)
@@ -433,9 +446,12 @@ class Engine(object):
                 r.out[0], r.out[1], r.out[2] = o.data_ptr(), None, None
                 rstart += (a.cols + RED_COLS - 1) // RED_COLS
                 k += 1
-            for (pw, rows, H, dg, db, dbp) in ln_parts:
+            for lp in ln_parts:
+                pw, rows, H, dg, db, dbp = lp[:6]
+                # (7th element: the partials came from zk_gemm_ln_bwd -- one partial row per 64-row block)
+                nblk = (rows + 63) // 64 if len(lp) > 6 else lib.raw("zk_ln_bwd_blocks")(rows)
                 r = rd[k]
-                r.partials, r.nblk, r.nq, r.H, r.block_start = pw.data_ptr(), lib.raw("zk_ln_bwd_blocks")(rows), 3, H, rstart
+                r.partials, r.nblk, r.nq, r.H, r.block_start = pw.data_ptr(), nblk, 3, H, rstart
                 r.out[0], r.out[1], r.out[2] = dg.data_ptr(), db.data_ptr(), hip.ptr(dbp)
                 rstart += 3 * ((H + RED_COLS - 1) // RED_COLS)
                 k += 1

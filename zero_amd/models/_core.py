@@ -107,6 +107,8 @@ class TransformerCore(object):
         self._pending_wgrads = []
         self._pending_colsums = []     # (dY Mat, bias-gradient view, private partial buffer)
         self._pending_lnred = []       # (partials, rows, H, dgamma, dbeta, dbias_prev)
+        self._ln_bwd_done = {}         # tag -> (ds, dy) of a LayerNorm backward that ran inside a dgrad launch
+        self._ln_next = None           # the LayerNorm below the sub-layer whose backward is being issued
         self._pending_rpr = []         # (partials address, slices, n, d rpr_k, d rpr_v): table gradients of the folded backward
         self._pending_adds = []        # (fp32 gradient view, fp32 temporary): dst += src after the flush
         self._mem_segs = []            # (dK or dV, W) pairs of the cross-attention memory side (see _finish_mem_grad)
@@ -140,6 +142,7 @@ class TransformerCore(object):
         # is an experiment: only in a `make EXPERIMENTS=1` library, only with ZERO_HIP_LAZY_LN=1.
         self.lazy_ln_mode = os.environ.get("ZERO_HIP_LAZY_LN", "0").lower() if self.eng.lib.experiments else "0"
         self.sync_ln_mode = os.environ.get("ZERO_HIP_SYNC_LN", "1") != "0"
+        self.sync_ln_bwd = os.environ.get("ZERO_HIP_SYNC_LN", "1") != "fwd"
         self._sync_ln = False
         # The update of the weight matrices inside the weight-gradient launch (round 4; zk_gemm_grouped_update): set by the
         # Trainer for a step whose update is norm-free, single-rank and unaccumulated; the backward's one grouped launch
@@ -291,7 +294,7 @@ class TransformerCore(object):
                       drop_p=drop_p, sid=sid)
 
     def _linear_bwd(self, x, dy, scope, dx=None, residual=None, bias_grad=True, act=0, aux=None, aux_scale=1.0,
-                    accumulate=False):
+                    accumulate=False, ln_next=None):
         """dW = x^T dy (fp32, overwrite), db = colsum(dy), dx = dy @ W^T (+residual).
         accumulate: the variable is used twice in the graph (v_map of the merged attention); this
         use's gradients go to temporaries that are added once the overwriting use has run."""
@@ -326,8 +329,28 @@ class TransformerCore(object):
             # the overwriting use of the variable must already have run: callers issue it first
             self._pending_adds += adds
         if dx is not None:
+            if ln_next is not None and act == 0 and residual is not None:
+                # dx is only read by the backward of the LayerNorm below this sub-layer: that backward runs in the
+                # epilogue of this product and dx is never written (zk_gemm_ln_bwd)
+                self._gemm_ln_bwd(dy, Wm, residual, ln_next)
+                return
             self.eng.gemm(dy, Wm, dx, dy.rows, Wm.rows, Wm.cols, 0, 1, residual=residual, act=act, aux=aux,
                           aux_scale=aux_scale)
+
+    def _gemm_ln_bwd(self, dy, Wm, residual, ln_next):
+        e, H = self.eng, self.H
+        scope, tag, prev_bias, drop_p, sid = ln_next
+        T = dy.rows
+        ds = e.mat("g.%s.ds" % tag, T, H)
+        dyo = e.mat("g.%s.dy" % tag, T, H) if drop_p > 0.0 else None
+        nbytes = max(e.lib.query("zk_gemm_ln_bwd_partials", T, H), e.lib.query("zk_add_ln_bwd_workspace", T, H))
+        pws = e.buf("g.%s.lnws" % tag, (nbytes // 4,), F32)
+        e.gemm_ln_bwd(dy, Wm, T, H, Wm.cols, residual, e.mat(tag + ".s", T, H), e.buf(tag + ".mean", (T,), F32),
+                      e.buf(tag + ".rstd", (T,), F32), self.b(scope + "/layer_norm/scale"), ds, dyo, pws, drop_p, sid)
+        dbp = self.gb(prev_bias) if prev_bias is not None else None
+        self._pending_lnred.append((pws, T, H, self.gb(scope + "/layer_norm/scale"), self.gb(scope + "/layer_norm/offset"),
+                                    dbp, True))
+        self._ln_bwd_done[tag] = (ds, dyo if dyo is not None else ds)
 
     # ------------------------------------------------------------------ sub-layers (forward)
     def _out_ln(self, a, lin, x, scope, tag, save, drop_p, sid, last=False):
@@ -474,6 +497,9 @@ class TransformerCore(object):
         """returns (ds, dy): grads of the residual input and of the sub-layer output."""
         e, H = self.eng, self.H
         T = dx.rows
+        done = self._ln_bwd_done.pop(tag, None)
+        if done is not None:          # ran inside the dgrad launch that produced dx (_linear_bwd(ln_next=...))
+            return done
         ds = e.mat("g.%s.ds" % tag, T, H)
         dy = e.mat("g.%s.dy" % tag, T, H) if drop_p > 0.0 else None
         dgam, dbet = self.gb(scope + "/layer_norm/scale"), self.gb(scope + "/layer_norm/offset")
@@ -512,7 +538,7 @@ class TransformerCore(object):
         rp = hp.relu_dropout
         self._linear_bwd(h, dy, p + "output", dx=dh, bias_grad=False, act=2, aux=h,
                          aux_scale=1.0 / (1.0 - rp) if rp > 0 else 1.0)
-        self._linear_bwd(x_in, dh, p + "enlarge", dx=dx_out, residual=ds)
+        self._linear_bwd(x_in, dh, p + "enlarge", dx=dx_out, residual=ds, ln_next=self._ln_next)
         return dx_out
 
     def _self_attn_bwd(self, dx, x_in, B, L, scope, tag, kmask, causal, sid0, side, dx_out):
@@ -538,7 +564,7 @@ class TransformerCore(object):
                    drpr_v=self.gb(p + "rpr_values/embeddings") if self.rpr else None,
                    max_rel=hp.max_relative_position, drop_p=hp.attention_dropout, sid=sid0,
                    defer_tables=(self._pending_rpr, tag) if self._defer_rpr() else None, oproj=oproj)
-        self._linear_bwd(x_in, dqkv, p + "qkv_map", dx=dx_out, residual=ds)
+        self._linear_bwd(x_in, dqkv, p + "qkv_map", dx=dx_out, residual=ds, ln_next=self._ln_next)
         return dx_out
 
     def _cross_attn_bwd(self, dx, x_in, mem, d_mem, B, Lq, Lk, scope, tag, kmask, sid0, side, dx_out,
@@ -568,7 +594,8 @@ class TransformerCore(object):
                    drpr_v=self.gb(p + "rpr_values/embeddings") if self.rpr else None,
                    max_rel=hp.max_relative_position, drop_p=hp.attention_dropout, sid=sid0,
                    defer_tables=(self._pending_rpr, tag) if self._defer_rpr() else None, oproj=oproj)
-        self._linear_bwd(x_in, dq, p + "q_map", dx=dx_out, residual=ds)
+        self._linear_bwd(x_in, dq, p + "q_map", dx=dx_out, residual=ds,
+                         ln_next=self._ln_next if fuse_tmask is None else None)
         # memory side: the gradients of all decoder layers add up in d_mem.  Default: every layer only records its
         # (dK, W_k) / (dV, W_v) pair and ONE K-segmented GEMM sums them after the decoder (see _finish_mem_grad);
         # otherwise each layer accumulates in place.
@@ -869,25 +896,65 @@ class TransformerCore(object):
                 return e.mat("%s%d.ff.o" % (side, l - 1), Tt if side == "d" else Ts, H)
             return e.mat("dec.x0" if side == "d" else "enc.x0", Tt if side == "d" else Ts, H)
 
+        fuse_ln_bwd = self.sync_ln_mode and self.sync_ln_bwd and self.group_wgrad and e.gemm_impl == 0 and \
+            H % 64 == 0 and H <= 1024 and not self.fuse and not self._lazy_tags and not e.lib.recording
+
+        def ln_below(side, l, kind):
+            """(scope, tag, bias of the linear layer before it, dropout, dropout site) of the LayerNorm whose output is the
+            residual input of sub-layer `kind` of layer l -- its backward runs inside the dgrad launch that ends `kind`'s
+            backward (zk_gemm_ln_bwd) -- or None (the embedding below the stack, the averaging sub-layer, switched off)."""
+            if not fuse_ln_bwd:
+                return None
+            if side == "d":
+                order = (["aa"] if self.aan else ["sa"]) + ["ca", "ff"]
+            else:
+                order = ["sa", "ff"]
+            i = order.index(kind)
+            if i > 0:
+                pk, pl = order[i - 1], l
+            elif l > 0:
+                pk, pl = "ff", l - 1
+            else:
+                return None
+            if pk == "aa":
+                return None
+            pre = ("decoder" if side == "d" else "encoder") + "/layer_%d" % pl
+            base = 100 * (NE + pl) if side == "d" else 100 * pl
+            if pk == "sa":
+                scope, sid0 = pre + "/self_attention", base + 1
+                pb = scope + "/dot_attention/o_map/b_0"
+            elif pk == "ca":
+                scope, sid0 = pre + "/" + self.cross, base + 11
+                pb = scope + "/dot_attention/o_map/b_0"
+            else:
+                scope, sid0 = pre + "/feed_forward", base + (21 if side == "d" else 11)
+                pb = scope + "/ffn_layer/output/b_0"
+            return (scope, "%s%d.%s" % (side, pl, pk), pb, hp.residual_dropout, sid0 + 1)
+
         ready_d = []
         for l in reversed(range(hp.num_decoder_layer)):
             pre = "decoder/layer_%d" % l
             sid = 100 * (NE + l)
+            self._ln_next = ln_below("d", l, "ff")
             self._ffn_bwd(P[cur], layer_input("d", l, "ff"), pre + "/feed_forward", "d%d.ff" % l, sid + 21, "d",
                           P[cur ^ 1])
             cur ^= 1
+            self._ln_next = ln_below("d", l, "ca")
             self._cross_attn_bwd(P[cur], layer_input("d", l, "ca"), enc, d_enc, B, Lt, Ls,
                                  pre + "/" + self.cross, "d%d.ca" % l, smask, sid + 11, "d", P[cur ^ 1],
                                  fuse_tmask=tmask if self.fuse else None)
             cur ^= 1
+            self._ln_next = None
             if self.aan:
                 self._aan_bwd(P[cur], B, Lt, pre + "/average_attention", "d%d.aa" % l, tmask, sid + 1, "d",
                               P[cur ^ 1])
                 cur ^= 1
             elif not self.fuse:
+                self._ln_next = ln_below("d", l, "sa")
                 self._self_attn_bwd(P[cur], layer_input("d", l, "sa"), B, Lt, pre + "/self_attention",
                                     "d%d.sa" % l, None, True, sid + 1, "d", P[cur ^ 1])
                 cur ^= 1
+            self._ln_next = None
             ready_d.append(pre)
             # (ZERO_HIP_GROUP_ALL=1, one rank: the decoder's weight gradients wait for the encoder's -- ONE grouped launch
             # per step, one partial last round of tiles instead of two)
@@ -920,15 +987,18 @@ class TransformerCore(object):
         for l in reversed(range(NE)):
             pre = "encoder/layer_%d" % l
             other = Q[cur ^ 1] if (Q[cur ^ 1] is not d_enc) else e.mat("ge.p0", Ts, H)
+            self._ln_next = ln_below("e", l, "ff")
             self._ffn_bwd(Q[cur], layer_input("e", l, "ff"), pre + "/feed_forward", "e%d.ff" % l, 100 * l + 11,
                           "e", other)
             Q[cur ^ 1] = other
             cur ^= 1
             other = Q[cur ^ 1] if (Q[cur ^ 1] is not d_enc) else e.mat("ge.p0", Ts, H)
+            self._ln_next = ln_below("e", l, "sa")
             self._self_attn_bwd(Q[cur], layer_input("e", l, "sa"), B, Ls, pre + "/self_attention", "e%d.sa" % l,
                                 smask, False, 100 * l + 1, "e", other)
             Q[cur ^ 1] = other
             cur ^= 1
+            self._ln_next = None
             ready_e.append(pre)
             if (not self.group_all and len(ready_e) >= self.group_layers) or l == 0:
                 self._flush_wgrads()
