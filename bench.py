@@ -103,16 +103,16 @@ HBM_PEAK_TBS = 8.0               # same guide: HBM3E peak
 
 # kernel classes of the step (roofline.by_class): name -> (bound, what it holds)
 CLASSES = (
-    ("small_gemm_chain", "mfma", "linear forward + dgrad on the 4096-row activations (k_gemm_dlds tiles), grouped K/V "
-                                 "projections, K-segmented d(encoder output)"),
-    ("big_gemms", "mfma", "all weight gradients (one grouped launch of 256x256 tiles; it also runs the Adam update of the "
-                          "weight matrices on its accumulators), logits forward, dlogits x E"),
+    ("small_gemm_chain", "mfma", "linear forward + dgrad on the 4096-row activations (k_gemm_dlds tiles; 58 of them carry a "
+                                 "residual + LayerNorm forward or backward in their epilogue), grouped K/V projections, "
+                                 "K-segmented d(encoder output)"),
+    ("big_gemms", "mfma", "all weight gradients (one grouped launch of 256x256 tiles), logits forward, dlogits x E"),
     ("attention", "hbm", "attention forward / backward, one (sentence, head) tile per workgroup (backward incl. the "
                          "folded o_map dgrad)"),
-    ("layernorm", "hbm", "residual + LayerNorm forward / backward"),
+    ("layernorm", "hbm", "residual + LayerNorm launches that remain (the backward at the top of each stack; the other 58 of "
+                         "60 run inside small_gemm_chain launches)"),
     ("cross_entropy", "hbm", "label-smoothed cross entropy: fp32 logits in, bf16 dlogits out"),
-    ("adam", "hbm", "TF1 Adam + bf16 shadow refresh + norms, 30 B / parameter, on what the weight-gradient launch did not "
-                    "update itself (embedding tables, biases, LayerNorm parameters)"),
+    ("adam", "hbm", "TF1 Adam + bf16 shadow refresh + norms, 30 B / parameter"),
 )
 
 
@@ -149,7 +149,7 @@ class LaunchProfiler(object):
         eng = self.eng
         keep = self._saved
         for k in ("gemm", "gemm_grouped", "gemm_grouped_update", "gemm_kseg", "attn_fwd", "attn_bwd", "add_ln_fwd",
-                  "add_ln_bwd", "ce_fused",
+                  "add_ln_bwd", "ce_fused", "gemm_add_ln", "gemm_ln_bwd",
                   "gemm_ln", "ln_fold", "add_ln_bwd_lazy"):      # (the last three: the EXPERIMENTS-only LayerNorm-free forward)
             keep[k] = getattr(eng, k)
         esz = lambda m: m.t.element_size()
@@ -224,6 +224,22 @@ class LaunchProfiler(object):
             return self._timed("layernorm", None, 0.0, 4 * dout.rows * dout.cols * 2,
                                lambda: keep["add_ln_bwd"](dout, *a, **kw))
 
+        def gemm_add_ln(A, Bm, M, N, K, *a, **kw):
+            # sub-layer output product + residual + LayerNorm in one launch (zk_gemm_add_ln): the GEMM's operands, the
+            # residual read, the sum and the normalised rows written
+            bm = 64
+            name = "k_gemm_dlds<%d, 64, %d, false, false, 4, %d, 3>" % (bm, 4, 4)
+            nbytes = (M * K + K * N) * 2 + 3 * M * N * 2
+            return self._timed("small_gemm_chain", name, 2.0 * M * N * K, nbytes,
+                               lambda: keep["gemm_add_ln"](A, Bm, M, N, K, *a, **kw))
+
+        def gemm_ln_bwd(dY, W, M, N, K, *a, **kw):
+            # dgrad + the LayerNorm backward its result feeds (zk_gemm_ln_bwd): operands, residual and saved sum read,
+            # ds and dy written (the dgrad result itself never leaves the workgroup)
+            nbytes = (M * K + K * N) * 2 + 4 * M * N * 2
+            return self._timed("small_gemm_chain", "k_gemm_dlds<64, 64, 4, false, true, 4, 4, 4>", 2.0 * M * N * K, nbytes,
+                               lambda: keep["gemm_ln_bwd"](dY, W, M, N, K, *a, **kw))
+
         def gemm_ln(A, Bm, C, M, N, K, bias, np_, **kw):
             # the linear layers of the LayerNorm-free forward (zk_gemm_ln): same tile kernels, LayerNorm in the epilogue
             name = self._name(M, N, K, 0, 0, 0, 0)
@@ -245,6 +261,7 @@ class LaunchProfiler(object):
         for k, fn in (("gemm", gemm), ("gemm_grouped", gemm_grouped), ("gemm_grouped_update", gemm_grouped_update_timed),
                       ("gemm_kseg", gemm_kseg), ("attn_fwd", attn_fwd),
                       ("attn_bwd", attn_bwd), ("add_ln_fwd", add_ln_fwd), ("add_ln_bwd", add_ln_bwd), ("ce_fused", ce_fused),
+                      ("gemm_add_ln", gemm_add_ln), ("gemm_ln_bwd", gemm_ln_bwd),
                       ("gemm_ln", gemm_ln), ("ln_fold", ln_fold), ("add_ln_bwd_lazy", add_ln_bwd_lazy)):
             setattr(eng, k, fn)
         if self.top is not None:

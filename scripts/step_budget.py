@@ -63,26 +63,33 @@ class Budget(object):
         self.add(cls, n, 2.0 * M * N * K, hbm, staged)
 
 
-def build(B, L=64, H=512, F=2048, V=32000, NE=6, ND=6, nh=8):
+def build(B, L=64, H=512, F=2048, V=32000, NE=6, ND=6, nh=8, sync_ln=True):
+    """sync_ln (round 4, the default launch structure): the residual + LayerNorm forward runs in the epilogue of the
+    sub-layer output products (zk_gemm_add_ln: + the residual read and the saved sum written) and its backward in the
+    dgrad launch that completes its input gradient (zk_gemm_ln_bwd: + the saved sum read and dy written; the dgrad result
+    itself is not written) -- 58 of the 60 LayerNorm launches are gone, the two at the top of the stacks stay."""
     T = B * L
     b = Budget()
     act = T * H * 2.0                     # one bf16 activation
+    fw = 2 * act if sync_ln else 0.0      # forward tail: residual in, saved sum out
+    bw = 2 * act if sync_ln else 0.0      # backward: saved sum in, dy out (ds takes the place of dx)
+    t64 = (64, 64) if sync_ln else None
     # ---- forward + dgrad chain of 4096-row GEMMs (func.py:14-65 and its mirrors)
     c = "small GEMM chain (linear fwd + dgrad, %d-row)" % T
     for _ in range(NE):
         b.gemm(c, 1, T, 3 * H, H)                        # qkv
-        b.gemm(c, 1, T, H, H)                            # o_map
+        b.gemm(c, 1, T, H, H, extra_in=fw, tile=t64)     # o_map (+ residual + LayerNorm)
         b.gemm(c, 1, T, F, H)                            # ffn enlarge
-        b.gemm(c, 1, T, H, F)                            # ffn output
-        b.gemm(c, 1, T, H, 3 * H, extra_in=act)          # d qkv -> dx (+ residual)
+        b.gemm(c, 1, T, H, F, extra_in=fw, tile=t64)     # ffn output (+ residual + LayerNorm)
+        b.gemm(c, 1, T, H, 3 * H, extra_in=act + bw, tile=t64)     # d qkv -> dx (+ residual) (+ LayerNorm backward below)
         # (d o_map: inside the attention backward launch since round 3, see c5)
         b.gemm(c, 1, T, F, H, extra_in=T * F * 2.0)      # d ffn output (ReLU mask)
-        b.gemm(c, 1, T, H, F, extra_in=act)              # d ffn enlarge (+ residual)
+        b.gemm(c, 1, T, H, F, extra_in=act + bw, tile=t64)         # d ffn enlarge (+ residual) (+ LayerNorm backward below)
     for _ in range(ND):
-        for (n_, k_) in ((3 * H, H), (H, H), (H, H), (H, H), (F, H), (H, F)):      # self qkv, o, cross q, o, ffn
-            b.gemm(c, 1, T, n_, k_)
-        for (n_, k_, ex) in ((H, 3 * H, act), (H, H, act), (F, H, T * F * 2.0), (H, F, act)):     # d qkv, d q, d ffn x 2
-            b.gemm(c, 1, T, n_, k_, extra_in=ex)
+        for (n_, k_, ln) in ((3 * H, H, 0), (H, H, 1), (H, H, 0), (H, H, 1), (F, H, 0), (H, F, 1)):      # self qkv, o, cross q, o, ffn
+            b.gemm(c, 1, T, n_, k_, extra_in=fw if ln else 0.0, tile=t64 if ln else None)
+        for (n_, k_, ex, ln) in ((H, 3 * H, act, 1), (H, H, act, 1), (F, H, T * F * 2.0, 0), (H, F, act, 1)):     # d qkv, d q, d ffn x 2
+            b.gemm(c, 1, T, n_, k_, extra_in=ex + (bw if ln else 0.0), tile=t64 if ln else None)
     # cross-attention K/V of all layers (one grouped launch), d(encoder output) (one K-segmented launch)
     c2 = "grouped K/V projections + K-segmented d(enc)"
     b.add(c2, 1, 2.0 * T * (2 * H * ND) * H, act + 2 * ND * H * H * 2 + 2 * ND * act,
@@ -113,13 +120,16 @@ def build(B, L=64, H=512, F=2048, V=32000, NE=6, ND=6, nh=8):
     # ---- residual + LayerNorm
     c6 = "residual + LayerNorm forward / backward"
     n_ln = 2 * NE + 3 * ND
-    b.add(c6, n_ln, 0, 4 * act)           # x, y in; out, saved sum out
-    b.add(c6, n_ln, 0, 4 * act)           # dout, saved sum in; dsum (+ dy with dropout) out
+    if sync_ln:
+        b.add(c6, 2, 0, 4 * act)          # the backward at the top of each stack (its dout comes from a 256-tile / K-segmented launch)
+    else:
+        b.add(c6, n_ln, 0, 4 * act)           # x, y in; out, saved sum out
+        b.add(c6, n_ln, 0, 4 * act)           # dout, saved sum in; dsum (+ dy with dropout) out
     # ---- cross entropy, Adam, the rest
     b.add("cross entropy (fp32 logits in, bf16 dlogits out)", 1, 0, T * V * 6.0)
     nparam = wg_enc + wg_dec + V * H + (NE * 2 + ND * 3) * 2 * H + H
     b.add("Adam (30 B / parameter)", 1, 0, nparam * 30.0)
-    b.add("embeddings, masks, loss, column / LayerNorm-parameter reductions, zero fill, norm", 17, 0, 12e6)
+    b.add("embeddings, masks, loss, column / LayerNorm-parameter reductions, zero fill, norm", 18 if sync_ln else 17, 0, 12e6)
     return b, nparam
 
 
@@ -166,9 +176,11 @@ def main():
     ap.add_argument("--sentences", type=int, default=64)
     ap.add_argument("--fixed-us", type=float, default=FIXED * 1e6,
                     help="fixed cost per launch (default: the measured kernel boundary, 1.5 us; rounds 2-3 used 5)")
+    ap.add_argument("--two-launch-ln", action="store_true",
+                    help="the launch structure of rounds 1-3: every residual + LayerNorm forward / backward a launch of its own")
     a = ap.parse_args()
     FIXED = a.fixed_us * 1e-6
-    b, nparam = build(a.sentences)
+    b, nparam = build(a.sentences, sync_ln=not a.two_launch_ln)
     meas = measured(a.stats) if a.stats else {}
     print("| kernel class | launches | GFLOP | HBM MB | L2->LDS MB | fixed us | **floor us** | measured us | excess us (fill / drain / restarts) |")
     print("|---|---|---|---|---|---|---|---|---|")

@@ -533,6 +533,7 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
         slot_st(p + 1, ((unsigned long long)tag << 32) | __float_as_uint(s2));
       }
     }
+    ZK_E(5);
     if (e.C != nullptr) {
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
@@ -551,6 +552,7 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
       }
       __syncthreads();
     }
+    ZK_E(6);
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int row = row0 + it * RSTEP, gm = m0 + row;
@@ -575,6 +577,7 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
       const float d0 = ps[0] * (1.f / 64.f) - mu, d1 = ps[1] * (1.f / 64.f) - mu;
       const float m2 = zk_sum8((have[0] ? pm[0] + 64.f * d0 * d0 : 0.f) + (have[1] ? pm[1] + 64.f * d1 * d1 : 0.f));
       const float rs = rsqrtf(m2 * e.ln_invh + e.ln_eps);
+      ZK_E(7);
       if (ok) {
         float o[8];
 #pragma unroll
