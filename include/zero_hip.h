@@ -70,6 +70,19 @@ int zk_gemm_add_ln(const void* A, const void* B, int M, int N, int K, int lda, i
  * partials (zk_gemm_ln_bwd_partials bytes: [ceil(M/64)][3][N]) = the per-row-block column sums {dout xhat, dout, dy} that
  * zk_add_ln_bwd_reduce / zk_reduce_grouped finish with nblk = ceil(M/64).  dY [M, lda], W [N, ldb] (both K contiguous).
  * Replaces zk_gemm(tb = 1, residual) + zk_add_ln_bwd(defer_reduce = 1); slots / epoch / site / err as for zk_gemm_add_ln. */
+/* Attention forward + output projection + residual + LayerNorm of a sub-layer in ONE launch: workgroup (sentence, head)
+ * computes its attention output (func.py:218-256, as zk_attn_fwd's MFMA kernel: att and lse are still written), waits for
+ * the other heads of its sentence and runs its 64-column tile of zk_gemm_add_ln over the sentence's rows.  d = 64,
+ * Lq <= 64, Lk <= 256, no relative positions; W_o [nh*64, nh*64]; flags: zk_attn_out_ln_flags bytes, zero-filled once;
+ * slots / epoch / site / err as for zk_gemm_add_ln.  Returns 2 (nothing launched) when the shape is not covered. */
+size_t zk_attn_out_ln_flags(int B, int nh);
+int zk_attn_out_ln(const void* q, const void* k, const void* v, void* att, float* lse, int B, int nh, int Lq, int Lk, int d,
+                   int ldq, int ldk, int ldv, int ldatt, const float* kmask, int causal, float scale, float mask_inf,
+                   float attn_drop_p, const uint64_t* seed, uint32_t attn_sid, int kv_group, const void* Wo, int ldw,
+                   const float* bias, const void* residual, int ldr, float drop_p, uint32_t sid, const float* gamma,
+                   const float* beta, float eps, void* s_out, void* y, float* mean, float* rstd, void* slots,
+                   size_t slots_bytes, void* flags, size_t flags_bytes, const uint32_t* epoch, uint32_t site, int* err,
+                   zk_stream_t stream);
 size_t zk_gemm_ln_bwd_partials(int rows, int N);
 int zk_gemm_ln_bwd(const void* dY, const void* W, int M, int N, int K, int lda, int ldb, const void* residual, int ldr,
                    const void* s, const float* mean, const float* rstd, const float* gamma, float drop_p,

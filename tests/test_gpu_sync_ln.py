@@ -121,6 +121,47 @@ def _ulp_close_abs(a, b):
     return bool(((a - b).abs() <= scale * 2.0 ** -6).all())
 
 
+@pytest.mark.parametrize("B,Lq,Lk,causal,masked,drop", [(64, 64, 64, True, False, 0.1), (64, 64, 64, False, True, 0.0),
+                                                        (16, 37, 37, True, False, 0.1), (8, 13, 150, False, True, 0.1),
+                                                        (5, 64, 64, False, True, 0.0), (24, 50, 256, False, True, 0.1)])
+def test_attention_inside_the_output_projection_launch(B, Lq, Lk, causal, masked, drop):
+    """zk_attn_out_ln against zk_attn_fwd followed by zk_gemm_add_ln: the attention output and its log-sum-exp are the
+    attention kernel's bit for bit (same tile function), and so are the sum, the normalised rows and the statistics
+    (same tile function over the same rows; sentence-aligned instead of 64-aligned row tiles do not change a row).
+    Self- and cross-shaped problems, one to four key tiles, ragged sentences, a grid whose row blocks straddle XCDs."""
+    e = eng()
+    e.set_seed(21)
+    nh, d = 8, 64
+    H = nh * d
+    Tq, Tk = B * Lq, B * Lk
+    q, k, v = rand_bf(Tq, H, seed=1), rand_bf(Tk, H, seed=2), rand_bf(Tk, H, seed=3)
+    Wo, R = rand_bf(H, H, seed=4, scale=0.05), rand_bf(Tq, H, seed=5)
+    g = torch.Generator().manual_seed(6)
+    b = (torch.randn(H, generator=g) * 0.1).cuda()
+    gam, bet = (1.0 + 0.2 * torch.randn(H, generator=g)).cuda(), (0.1 * torch.randn(H, generator=g)).cuda()
+    kmask = None
+    if masked:
+        kmask = torch.ones(B, Lk, device="cuda")
+        for i in range(B):
+            kmask[i, Lk - (i % max(1, Lk // 2)):] = 0.0
+    def outs():
+        return (torch.full((Tq, H), 3.0, dtype=torch.bfloat16, device="cuda"), torch.zeros(B * nh * Lq, device="cuda"),
+                torch.full((Tq, H), 3.0, dtype=torch.bfloat16, device="cuda"), torch.full((Tq, H), 3.0, dtype=torch.bfloat16, device="cuda"),
+                torch.zeros(Tq, device="cuda"), torch.zeros(Tq, device="cuda"))
+    att0, lse0, y0, s0, mean0, rstd0 = outs()
+    e.attn_fwd(mat(q), mat(k), mat(v), mat(att0), lse0, B, nh, Lq, Lk, d, kmask=kmask, causal=causal, drop_p=drop, sid=7)
+    e.ln_epoch_bump()
+    e.gemm_add_ln(mat(att0), mat(Wo), Tq, H, H, b, mat(R), gam, bet, mat(y0), mat(s0), mean0, rstd0, drop, 8)
+    att1, lse1, y1, s1, mean1, rstd1 = outs()
+    e.ln_epoch_bump()
+    ok = e.attn_out_ln(mat(q), mat(k), mat(v), mat(att1), lse1, B, nh, Lq, Lk, d, kmask, causal, drop, 7, mat(Wo), b, mat(R),
+                       gam, bet, mat(y1), mat(s1), mean1, rstd1, drop, 8)
+    torch.cuda.synchronize()
+    assert ok and e.sync_ln_errors() == 0
+    assert torch.equal(att1, att0) and torch.equal(lse1, lse0)
+    assert torch.equal(s1, s0) and torch.equal(y1, y0) and torch.equal(mean1, mean0) and torch.equal(rstd1, rstd0)
+
+
 def test_repeated_launches_reuse_the_slots():
     """Several hundred launches back to back on the same slots, different inputs and sites, the epoch advancing every 30
     launches as it does in a training step (30 sub-layers): every one of them must see this launch's partials, never an
@@ -152,7 +193,7 @@ def test_repeated_launches_reuse_the_slots():
 
 @pytest.mark.parametrize("model", ["transformer", "transformer_rpr"])
 def test_training_steps_with_the_layernorm_inside_the_launch(model, monkeypatch):
-    """Trainer with ZERO_HIP_SYNC_LN = 1 (forward and backward) / fwd / 0: the same losses and weights after five steps up to the last-bit difference
+    """Trainer with ZERO_HIP_SYNC_LN = 1 (everything) / noattn / fwd / 0: the same losses and weights after five steps up to the last-bit difference
     of the statistics; captured replay == eager bit for bit with it on (the epoch word lives on the device)."""
     from tests.common import make_hp, make_batch, perturb
     from oracle import ref_torch as rt
@@ -164,12 +205,13 @@ def test_training_steps_with_the_layernorm_inside_the_launch(model, monkeypatch)
     src, tgt = make_batch(rng, 6, 11, 13, hp.src_vocab.size(), hp.tgt_vocab.size())
     Pn = perturb(rt.init_params(hp, model, seed=8), rng)
     out = {}
-    for sync in ("1", "fwd", "0"):
+    for sync in ("1", "noattn", "fwd", "0"):
         monkeypatch.setenv("ZERO_HIP_SYNC_LN", sync)
         for use_graph in (False, True):
             reset_cores(); reset_stores()
             tr = Trainer(hp, initializer=Pn)
-            assert tr.core.sync_ln_mode == (sync != "0") and tr.core.sync_ln_bwd == (sync != "fwd")
+            assert tr.core.sync_ln_mode == (sync != "0") and tr.core.sync_ln_bwd == (sync != "fwd") and \
+                tr.core.sync_attn == (sync == "1")
             tr.prepare_static({"source": src, "target": tgt})
             tr.core.eng.set_seed(11)
             losses = [float(tr.step_static(use_graph).cpu()[0]) for _ in range(5)]
@@ -179,6 +221,9 @@ def test_training_steps_with_the_layernorm_inside_the_launch(model, monkeypatch)
     a, b = out[("1", False)], out[("1", True)]
     assert a[0] == b[0] and np.array_equal(a[1], b[1])
     off = out[("0", True)]
+    a, b = out[("1", True)], out[("noattn", True)]           # the attention inside the projection launch changes no bit
+    if model == "transformer":
+        assert a[0] == b[0] and np.array_equal(a[1], b[1])
     for mode in ("1", "fwd"):
         on = out[(mode, True)]
         assert np.allclose(on[0], off[0], rtol=2e-3, atol=0), (mode, on[0], off[0])

@@ -18,6 +18,7 @@
 //     tile) -> dK, dV.
 #include "zk_attn_dev.h"
 #include "zk_prog.h"
+#include "zk_gemm2_dev.h"      // gemm_tile: the output projection + residual + LayerNorm of k_attn_out_ln
 
 // =====================================================================================
 // reference kernels
@@ -239,6 +240,67 @@ __global__ void __launch_bounds__(256) k_attn_fwd_mfma(AttnArgs a, bf16_t* __res
   __shared__ __attribute__((aligned(16))) unsigned char smem[AttnFwdLds<NKT, RPR>::BYTES];
   attn_apply_pos(a);
   attn_fwd_tile<NKT, false, RPR>(smem, a, out, ldo, lse, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ---- attention + output projection + residual + LayerNorm of a sub-layer in ONE launch (zk_attn_out_ln; func.py:218-256
+// dot_attention core, func.py:206-216 o_map, func.py:321-324 + 289-303 in the order of transformer.py:57-58).
+// Workgroup (sentence b, head h) -- 512 threads, the grid of the 64x64 o_map tiles with SENTENCE-ALIGNED row tiles (rows
+// b Lq .. b Lq + Lq - 1, Lq <= 64) and nh = N/64 column tiles -- first computes the attention output of its (b, h) into
+// `att` exactly as k_attn_fwd_mfma does (waves 0-3; the producer waves of the GEMM only keep the barrier count), makes
+// it visible and raises flag (b, h); once the nh heads of the sentence are there it runs its o_map tile over
+// A = att[rows of b, :] with the in-launch LayerNorm epilogue (gemm_tile<.., LN = 3>, the row block's workgroups ARE the
+// sentence's heads).  The attention launch, its drain and the cold start of the projection disappear; att still goes to
+// memory once (the backward reads it).  Visibility: with the sentence's workgroups on one XCD (local) the L2 is the
+// point of coherence -- stores acknowledged (vmcnt) before the flag, the LDS-DMA of the K loop misses the L1 (nothing of
+// `att` was read by this CU before) -- otherwise agent-scope release / acquire around the flag.
+#define ZK_ATTN_FWD_BARRIERS(NKT) (4 * (NKT))     // workgroup barriers inside attn_fwd_tile<NKT> (no relative positions)
+template <int NKT>
+__global__ void __launch_bounds__(512) k_attn_out_ln(AttnArgs a, bf16_t* __restrict__ att, int ldatt, float* __restrict__ lse,
+                                                     const bf16_t* __restrict__ Wo, int ldw, int M, int N, TileSched ts,
+                                                     GemmEpi e, unsigned long long* __restrict__ flags) {
+  constexpr int GEMM_LDS = DldsCfg<64, 64, 4>::LDS_BYTES, ATT_LDS = AttnFwdLds<NKT, false>::BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[GEMM_LDS > ATT_LDS ? GEMM_LDS : ATT_LDS];
+  int tm, tn, z;
+  tile_of_block(ts, tm, tn, z);                   // tm: sentence, tn: head
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave < 4) {
+    attn_fwd_tile<NKT, false, false>(smem, a, att, ldatt, lse, 0, tn, tm);
+  } else {
+#pragma unroll 1
+    for (int i = 0; i < ZK_ATTN_FWD_BARRIERS(NKT); ++i) __syncthreads();
+  }
+  const bool local = e.sy_local != 0;
+  const uint32_t tag = (*e.sy_epoch << 8) | e.sy_site;
+  unsigned long long* fl = flags + (size_t)tm * a.nh;
+  __builtin_amdgcn_s_waitcnt(0);                  // this thread's rows of att have reached the L2
+  __syncthreads();
+  if (tid == 0) {
+    if (local) __hip_atomic_store(fl + tn, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    else __hip_atomic_store(fl + tn, (unsigned long long)tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid < a.nh && tid != tn) {
+    int spins = 0;
+    for (;;) {
+      unsigned long long v;
+      if (local) {
+        const unsigned long long zero = 0;      // an atomic OR of zero executes in the L2 whatever the L1 holds
+        asm volatile("global_atomic_or_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(fl + tid), "v"(zero) : "memory");
+      } else {
+        v = __hip_atomic_load(fl + tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if ((uint32_t)v == tag) break;
+      if (++spins > (1 << 15)) {
+        if (e.sy_err != nullptr) __hip_atomic_store(e.sy_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  __syncthreads();
+  if (!local) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  gemm_tile<64, 64, 4, false, false, 4, 4, false, false, 3>(smem, att, Wo, M, N, ldatt, ldw, 0, N, tm * a.Lq, tn * 64,
+                                                            nullptr, e, 1);
 }
 
 // ---- backward A: grid (ceil(Lq/64), nh, B) -> dQ, Dbuf
@@ -617,6 +679,66 @@ int zk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* l
   const long rows = (long)B * nh * Lq;
   hipLaunchKernelGGL(k_attn_fwd_naive, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a, (bf16_t*)out, ldo,
                      lse);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+// Attention forward + output projection + residual + LayerNorm in one launch (see k_attn_out_ln): the arguments of
+// zk_attn_fwd (MFMA path only: d = 64, Lq <= 64, Lk <= 256, no relative positions; `att` [B*Lq, nh*64] and lse are still
+// written, the backward reads them) and of zk_gemm_add_ln (W_o [nh*64, N = nh*64]; slots / epoch / site / err shared with
+// it; `flags`: zk_attn_out_ln_flags(B, nh) bytes, zero-filled once).  Returns 2 without launching when the shape is
+// not covered (the caller issues zk_attn_fwd and zk_gemm_add_ln).
+size_t zk_attn_out_ln_flags(int B, int nh) { return (size_t)B * nh * sizeof(unsigned long long); }
+
+int zk_attn_out_ln(const void* q, const void* k, const void* v, void* att, float* lse, int B, int nh, int Lq, int Lk, int d,
+                   int ldq, int ldk, int ldv, int ldatt, const float* kmask, int causal, float scale, float mask_inf,
+                   float attn_drop_p, const uint64_t* seed, uint32_t attn_sid, int kv_group, const void* Wo, int ldw,
+                   const float* bias, const void* residual, int ldr, float drop_p, uint32_t sid, const float* gamma,
+                   const float* beta, float eps, void* s_out, void* y, float* mean, float* rstd, void* slots,
+                   size_t slots_bytes, void* flags, size_t flags_bytes, const uint32_t* epoch, uint32_t site, int* err,
+                   hipStream_t stream) {
+  const int N = nh * AD, M = B * Lq;
+  if (d != AD || Lq < 1 || Lq > 64 || Lk < 1 || Lk > 256 || N > 1024 || kv_group < 1) return 2;
+  ZK_CHECK_ARG(residual != nullptr && ldr % 8 == 0 && gamma != nullptr && beta != nullptr && y != nullptr && att != nullptr,
+               "zk_attn_out_ln: att, residual (row stride a multiple of 8), gamma, beta and y are required");
+  ZK_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "zk_attn_out_ln: mean / rstd must both be given");
+  ZK_CHECK_ARG((attn_drop_p == 0.f && drop_p == 0.f) || seed != nullptr, "zk_attn_out_ln: dropout needs a seed pointer");
+  ZK_CHECK_ARG(slots != nullptr && flags != nullptr && epoch != nullptr && site >= 1 && site <= 255,
+               "zk_attn_out_ln: slots, flags, epoch and a site in 1..255 are required");
+  ZK_CHECK_ARG(slots_bytes >= (size_t)((M + 127) / 128 * 128) * (size_t)(N / 64) * 16 && flags_bytes >= zk_attn_out_ln_flags(B, nh),
+               "zk_attn_out_ln: slots / flags too small");
+  if (B == 0) return 0;
+  AttnArgs a;
+  fill_args(&a, q, k, v, ldq, ldk, ldv, B, nh, Lq, Lk, d, kmask, causal, 0, scale, mask_inf, nullptr, nullptr, 0, attn_drop_p,
+            seed, attn_sid);
+  a.kv_group = kv_group;
+  const uintptr_t al = (uintptr_t)att | (uintptr_t)Wo | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)gamma |
+                       (uintptr_t)beta | (uintptr_t)s_out | (uintptr_t)y | (uintptr_t)slots | (uintptr_t)flags;
+  if (!attn_mfma_ok(a, ldatt | ldw) || (al & 15) != 0 || (a.bsq % 8) || (a.bsk % 8) || (a.bsv % 8)) return 2;
+  if (zk_prog_active()) return 2;
+  GemmEpi e;
+  e.C = s_out; e.ldc = N; e.out_f32 = 0; e.alpha = 1.f; e.bias = bias;
+  e.res = (const bf16_t*)residual; e.ldr = ldr; e.act = 0; e.aux = nullptr; e.ldaux = 0; e.aux_scale = 1.f;
+  e.thr = drop_p > 0.f ? zk_drop_threshold(drop_p) : 0;
+  e.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  e.seed = seed; e.sid = sid;
+  e.ln_eps = eps; e.ln_invh = 1.f / (float)N;
+  e.sy_slots = (unsigned long long*)slots; e.sy_epoch = epoch; e.sy_site = site;
+  e.sy_gamma = gamma; e.sy_beta = beta; e.sy_y = (bf16_t*)y; e.sy_ldy = N;
+  e.sy_mean = mean; e.sy_rstd = rstd; e.sy_err = err; e.sy_rows = Lq;
+  TileSched ts;
+  ts.tiles_m = B; ts.tiles_n = nh; ts.n_major = 0; ts.xcd_remap = 1;
+  const long nwg = (long)B * nh;
+  e.sy_local = (nwg % (8 * nh) == 0 && !(g_tune[15] & 1)) ? 1 : 0;
+  const int nkt = (Lk + 63) / 64;
+  const dim3 grid((unsigned)nwg), blk(512);
+#define ZK_AOL(NKT_) hipLaunchKernelGGL(k_attn_out_ln<NKT_>, grid, blk, 0, stream, a, (bf16_t*)att, ldatt, lse, \
+                                         (const bf16_t*)Wo, ldw, M, N, ts, e, (unsigned long long*)flags)
+  if (nkt == 1) ZK_AOL(1);
+  else if (nkt == 2) ZK_AOL(2);
+  else if (nkt == 3) ZK_AOL(3);
+  else ZK_AOL(4);
+#undef ZK_AOL
   ZK_LAUNCH_CHECK();
   return 0;
 }

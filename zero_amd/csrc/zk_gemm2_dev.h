@@ -490,12 +490,13 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
       }
     };
     if constexpr (LN == 3) {
+    const int rlim = e.sy_rows > 0 ? e.sy_rows : BM;
     float r8[ITER][8], own1[ITER], own2[ITER];
     uint4 pk[ITER];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int row = row0 + it * RSTEP, gm = m0 + row;
-      const bool ok = gm < M;
+      const bool ok = gm < M && row < rlim;
       float v[8];
       {
         const float4 a = *reinterpret_cast<const float4*>(sC + row * CLD + cc);
@@ -538,14 +539,14 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
         const int gm = m0 + row0 + it * RSTEP;
-        if (gm < M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)gm * e.ldc + gn) = pk[it];
+        if (gm < M && row0 + it * RSTEP < rlim) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)gm * e.ldc + gn) = pk[it];
       }
     }
     // a few lanes watch ONE row's slots (the block's last row, one lane per peer) until every peer has published; only
     // then does every thread fetch its own slots.  [All threads polling from the start: 30.7 us a launch against
     // 13.9 + 7.0 for the two launches; a few lanes of every wave: 23.4 us; this: 20.0 us through memory.]
     {
-      const int grep = min(m0 + BM, M) - 1;
+      const int grep = min(m0 + rlim, M) - 1;
       if (tid < np && tid != tn) {
         unsigned long long a, b;
         slot_wait(e.sy_slots + ((size_t)grep * np + tid) * 2, a, b, false);
@@ -556,7 +557,7 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int row = row0 + it * RSTEP, gm = m0 + row;
-      const bool ok = gm < M;
+      const bool ok = gm < M && row < rlim;
       float ps[2] = {0.f, 0.f}, pm[2] = {0.f, 0.f};
       bool have[2] = {false, false};
 #pragma unroll

@@ -257,6 +257,36 @@ class Engine(object):
                       s_out.ptr if s_out is not None else None, y.ptr, hip.ptr(mean), hip.ptr(rstd), slots.data_ptr(),
                       slots.numel(), meta.data_ptr(), self._sync_site, meta.data_ptr() + 4, self.stream)
 
+    def attn_out_ln(self, q, k, v, att, lse, B, nh, Lq, Lk, d, kmask, causal, attn_drop_p, attn_sid, Wo, bias, residual,
+                    gamma, beta, y, s_out=None, mean=None, rstd=None, drop_p=0.0, sid=0, kv_group=1):
+        """Attention forward + o_map + residual + LayerNorm in one launch (zk_attn_out_ln).  False (nothing launched)
+        when the shape is not covered: the caller issues attn_fwd and gemm_add_ln."""
+        if self.__dict__.get("_sync_site", 255) >= 255:
+            self.ln_epoch_bump()
+        M, N = B * Lq, nh * d
+        slots, meta = self.sync_ln_state(M, N)
+        need = self.lib.query("zk_attn_out_ln_flags", B, nh)
+        fl = self.__dict__.get("_sync_flags")
+        if fl is None or fl.numel() < need:
+            if fl is not None:
+                self.realloc_gen += 1
+            fl = self._sync_flags = torch.empty(max(int(need), 1 << 16), dtype=torch.uint8, device=self.device)
+            self.zero(fl)
+        args = (q.ptr, k.ptr, v.ptr, att.ptr, hip.ptr(lse), B, nh, Lq, Lk, d, q.ld, k.ld, v.ld, att.ld, hip.ptr(kmask),
+                1 if causal else 0, float(d) ** -0.5, zdtype.inf(), float(attn_drop_p), self.seed.data_ptr(), attn_sid, kv_group,
+                Wo.ptr, Wo.ld, hip.ptr(bias), residual.ptr, residual.ld, float(drop_p), sid, gamma.data_ptr(), beta.data_ptr(),
+                zdtype.epsilon(), s_out.ptr if s_out is not None else None, y.ptr, hip.ptr(mean), hip.ptr(rstd),
+                slots.data_ptr(), slots.numel(), fl.data_ptr(), fl.numel(), meta.data_ptr(), self._sync_site + 1,
+                meta.data_ptr() + 4, self.stream)
+        self.lib.ncalls += 1
+        rc = self.lib.raw("zk_attn_out_ln")(*args)
+        if rc == 2:
+            return False
+        if rc != 0:
+            self.lib.call("zk_attn_out_ln", *args)      # raises with the library's message
+        self._sync_site += 1
+        return True
+
     def gemm_ln_bwd(self, dY, W, M, N, K, residual, s, mean, rstd, gamma, dsum, dy_out, partials, drop_p=0.0, sid=0):
         """dgrad dY @ W^T (+ residual) and the backward of the residual + LayerNorm it feeds, in one launch."""
         if self.__dict__.get("_sync_site", 255) >= 255:

@@ -142,7 +142,9 @@ class TransformerCore(object):
         # is an experiment: only in a `make EXPERIMENTS=1` library, only with ZERO_HIP_LAZY_LN=1.
         self.lazy_ln_mode = os.environ.get("ZERO_HIP_LAZY_LN", "0").lower() if self.eng.lib.experiments else "0"
         self.sync_ln_mode = os.environ.get("ZERO_HIP_SYNC_LN", "1") != "0"
+        # (A/B: "noattn" keeps the attention forward a launch of its own, "fwd" also the LayerNorm backward)
         self.sync_ln_bwd = os.environ.get("ZERO_HIP_SYNC_LN", "1") != "fwd"
+        self.sync_attn = os.environ.get("ZERO_HIP_SYNC_LN", "1") not in ("noattn", "fwd", "0")
         self._sync_ln = False
         # The update of the weight matrices inside the weight-gradient launch (round 4; zk_gemm_grouped_update): set by the
         # Trainer for a step whose update is norm-free, single-rank and unaccumulated; the backward's one grouped launch
@@ -393,6 +395,25 @@ class TransformerCore(object):
                      e.buf(tag + ".mean", (T,), F32), e.buf(tag + ".rstd", (T,), F32), 0.0, sid)
         return out
 
+    def _attn_out_ln(self, q, k, v, att, lse, B, Lq, Lk, kmask, causal, attn_drop, attn_sid, lin, x, scope, tag, save,
+                     drop_p, sid):
+        """attention + o_map + residual + LayerNorm in one launch when the in-launch LayerNorm is on and the shape is
+        covered (zk_attn_out_ln: no relative positions, Lq <= 64, Lk <= 256, 64-wide heads); None otherwise."""
+        e, H = self.eng, self.H
+        if not (self._sync_ln and self.sync_attn and not self.rpr and not e.lib.recording and self.d == 64 and
+                Lq <= 64 and Lk <= 256 and e.attn_impl in (0, 2)):
+            return None
+        T = x.rows
+        Wm = self.W(lin + "/W_0_0")
+        out = e.mat(tag + ".o", T, H)
+        s = e.mat(tag + ".s", T, H) if save else None
+        mean = e.buf(tag + ".mean", (T,), F32) if save else None
+        rstd = e.buf(tag + ".rstd", (T,), F32) if save else None
+        ok = e.attn_out_ln(q, k, v, att, lse, B, self.nh, Lq, Lk, self.d, kmask, causal, attn_drop, attn_sid, Wm,
+                           self.b(lin + "/b_0"), x, self.b(scope + "/layer_norm/scale"), self.b(scope + "/layer_norm/offset"),
+                           out, s, mean, rstd, drop_p, sid)
+        return out if ok else None
+
     def _ln_fwd(self, x, y, scope, tag, save, drop_p, sid):
         T, H = x.rows, self.H
         e = self.eng
@@ -418,6 +439,11 @@ class TransformerCore(object):
         lse = e.buf(tag + ".lse", (B * self.nh * L,), F32) if save else None
         rk = self.store.s(p + "rpr_keys/embeddings") if self.rpr else None
         rv = self.store.s(p + "rpr_values/embeddings") if self.rpr else None
+        out = self._attn_out_ln(qkv.cols_slice(0, H), qkv.cols_slice(H, 2 * H), qkv.cols_slice(2 * H, 3 * H), att, lse, B, L, L,
+                                kmask, causal, hp.attention_dropout if train else 0.0, sid0, p + "o_map", x, scope, tag, save,
+                                hp.residual_dropout if train else 0.0, sid0 + 1)
+        if out is not None:
+            return out
         e.attn_fwd(qkv.cols_slice(0, H), qkv.cols_slice(H, 2 * H), qkv.cols_slice(2 * H, 3 * H), att, lse, B,
                    self.nh, L, L, self.d, kmask=kmask, causal=causal, rpr_k=rk, rpr_v=rv,
                    max_rel=hp.max_relative_position, drop_p=hp.attention_dropout if train else 0.0, sid=sid0)
@@ -451,6 +477,12 @@ class TransformerCore(object):
         lse = e.buf(tag + ".lse", (B * self.nh * Lq,), F32) if save else None
         rk = self.store.s(p + "rpr_keys/embeddings") if self.rpr else None
         rv = self.store.s(p + "rpr_values/embeddings") if self.rpr else None
+        if fuse_tmask is None:
+            out = self._attn_out_ln(q, kv.cols_slice(0, H), kv.cols_slice(H, 2 * H), att, lse, B, Lq, Lk, kmask, False,
+                                    hp.attention_dropout if train else 0.0, sid0, p + "o_map", x, scope, tag, save,
+                                    hp.residual_dropout if train else 0.0, sid0 + 1)
+            if out is not None:
+                return out
         e.attn_fwd(q, kv.cols_slice(0, H), kv.cols_slice(H, 2 * H), att, lse, B, self.nh, Lq, Lk, self.d,
                    kmask=kmask, causal=False, rpr_k=rk, rpr_v=rv, max_rel=hp.max_relative_position,
                    drop_p=hp.attention_dropout if train else 0.0, sid=sid0)
