@@ -104,11 +104,12 @@ HBM_PEAK_TBS = 8.0               # same guide: HBM3E peak
 # kernel classes of the step (roofline.by_class): name -> (bound, what it holds)
 CLASSES = (
     ("small_gemm_chain", "mfma", "linear forward + dgrad on the 4096-row activations (k_gemm_dlds tiles; 58 of them carry a "
-                                 "residual + LayerNorm forward or backward in their epilogue), grouped K/V projections, "
-                                 "K-segmented d(encoder output)"),
+                                 "residual + LayerNorm forward or backward in their epilogue, 18 of those also the "
+                                 "attention forward of their sub-layer), grouped K/V projections, K-segmented d(encoder "
+                                 "output)"),
     ("big_gemms", "mfma", "all weight gradients (one grouped launch of 256x256 tiles), logits forward, dlogits x E"),
-    ("attention", "hbm", "attention forward / backward, one (sentence, head) tile per workgroup (backward incl. the "
-                         "folded o_map dgrad)"),
+    ("attention", "hbm", "attention backward, one (sentence, head) tile per workgroup, incl. the folded o_map dgrad (the "
+                         "forward runs inside the output-projection launches of small_gemm_chain)"),
     ("layernorm", "hbm", "residual + LayerNorm launches that remain (the backward at the top of each stack; the other 58 of "
                          "60 run inside small_gemm_chain launches)"),
     ("cross_entropy", "hbm", "label-smoothed cross entropy: fp32 logits in, bf16 dlogits out"),
@@ -149,7 +150,7 @@ class LaunchProfiler(object):
         eng = self.eng
         keep = self._saved
         for k in ("gemm", "gemm_grouped", "gemm_grouped_update", "gemm_kseg", "attn_fwd", "attn_bwd", "add_ln_fwd",
-                  "add_ln_bwd", "ce_fused", "gemm_add_ln", "gemm_ln_bwd",
+                  "add_ln_bwd", "ce_fused", "gemm_add_ln", "gemm_ln_bwd", "attn_out_ln",
                   "gemm_ln", "ln_fold", "add_ln_bwd_lazy"):      # (the last three: the EXPERIMENTS-only LayerNorm-free forward)
             keep[k] = getattr(eng, k)
         esz = lambda m: m.t.element_size()
@@ -233,6 +234,22 @@ class LaunchProfiler(object):
             return self._timed("small_gemm_chain", name, 2.0 * M * N * K, nbytes,
                                lambda: keep["gemm_add_ln"](A, Bm, M, N, K, *a, **kw))
 
+        def attn_out_ln(q, k, v, att, lse, Bn, nh, Lq, Lk, d, *a, **kw):
+            # attention forward + o_map + residual + LayerNorm in one launch (zk_attn_out_ln): booked with the chain (its
+            # larger part); falls back to the two launches (booked by their own wrappers) when it returns False
+            H = nh * d
+            M = Bn * Lq
+            fl = 4.0 * Bn * Lq * Lk * H + 2.0 * M * H * H
+            by = (2 * Bn * Lq + 2 * Bn * Lk) * H * 2 + (M * H + H * H) * 2 + 3 * M * H * 2
+            nkt = (Lk + 63) // 64
+            s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            ok = keep["attn_out_ln"](q, k, v, att, lse, Bn, nh, Lq, Lk, d, *a, **kw)
+            e0.record()
+            if ok:
+                self.records.append(("small_gemm_chain", "k_attn_out_ln<%d>" % nkt, fl, float(by), s0, e0))
+            return ok
+
         def gemm_ln_bwd(dY, W, M, N, K, *a, **kw):
             # dgrad + the LayerNorm backward its result feeds (zk_gemm_ln_bwd): operands, residual and saved sum read,
             # ds and dy written (the dgrad result itself never leaves the workgroup)
@@ -261,7 +278,7 @@ class LaunchProfiler(object):
         for k, fn in (("gemm", gemm), ("gemm_grouped", gemm_grouped), ("gemm_grouped_update", gemm_grouped_update_timed),
                       ("gemm_kseg", gemm_kseg), ("attn_fwd", attn_fwd),
                       ("attn_bwd", attn_bwd), ("add_ln_fwd", add_ln_fwd), ("add_ln_bwd", add_ln_bwd), ("ce_fused", ce_fused),
-                      ("gemm_add_ln", gemm_add_ln), ("gemm_ln_bwd", gemm_ln_bwd),
+                      ("gemm_add_ln", gemm_add_ln), ("gemm_ln_bwd", gemm_ln_bwd), ("attn_out_ln", attn_out_ln),
                       ("gemm_ln", gemm_ln), ("ln_fold", ln_fold), ("add_ln_bwd_lazy", add_ln_bwd_lazy)):
             setattr(eng, k, fn)
         if self.top is not None:

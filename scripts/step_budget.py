@@ -51,7 +51,7 @@ class Budget(object):
         r["floor"] += n * t
         r["fixed"] += n * FIXED
 
-    def gemm(self, cls, n, M, N, K, out_bytes=2, extra_in=0.0, tile=None, splits=None):
+    def gemm(self, cls, n, M, N, K, out_bytes=2, extra_in=0.0, tile=None, splits=None, extra_flops=0.0):
         bm, bn, s = plan(M, N, K, 1 if out_bytes == 4 else 0)
         if tile is not None:
             bm, bn = tile
@@ -60,7 +60,7 @@ class Budget(object):
         tiles = -(-M // bm) * -(-N // bn)
         staged = tiles * (bm + bn) * K * 2.0
         hbm = (M * K + K * N) * 2.0 + M * N * out_bytes + extra_in
-        self.add(cls, n, 2.0 * M * N * K, hbm, staged)
+        self.add(cls, n, 2.0 * M * N * K + extra_flops, hbm, staged)
 
 
 def build(B, L=64, H=512, F=2048, V=32000, NE=6, ND=6, nh=8, sync_ln=True):
@@ -71,6 +71,8 @@ def build(B, L=64, H=512, F=2048, V=32000, NE=6, ND=6, nh=8, sync_ln=True):
     T = B * L
     b = Budget()
     act = T * H * 2.0                     # one bf16 activation
+    # (zk_attn_out_ln: the attention forward of a sub-layer runs in its output-projection launch: q, k, v in, att out)
+    af, ab_ = (4.0 * B * L * L * H, 4 * act) if sync_ln else (0.0, 0.0)
     fw = 2 * act if sync_ln else 0.0      # forward tail: residual in, saved sum out
     bw = 2 * act if sync_ln else 0.0      # backward: saved sum in, dy out (ds takes the place of dx)
     t64 = (64, 64) if sync_ln else None
@@ -78,7 +80,7 @@ def build(B, L=64, H=512, F=2048, V=32000, NE=6, ND=6, nh=8, sync_ln=True):
     c = "small GEMM chain (linear fwd + dgrad, %d-row)" % T
     for _ in range(NE):
         b.gemm(c, 1, T, 3 * H, H)                        # qkv
-        b.gemm(c, 1, T, H, H, extra_in=fw, tile=t64)     # o_map (+ residual + LayerNorm)
+        b.gemm(c, 1, T, H, H, extra_in=fw + ab_, tile=t64, extra_flops=af)     # o_map (+ attention forward + residual + LayerNorm)
         b.gemm(c, 1, T, F, H)                            # ffn enlarge
         b.gemm(c, 1, T, H, F, extra_in=fw, tile=t64)     # ffn output (+ residual + LayerNorm)
         b.gemm(c, 1, T, H, 3 * H, extra_in=act + bw, tile=t64)     # d qkv -> dx (+ residual) (+ LayerNorm backward below)
@@ -86,8 +88,9 @@ def build(B, L=64, H=512, F=2048, V=32000, NE=6, ND=6, nh=8, sync_ln=True):
         b.gemm(c, 1, T, F, H, extra_in=T * F * 2.0)      # d ffn output (ReLU mask)
         b.gemm(c, 1, T, H, F, extra_in=act + bw, tile=t64)         # d ffn enlarge (+ residual) (+ LayerNorm backward below)
     for _ in range(ND):
-        for (n_, k_, ln) in ((3 * H, H, 0), (H, H, 1), (H, H, 0), (H, H, 1), (F, H, 0), (H, F, 1)):      # self qkv, o, cross q, o, ffn
-            b.gemm(c, 1, T, n_, k_, extra_in=fw if ln else 0.0, tile=t64 if ln else None)
+        for (n_, k_, ln) in ((3 * H, H, 0), (H, H, 2), (H, H, 0), (H, H, 2), (F, H, 0), (H, F, 1)):      # self qkv, o, cross q, o, ffn
+            b.gemm(c, 1, T, n_, k_, extra_in=(fw if ln else 0.0) + (ab_ if ln == 2 else 0.0), tile=t64 if ln else None,
+                   extra_flops=af if ln == 2 else 0.0)
         for (n_, k_, ex, ln) in ((H, 3 * H, act, 1), (H, H, act, 1), (F, H, T * F * 2.0, 0), (H, F, act, 1)):     # d qkv, d q, d ffn x 2
             b.gemm(c, 1, T, n_, k_, extra_in=ex + (bw if ln else 0.0), tile=t64 if ln else None)
     # cross-attention K/V of all layers (one grouped launch), d(encoder output) (one K-segmented launch)
@@ -114,7 +117,8 @@ def build(B, L=64, H=512, F=2048, V=32000, NE=6, ND=6, nh=8, sync_ln=True):
     # ---- attention (func.py:218-256): forward reads q, k, v, writes out; backward reads q, k, v, dO, writes dq, dk, dv
     c5 = "attention forward / backward (one (sentence, head) tile per workgroup)"
     n_att = NE + 2 * ND
-    b.add(c5, n_att, 4.0 * B * L * L * H, 4 * act)
+    if not sync_ln:
+        b.add(c5, n_att, 4.0 * B * L * L * H, 4 * act)
     # backward: + the o_map dgrad of its (sentence, head): 2 T H H FLOPs, W_o once, per workgroup 64 x H of dY and of W_o staged
     b.add(c5, n_att, 10.0 * B * L * L * H + 2.0 * T * H * H, 7 * act + H * H * 2.0, B * nh * 2 * 64 * H * 2.0)
     # ---- residual + LayerNorm
@@ -151,6 +155,8 @@ def measured(path):
         elif "k_gemm_grouped<128, 128" in name or "k_gemm_kseg" in name:
             cls = "grouped K/V projections + K-segmented d(enc)"
         elif "k_gemm_dlds" in name:
+            cls = "small GEMM chain"
+        elif "k_attn_out_ln" in name:
             cls = "small GEMM chain"
         elif "k_attn" in name:
             cls = "attention forward / backward"

@@ -24,7 +24,7 @@ def test_step_budget_enumerates_the_step():
     assert abs(nparam - 76.8e6) < 0.2e6                      # Transformer-base, V = 32000, tied target / softmax table
     rows = b.rows
     n = sum(r["n"] for r in rows.values())
-    assert 160 <= n <= 170, n                                # the launches of the step (round 4: 58 LayerNorm launches run inside GEMM launches)
+    assert 140 <= n <= 152, n                                # the launches of the step (round 4: 58 LayerNorm and 18 attention-forward launches run inside GEMM launches)
     old_rows = sb.build(64, sync_ln=False)[0].rows
     assert 215 <= sum(r["n"] for r in old_rows.values()) <= 230     # rounds 1-3: the hipGraph held 219 nodes
     assert abs(sum(r["flops"] for r in old_rows.values()) - sum(r["flops"] for r in rows.values())) < 1e6
