@@ -83,6 +83,21 @@ int zk_attn_out_ln(const void* q, const void* k, const void* v, void* att, float
                    const float* beta, float eps, void* s_out, void* y, float* mean, float* rstd, void* slots,
                    size_t slots_bytes, void* flags, size_t flags_bytes, const uint32_t* epoch, uint32_t site, int* err,
                    zk_stream_t stream);
+#ifdef ZK_EXPERIMENTS   /* measured, no gain over the two launches (profiles/r04_negative_results.txt item 8) */
+/* Attention backward (single-tile path of zk_attn_bwd with the o_map dgrad folded in: d = 64, Lq, Lk <= 64, no relative
+ * positions) + the dgrad dx = dA W^T + residual that consumes its dq / dk / dv (dA [B*Lq, K]: the matrix they are columns of)
+ * + the LayerNorm backward of the sub-layer below (as zk_gemm_ln_bwd), one launch: workgroup (sentence, head) computes its
+ * head's gradients, waits for the sentence's heads, runs its 64-column dgrad tile.  partials: [B][3][nh*64] (one row per
+ * sentence).  flags: zk_attn_out_ln_flags bytes, zero-filled once.  Returns 2 (nothing launched) when not covered. */
+int zk_attn_bwd_ln(const void* q, const void* k, const void* v, const void* out, const float* lse, void* dq, void* dk, void* dv,
+                   int B, int nh, int Lq, int Lk, int d, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
+                   const float* kmask, int causal, float scale, float mask_inf, float attn_drop_p, const uint64_t* seed,
+                   uint32_t attn_sid, const void* oproj_dy, int oproj_lddy, const void* oproj_w, int oproj_ldw, int oproj_n,
+                   const void* dA, int lda, const void* W, int ldw, int K, const void* residual, int ldr, const void* s,
+                   const float* mean, const float* rstd, const float* gamma, float drop_p, uint32_t sid, void* dsum,
+                   void* dy_out, float* partials, void* slots, size_t slots_bytes, void* flags, size_t flags_bytes,
+                   const uint32_t* epoch, uint32_t site, int* err, zk_stream_t stream);
+#endif
 size_t zk_gemm_ln_bwd_partials(int rows, int N);
 int zk_gemm_ln_bwd(const void* dY, const void* W, int M, int N, int K, int lda, int ldb, const void* residual, int ldr,
                    const void* s, const float* mean, const float* rstd, const float* gamma, float drop_p,

@@ -547,6 +547,60 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_fused64(AttnArgs a, const b
                                     rpr_part, op);
 }
 
+#ifdef ZK_EXPERIMENTS   // measured, no gain over the two launches (profiles/r04_negative_results.txt item 8)
+// ---- attention backward + the dgrad that consumes its dq / dk / dv + the LayerNorm backward below, ONE launch
+// (zk_attn_bwd_ln; the mirror of k_attn_out_ln): workgroup (sentence b, head h) -- 256 threads, the grid of the 64x64 tiles
+// of the dgrad with sentence-aligned row tiles -- runs the single-tile attention backward of its (b, h) with the o_map dgrad
+// folded in (attn_bwd_fused64_tile<false, true>, unchanged), which writes its 64 columns of dQ / dK / dV; once the nh heads
+// of the sentence have raised their flags it runs its tile of   dx = [dQ dK dV](b) W_qkv^T (+ ds)   (or dQ W_q^T for the
+// cross-attention) with the LayerNorm-backward epilogue of zk_gemm_ln_bwd (gemm_tile<.., LN = 4>, four waves issuing
+// their own LDS-DMA).  Visibility as in k_attn_out_ln.
+__global__ void __launch_bounds__(256, 2) k_attn_bwd_ln(AttnArgs a, const bf16_t* __restrict__ o, int ldo,
+                                                        const float* __restrict__ lse, bf16_t* __restrict__ dq, int lddq,
+                                                        bf16_t* __restrict__ dk, int lddk, bf16_t* __restrict__ dv, int lddv,
+                                                        AttnOProj op, const bf16_t* __restrict__ dA, int lda,
+                                                        const bf16_t* __restrict__ W, int ldw, int K, int M, int N,
+                                                        TileSched ts, GemmEpi e, unsigned long long* __restrict__ flags) {
+  constexpr int GEMM_LDS = DldsCfg<64, 64, 4>::LDS_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[GEMM_LDS > ATTN_BWD64_LDS_BYTES ? GEMM_LDS : ATTN_BWD64_LDS_BYTES];
+  int tm, tn, z;
+  tile_of_block(ts, tm, tn, z);                   // tm: sentence, tn: head
+  const int tid = threadIdx.x;
+  attn_bwd_fused64_tile<false, true>(smem, a, o, ldo, nullptr, 0, lse, dq, lddq, dk, lddk, dv, lddv, tn, tm, nullptr, op);
+  const bool local = e.sy_local != 0;
+  const uint32_t tag = (*e.sy_epoch << 8) | e.sy_site;
+  unsigned long long* fl = flags + (size_t)tm * a.nh;
+  __builtin_amdgcn_s_waitcnt(0);                  // this thread's rows of dQ / dK / dV have reached the L2
+  __syncthreads();
+  if (tid == 0) {
+    if (local) __hip_atomic_store(fl + tn, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    else __hip_atomic_store(fl + tn, (unsigned long long)tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid < a.nh && tid != tn) {
+    int spins = 0;
+    for (;;) {
+      unsigned long long v;
+      if (local) {
+        const unsigned long long zero = 0;
+        asm volatile("global_atomic_or_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(fl + tid), "v"(zero) : "memory");
+      } else {
+        v = __hip_atomic_load(fl + tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if ((uint32_t)v == tag) break;
+      if (++spins > (1 << 15)) {
+        if (e.sy_err != nullptr) __hip_atomic_store(e.sy_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  __syncthreads();
+  if (!local) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  gemm_tile<64, 64, 4, false, true, 4, 0, false, false, 4>(smem, dA, W, M, N, lda, ldw, 0, K, tm * a.Lq, tn * 64, nullptr, e, 1);
+}
+
+#endif  // ZK_EXPERIMENTS
+
 // relative positions folded in, tiles taking turns in 72 KB of LDS: two workgroups per CU (attn_bwd_rpr64_tile)
 __global__ void __launch_bounds__(256, 2) k_attn_bwd_rpr64(AttnArgs a, const bf16_t* __restrict__ dout, int lddo,
                                                            const float* __restrict__ lse, bf16_t* __restrict__ dq, int lddq,
@@ -742,6 +796,70 @@ int zk_attn_out_ln(const void* q, const void* k, const void* v, void* att, float
   ZK_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef ZK_EXPERIMENTS   // measured, no gain over the two launches (profiles/r04_negative_results.txt item 8)
+// Attention backward + the dgrad of the projection(s) in front of it + the LayerNorm backward of the sub-layer below, one
+// launch (see k_attn_bwd_ln).  The attention arguments of zk_attn_bwd on its single-tile path with the o_map dgrad folded in
+// (d = 64, Lq, Lk <= 64, no relative positions; (oproj_dy, oproj_w): dO = dY W_o[h*64.., :]^T); dq / dk / dv are written as
+// before (the weight gradients read them).  Then dx = dA W^T + residual with dA [B*Lq, K] = the matrix dq (dk, dv) are
+// columns of (K = 3 nh 64 for a merged q/k/v projection, nh 64 for a query projection), W [N = nh*64, ldw] K-contiguous,
+// and the arguments of zk_gemm_ln_bwd for the LayerNorm below; partials: [B][3][N] (one row per SENTENCE: nblk = B for the
+// reduction).  flags: zk_attn_out_ln_flags(B, nh) bytes, zero-filled once (may be the forward's).  Returns 2 without
+// launching when the shape is not covered.
+int zk_attn_bwd_ln(const void* q, const void* k, const void* v, const void* out, const float* lse, void* dq, void* dk, void* dv,
+                   int B, int nh, int Lq, int Lk, int d, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
+                   const float* kmask, int causal, float scale, float mask_inf, float attn_drop_p, const uint64_t* seed,
+                   uint32_t attn_sid, const void* oproj_dy, int oproj_lddy, const void* oproj_w, int oproj_ldw, int oproj_n,
+                   const void* dA, int lda, const void* W, int ldw, int K, const void* residual, int ldr, const void* s,
+                   const float* mean, const float* rstd, const float* gamma, float drop_p, uint32_t sid, void* dsum,
+                   void* dy_out, float* partials, void* slots, size_t slots_bytes, void* flags, size_t flags_bytes,
+                   const uint32_t* epoch, uint32_t site, int* err, hipStream_t stream) {
+  const int N = nh * AD, M = B * Lq;
+  if (d != AD || Lq < 1 || Lq > TQ || Lk < 1 || Lk > TQ || N > 1024 || K < 64 || K % 64 != 0) return 2;
+  ZK_CHECK_ARG(oproj_dy != nullptr && oproj_w != nullptr, "zk_attn_bwd_ln: the (dY, W_o) pair is required");
+  ZK_CHECK_ARG(s != nullptr && mean != nullptr && rstd != nullptr && gamma != nullptr && dsum != nullptr && partials != nullptr,
+               "zk_attn_bwd_ln: s, mean, rstd, gamma, dsum and partials are required");
+  ZK_CHECK_ARG(residual == nullptr || ldr % 8 == 0, "zk_attn_bwd_ln: residual row stride must be a multiple of 8");
+  ZK_CHECK_ARG((attn_drop_p == 0.f && drop_p == 0.f) || seed != nullptr, "zk_attn_bwd_ln: dropout needs a seed pointer");
+  ZK_CHECK_ARG(drop_p == 0.f || dy_out != nullptr, "zk_attn_bwd_ln: dropout needs dy_out");
+  ZK_CHECK_ARG(slots != nullptr && flags != nullptr && epoch != nullptr && site >= 1 && site <= 255,
+               "zk_attn_bwd_ln: slots, flags, epoch and a site in 1..255 are required");
+  ZK_CHECK_ARG(slots_bytes >= (size_t)((M + 127) / 128 * 128) * (size_t)(N / 64) * 16 && flags_bytes >= zk_attn_out_ln_flags(B, nh),
+               "zk_attn_bwd_ln: slots / flags too small");
+  if (B == 0) return 0;
+  AttnArgs a;
+  fill_args(&a, q, k, v, ldq, ldk, ldv, B, nh, Lq, Lk, d, kmask, causal, 0, scale, mask_inf, nullptr, nullptr, 0, attn_drop_p,
+            seed, attn_sid);
+  const bool shape = oproj_n >= 128 && oproj_n % 128 == 0 && oproj_lddy % 8 == 0 && oproj_ldw % 8 == 0 &&
+                     oproj_lddy >= oproj_n && oproj_ldw >= oproj_n && ((((uintptr_t)oproj_dy | (uintptr_t)oproj_w) & 15) == 0);
+  const uintptr_t al = (uintptr_t)out | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)dA | (uintptr_t)W |
+                       (uintptr_t)residual | (uintptr_t)s | (uintptr_t)gamma | (uintptr_t)dsum | (uintptr_t)dy_out |
+                       (uintptr_t)partials | (uintptr_t)slots | (uintptr_t)flags;
+  if (!attn_mfma_ok(a, ldo | lddq | lddk | lddv | lda | ldw) || !shape || (al & 15) != 0 || zk_prog_active()) return 2;
+  AttnOProj op = {(const bf16_t*)oproj_dy, oproj_lddy, (const bf16_t*)oproj_w, oproj_ldw, oproj_n};
+  GemmEpi e;
+  e.C = nullptr; e.ldc = N; e.out_f32 = 0; e.alpha = 1.f; e.bias = nullptr;
+  e.res = (const bf16_t*)residual; e.ldr = ldr; e.act = 0; e.aux = nullptr; e.ldaux = 0; e.aux_scale = 1.f;
+  e.thr = drop_p > 0.f ? zk_drop_threshold(drop_p) : 0;
+  e.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  e.seed = seed; e.sid = sid;
+  e.ln_invh = 1.f / (float)N;
+  e.sy_slots = (unsigned long long*)slots; e.sy_epoch = epoch; e.sy_site = site;
+  e.sy_gamma = gamma; e.sy_y = (bf16_t*)dsum; e.sy_ldy = N; e.sy_err = err;
+  e.sy_s = (const bf16_t*)s; e.sy_lds = N; e.sy_mean_in = mean; e.sy_rstd_in = rstd;
+  e.sy_dy = (bf16_t*)dy_out; e.sy_part = partials; e.sy_rows = Lq;
+  TileSched ts;
+  ts.tiles_m = B; ts.tiles_n = nh; ts.n_major = 0; ts.xcd_remap = 1;
+  const long nwg = (long)B * nh;
+  e.sy_local = (nwg % (8 * nh) == 0 && !(g_tune[15] & 1)) ? 1 : 0;
+  hipLaunchKernelGGL(k_attn_bwd_ln, dim3((unsigned)nwg), dim3(256), 0, stream, a, (const bf16_t*)out, ldo, lse, (bf16_t*)dq,
+                     lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, op, (const bf16_t*)dA, lda, (const bf16_t*)W, ldw, K, M, N, ts, e,
+                     (unsigned long long*)flags);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+#endif  // ZK_EXPERIMENTS
 
 size_t zk_attn_bwd_workspace(int B, int nh, int Lq) { return (size_t)B * nh * Lq * sizeof(float); }
 

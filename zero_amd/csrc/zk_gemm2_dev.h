@@ -591,12 +591,14 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
     if constexpr (LN == 4) {
       // backward of the residual + LayerNorm whose input gradient this product completes (GemmEpi.sy_s ..): see zk_gemm.h
       static_assert(ITER <= 4, "lbv holds (mu, rstd) of at most four rows");
+      // sentence-aligned row tiles (zk_attn_bwd_ln): only the first sy_rows rows are this tile's, one partial row per tile
+      const int rlim = e.sy_rows > 0 ? e.sy_rows : BM, pidx = e.sy_rows > 0 ? m0 / e.sy_rows : m0 / BM;
       float* red = reinterpret_cast<float*>(smem);         // [3][BM][64] column-partial staging (the fp32 tile is consumed first)
       float d[ITER][8], xh[ITER][8], g[ITER][8], own1[ITER], own2[ITER];
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
         const int row = row0 + it * RSTEP, gm = m0 + row;
-        const bool ok = gm < M;
+        const bool ok = gm < M && row < rlim;
         float v[8];
         {
           const float4 a = *reinterpret_cast<const float4*>(sC + row * CLD + cc);
@@ -651,10 +653,10 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
         float t = 0.f;
 #pragma unroll 8
         for (int r = 0; r < BM; ++r) t += red[(q * BM + r) * 64 + col];
-        e.sy_part[((size_t)(m0 / BM) * 3 + q) * N + n0 + col] = t;
+        e.sy_part[((size_t)pidx * 3 + q) * N + n0 + col] = t;
       }
       {
-        const int grep = min(m0 + BM, M) - 1;
+        const int grep = min(m0 + rlim, M) - 1;
         if (tid < np && tid != tn) {
           unsigned long long a, b;
           slot_wait(e.sy_slots + ((size_t)grep * np + tid) * 2, a, b, false);
@@ -665,7 +667,7 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
         const int row = row0 + it * RSTEP, gm = m0 + row;
-        const bool ok = gm < M;
+        const bool ok = gm < M && row < rlim;
         float ps[2] = {0.f, 0.f}, pm[2] = {0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -708,7 +710,7 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
         float t = 0.f;
 #pragma unroll 8
         for (int r = 0; r < BM; ++r) t += red2[r * 64 + tid];
-        e.sy_part[((size_t)(m0 / BM) * 3 + 2) * N + n0 + tid] = t;
+        e.sy_part[((size_t)pidx * 3 + 2) * N + n0 + tid] = t;
       }
     }
     return;

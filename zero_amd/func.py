@@ -265,13 +265,7 @@ class Engine(object):
             self.ln_epoch_bump()
         M, N = B * Lq, nh * d
         slots, meta = self.sync_ln_state(M, N)
-        need = self.lib.query("zk_attn_out_ln_flags", B, nh)
-        fl = self.__dict__.get("_sync_flags")
-        if fl is None or fl.numel() < need:
-            if fl is not None:
-                self.realloc_gen += 1
-            fl = self._sync_flags = torch.empty(max(int(need), 1 << 16), dtype=torch.uint8, device=self.device)
-            self.zero(fl)
+        fl = self._sync_flags_buf(B, nh)
         args = (q.ptr, k.ptr, v.ptr, att.ptr, hip.ptr(lse), B, nh, Lq, Lk, d, q.ld, k.ld, v.ld, att.ld, hip.ptr(kmask),
                 1 if causal else 0, float(d) ** -0.5, zdtype.inf(), float(attn_drop_p), self.seed.data_ptr(), attn_sid, kv_group,
                 Wo.ptr, Wo.ld, hip.ptr(bias), residual.ptr, residual.ld, float(drop_p), sid, gamma.data_ptr(), beta.data_ptr(),
@@ -284,6 +278,43 @@ class Engine(object):
             return False
         if rc != 0:
             self.lib.call("zk_attn_out_ln", *args)      # raises with the library's message
+        self._sync_site += 1
+        return True
+
+    def _sync_flags_buf(self, B, nh):
+        need = self.lib.query("zk_attn_out_ln_flags", B, nh)
+        fl = self.__dict__.get("_sync_flags")
+        if fl is None or fl.numel() < need:
+            if fl is not None:
+                self.realloc_gen += 1
+            fl = self._sync_flags = torch.empty(max(int(need), 1 << 16), dtype=torch.uint8, device=self.device)
+            self.zero(fl)
+        return fl
+
+    def attn_bwd_ln(self, q, k, v, out, lse, dq, dk, dv, B, nh, Lq, Lk, d, kmask, causal, attn_drop_p, attn_sid, oproj,
+                    dA, W, residual, s, mean, rstd, gamma, dsum, dy_out, partials, drop_p=0.0, sid=0):
+        """Attention backward (o_map dgrad folded in: oproj = (dY Mat, W_o Mat)) + dx = dA @ W^T + residual + the LayerNorm
+        backward below, one launch (zk_attn_bwd_ln).  False (nothing launched) when the shape is not covered."""
+        if self.__dict__.get("_sync_site", 255) >= 255:
+            self.ln_epoch_bump()
+        M, N = B * Lq, nh * d
+        slots, meta = self.sync_ln_state(M, N)
+        fl = self._sync_flags_buf(B, nh)
+        dy, Wo = oproj
+        assert partials.numel() * 4 >= B * 3 * N * 4
+        args = (q.ptr, k.ptr, v.ptr, out.ptr, lse.data_ptr(), dq.ptr, dk.ptr, dv.ptr, B, nh, Lq, Lk, d, q.ld, k.ld, v.ld, out.ld,
+                dq.ld, dk.ld, dv.ld, hip.ptr(kmask), 1 if causal else 0, float(d) ** -0.5, zdtype.inf(), float(attn_drop_p),
+                self.seed.data_ptr(), attn_sid, dy.ptr, dy.ld, Wo.ptr, Wo.ld, Wo.cols, dA.ptr, dA.ld, W.ptr, W.ld, dA.cols,
+                residual.ptr if residual is not None else None, residual.ld if residual is not None else 0, s.ptr,
+                mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), float(drop_p), sid, dsum.ptr,
+                dy_out.ptr if dy_out is not None else None, partials.data_ptr(), slots.data_ptr(), slots.numel(),
+                fl.data_ptr(), fl.numel(), meta.data_ptr(), self._sync_site + 1, meta.data_ptr() + 4, self.stream)
+        self.lib.ncalls += 1
+        rc = self.lib.raw("zk_attn_bwd_ln")(*args)
+        if rc == 2:
+            return False
+        if rc != 0:
+            self.lib.call("zk_attn_bwd_ln", *args)      # raises with the library's message
         self._sync_site += 1
         return True
 
@@ -454,7 +485,7 @@ class Engine(object):
         partials the folded relative-position backward left behind (attn_bwd(defer_tables=...)).
         Two launches: column partial sums of every dY, then every final reduction."""
         key = tuple((a.ptr, o.data_ptr()) for a, o, _ in colsums) + \
-            tuple((lp[0].data_ptr(), lp[1], len(lp), lp[3].data_ptr()) for lp in ln_parts) + \
+            tuple((lp[0].data_ptr(), lp[1], lp[6] if len(lp) > 6 else None, lp[3].data_ptr()) for lp in ln_parts) + \
             tuple((pp, ns, n, dk.data_ptr()) for pp, ns, n, dk, _ in rpr_parts)
         cache = self.__dict__.setdefault("_red_cache", {})
         ent = cache.get(key)
@@ -479,7 +510,11 @@ class Engine(object):
             for lp in ln_parts:
                 pw, rows, H, dg, db, dbp = lp[:6]
                 # (7th element: the partials came from zk_gemm_ln_bwd -- one partial row per 64-row block)
-                nblk = (rows + 63) // 64 if len(lp) > 6 else lib.raw("zk_ln_bwd_blocks")(rows)
+                # (or an int: that many partial rows -- one per sentence from attn_bwd_ln)
+                if len(lp) > 6:
+                    nblk = (rows + 63) // 64 if lp[6] is True else int(lp[6])
+                else:
+                    nblk = lib.raw("zk_ln_bwd_blocks")(rows)
                 r = rd[k]
                 r.partials, r.nblk, r.nq, r.H, r.block_start = pw.data_ptr(), nblk, 3, H, rstart
                 r.out[0], r.out[1], r.out[2] = dg.data_ptr(), db.data_ptr(), hip.ptr(dbp)

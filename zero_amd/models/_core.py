@@ -145,6 +145,8 @@ class TransformerCore(object):
         # (A/B: "noattn" keeps the attention forward a launch of its own, "fwd" also the LayerNorm backward)
         self.sync_ln_bwd = os.environ.get("ZERO_HIP_SYNC_LN", "1") != "fwd"
         self.sync_attn = os.environ.get("ZERO_HIP_SYNC_LN", "1") not in ("noattn", "fwd", "0")
+        # the attention BACKWARD inside the dgrad launch: measured, no gain (EXPERIMENTS=1 library, ZERO_HIP_SYNC_LN=attnbwd)
+        self.sync_attn_bwd = os.environ.get("ZERO_HIP_SYNC_LN", "1") == "attnbwd" and self.eng.lib.experiments
         self._sync_ln = False
         # The update of the weight matrices inside the weight-gradient launch (round 4; zk_gemm_grouped_update): set by the
         # Trainer for a step whose update is norm-free, single-rank and unaccumulated; the backward's one grouped launch
@@ -338,6 +340,31 @@ class TransformerCore(object):
                 return
             self.eng.gemm(dy, Wm, dx, dy.rows, Wm.rows, Wm.cols, 0, 1, residual=residual, act=act, aux=aux,
                           aux_scale=aux_scale)
+
+    def _attn_bwd_ln(self, q, k, v, att, lse, dq, dk, dv, B, Lq, Lk, kmask, causal, attn_sid, oproj, dA, Wm, residual):
+        """attention backward + the dgrad of the projection in front of it + the LayerNorm backward below in one launch
+        (zk_attn_bwd_ln) when self._ln_next names that LayerNorm and the shape is covered; False otherwise (the caller
+        issues attn_bwd and the dgrad)."""
+        e, H, hp = self.eng, self.H, self.hp
+        if not (self._ln_next is not None and self.sync_attn_bwd and oproj is not None and not self.rpr and self.d == 64 and
+                Lq <= 64 and Lk <= 64 and e.attn_impl in (0, 2)):
+            return False
+        scope, tag, prev_bias, drop_p, sid = self._ln_next
+        T = B * Lq
+        ds = e.mat("g.%s.ds" % tag, T, H)
+        dyo = e.mat("g.%s.dy" % tag, T, H) if drop_p > 0.0 else None
+        nbytes = max(B * 3 * H * 4, e.lib.query("zk_gemm_ln_bwd_partials", T, H), e.lib.query("zk_add_ln_bwd_workspace", T, H))
+        pws = e.buf("g.%s.lnws" % tag, (nbytes // 4,), F32)
+        ok = e.attn_bwd_ln(q, k, v, att, lse, dq, dk, dv, B, self.nh, Lq, Lk, self.d, kmask, causal, hp.attention_dropout,
+                           attn_sid, oproj, dA, Wm, residual, e.mat(tag + ".s", T, H), e.buf(tag + ".mean", (T,), F32),
+                           e.buf(tag + ".rstd", (T,), F32), self.b(scope + "/layer_norm/scale"), ds, dyo, pws, drop_p, sid)
+        if not ok:
+            return False
+        dbp = self.gb(prev_bias) if prev_bias is not None else None
+        self._pending_lnred.append((pws, T, H, self.gb(scope + "/layer_norm/scale"), self.gb(scope + "/layer_norm/offset"),
+                                    dbp, B))
+        self._ln_bwd_done[tag] = (ds, dyo if dyo is not None else ds)
+        return True
 
     def _gemm_ln_bwd(self, dy, Wm, residual, ln_next):
         e, H = self.eng, self.H
@@ -588,6 +615,12 @@ class TransformerCore(object):
         dqkv = e.mat("g.%s.dqkv" % tag, T, 3 * H)
         rk = self.store.s(p + "rpr_keys/embeddings") if self.rpr else None
         rv = self.store.s(p + "rpr_values/embeddings") if self.rpr else None
+        if self._attn_bwd_ln(qkv.cols_slice(0, H), qkv.cols_slice(H, 2 * H), qkv.cols_slice(2 * H, 3 * H), att,
+                             e.buf(tag + ".lse", (B * self.nh * L,), F32), dqkv.cols_slice(0, H), dqkv.cols_slice(H, 2 * H),
+                             dqkv.cols_slice(2 * H, 3 * H), B, L, L, kmask, causal, sid0, oproj, dqkv,
+                             self.W(p + "qkv_map/W_0_0"), ds):
+            self._linear_bwd(x_in, dqkv, p + "qkv_map", dx=None)          # the weight gradient only
+            return dx_out
         e.attn_bwd(qkv.cols_slice(0, H), qkv.cols_slice(H, 2 * H), qkv.cols_slice(2 * H, 3 * H), att, datt,
                    e.buf(tag + ".lse", (B * self.nh * L,), F32), dqkv.cols_slice(0, H), dqkv.cols_slice(H, 2 * H),
                    dqkv.cols_slice(2 * H, 3 * H), B, self.nh, L, L, self.d, kmask=kmask, causal=causal,
@@ -618,16 +651,22 @@ class TransformerCore(object):
         dkv = e.mat("g.%s.dkv" % tag, mem.rows, 2 * H)
         rk = self.store.s(p + "rpr_keys/embeddings") if self.rpr else None
         rv = self.store.s(p + "rpr_values/embeddings") if self.rpr else None
-        e.attn_bwd(q, kv.cols_slice(0, H), kv.cols_slice(H, 2 * H), att, datt,
-                   e.buf(tag + ".lse", (B * self.nh * Lq,), F32), dq, dkv.cols_slice(0, H),
-                   dkv.cols_slice(H, 2 * H), B, self.nh, Lq, Lk, self.d, kmask=kmask, causal=False,
-                   rpr_k=rk, rpr_v=rv,
-                   drpr_k=self.gb(p + "rpr_keys/embeddings") if self.rpr else None,
-                   drpr_v=self.gb(p + "rpr_values/embeddings") if self.rpr else None,
-                   max_rel=hp.max_relative_position, drop_p=hp.attention_dropout, sid=sid0,
-                   defer_tables=(self._pending_rpr, tag) if self._defer_rpr() else None, oproj=oproj)
-        self._linear_bwd(x_in, dq, p + "q_map", dx=dx_out, residual=ds,
-                         ln_next=self._ln_next if fuse_tmask is None else None)
+        if fuse_tmask is None and self._attn_bwd_ln(q, kv.cols_slice(0, H), kv.cols_slice(H, 2 * H), att,
+                                                    e.buf(tag + ".lse", (B * self.nh * Lq,), F32), dq, dkv.cols_slice(0, H),
+                                                    dkv.cols_slice(H, 2 * H), B, Lq, Lk, kmask, False, sid0, oproj, dq,
+                                                    self.W(p + "q_map/W_0_0"), ds):
+            self._linear_bwd(x_in, dq, p + "q_map", dx=None)              # the weight gradient only
+        else:
+            e.attn_bwd(q, kv.cols_slice(0, H), kv.cols_slice(H, 2 * H), att, datt,
+                       e.buf(tag + ".lse", (B * self.nh * Lq,), F32), dq, dkv.cols_slice(0, H),
+                       dkv.cols_slice(H, 2 * H), B, self.nh, Lq, Lk, self.d, kmask=kmask, causal=False,
+                       rpr_k=rk, rpr_v=rv,
+                       drpr_k=self.gb(p + "rpr_keys/embeddings") if self.rpr else None,
+                       drpr_v=self.gb(p + "rpr_values/embeddings") if self.rpr else None,
+                       max_rel=hp.max_relative_position, drop_p=hp.attention_dropout, sid=sid0,
+                       defer_tables=(self._pending_rpr, tag) if self._defer_rpr() else None, oproj=oproj)
+            self._linear_bwd(x_in, dq, p + "q_map", dx=dx_out, residual=ds,
+                             ln_next=self._ln_next if fuse_tmask is None else None)
         # memory side: the gradients of all decoder layers add up in d_mem.  Default: every layer only records its
         # (dK, W_k) / (dV, W_v) pair and ONE K-segmented GEMM sums them after the decoder (see _finish_mem_grad);
         # otherwise each layer accumulates in place.
