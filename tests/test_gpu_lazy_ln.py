@@ -212,6 +212,7 @@ def test_training_step_with_and_without_the_layernorm_free_forward(model, drop, 
     hp, Pn, src, tgt = _setup(model, seed=11, **kw)
     g = registry.get_model(model)
     res = {}
+    monkeypatch.setenv("ZERO_HIP_SYNC_LN", "0")      # against the launch structure this experiment was built on (rounds 1-3)
     for flag in ("0", "1"):
         monkeypatch.setenv("ZERO_HIP_LAZY_LN", flag)
         reset_cores()

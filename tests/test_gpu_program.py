@@ -21,6 +21,7 @@ def _run(hp, Pn, src, tgt, program, seed=11):
     reset_cores()
     core = get_core(hp, hp.model_name, Pn)
     core.eng.programs_enabled = program
+    core.sync_ln_mode = False      # the program's ops are those of the launch-per-op structure of rounds 1-3 (zk_gemm, zk_add_ln_fwd, ..)
     core.eng.set_seed(seed)
     batch = core.upload(src, tgt)
     loss, ps, _ = core.forward(batch, train=True, save=True)
