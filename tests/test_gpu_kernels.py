@@ -1085,3 +1085,40 @@ def test_grouped_wgrad_with_folded_bias_column_sums(tile):
             assert rel_err(cs, cref) < 1e-5, (i, rel_err(cs, cref))
         else:
             assert float(cs.min()) == 7.0                 # no output requested: untouched
+
+
+def test_dropout_decisions_are_fair_and_independent():
+    """The dropout hash (zk_common.h: two decisions per mixer round, 16 bits each): keep rate = 1 - p to sampling noise
+    for several p, the two halves of a pair and neighbouring pairs are independent (joint drop rate p^2), different sites
+    and seeds give different masks, and the 8-element form used by the row kernels is the per-element function."""
+    e = eng()
+    n = 1 << 22
+    msk = torch.empty(n, device="cuda")
+    for p in (0.1, 0.3, 0.5):
+        e.set_seed(123)
+        e.lib.call("zk_dropout_mask", msk.data_ptr(), n, p, e.seed.data_ptr(), 9, e.stream)
+        torch.cuda.synchronize()
+        keep = (msk > 0).double()
+        assert abs(float(msk.max()) - 1.0 / (1.0 - p)) < 1e-5
+        sd = (p * (1 - p) / n) ** 0.5
+        assert abs(float(keep.mean()) - (1 - p)) < 5 * sd + 2.0 ** -16, (p, float(keep.mean()))
+        d = 1.0 - keep
+        for lag in (1, 2, 3, 8, 512):           # within a pair, across pairs, the next row of a 512-wide matrix
+            joint = float((d[:-lag] * d[lag:]).mean())
+            assert abs(joint - p * p) < 6 * (p * p * (1 - p * p) / n) ** 0.5 + 1e-4, (p, lag, joint)
+    e.lib.call("zk_dropout_mask", msk.data_ptr(), n, 0.1, e.seed.data_ptr(), 9, e.stream)
+    m2 = torch.empty(n, device="cuda")
+    e.lib.call("zk_dropout_mask", m2.data_ptr(), n, 0.1, e.seed.data_ptr(), 10, e.stream)
+    torch.cuda.synchronize()
+    agree = float(((msk > 0) == (m2 > 0)).double().mean())
+    assert abs(agree - (0.81 + 0.01)) < 2e-3          # independent masks agree with probability (1-p)^2 + p^2
+    # the row kernels' 8-wide form == the per-element mask: residual + LayerNorm forward stores x + dropout(y)
+    T, H = 257, 512
+    x, y = rand_bf(T, H, seed=1), rand_bf(T, H, seed=2)
+    out, ssum = torch.empty_like(x), torch.empty_like(x)
+    e.add_ln_fwd(mat(x), mat(y), torch.ones(H, device="cuda"), torch.zeros(H, device="cuda"), mat(out), mat(ssum), None, None, 0.3, 21)
+    mk = torch.empty(T * H, device="cuda")
+    e.lib.call("zk_dropout_mask", mk.data_ptr(), T * H, 0.3, e.seed.data_ptr(), 21, e.stream)
+    torch.cuda.synchronize()
+    want = (x.float() + y.float() * mk.view(T, H)).to(torch.bfloat16)
+    assert torch.equal(ssum, want)

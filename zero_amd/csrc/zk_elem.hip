@@ -60,9 +60,10 @@ __global__ void __launch_bounds__(256) k_embed_fwd(
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] += tim[c + j];
       if (thr != 0) {
+        float dm[8];
+        zk_drop_scale8(seed, sid, (uint64_t)r * H + c, thr, inv_keep, dm);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          v[j] *= zk_drop_scale(seed, sid, (uint64_t)r * H + c + j, thr, inv_keep);
+        for (int j = 0; j < 8; ++j) v[j] *= dm[j];
       }
       *reinterpret_cast<uint4*>(out + (size_t)r * H + c) = pack8(v);
     }
@@ -89,9 +90,10 @@ __global__ void __launch_bounds__(256) k_embed_bwd(
       float v[8];
       unpack8(*reinterpret_cast<const uint4*>(dout + (size_t)r * H + c), v);
       if (thr != 0) {
+        float dm[8];
+        zk_drop_scale8(seed, sid, (uint64_t)r * H + c, thr, inv_keep, dm);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          v[j] *= zk_drop_scale(seed, sid, (uint64_t)r * H + c + j, thr, inv_keep);
+        for (int j = 0; j < 8; ++j) v[j] *= dm[j];
       }
       float* dst = dtable + (size_t)id * H + c;
 #pragma unroll
@@ -196,9 +198,10 @@ __global__ void __launch_bounds__(256) k_add_ln_bwd(
         *reinterpret_cast<uint4*>(dsum + (size_t)r * H + c) = p;
         unpack8(p, o);  // dy derives from the stored (rounded) ds
         if (thr != 0) {
+          float dm[8];
+          zk_drop_scale8(seed, sid, (uint64_t)r * H + c, thr, inv_keep, dm);
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            oy[j] = o[j] * zk_drop_scale(seed, sid, (uint64_t)r * H + c + j, thr, inv_keep);
+          for (int j = 0; j < 8; ++j) oy[j] = o[j] * dm[j];
           if (dy != nullptr) {
             uint4 py = pack8(oy);
             *reinterpret_cast<uint4*>(dy + (size_t)r * H + c) = py;
@@ -316,9 +319,10 @@ __global__ void __launch_bounds__(1024) k_add_ln_bwd_wide(
       *reinterpret_cast<uint4*>(dsum + (size_t)r * H + c) = p;
       unpack8(p, o);
       if (thr != 0) {
+        float dm[8];
+        zk_drop_scale8(seed, sid, (uint64_t)r * H + c, thr, inv_keep, dm);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          oy[j] = o[j] * zk_drop_scale(seed, sid, (uint64_t)r * H + c + j, thr, inv_keep);
+        for (int j = 0; j < 8; ++j) oy[j] = o[j] * dm[j];
         if (dy != nullptr) {
           uint4 py = pack8(oy);
           *reinterpret_cast<uint4*>(dy + (size_t)r * H + c) = py;
@@ -395,8 +399,10 @@ __global__ void __launch_bounds__(256) k_colsum(const bf16_t* __restrict__ a, in
       float v[8];
       unpack8(*reinterpret_cast<const uint4*>(a + (size_t)r * lda + c0), v);
       if (thr) {
+        float dm[8];
+        zk_drop_scale8(seed, sid, (uint64_t)r * N + c0, thr, inv_keep, dm);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= zk_drop_scale(seed, sid, (uint64_t)r * N + c0 + j, thr, inv_keep);
+        for (int j = 0; j < 8; ++j) v[j] *= dm[j];
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] += v[j];
@@ -556,8 +562,10 @@ __global__ void __launch_bounds__(256) k_embed_bwd_sorted(
             float v[8];
             unpack8(raw[j], v);
             if (thr) {
+              float dm[8];
+              zk_drop_scale8(seed, sid, (uint64_t)rr[j] * H + c, thr, inv_keep, dm);
 #pragma unroll
-              for (int q = 0; q < 8; ++q) v[q] *= zk_drop_scale(seed, sid, (uint64_t)rr[j] * H + c + q, thr, inv_keep);
+              for (int q = 0; q < 8; ++q) v[q] *= dm[q];
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc[q] += v[q];

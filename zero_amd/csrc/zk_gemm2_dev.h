@@ -507,8 +507,10 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
       for (int j = 0; j < 8; ++j) v[j] = v[j] * e.alpha + bv[j];
       unpack8(pack8(v), v);
       if (e.thr) {
+        float dm[8];
+        zk_drop_scale8(seed, e.sid, (uint64_t)gm * N + gn, e.thr, e.inv_keep, dm);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= zk_drop_scale(seed, e.sid, (uint64_t)gm * N + gn + j, e.thr, e.inv_keep);
+        for (int j = 0; j < 8; ++j) v[j] *= dm[j];
       }
       if (e.res) {
         float rv[8];
@@ -692,8 +694,10 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
         if (ok) *reinterpret_cast<uint4*>(e.sy_y + (size_t)gm * e.sy_ldy + gn) = po;
         unpack8(po, o);                                     // dy derives from the stored (rounded) ds
         if (e.thr) {
+          float dm[8];
+          zk_drop_scale8(seed, e.sid, (uint64_t)gm * N + gn, e.thr, e.inv_keep, dm);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) oy[j] = o[j] * zk_drop_scale(seed, e.sid, (uint64_t)gm * N + gn + j, e.thr, e.inv_keep);
+          for (int j = 0; j < 8; ++j) oy[j] = o[j] * dm[j];
           const uint4 py = pack8(oy);
           if (ok && e.sy_dy != nullptr) *reinterpret_cast<uint4*>(e.sy_dy + (size_t)gm * e.sy_ldy + gn) = py;
           unpack8(py, oy);
@@ -762,9 +766,10 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
         for (int j = 0; j < 8; ++j) v[it][j] = av[j] > 0.f ? v[it][j] * e.aux_scale : 0.f;
       }
       if (e.thr) {
+        float dm8[8];
+        zk_drop_scale8(seed, e.sid, (uint64_t)gm * N + gn, e.thr, e.inv_keep, dm8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          v[it][j] *= zk_drop_scale(seed, e.sid, (uint64_t)gm * N + gn + j, e.thr, e.inv_keep);
+        for (int j = 0; j < 8; ++j) v[it][j] *= dm8[j];
       }
       if constexpr (LN == 2) {
         if (e.res && e.res_after_drop) {     // residual_fn: x + dropout(y) (func.py:321-324)
@@ -867,8 +872,9 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
         for (int j = 0; j < 8; ++j) v[j] = av[j] > 0.f ? v[j] * e.aux_scale : 0.f;
       }
       if (e.thr) {
+        { float dm[8]; zk_drop_scale8(seed, e.sid, (uint64_t)gm * N + gn, e.thr, e.inv_keep, dm);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= zk_drop_scale(seed, e.sid, (uint64_t)gm * N + gn + j, e.thr, e.inv_keep);
+          for (int j = 0; j < 8; ++j) v[j] *= dm[j]; }
       }
       if constexpr (LN == 2) {
         if (e.res && e.res_after_drop) {

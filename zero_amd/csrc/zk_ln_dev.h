@@ -35,9 +35,10 @@ __device__ __forceinline__ void add_ln_fwd_row(
       if (y != nullptr) {
         unpack8(zk_ld16<FRESH>(y + (size_t)r * H + c), b);
         if (thr != 0) {
+          float dm[8];
+          zk_drop_scale8(seed, sid, (uint64_t)r * H + c, thr, inv_keep, dm);
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            b[j] *= zk_drop_scale(seed, sid, (uint64_t)r * H + c + j, thr, inv_keep);
+          for (int j = 0; j < 8; ++j) b[j] *= dm[j];
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] += b[j];

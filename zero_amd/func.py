@@ -485,7 +485,7 @@ class Engine(object):
         partials the folded relative-position backward left behind (attn_bwd(defer_tables=...)).
         Two launches: column partial sums of every dY, then every final reduction."""
         key = tuple((a.ptr, o.data_ptr()) for a, o, _ in colsums) + \
-            tuple((lp[0].data_ptr(), lp[1], lp[6] if len(lp) > 6 else None, lp[3].data_ptr()) for lp in ln_parts) + \
+            tuple((lp[0].data_ptr(), lp[1], lp[6] if len(lp) > 6 else None, lp[3].data_ptr(), lp[4].data_ptr(), hip.ptr(lp[5])) for lp in ln_parts) + \
             tuple((pp, ns, n, dk.data_ptr()) for pp, ns, n, dk, _ in rpr_parts)
         cache = self.__dict__.setdefault("_red_cache", {})
         ent = cache.get(key)
