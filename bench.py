@@ -861,6 +861,11 @@ def main():
     flops = train_flops_per_step(hp, b=nb)
     out = bench_line(chosen, legs)
     out.update({"loss": loss_v, "gnorm": gnorm, "update_skipped": skipped, "launches_per_step": step_launches})
+    # the in-launch LayerNorm exchange bounds every wait and records a give-up on the device: a line measured with one is void
+    out["sync_ln_errors"] = int(tr.core.eng.sync_ln_errors())
+    if out["sync_ln_errors"]:
+        raise RuntimeError("bench.py: a workgroup of an in-launch LayerNorm exchange gave up waiting for its peers; "
+                           "the measurement is void (ZERO_HIP_SYNC_LN=0 runs the launch structure without it)")
     if ms_other is not None:
         out["static_batch_ms_per_step" if not args.static_batch else "rotating_batches_ms_per_step"] = ms_other
         rot, sta = (ms, ms_other) if not args.static_batch else (ms_other, ms)

@@ -691,6 +691,12 @@ def train(params):
                 # reads is lost, and it is read before anything is written to disk
                 bad_total = trainer.train_op.bad_updates()
                 bad_new, bad_seen = bad_total > bad_seen, bad_total
+                # the in-launch LayerNorm exchange (zk_gemm_add_ln ..) bounds every wait and records a give-up on the
+                # device: results since the last read would be wrong -- stop loudly before anything is written
+                if trainer.core.eng.sync_ln_errors():
+                    from zero_amd.hip import ZeroHipError
+                    raise ZeroHipError("a workgroup of an in-launch LayerNorm exchange gave up waiting for its peers "
+                                       "(zk_gemm_add_ln / zk_gemm_ln_bwd / zk_attn_out_ln); rerun with ZERO_HIP_SYNC_LN=0")
                 if skipped or bad_new or not np.isfinite(loss_v) or not np.isfinite(gnorm):
                     if not params.safe_nan:          # main.py:316-319
                         log.error("Nan or Inf raised! Loss %s GNorm %s.", loss_v, gnorm)
