@@ -104,6 +104,7 @@ class Engine(object):
         self._ws = {}
         self.gemm_impl = _impl_from_env("ZERO_HIP_GEMM")
         self.attn_impl = _impl_from_env("ZERO_HIP_ATTN")
+        self.cu_count = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == "cuda" else 256
         self.seed = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.realloc_gen = 0
         self._timing = None

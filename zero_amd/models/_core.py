@@ -333,7 +333,7 @@ class TransformerCore(object):
             # the overwriting use of the variable must already have run: callers issue it first
             self._pending_adds += adds
         if dx is not None:
-            if ln_next is not None and act == 0 and residual is not None:
+            if ln_next is not None and act == 0 and residual is not None and self._sync_fits(dy.rows):
                 # dx is only read by the backward of the LayerNorm below this sub-layer: that backward runs in the
                 # epilogue of this product and dx is never written (zk_gemm_ln_bwd)
                 self._gemm_ln_bwd(dy, Wm, residual, ln_next)
@@ -390,7 +390,7 @@ class TransformerCore(object):
         e, H = self.eng, self.H
         T = a.rows
         if not self._lazy:
-            if self._sync_ln and not e.lib.recording:
+            if self._sync_ln and not e.lib.recording and self._sync_fits(T):
                 # one launch: the workgroups of a block of rows exchange their LayerNorm partials (zk_gemm_add_ln)
                 Wm = self.W(lin + "/W_0_0")
                 out = e.mat(tag + ".o", T, H)
@@ -422,13 +422,21 @@ class TransformerCore(object):
                      e.buf(tag + ".mean", (T,), F32), e.buf(tag + ".rstd", (T,), F32), 0.0, sid)
         return out
 
+    def _sync_fits(self, rows):
+        """The in-launch exchange pays while the launch is little more than ONE resident round of workgroups (two 64x64-tile
+        workgroups per CU): a workgroup that waits for its peers keeps its slot, and with several rounds the waiting slots
+        are taken from workgroups that could run.  Measured, ms per step with / without it: 2560 rows x 512: 3.80 / 4.03;
+        4096 x 512 (512 workgroups): 4.26 / 4.55; 6144 x 512 (768): 6.17 / 6.34; 8192 x 512 (1024): 7.26 / 7.25; 16384 x 512:
+        13.15 / 12.22; 4096 x 1024 (1024, sixteen peers): 10.63 / 10.51.  Rule: at most three workgroups per CU."""
+        return ((rows + 63) // 64) * (self.H // 64) <= 3 * self.eng.cu_count
+
     def _attn_out_ln(self, q, k, v, att, lse, B, Lq, Lk, kmask, causal, attn_drop, attn_sid, lin, x, scope, tag, save,
                      drop_p, sid):
         """attention + o_map + residual + LayerNorm in one launch when the in-launch LayerNorm is on and the shape is
         covered (zk_attn_out_ln: no relative positions, Lq <= 64, Lk <= 256, 64-wide heads); None otherwise."""
         e, H = self.eng, self.H
         if not (self._sync_ln and self.sync_attn and not self.rpr and not e.lib.recording and self.d == 64 and
-                Lq <= 64 and Lk <= 256 and e.attn_impl in (0, 2)):
+                Lq <= 64 and Lk <= 256 and e.attn_impl in (0, 2) and B * self.nh <= 3 * e.cu_count):
             return None
         T = x.rows
         Wm = self.W(lin + "/W_0_0")
