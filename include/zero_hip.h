@@ -103,6 +103,14 @@ int zk_gemm_ln_bwd(const void* dY, const void* W, int M, int N, int K, int lda, 
                    const void* s, const float* mean, const float* rstd, const float* gamma, float drop_p,
                    const uint64_t* seed, uint32_t sid, void* dsum, void* dy_out, float* partials, void* slots,
                    size_t slots_bytes, const uint32_t* epoch, uint32_t site, int* err, zk_stream_t stream);
+#ifdef ZK_EXPERIMENTS   /* measured: slower than the two launches (profiles/r04_negative_results.txt item 9) */
+/* The two products of a feed-forward sub-layer on few rows (the decode step: func.py:327-338 at batch x beam rows) in one
+ * launch: h = relu(x W1 + b1) (bf16 [M, F]), then -- behind a barrier among the launch's workgroups -- parts[z] = h[:, K_z]
+ * W2[K_z, :] as zk_gemm_parts leaves them (fp32 [M, H] at parts + z M H; *nparts_out parts).  counter: a zeroed device
+ * uint64 shared only by calls with the same (ceil(M/64), F).  Returns 2 (nothing launched) when the shape is not covered. */
+int zk_ffn_pair(const void* x, const void* W1, const float* b1, void* h, const void* W2, float* parts, int M, int F, int H, int K1,
+                int ldx, int ldw1, int ldw2, int splits, int* nparts_out, void* counter, int* err, zk_stream_t stream);
+#endif
 int zk_gemm_plan(int M, int N, int K, int out_f32, int plain);  /* gen | (bm/8)<<8 | (bn/8)<<16 | splits<<24 | producer waves<<28 chosen by impl=0 */
 int zk_gemm_set_generation(int gen);   /* 1 = register-staged kernel, 2 = LDS-DMA ring kernel (default) */
 /* K-segmented GEMM: C bf16 [M, ldc] = sum_s A_s [M, kseg] x B_s (+ bf16 residual, may alias C) in ONE launch --

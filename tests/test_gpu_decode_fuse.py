@@ -120,3 +120,32 @@ def test_dec_cross_argument_checks():
         lib.call("zk_dec_cross", x.data_ptr(), None, None, None, None, 192, 1e-6, None, None, None, 0, 0, None, None, None,
                  1.0, None, w.data_ptr(), 192, f.data_ptr(), x.data_ptr(), x.data_ptr(), 192, 192, 192 * 4,
                  192 * 4, None, 0, w.data_ptr(), 192, f.data_ptr(), 2, 4, 3, 4, 0.125, 1e9, None, None, 0, 0, None, st)
+
+
+@pytest.mark.parametrize("M,H,F,splits", [(128, 512, 2048, 4), (64, 512, 2048, 4), (128, 128, 256, 2), (100, 512, 2048, 4)])
+def test_feed_forward_pair_in_one_launch(M, H, F, splits):
+    """zk_ffn_pair against zk_gemm(act = 1) followed by zk_gemm_parts: h and every partial product bit for bit (same tile
+    function, same K order), launch after launch on the same arrival counter (the barrier's window advances by the number
+    of phase-1 tiles per launch) with the input changing in between."""
+    import ctypes
+    from tests.util_gpu import eng, rand_bf, mat
+    e = eng()
+    if not e.lib.experiments:
+        pytest.skip("the feed-forward pair in one launch is an EXPERIMENTS=1 build (measured, slower)")
+    W1, W2 = rand_bf(H, F, seed=2, scale=0.05), rand_bf(F, H, seed=3, scale=0.05)
+    b1 = (torch.randn(F, generator=torch.Generator().manual_seed(4)) * 0.1).cuda()
+    for rep in range(12):
+        x = rand_bf(M, H, seed=10 + rep)
+        h0 = torch.empty(M, F, dtype=torch.bfloat16, device="cuda")
+        p0 = torch.zeros(splits, M, H, device="cuda")
+        e.gemm(mat(x), mat(W1), mat(h0), M, F, H, 0, 0, bias=b1, act=1)
+        n0 = ctypes.c_int(0)
+        e.lib.call("zk_gemm_parts", h0.data_ptr(), W2.data_ptr(), p0.data_ptr(), M, H, F, F, H, 0, 0, splits, ctypes.byref(n0), e.stream)
+        h1 = torch.full((M, F), 3.0, dtype=torch.bfloat16, device="cuda")
+        p1 = torch.full((splits, M, H), 7.0, device="cuda")
+        n1 = e.ffn_pair(mat(x), mat(W1), b1, mat(h1), mat(W2), p1, splits)
+        torch.cuda.synchronize()
+        assert n1 == n0.value
+        assert torch.equal(h1, h0)
+        assert torch.equal(p1[:n1], p0[:n1])
+    assert e.sync_ln_errors() == 0

@@ -298,6 +298,11 @@ int zk_gemm_dlds_sync_ln_dispatch(const bf16_t* A, const bf16_t* B, int M, int N
                                   const GemmEpi& e, hipStream_t stream);
 int zk_gemm_dlds_sync_ln_bwd_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb,
                                       const GemmEpi& e, hipStream_t stream);
+#ifdef ZK_EXPERIMENTS
+int zk_ffn_pair_launch(const bf16_t* x, const bf16_t* W1, bf16_t* h, const bf16_t* W2, float* parts, int M, int F, int H, int K1,
+                       int ldx, int ldw1, int ldw2, int kchunk, int nparts, const GemmEpi& e1, const GemmEpi& e2,
+                       unsigned long long* cnt, int* err, hipStream_t stream);
+#endif
 int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
                           int bm, int bn, int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags,
                           hipStream_t stream);
@@ -593,5 +598,38 @@ int zk_gemm_parts(const void* A, const void* B, float* parts, int M, int N, int 
   return zk_gemm_dlds_dispatch((const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, ta, tb, 64, 64, n, kchunk, parts, e, 0,
                                stream);
 }
+
+#ifdef ZK_EXPERIMENTS   // measured: slower than the two launches (profiles/r04_negative_results.txt item 9)
+// The two products of a feed-forward sub-layer on few rows in one launch (see k_ffn_pair, zk_gemm2.hip):
+//   h = relu(x W1 + b1)  (bf16 [M, F], written: ldh = F),   parts[z] = h[:, K_z] W2[K_z, :]  (fp32 [M, H] at parts + z M H)
+// for the z-th of *nparts_out <= splits K ranges (multiples of 64) -- exactly what zk_gemm(act = 1) followed by zk_gemm_parts
+// leaves (same tile function, same K order).  x [M, ldx] (K1 = the model width contiguous), W1 [K1, ldw1], W2 [F, ldw2].
+// counter: a zeroed device uint64 that only calls with the same (ceil(M/64), F) may share (the barrier's arrival count);
+// *err (device int, may be null) is set if a workgroup gave up waiting.  Returns 2 without launching when the shape is not
+// covered (more workgroups than are resident at once, or fewer phase-1 than phase-2 tiles): call the two entry points.
+int zk_ffn_pair(const void* x, const void* W1, const float* b1, void* h, const void* W2, float* parts, int M, int F, int H, int K1,
+                int ldx, int ldw1, int ldw2, int splits, int* nparts_out, void* counter, int* err, hipStream_t stream) {
+  ZK_CHECK_ARG(M >= 1 && F >= 64 && H >= 64 && K1 >= 64 && splits >= 2 && splits <= 64, "zk_ffn_pair: bad sizes");
+  ZK_CHECK_ARG(h != nullptr && parts != nullptr && nparts_out != nullptr && counter != nullptr, "zk_ffn_pair: h, parts, nparts_out and counter are required");
+  if (F % 64 != 0 || H % 64 != 0 || K1 % 64 != 0) return 2;
+  if (!mfma_ok(x, W1, M, F, K1, ldx, ldw1, 0, 0) || !mfma_ok(h, W2, M, H, F, F, ldw2, 0, 0) || zk_prog_active()) return 2;
+  if ((((uintptr_t)b1 | (uintptr_t)h | (uintptr_t)parts | (uintptr_t)counter) & 15) != 0) return 2;
+  const int kchunk = ((F + splits - 1) / splits + BK - 1) / BK * BK;
+  const int n = (F + kchunk - 1) / kchunk;
+  const int tiles_m = (M + 63) / 64, T1 = tiles_m * (F / 64), T2 = tiles_m * (H / 64) * n;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 2;
+  if (n < 2 || T2 > T1 || T1 > 2 * cus) return 2;               // every workgroup must be resident while it waits
+  *nparts_out = n;
+  GemmEpi e1, e2;
+  e1.C = h; e1.ldc = F; e1.out_f32 = 0; e1.alpha = 1.f; e1.bias = b1; e1.res = nullptr; e1.ldr = 0; e1.act = 1;
+  e1.aux = nullptr; e1.ldaux = 0; e1.aux_scale = 1.f; e1.thr = 0; e1.inv_keep = 1.f; e1.seed = nullptr; e1.sid = 0;
+  e2.C = nullptr; e2.ldc = H; e2.out_f32 = 1; e2.alpha = 1.f; e2.bias = nullptr; e2.res = nullptr; e2.ldr = 0; e2.act = 0;
+  e2.aux = nullptr; e2.ldaux = 0; e2.aux_scale = 1.f; e2.thr = 0; e2.inv_keep = 1.f; e2.seed = nullptr; e2.sid = 0;
+  return zk_ffn_pair_launch((const bf16_t*)x, (const bf16_t*)W1, (bf16_t*)h, (const bf16_t*)W2, parts, M, F, H, K1, ldx, ldw1, ldw2,
+                            kchunk, n, e1, e2, (unsigned long long*)counter, err, stream);
+}
+
+#endif  // ZK_EXPERIMENTS
 
 }  // extern "C"

@@ -1048,6 +1048,68 @@ int zk_gemm_dlds_sync_ln_bwd_dispatch(const bf16_t* A, const bf16_t* B, int M, i
   return 0;
 }
 
+#ifdef ZK_EXPERIMENTS   // measured: slower than the two launches, alone and with four lanes (profiles/r04_negative_results.txt item 9)
+// ---- the two products of a feed-forward sub-layer on few rows in ONE launch (zk_ffn_pair; the decode step's
+// func.py:327-338 ffn_layer at 128 rows): phase 1  h = relu(x W1 + b1)  on 64x64 tiles, a barrier among the launch's
+// workgroups (all resident: the grid is at most two per CU), phase 2  parts[z] = h[:, K_z] W2[K_z, :]  (split-K partial
+// sums as zk_gemm_parts leaves them for zk_ln_decode) on 64x64 tiles.  The barrier is a 64-bit arrival counter that is
+// never reset: every launch with the same number T1 of phase-1 tiles adds exactly T1, so the window a launch waits for is
+// (count at its start / T1 + 1) T1.  h crosses XCDs: agent-scope release (L2 write-back) before the arrival, acquire
+// (invalidate) after the wait.
+__global__ void __launch_bounds__(512) k_ffn_pair(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W1, bf16_t* __restrict__ h,
+                                                   const bf16_t* __restrict__ W2, float* __restrict__ parts, int M, int F, int H,
+                                                   int K1, int ldx, int ldw1, int ldw2, int kchunk, int tiles_m, int T1, int T2,
+                                                   GemmEpi e1, GemmEpi e2, unsigned long long* __restrict__ cnt,
+                                                   int* __restrict__ err) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DldsCfg<64, 64, 4>::LDS_BYTES];
+  const int bid = blockIdx.x, tid = threadIdx.x;
+  __shared__ unsigned long long s_target;
+  if (tid == 0) {
+    const unsigned long long v0 = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_target = (v0 / (unsigned long long)T1 + 1ull) * (unsigned long long)T1;
+  }
+  {
+    const int tm = bid % tiles_m, tn = bid / tiles_m;                 // bid < T1: the grid IS the phase-1 tiles
+    gemm_tile<64, 64, 4, false, false, 4, 4>(smem, x, W1, M, F, ldx, ldw1, 0, K1, tm * 64, tn * 64, nullptr, e1, 1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                  // this thread's part of h is written back
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (bid < T2) {
+      const unsigned long long target = s_target;
+      int spins = 0;
+      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (++spins > (1 << 15)) {
+          if (err != nullptr) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+  }
+  if (bid >= T2) return;
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const int per = tiles_m * (H / 64);
+  const int z = bid / per, rem = bid - z * per;
+  const int tm = rem % tiles_m, tn = rem / tiles_m;
+  gemm_tile<64, 64, 4, false, false, 4, 4>(smem, h, W2, M, H, F, ldw2, z * kchunk, min(F, (z + 1) * kchunk), tm * 64, tn * 64,
+                                           parts + (size_t)z * M * H, e2, 0);
+}
+
+int zk_ffn_pair_launch(const bf16_t* x, const bf16_t* W1, bf16_t* h, const bf16_t* W2, float* parts, int M, int F, int H, int K1,
+                       int ldx, int ldw1, int ldw2, int kchunk, int nparts, const GemmEpi& e1, const GemmEpi& e2,
+                       unsigned long long* cnt, int* err, hipStream_t stream) {
+  const int tiles_m = (M + 63) / 64, T1 = tiles_m * (F / 64), T2 = tiles_m * (H / 64) * nparts;
+  hipLaunchKernelGGL(k_ffn_pair, dim3((unsigned)T1), dim3(512), 0, stream, x, W1, h, W2, parts, M, F, H, K1, ldx, ldw1, ldw2,
+                     kchunk, tiles_m, T1, T2, e1, e2, cnt, err);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+#endif  // ZK_EXPERIMENTS
+
 // entry used by zk_gemm (zk_gemm.hip)
 int zk_gemm_dlds_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int ta, int tb,
                           int bm, int bn, int splits, int kchunk, float* slabs, const GemmEpi& e, int sched_flags,

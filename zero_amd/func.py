@@ -332,6 +332,28 @@ class Engine(object):
                       dy_out.ptr if dy_out is not None else None, partials.data_ptr(), slots.data_ptr(), slots.numel(),
                       meta.data_ptr(), self._sync_site, meta.data_ptr() + 4, self.stream)
 
+    def ffn_pair(self, x, W1, b1, h, W2, parts, splits):
+        """h = relu(x @ W1 + b1) and the split-K partial products of h @ W2 in ONE launch (zk_ffn_pair: the decode step's
+        feed-forward pair).  Returns the number of parts, or None (nothing launched) when the shape is not covered."""
+        import ctypes
+        M, F, H = x.rows, W1.cols, W2.cols
+        key = "ffpair.cnt.%d.%d" % ((M + 63) // 64, F)
+        fresh = key not in self.bufs
+        cnt = self.buf(key, (2,), torch.int64)
+        if fresh:
+            self.zero(cnt)
+        _, meta = self.sync_ln_state(1, 64)
+        n = ctypes.c_int(0)
+        args = (x.ptr, W1.ptr, hip.ptr(b1), h.ptr, W2.ptr, parts.data_ptr(), M, F, H, W1.rows, x.ld, W1.ld, W2.ld, int(splits),
+                ctypes.byref(n), cnt.data_ptr(), meta.data_ptr() + 4, self.stream)
+        self.lib.ncalls += 1
+        rc = self.lib.raw("zk_ffn_pair")(*args)
+        if rc == 2:
+            return None
+        if rc != 0:
+            self.lib.call("zk_ffn_pair", *args)      # raises with the library's message
+        return n.value
+
     def sync_ln_errors(self):
         """1 if a workgroup of some zk_gemm_add_ln launch ever gave up waiting for its peers (synchronises)."""
         st = self.__dict__.get("_sync_ln")

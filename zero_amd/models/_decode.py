@@ -481,6 +481,8 @@ def make_infer_fns(params, model_name):
             e.lib.call("zk_all_equal", target.data_ptr(), BK, hp.tgt_vocab.pad(), zf.data_ptr(), e.stream)
         import os as _os
         fuse_ln = core.aan and _os.environ.get("ZERO_HIP_DECODE_FUSE_LN", "1") != "0"
+        # the feed-forward pair as one launch: measured slower (EXPERIMENTS=1 library only, profiles/r04_negative_results.txt)
+        FFN_PAIR = _os.environ.get("ZERO_HIP_DECODE_FFN_PAIR", "0") == "1" and e.lib.experiments
         # an attention sub-layer (projection, attention, the head's share of the output projection) as ONE launch per
         # (sentence, head) with the previous LayerNorm as its prologue (zk_dec_cross / zk_dec_self)
         fuse_att = bool(state.get("wt")) and _fuse_att_ok(core, hp, K)
@@ -540,9 +542,17 @@ def make_infer_fns(params, model_name):
             arguments of the row-local LayerNorm form (ln_args / zk_ln_decode)."""
             import ctypes
             hh = e.mat("dc%d.ff.h" % l, BK, core.F)
-            core._linear(x_in, f + "/ffn_layer/enlarge", hh, act=1)
             W2 = core.W(f + "/ffn_layer/output/W_0_0")
             parts = e.buf("dc.ff.parts.%d" % (l & 1), (ffn_split, BK, H), F32)
+            npair = None
+            if FFN_PAIR and e.gemm_impl == 0:
+                # both products in one launch, a barrier among its 64 workgroups between them (zk_ffn_pair)
+                npair = e.ffn_pair(x_in, core.W(f + "/ffn_layer/enlarge/W_0_0"), core.b(f + "/ffn_layer/enlarge/b_0"), hh, W2,
+                                   parts, ffn_split)
+            if npair is not None:
+                return dict(x=x_in.ptr, parts=parts.data_ptr(), nparts=npair, stride=BK * H,
+                            bias=core.b(f + "/ffn_layer/output/b_0").data_ptr(), **ln_scope(f))
+            core._linear(x_in, f + "/ffn_layer/enlarge", hh, act=1)
             n = ctypes.c_int(0)
             e.lib.call("zk_gemm_parts", hh.ptr, W2.ptr, parts.data_ptr(), BK, H, core.F, hh.ld, W2.ld, 0, 0, ffn_split,
                        ctypes.byref(n), e.stream)
