@@ -519,10 +519,9 @@ int zk_gemm_add_ln(const void* A, const void* B, int M, int N, int K, int lda, i
   e.sy_slots = (unsigned long long*)slots; e.sy_epoch = epoch; e.sy_site = site;
   e.sy_gamma = gamma; e.sy_beta = beta; e.sy_y = (bf16_t*)y; e.sy_ldy = N;
   e.sy_mean = mean; e.sy_rstd = rstd; e.sy_err = err;
-  int bm, bn, splits;
-  pick_config(M, N, K, 0, &bm, &bn, &splits);
-  (void)splits; (void)bn;          // never split, always 64 columns: the epilogue needs the whole sum of a 64-column group
-  return zk_gemm_dlds_sync_ln_dispatch((const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, bm >= 128 ? 128 : 64, e, stream);
+  // always 64 x 64 tiles, never split: the epilogue needs the whole sum of a 64-column group, and 128-row tiles were
+  // measured slower for these products (profiles/r04_negative_results.txt item 6)
+  return zk_gemm_dlds_sync_ln_dispatch((const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, 64, e, stream);
 }
 
 // The backward of that tail inside the dgrad launch that completes its input gradient (autodiff of transformer.py:57-58

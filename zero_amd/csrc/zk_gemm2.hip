@@ -997,10 +997,9 @@ int zk_gemm_dlds_ln_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int
 
 #endif  // ZK_EXPERIMENTS
 
-// residual + LayerNorm inside the producing launch (zk_gemm_add_ln; A [M,K] x B [K,N], no split-K): the two tiles the
-// default dispatch gives the sub-layer output products (64x64 with four producer waves; 128x64 for the long K of the
-// feed-forward output) with the LN = 3 epilogue.  Tile order: row-block major, so that the N/64 workgroups that wait for
-// each other are consecutive in the dispatch order (and, with the XCD remap, on one XCD whenever the grid is a multiple
+// residual + LayerNorm inside the producing launch (zk_gemm_add_ln; A [M,K] x B [K,N], no split-K): the 64x64 tile with
+// four producer waves that the default dispatch gives the sub-layer output products, with the LN = 3 epilogue.  Tile
+// order: row-block major, so that the N/64 workgroups that wait for each other are consecutive in the dispatch order (and, with the XCD remap, on one XCD whenever the grid is a multiple
 // of 64): a workgroup only ever waits for workgroups that are already resident or next in line.
 template <int BM, int NS, int PW>
 static int launch_dlds_sync_ln(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, const GemmEpi& e,
@@ -1025,7 +1024,7 @@ static int launch_dlds_sync_ln(const bf16_t* A, const bf16_t* B, int M, int N, i
 }
 int zk_gemm_dlds_sync_ln_dispatch(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int bm,
                                   const GemmEpi& e, hipStream_t stream) {
-  if (bm == 128) return launch_dlds_sync_ln<128, 2, 0>(A, B, M, N, K, lda, ldb, e, stream);
+  (void)bm;
   return launch_dlds_sync_ln<64, 4, 4>(A, B, M, N, K, lda, ldb, e, stream);
 }
 
