@@ -307,3 +307,11 @@ def test_training_steps_with_the_layernorm_inside_the_launch(model, monkeypatch)
         on = out[(mode, True)]
         assert np.allclose(on[0], off[0], rtol=2e-3, atol=0), (mode, on[0], off[0])
         assert np.linalg.norm(on[1] - off[1]) <= 2e-3 * np.linalg.norm(off[1])
+
+
+def test_the_exchange_passes_its_self_test_on_this_device():
+    """Engine.sync_ln_usable(): the one-time probe that decides whether the in-launch forms are used at all (a device on
+    which it fails runs the two-launch structure with a warning)."""
+    e = eng()
+    assert e.sync_ln_usable() is True
+    assert e.sync_ln_errors() == 0

@@ -354,6 +354,48 @@ class Engine(object):
             self.lib.call("zk_ffn_pair", *args)      # raises with the library's message
         return n.value
 
+    def sync_ln_usable(self):
+        """One-time self-test of the in-launch exchange on this device (cached): two small zk_gemm_add_ln launches -- a
+        grid whose row blocks sit on one XCD each (exchange through the L2) and one that straddles XCDs (through memory)
+        -- must finish without a workgroup giving up and must normalise their rows.  A platform on which the dispatch
+        assumptions do not hold (another partition mode, a runtime that places workgroups differently) then runs the
+        two-launch structure with a warning instead of wrong numbers."""
+        ok = self.__dict__.get("_sync_ln_ok")
+        if ok is not None:
+            return ok
+        ok = True
+        try:
+            for M in (4096, 320):
+                N, K = 512, 64
+                g = torch.Generator(device="cpu").manual_seed(7)
+                A = (torch.randn(M, K, generator=g)).to(torch.bfloat16).to(self.device)
+                W = (torch.randn(K, N, generator=g) * 0.1).to(torch.bfloat16).to(self.device)
+                R = torch.randn(M, N, generator=g).to(torch.bfloat16).to(self.device)
+                y = torch.empty(M, N, dtype=torch.bfloat16, device=self.device)
+                ones, zeros = torch.ones(N, device=self.device), torch.zeros(N, device=self.device)
+                self.ln_epoch_bump()
+                self.gemm_add_ln(Mat(A, M, K), Mat(W, K, N), M, N, K, None, Mat(R, M, N), ones, zeros, Mat(y, M, N))
+                torch.cuda.synchronize(self.device)
+                yf = y.float()
+                if self.sync_ln_errors() or not bool(torch.isfinite(yf).all()) or float(yf.mean(1).abs().max()) > 0.05 or \
+                        abs(float(yf.var(1, unbiased=False).mean()) - 1.0) > 0.05:
+                    ok = False
+                    break
+        except hip.ZeroHipError:
+            ok = False
+        if not ok:
+            import logging
+            logging.getLogger("zero_amd").warning(
+                "the in-launch LayerNorm exchange failed its self-test on this device; running the two-launch structure "
+                "(ZERO_HIP_SYNC_LN=0)")
+            st = self.__dict__.get("_sync_ln")
+            if st is not None:
+                torch.cuda.synchronize(self.device)
+                st[1][1:2].zero_()         # the error word of the failed probe must not fail a later check
+                torch.cuda.synchronize(self.device)
+        self._sync_ln_ok = ok
+        return ok
+
     def sync_ln_errors(self):
         """1 if a workgroup of some zk_gemm_add_ln launch ever gave up waiting for its peers (synchronises)."""
         st = self.__dict__.get("_sync_ln")

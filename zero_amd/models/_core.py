@@ -908,7 +908,7 @@ class TransformerCore(object):
         self._lazy_tags = {}
         # residual + LayerNorm inside the sub-layer output GEMMs (ZERO_HIP_SYNC_LN=0: a launch of their own)
         self._sync_ln = self.sync_ln_mode and not self._lazy and self.eng.gemm_impl == 0 and self.H % 64 == 0 and \
-            self.H <= 1024 and self.F % 64 == 0
+            self.H <= 1024 and self.F % 64 == 0 and self.eng.sync_ln_usable()
         if self._sync_ln:
             self.eng.ln_epoch_bump()
         if self._lazy:
