@@ -356,6 +356,10 @@ int zk_aan_gate_bwd(const void* dg, const void* z, const void* cat, void* dz, vo
  * TF1 Adam, bf16 shadow refresh and parameter norm in ONE pass over the flat buffers (the reference fetches
  * train_op and gradient_norm together, main.py:309-312); norm_free = 0: hyper[6] must hold the norm (zk_l2norm).
  * seed (device uint64, may be NULL): the dropout step seed, advanced by one in the same launch.
+ * skip_word (device int, may be NULL; round 5): non-zero = a launch of this step reported a fault of its own (the error word
+ * of the in-launch LayerNorm exchange, zk_gemm_add_ln's `err`): the update is NOT applied, hyper[6] = NaN, hyper[7] = 1 and
+ * the sticky hyper[10] is incremented -- the failure-detection rule of main.py:316-332 applied on the device, on the step
+ * that failed.  The word itself is left as it is (the host reads and reports it).
  * zk_norm_flag: fold a norm that zk_l2norm wrote to hyper[6] AFTER per-bucket updates into hyper[7] / hyper[10]. */
 size_t zk_norm_workspace(void);
 int zk_l2norm(const float* x, size_t n, float scale, float* out, void* workspace, size_t ws_bytes,
@@ -364,7 +368,7 @@ int zk_adam(float* p, const float* g, float* m, float* v, void* shadow_bf16, siz
             float* pnorm_out, void* workspace, size_t ws_bytes, zk_stream_t stream);
 size_t zk_adam_step_workspace(void);
 int zk_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n, float* hyper,
-                 float* pnorm_out, uint64_t* seed, int norm_free, void* workspace, size_t ws_bytes,
+                 float* pnorm_out, uint64_t* seed, int norm_free, const int* skip_word, void* workspace, size_t ws_bytes,
                  zk_stream_t stream);
 #ifdef ZK_EXPERIMENTS   /* measured slower than gradient launch + Adam pass (profiles/r04_negative_results.txt): make EXPERIMENTS=1 */
 /* ---- round 4: the optimiser update of the weight matrices INSIDE the launch that makes their gradients

@@ -29,7 +29,7 @@ ws2 = torch.empty(e.lib.query("zk_adam_step_workspace"), dtype=torch.uint8, devi
 seed = torch.zeros(1, dtype=torch.int64, device="cuda")
 def run2():
     e.lib.call("zk_adam_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr(), n, hyper.data_ptr(),
-               pn.data_ptr(), seed.data_ptr(), 1, ws2.data_ptr(), ws2.numel(), e.stream)
+               pn.data_ptr(), seed.data_ptr(), 1, None, ws2.data_ptr(), ws2.numel(), e.stream)
 for u, gb in ((0, 0), (1, 0), (2, 0), (4, 0), (2, 1024), (4, 1024), (4, 512), (2, 512), (1, 1024), (0, 0), (1, 0)):
     e.lib.raw("zk_tune")(9, u)
     e.lib.raw("zk_tune")(10, gb)

@@ -315,3 +315,181 @@ def test_the_exchange_passes_its_self_test_on_this_device():
     e = eng()
     assert e.sync_ln_usable() is True
     assert e.sync_ln_errors() == 0
+
+
+def _clear_exchange_error(e):
+    torch.cuda.synchronize()
+    e._sync_ln[1][1:2].zero_()
+    torch.cuda.synchronize()
+
+
+def test_a_peer_that_never_publishes_is_bounded_loud_and_poisons_its_rows():
+    """Round 5: fault injection (tuning key 15 bit 1: the tn = 1 tiles never publish
+    their statistics).  The launch must END (bounded spins -- and ONE budget per workgroup, not one per row and peer),
+    raise the device error word, and leave NaN rows -- so that the step's own non-finite guard trips on the very step --
+    instead of rows normalised with garbage statistics.  Forward and backward forms; afterwards the exchange works again."""
+    import time
+    e = eng()
+    M, N, K = 4096, 512, 512
+    A, W, R = rand_bf(M, K, seed=1, scale=0.5), rand_bf(K, N, seed=2, scale=0.05), rand_bf(M, N, seed=3)
+    gam, bet = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
+    e.ln_epoch_bump()
+    good = _one_launch(e, A, W, None, R, gam, bet, 0.0, 0)
+    torch.cuda.synchronize()
+    assert e.sync_ln_errors() == 0
+    tune = e.lib.raw("zk_tune")
+    tune(15, 2)
+    try:
+        e.ln_epoch_bump()
+        t0 = time.time()
+        bad = _one_launch(e, A, W, None, R, gam, bet, 0.0, 0)
+        torch.cuda.synchronize()
+        dt_fwd = time.time() - t0
+        assert e.sync_ln_errors() == 1
+        assert bool(torch.isnan(bad[0].float()).all(dim=1).all()), "rows normalised without a peer's partial must be NaN"
+        assert torch.equal(bad[1], good[1])            # the stored sum does not depend on the peers
+        _clear_exchange_error(e)
+        dY, W2 = rand_bf(M, K, seed=4, scale=0.5), rand_bf(N, K, seed=5, scale=0.05)
+        ds = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        part = torch.empty(e.lib.query("zk_gemm_ln_bwd_partials", M, N) // 4, device="cuda")
+        e.ln_epoch_bump()
+        t0 = time.time()
+        e.gemm_ln_bwd(mat(dY), mat(W2), M, N, K, None, mat(good[1]), good[2], good[3], gam, mat(ds), None, part)
+        torch.cuda.synchronize()
+        dt_bwd = time.time() - t0
+        assert e.sync_ln_errors() == 1
+        assert bool(torch.isnan(ds.float()).all())
+        # one spin budget per workgroup (2^15 polls of a few hundred ns .. 2 us), three resident rounds at most
+        assert dt_fwd < 5.0 and dt_bwd < 5.0, (dt_fwd, dt_bwd)
+    finally:
+        tune(15, 0)
+        _clear_exchange_error(e)
+    e.ln_epoch_bump()
+    again = _one_launch(e, A, W, None, R, gam, bet, 0.0, 0)
+    torch.cuda.synchronize()
+    assert e.sync_ln_errors() == 0 and torch.equal(again[0], good[0])
+
+
+def test_a_failed_self_test_switches_forward_and_backward_to_the_two_launch_structure():
+    """with the self-test failing (fault injection) Engine.sync_ln_usable() is False and NEITHER
+    direction of the training step uses the exchange: the step runs, finite, with the error word clear."""
+    from tests.common import make_hp, make_batch, perturb
+    from oracle import ref_torch as rt
+    from zero_amd.main import Trainer
+    from zero_amd.models._factory import reset_cores
+    from zero_amd.variables import reset_stores
+    e = eng()
+    tune = e.lib.raw("zk_tune")
+    hp = make_hp("transformer", H=128, F=256, lrate=0.02, warmup_steps=10)
+    rng = np.random.default_rng(3)
+    src, tgt = make_batch(rng, 6, 11, 13, hp.src_vocab.size(), hp.tgt_vocab.size())
+    Pn = perturb(rt.init_params(hp, "transformer", seed=8), rng)
+    reset_cores(); reset_stores()
+    tr = Trainer(hp, initializer=Pn)
+    eng2 = tr.core.eng
+    tune(15, 2)
+    try:
+        eng2.__dict__.pop("_sync_ln_ok", None)
+        assert eng2.sync_ln_usable() is False
+    finally:
+        tune(15, 0)
+    try:
+        tr.prepare_static({"source": src, "target": tgt})
+        losses = [float(tr.step_static(False).cpu()[0]) for _ in range(2)]
+        torch.cuda.synchronize()
+        assert np.isfinite(losses).all() and eng2.sync_ln_errors() == 0
+        # the reference run with the exchange switched off by hand gives the same numbers bit for bit
+        reset_cores(); reset_stores()
+        os.environ["ZERO_HIP_SYNC_LN"] = "0"
+        try:
+            tr0 = Trainer(hp, initializer=Pn)
+            tr0.prepare_static({"source": src, "target": tgt})
+            losses0 = [float(tr0.step_static(False).cpu()[0]) for _ in range(2)]
+        finally:
+            del os.environ["ZERO_HIP_SYNC_LN"]
+        assert losses == losses0
+    finally:
+        eng2.__dict__.pop("_sync_ln_ok", None)
+        reset_cores(); reset_stores()
+
+
+def test_a_step_whose_exchange_gave_up_is_skipped_on_the_device():
+    """zk_adam_step(skip_word): non-zero -> parameters, moments and shadow untouched, hyper[6] = NaN, hyper[7] = 1, the
+    sticky hyper[10] incremented, in both update forms; zero / NULL -> the ordinary update (bit-identical)."""
+    lib = eng().lib
+    n = 64 * 1000 + 8
+    g = torch.Generator().manual_seed(3)
+    mk = lambda s: (torch.randn(n, generator=g) * s).cuda()
+    p0, gr, m0, v0 = mk(0.1), mk(0.02), mk(0.01), mk(0.001).abs()
+    ws = torch.empty(lib.query("zk_adam_step_workspace"), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(word, norm_free):
+        hyper = torch.tensor([3e-3, 0.9, 0.98, 1e-8, 0.25, 0.0, 0.5, 0, 0, 0, 0, 0], dtype=torch.float32, device="cuda")
+        p, m, v = p0.clone(), m0.clone(), v0.clone()
+        sh = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+        pn = torch.zeros(1, device="cuda")
+        seed = torch.zeros(1, dtype=torch.int64, device="cuda")
+        wd = None if word is None else torch.tensor([word], dtype=torch.int32, device="cuda")
+        lib.call("zk_adam_step", p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr(), n, hyper.data_ptr(),
+                 pn.data_ptr(), seed.data_ptr(), norm_free, None if wd is None else wd.data_ptr(), ws.data_ptr(), ws.numel(),
+                 stream)
+        torch.cuda.synchronize()
+        return p, m, v, sh, hyper.cpu().numpy(), int(seed.item())
+    for nf in (1, 0):
+        ref = run(None, nf)
+        ok = run(0, nf)
+        for a, b in zip(ref[:4], ok[:4]):
+            assert torch.equal(a, b)
+        assert not torch.equal(ref[0], p0) and ref[4][7] == 0 and ref[4][10] == 0
+        sk = run(1, nf)
+        assert torch.equal(sk[0], p0) and torch.equal(sk[1], m0) and torch.equal(sk[2], v0)
+        assert not sk[3].float().abs().sum().item()           # shadow untouched
+        assert sk[4][7] == 1 and sk[4][10] == 1 and sk[5] == 1
+        if nf:
+            assert np.isnan(sk[4][6])
+
+
+def test_the_exchange_survives_a_busy_second_stream():
+    """co-residency of a row block's workgroups is assumed from the grid size; a concurrent stream
+    (side-stream batch prep, decode lanes during a dev evaluation) takes CU slots away.  200 exchange launches of the
+    training shape (forward and backward forms) run while a second stream keeps every CU busy with large GEMM launches:
+    no give-up, no deadlock, results bit-identical to the quiescent ones."""
+    e = eng()
+    M, N, K = 4096, 512, 512
+    A, W, R = rand_bf(M, K, seed=1, scale=0.5), rand_bf(K, N, seed=2, scale=0.05), rand_bf(M, N, seed=3)
+    gam, bet = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
+    dY, W2 = rand_bf(M, K, seed=4, scale=0.5), rand_bf(N, K, seed=5, scale=0.05)
+    e.ln_epoch_bump()
+    good = _one_launch(e, A, W, None, R, gam, bet, 0.0, 0)
+    ds0 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    part = torch.empty(e.lib.query("zk_gemm_ln_bwd_partials", M, N) // 4, device="cuda")
+    e.gemm_ln_bwd(mat(dY), mat(W2), M, N, K, None, mat(good[1]), good[2], good[3], gam, mat(ds0), None, part)
+    torch.cuda.synchronize()
+    assert e.sync_ln_errors() == 0
+    # the competitor: 4096 x 2048 x 2048 products (512 workgroups of 128 x 128, two rounds of the chip each) and the
+    # 1024-thread cross-entropy-sized streaming kernel (zk_zero over 256 MB), alternating
+    side = torch.cuda.Stream()
+    Xa, Xb = rand_bf(4096, 2048, seed=7, scale=0.1), rand_bf(2048, 2048, seed=8, scale=0.1)
+    Xc = torch.empty(4096, 2048, dtype=torch.bfloat16, device="cuda")
+    big = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ds = torch.empty_like(ds0)
+    bad = 0
+    for rep in range(4):
+        with torch.cuda.stream(side):
+            for i in range(60):
+                e.gemm(mat(Xa), mat(Xb), mat(Xc), 4096, 2048, 2048, 0, 0)
+                if i % 6 == 0:
+                    e.zero(big)
+        for it in range(50):
+            if it % 25 == 0:
+                e.ln_epoch_bump()
+            e.gemm_add_ln(mat(A), mat(W), M, N, K, None, mat(R), gam, bet, mat(out))
+            e.gemm_ln_bwd(mat(dY), mat(W2), M, N, K, None, mat(good[1]), good[2], good[3], gam, mat(ds), None, part)
+            if it % 10 == 9:
+                torch.cuda.current_stream().synchronize()
+                bad += int(not torch.equal(out, good[0])) + int(not torch.equal(ds, ds0))
+        torch.cuda.synchronize()
+    assert e.sync_ln_errors() == 0 and bad == 0

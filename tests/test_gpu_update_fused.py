@@ -96,7 +96,7 @@ def test_segmented_adam_is_the_flat_adam_on_the_complement():
     sa = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
     pn_a, ha = torch.zeros(1, device="cuda"), hyper.clone()
     lib.call("zk_adam_step", pa.data_ptr(), gr.data_ptr(), ma.data_ptr(), va.data_ptr(), sa.data_ptr(), n, ha.data_ptr(),
-             pn_a.data_ptr(), None, 1, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+             pn_a.data_ptr(), None, 1, None, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
     # segments = complement of three ranges
     ranges = [(64 * 10, 64 * 400), (64 * 1000, 64 * 1001), (64 * 3000, 64 * 4990)]
     segs, lo = [], 0

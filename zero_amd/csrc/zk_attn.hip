@@ -299,7 +299,12 @@ __global__ void __launch_bounds__(512) k_attn_out_ln(AttnArgs a, bf16_t* __restr
   }
   __syncthreads();
   if (!local) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  gemm_tile<64, 64, 4, false, false, 4, 4, false, false, 3>(smem, att, Wo, M, N, ldatt, ldw, 0, N, tm * a.Lq, tn * 64,
+  // The A operand is clamped to the SENTENCE's own rows (M_own): with Lq < 64 the 64-row tile would otherwise fetch rows
+  // of sentence tm + 1 -- masked later by sy_rows, but the fetch could leave lines of `att` in this CU's L1 BEFORE that
+  // sentence's heads have written them, and a workgroup of sentence tm + 1 placed on this CU in a later resident round
+  // would then read them stale on the sy_local path (no L1 invalidate there).  Clamped rows only feed rows >= sy_rows.
+  const int M_own = min(M, (tm + 1) * a.Lq);
+  gemm_tile<64, 64, 4, false, false, 4, 4, false, false, 3>(smem, att, Wo, M_own, N, ldatt, ldw, 0, N, tm * a.Lq, tn * 64,
                                                             nullptr, e, 1);
 }
 
@@ -596,7 +601,8 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_ln(AttnArgs a, const bf16_t
   }
   __syncthreads();
   if (!local) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  gemm_tile<64, 64, 4, false, true, 4, 0, false, false, 4>(smem, dA, W, M, N, lda, ldw, 0, K, tm * a.Lq, tn * 64, nullptr, e, 1);
+  const int M_own = min(M, (tm + 1) * a.Lq);      // (as in k_attn_out_ln: never fetch another sentence's rows of dA)
+  gemm_tile<64, 64, 4, false, true, 4, 0, false, false, 4>(smem, dA, W, M_own, N, lda, ldw, 0, K, tm * a.Lq, tn * 64, nullptr, e, 1);
 }
 
 #endif  // ZK_EXPERIMENTS

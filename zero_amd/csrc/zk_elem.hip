@@ -1106,13 +1106,26 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
                                               float* __restrict__ m, float* __restrict__ v,
                                               bf16_t* __restrict__ shadow, size_t n,
                                               float* __restrict__ hyper, float* __restrict__ psq,
-                                              float* __restrict__ gsq, uint64_t* __restrict__ seed) {
+                                              float* __restrict__ gsq, uint64_t* __restrict__ seed,
+                                              const int* __restrict__ skip_word = nullptr) {
   __shared__ float sm_[8];
   float pacc = 0.f;   // sum of squares of the parameters BEFORE this update (tf.global_norm(variables))
   float gacc = 0.f;   // sum of squares of the scaled gradient (GSQ)
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
   const float gs = hyper[4], clip = hyper[5], gnorm = hyper[6];
   if (seed != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *seed += 1;
+  // skip_word (device int, may be NULL): non-zero = a launch of THIS step reported a fault of its own (the in-launch
+  // LayerNorm exchange gave up waiting, GemmEpi.sy_err): the gradients are not to be trusted, so the update is not
+  // applied -- parameters, moments and shadow stay as they are -- and the step is booked as skipped: the gradient
+  // norm is reported as NaN (GSQ: k_norm_final2 turns it into hyper[7] / the sticky hyper[10]; !GSQ: set here).
+  if (skip_word != nullptr && *skip_word != 0) {
+    if (threadIdx.x == 0) {
+      if (psq != nullptr) psq[blockIdx.x] = 0.f;
+      if (GSQ && gsq != nullptr) gsq[blockIdx.x] = __builtin_nanf("");
+      if (!GSQ && blockIdx.x == 0) { hyper[7] = 1.f; hyper[10] += 1.f; }
+    }
+    return;
+  }
   float f = gs;
   if (!GSQ) {
     // NaN/Inf guard (main.py:316-319); hyper[9] > 0: also skip when gnorm exceeds it (safe_nan, main.py:325-329)
@@ -1773,7 +1786,7 @@ size_t zk_adam_step_workspace(void) { return 2 * 2048 * sizeof(float); }
 // norm in ONE pass over the buffers + a one-block finish.  norm_free = 0: hyper[6] must already hold the gradient norm
 // (zk_l2norm); the update is skipped when it is not finite / above hyper[9].  seed (device uint64, may be NULL) += 1.
 int zk_adam_step(float* p, const float* g, float* m, float* v, void* shadow, size_t n, float* hyper,
-                 float* pnorm_out, uint64_t* seed, int norm_free, void* workspace, size_t ws_bytes,
+                 float* pnorm_out, uint64_t* seed, int norm_free, const int* skip_word, void* workspace, size_t ws_bytes,
                  hipStream_t stream) {
   ZK_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                "zk_adam_step: buffers must be 16-byte aligned");
@@ -1788,7 +1801,7 @@ int zk_adam_step(float* p, const float* g, float* m, float* v, void* shadow, siz
     // (default 2); tuning key 10: blocks (default 512; 0 = 2048).  scripts/adam_bench.py: 405 -> 391 us on one box
     // (fewer open DRAM pages); the box-to-box spread of this pass is larger than that (405 .. 477 us)
     const int gb = g_tune[10] > 0 && g_tune[10] <= 2048 ? (grid < g_tune[10] ? grid : g_tune[10]) : grid;
-#define ZK_ADAM_L(...) hipLaunchKernelGGL((k_adam<__VA_ARGS__>), dim3(gb), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n, hyper, psq, gsq, seed)
+#define ZK_ADAM_L(...) hipLaunchKernelGGL((k_adam<__VA_ARGS__>), dim3(gb), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n, hyper, psq, gsq, seed, skip_word)
     if (g_tune[9] == 1) ZK_ADAM_L(true, 1, true);
     else if (g_tune[9] == 2) ZK_ADAM_L(true, 2, true);
     else if (g_tune[9] == 4) ZK_ADAM_L(true, 4, true);
@@ -1799,7 +1812,7 @@ int zk_adam_step(float* p, const float* g, float* m, float* v, void* shadow, siz
                        pnorm_out);
   } else {
     hipLaunchKernelGGL(k_adam<false>, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n, hyper, psq,
-                       (float*)nullptr, seed);
+                       (float*)nullptr, seed, skip_word);
     ZK_LAUNCH_CHECK();
     if (pnorm_out) hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, stream, (const float*)psq, grid, 1.f, pnorm_out);
   }

@@ -47,6 +47,7 @@ struct GemmEpi {
   // are exchanged between the row block's workgroups exactly as the forward's {sum, M2} (same slots, epoch and sites).
   const bf16_t* sy_s = nullptr; int sy_lds = 0; const float* sy_mean_in = nullptr; const float* sy_rstd_in = nullptr;
   bf16_t* sy_dy = nullptr; float* sy_part = nullptr;
+  int sy_fault = 0;         // tests only (tuning key 15 bit 1): the tn = 1 tiles never publish -> every peer runs into its spin budget
   int sy_rows = 0;          // > 0: only the first sy_rows rows of the tile are this tile's (sentence-aligned row tiles, zk_attn_out_ln)
 };
 

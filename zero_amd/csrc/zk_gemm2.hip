@@ -1017,6 +1017,7 @@ static int launch_dlds_sync_ln(const bf16_t* A, const bf16_t* B, int M, int N, i
   // every XCD owns a contiguous range of nwg / 8 tiles: with that a multiple of the group size no group straddles two
   // XCDs and the exchange stays in their L2 (tuning key 15 = 1: never assume it -- exchange through memory)
   el.sy_local = (nwg % (8 * ts.tiles_n) == 0 && !(g_tune[15] & 1)) ? 1 : 0;
+  el.sy_fault = (g_tune[15] & 2) ? 1 : 0;       // fault injection for tests/test_gpu_sync_ln.py: a peer that never publishes
   hipLaunchKernelGGL((k_gemm_dlds<BM, 64, NS, false, false, 4, PW, 3>), grid, dim3((4 + PW) * 64), 0, stream, A, B, M, N, K,
                      lda, ldb, K, (float*)nullptr, ts, el, ev);
   ZK_LAUNCH_CHECK();
@@ -1041,6 +1042,7 @@ int zk_gemm_dlds_sync_ln_bwd_dispatch(const bf16_t* A, const bf16_t* B, int M, i
   const long nwg = (long)ts.tiles_m * ts.tiles_n;
   GemmEpi el = e;
   el.sy_local = (nwg % (8 * ts.tiles_n) == 0 && !(g_tune[15] & 1)) ? 1 : 0;
+  el.sy_fault = (g_tune[15] & 2) ? 1 : 0;       // fault injection for tests/test_gpu_sync_ln.py: a peer that never publishes
   hipLaunchKernelGGL((k_gemm_dlds<64, 64, 4, false, true, 4, 4, 4>), dim3((unsigned)nwg), dim3(512), 0, stream, A, B, M, N, K,
                      lda, ldb, K, (float*)nullptr, ts, el, ev);
   ZK_LAUNCH_CHECK();

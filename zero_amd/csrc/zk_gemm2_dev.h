@@ -425,6 +425,12 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
     if (fast) load_epi();
   }
   __shared__ float2 s_lnstat[LN ? BM : 1];     // (mu, rstd) of the tile's rows: of the A operand (LN = 1) / of the residual (LN = 2)
+  // LN >= 3: a wait of the in-launch exchange ran out of its spin budget somewhere in this workgroup.  Set by the lanes that
+  // watch the peers, read by everybody behind the barrier that follows: the remaining waits of the workgroup return at once
+  // (one budget per launch instead of one per row and peer) and the rows leave as NaN, so that the step's own non-finite
+  // guard (k_adam / k_norm_final2: flag, sticky count, skipped update) trips on THIS step, not at the next host read.
+  __shared__ int s_giveup;
+  if constexpr (LN >= 3) { if (tid == 0) s_giveup = 0; }   // (the K loop's barriers order this before any use)
   if constexpr (LN != 0) {
     auto ln_rows = [&]() {
       const float* part = LN == 1 ? e.ln_in_part : e.res_part;
@@ -464,8 +470,10 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
     };
     // one slot of a peer, valid once both halves carry this launch's tag.  plain_first (local): the line has not been
     // touched by this CU in this launch, an ordinary load misses the L1 and is served by the L2
+    bool gave_up = false;
     auto slot_wait = [&](unsigned long long* p, unsigned long long& a, unsigned long long& b, bool plain_first) {
       int spins = 0;
+      if (gave_up) { a = b = 0; return; }
       if (local && plain_first) {
         a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -484,6 +492,8 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
         if ((uint32_t)(a >> 32) == tag && (uint32_t)(b >> 32) == tag) return;
         if (++spins > (1 << 15)) {             // tens of milliseconds: a peer that never came (must not happen)
           if (e.sy_err != nullptr) __hip_atomic_store(e.sy_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          gave_up = true;
+          a = b = 0;
           return;
         }
         __builtin_amdgcn_s_sleep(4);
@@ -530,7 +540,7 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
       for (int j = 0; j < 8; ++j) { const float d = r8[it][j] - mt; s2 += d * d; }
       s2 = zk_sum8(s2);
       own1[it] = s1; own2[it] = s2;
-      if (ok && j8 == 0) {       // published first: the peers are waiting for this, nobody for the sum below
+      if (ok && j8 == 0 && !(e.sy_fault && tn == 1)) {       // published first: the peers are waiting for this, nobody for the sum below
         unsigned long long* p = e.sy_slots + ((size_t)gm * np + tn) * 2;
         slot_st(p, ((unsigned long long)tag << 32) | __float_as_uint(s1));
         slot_st(p + 1, ((unsigned long long)tag << 32) | __float_as_uint(s2));
@@ -552,8 +562,10 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
       if (tid < np && tid != tn) {
         unsigned long long a, b;
         slot_wait(e.sy_slots + ((size_t)grep * np + tid) * 2, a, b, false);
+        if (gave_up) __hip_atomic_store(&s_giveup, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       __syncthreads();
+      gave_up = __hip_atomic_load(&s_giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
     }
     ZK_E(6);
 #pragma unroll
@@ -584,7 +596,7 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
       if (ok) {
         float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = lgv[j] * (r8[it][j] - mu) * rs + lbv[j];
+        for (int j = 0; j < 8; ++j) o[j] = gave_up ? __builtin_nanf("") : lgv[j] * (r8[it][j] - mu) * rs + lbv[j];
         *reinterpret_cast<uint4*>(e.sy_y + (size_t)gm * e.sy_ldy + gn) = pack8(o);
         if (tn == 0 && j8 == 0 && e.sy_mean != nullptr) { e.sy_mean[gm] = mu; e.sy_rstd[gm] = rs; }
       }
@@ -631,7 +643,7 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
         sg = zk_sum8(sg);
         sgx = zk_sum8(sgx);
         own1[it] = sg; own2[it] = sgx;
-        if (ok && j8 == 0) {
+        if (ok && j8 == 0 && !(e.sy_fault && tn == 1)) {
           unsigned long long* p = e.sy_slots + ((size_t)gm * np + tn) * 2;
           slot_st(p, ((unsigned long long)tag << 32) | __float_as_uint(sg));
           slot_st(p + 1, ((unsigned long long)tag << 32) | __float_as_uint(sgx));
@@ -662,8 +674,10 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
         if (tid < np && tid != tn) {
           unsigned long long a, b;
           slot_wait(e.sy_slots + ((size_t)grep * np + tid) * 2, a, b, false);
+          if (gave_up) __hip_atomic_store(&s_giveup, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
+        gave_up = __hip_atomic_load(&s_giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
       }
       float* red2 = red + 2 * BM * 64;
 #pragma unroll
@@ -689,7 +703,7 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
         const float rs = lbv[2 * it + 1];
         float o[8], oy[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = rs * (g[it][j] - mg - xh[it][j] * mgx);
+        for (int j = 0; j < 8; ++j) o[j] = gave_up ? __builtin_nanf("") : rs * (g[it][j] - mg - xh[it][j] * mgx);
         const uint4 po = pack8(o);
         if (ok) *reinterpret_cast<uint4*>(e.sy_y + (size_t)gm * e.sy_ldy + gn) = po;
         unpack8(po, o);                                     // dy derives from the stored (rounded) ds

@@ -976,7 +976,8 @@ class TransformerCore(object):
             return e.mat("dec.x0" if side == "d" else "enc.x0", Tt if side == "d" else Ts, H)
 
         fuse_ln_bwd = self.sync_ln_mode and self.sync_ln_bwd and self.group_wgrad and e.gemm_impl == 0 and \
-            H % 64 == 0 and H <= 1024 and not self.fuse and not self._lazy_tags and not e.lib.recording
+            H % 64 == 0 and H <= 1024 and not self.fuse and not self._lazy_tags and not e.lib.recording and \
+            e.sync_ln_usable()       # (the fallback of a failed self-test covers the backward too)
 
         def ln_below(side, l, kind):
             """(scope, tag, bias of the linear layer before it, dropout, dropout site) of the LayerNorm whose output is the

@@ -158,6 +158,7 @@ class TrainOp(object):
         lib.call("zk_adam_step", st.master.data_ptr(), st.grad.data_ptr(), st.m.data_ptr(), st.v.data_ptr(),
                  st.shadow.data_ptr(), st.numel, self.hyper.data_ptr(), self.pnorm.data_ptr(),
                  self.eng.seed.data_ptr() if advance_seed else None, 1 if norm_free else 0,
+                 self.eng.sync_ln_err_ptr(),      # a step whose in-launch exchange gave up is skipped ON the device
                  self._ws.data_ptr(), self._ws.numel(), s)
         if self.ema is not None:
             lib.call("zk_ema", self.ema.data_ptr(), st.master.data_ptr(), self.hyper.data_ptr(), st.numel, s)
