@@ -608,6 +608,38 @@ int zk_dec_embed(const int* ids, int pad_id, const void* table, const float* bia
 int zk_beam_dev_run(void* graph_even, void* graph_odd, int parity, const int* ctrl_dev, int* ctrl_pinned8, int max_launch,
                     int poll, zk_stream_t stream, int* launched_out, int* newest_slot_out);
 
+/* ---- round 5: the fp32 decode path (hp.decode_dtype = "float32"; zero_amd/csrc/zk_f32.hip, zero_amd/models/_decode_f32.py).
+ * The reference computes in float32 by default (utils/dtype.py:12-15, run.py `default_dtype`); this mode rounds where it
+ * rounds -- fp32 MASTER weights, fp32 activations, fp32 accumulation -- so that greedy / beam hypotheses can be compared
+ * token for token with the fp32 oracle (the bf16 path cannot be: two correct implementations that round at different points
+ * part on ~3 % of the sentences).  Every matrix is plain fp32 row-major; all pointers are device pointers.
+ *   zk_f32_gemm       func.py:14-65 linear / transformer.py:182-196 logits: C[M,N] = A[M,K] x (tb ? B[N,K]^T : B[K,N])
+ *                     (+ bias[N]) (act 1: ReLU, func.py:332).  K % 4 == 0, lda % 4 == 0 (tb: ldb % 4 == 0), A (tb: B) 16-byte
+ *                     aligned.  v_mfma_f32_32x32x2_f32 = an fp32 fmaf chain per output in a fixed k order.
+ *   zk_f32_embed      transformer.py:16-33 / 88-119: out[r] = table[ids[r]] * scale + bias + timing[pos0 (or *pos_dev) + r % L];
+ *                     all_pad (device flag from zk_all_equal, may be NULL): non-zero -> the embedding part is exact zeros
+ *                     (transformer.py:113-115, the first decode step).
+ *   zk_f32_add_ln     func.py:321-324 + 289-303: out = gamma (s - mean) / sqrt(var + eps) + beta, s = x + y (y may be NULL).
+ *   zk_f32_attn       func.py:218-256 on q [B][Lq][..] / k, v [B / kv_group][Lk][..] (row strides ld*, sentence strides bs*
+ *                     in elements; head h at columns h d ..): q * scale, + (1 - kmask) * (-mask_inf) (func.py:372-387;
+ *                     kmask fp32 [B / kv_group, ldmask] may be NULL), softmax, x V.  nkeys_dev (may be NULL): only the
+ *                     first *nkeys_dev + 1 keys exist (the self-attention cache of decode position *nkeys_dev).
+ *   zk_f32_aan_step   transformer_aan.py:110-112: cat[r] = [x[r] | (x[r] + cache[r]) / (t + 1)], cache[r] += x[r].
+ *   zk_f32_gate       transformer_aan.py:186-189: g = sigmoid(z[:, :H]) cat[:, :H] + sigmoid(z[:, H:]) cat[:, H:].
+ * (cache appends and beam reorders are byte moves: zk_cache_rows / zk_gather_rows_ex with 4-byte elements.) */
+int zk_f32_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int tb,
+                const float* bias, int act, zk_stream_t stream);
+int zk_f32_embed(const int* ids, int rows, int L, const float* table, const float* bias, const float* timing, int timing_rows,
+                 float* out, int H, float scale, int pos0, const int* pos_dev, const int* all_pad, zk_stream_t stream);
+int zk_f32_add_ln(const float* x, const float* y, const float* gamma, const float* beta, float* out, int rows, int H, float eps,
+                  zk_stream_t stream);
+int zk_f32_attn(const float* q, const float* k, const float* v, float* out, int B, int nh, int Lq, int Lk, int d, int ldq,
+                int ldk, int ldv, int ldo, long bsq, long bsk, long bsv, long bso, const float* kmask, int ldmask, int kv_group,
+                float scale, float mask_inf, const int* nkeys_dev, zk_stream_t stream);
+int zk_f32_aan_step(const float* x, float* cache, float* cat, int rows, int H, int time, const int* time_dev,
+                    zk_stream_t stream);
+int zk_f32_gate(const float* z, const float* cat, float* g, int rows, int H, zk_stream_t stream);
+
 /* hipGraph plumbing: capture a sequence of the calls above once, replay per step */
 int zk_graph_begin(zk_stream_t stream);
 int zk_graph_end(zk_stream_t stream, void** exec_out);

@@ -13,7 +13,9 @@ these sizes, so its outputs are committed here and the `-m gpu` tests compare ag
                            num_encoder_layer=12 (transformer.py:35-69)
   big_synth_seed1234.npz   BASELINE configs[2] widths: d=1024, F=4096, h=16, 6+6 layers
   aan_base_beam.npz        BASELINE configs[3] subset: transformer_aan, d=512, 256 sentences, beam 1 and 4, by the fp32
-                           oracle and by the oracle under the bf16 storage model (keys bf16_*)
+                           oracle and by the oracle under the bf16 storage model (keys bf16_*).  Round 5: the weight set
+                           of tests/fullsize.py beam_params (decodes like a model: hypotheses end in EOS at lengths around
+                           the source length, few repeats; `stats_k*` = STAT_KEYS below)
 
 Parameters are NOT stored (77-242 M floats): both sides regenerate them from
 ``oracle.ref_torch.init_params(hp, model, seed)`` + ``tests.common.perturb`` (numpy Generator streams are
@@ -38,7 +40,7 @@ sys.path.insert(0, ROOT)
 from oracle import ref_torch as rt  # noqa: E402
 from tests.common import perturb  # noqa: E402
 from tests.fullsize import (fullsize_hp, fullsize_batch, fullsize_params, param_probe, SLICES,  # noqa: E402
-                            beam_hp, beam_sources, BEAM_SENTENCES)
+                            beam_hp, beam_params, beam_sources, BEAM_SENTENCES)
 
 
 def train_fixture(name, **kw):
@@ -68,6 +70,37 @@ def train_fixture(name, **kw):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
+STAT_KEYS = ("eos_terminated_frac", "repeat_frac", "mean_len", "mean_src_len", "len_minus_src_std", "corr_len_src",
+             "min_boundary_gap", "p1_boundary_gap", "median_boundary_gap", "decode_steps")
+
+
+def beam_stats(best, src, tsc, K):
+    """What makes the fixture a decode WORKLOAD: share of best hypotheses that end in an EOS, share
+    of positions that repeat the previous token, hypothesis lengths against source lengths, and the score gaps at the
+    boundary that decides which candidates stay alive (rank K against K + 1 of the step's table)."""
+    slen = (src != 0).sum(1)
+    ends, lens, reps, tot = 0, [], 0, 0
+    for s in best:
+        s = [int(x) for x in s]
+        if 2 in s:
+            ends += 1
+            L = s.index(2) + 1
+        else:
+            L = len([x for x in s if x != 0])
+        lens.append(L)
+        reps += sum(1 for a, b in zip(s[1:L], s[:L - 1]) if a == b)
+        tot += max(L - 1, 1)
+    lens = np.array(lens, dtype=np.float64)
+    with np.errstate(invalid="ignore"):
+        g = tsc[:, :, K - 1] - tsc[:, :, K]
+    g = g[np.isfinite(g) & (tsc[:, :, K] > -1e30)]
+    return {"eos_terminated_frac": ends / float(len(best)), "repeat_frac": reps / float(tot), "mean_len": lens.mean(),
+            "mean_src_len": slen.mean(), "len_minus_src_std": (lens - slen).std(),
+            "corr_len_src": float(np.corrcoef(lens, slen)[0, 1]), "min_boundary_gap": g.min(),
+            "p1_boundary_gap": np.percentile(g, 1), "median_boundary_gap": np.median(g),
+            "decode_steps": float(np.isfinite(tsc[:, :, 0]).any(axis=1).sum())}
+
+
 def beam_fixture():
     """256 sentences (round 4; 64 before), each decoded by the fp32 oracle AND by the oracle under the bf16 storage
     model (Cfg.store_bf16: the tensors the HIP path keeps as bf16 rounded at the same points).  The second run is what
@@ -76,7 +109,7 @@ def beam_fixture():
     same choice as the HIP path, or whether the gap is inside the two oracles' own disagreement at that step."""
     hp = beam_hp()
     model = hp.model_name
-    Pn = fullsize_params(hp, model)
+    Pn = beam_params(hp, model)          # round 5: the weight set that decodes like a model (tests/fullsize.py)
     P = rt.to_torch(Pn)
     src = beam_sources(BEAM_SENTENCES)
     out = {"param_probe": param_probe(Pn), "source": src}
@@ -115,6 +148,9 @@ def beam_fixture():
             out[prefix + "seqs_k%d" % K] = np.concatenate(seqs, 0).astype(np.int32)
             out[prefix + "scores_k%d" % K] = np.concatenate(scores, 0).astype(np.float32)
             print("%sbeam %d: %s (%.0f s)" % (prefix, K, out[prefix + "seqs_k%d" % K].shape, time.time() - t0), flush=True)
+            st = beam_stats(out[prefix + "seqs_k%d" % K][:, 0], src, tsc, K)
+            out[prefix + "stats_k%d" % K] = np.array([st[k] for k in STAT_KEYS], dtype=np.float64)
+            print("   " + ", ".join("%s %.4g" % (k, st[k]) for k in STAT_KEYS), flush=True)
             np.savez_compressed(os.path.join(HERE, "aan_base_beam.partial.npz"), **out)
     np.savez_compressed(os.path.join(HERE, "aan_base_beam.npz"), **out)
     os.remove(os.path.join(HERE, "aan_base_beam.partial.npz"))

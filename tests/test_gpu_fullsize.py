@@ -39,7 +39,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from tests.fullsize import (fullsize_hp, fullsize_batch, fullsize_params, param_probe, SLICES,  # noqa: E402
-                            beam_hp, beam_sources)
+                            beam_hp, beam_params, beam_sources)
 from zero_amd.models._factory import get_core, reset_cores  # noqa: E402
 from zero_amd.models import model as registry, load_all  # noqa: E402
 
@@ -219,7 +219,7 @@ def test_aan_beam_search_base_size(K):
     hp = beam_hp()
     hp.beam_size = K
     model = hp.model_name
-    Pn = fullsize_params(hp, model)
+    Pn = beam_params(hp, model)          # round 5: the weight set that decodes like a model (tests/fullsize.py)
     assert np.allclose(param_probe(Pn), fx["param_probe"], rtol=1e-12, atol=0)
     src = beam_sources()
     assert np.array_equal(src, fx["source"])
@@ -309,3 +309,94 @@ def test_aan_beam_search_base_size(K):
             ("neither reproduced by the bf16-storage oracle nor inside the oracle pair's own disagreement", d)
     # and the HIP path must not disagree with the fp32 oracle (much) more often than the bf16-storage oracle does
     assert n - exact <= 2 * (n - rep["oracle_fp32_vs_bf16storage_token_exact"]) + 2, rep
+
+
+def _hyp_stats(seqs, src):
+    """share of best hypotheses that end in an EOS / of positions that repeat the previous token (the fixture's own
+    `stats_k*` hold the oracle's figures; make_fullsize_golden.py beam_stats)"""
+    ends = reps = tot = 0
+    for s_ in np.asarray(seqs)[:, 0]:
+        s_ = [int(x) for x in s_]
+        L = s_.index(2) + 1 if 2 in s_ else len([x for x in s_ if x != 0])
+        ends += int(2 in s_)
+        reps += sum(1 for a, b in zip(s_[1:L], s_[:L - 1]) if a == b)
+        tot += max(L - 1, 1)
+    return ends / float(len(seqs)), reps / float(tot)
+
+
+def test_the_decode_fixture_is_a_decode_workload():
+    """the committed fixture itself -- >= 90 % of the oracle's best hypotheses end in an EOS, < 30 % of
+    the positions repeat the previous token, hypothesis lengths follow the source lengths (correlation > 0.8), and the
+    steps are not all trivial (1 % of the alive / dropped boundaries closer than 0.05)."""
+    from tests.golden.make_fullsize_golden import STAT_KEYS
+    fx = np.load(os.path.join(GOLD, "aan_base_beam.npz"))
+    for K in (1, 4):
+        for prefix in ("", "bf16_"):
+            st = dict(zip(STAT_KEYS, fx[prefix + "stats_k%d" % K]))
+            assert st["eos_terminated_frac"] >= 0.9 and st["repeat_frac"] < 0.3, st
+            assert st["corr_len_src"] > 0.8 and abs(st["mean_len"] - st["mean_src_len"]) < 0.35 * st["mean_src_len"], st
+            assert st["p1_boundary_gap"] < 0.05 and st["decode_steps"] >= 40, st
+            ends, reps = _hyp_stats(fx[prefix + "seqs_k%d" % K], fx["source"])
+            assert abs(ends - st["eos_terminated_frac"]) < 1e-9 and abs(reps - st["repeat_frac"]) < 1e-9
+
+
+@pytest.mark.parametrize("K", [1, 4])
+def test_aan_beam_search_base_size_fp32_is_token_exact(K):
+    """north_star: "token-id exact for greedy decode" against the fp32 reference.  In the fp32 decode mode
+    (decode_dtype = float32: fp32 masters / activations / accumulation, zk_f32_*) EVERY one of the 256 best hypotheses
+    must equal the fp32 oracle's token for token, beam 1 and beam 4, scores within 1e-4 relative -- on a fixture whose
+    hypotheses end in an EOS at lengths around the source length (EOS routing, finished-set merging and the stop bound of
+    search.py:85-113, 192-228 are exercised at d = 512, V = 32000)."""
+    from zero_amd.main import tower_infer_graph
+    from zero_amd.search import decode_hypothesis
+    fx = np.load(os.path.join(GOLD, "aan_base_beam.npz"))
+    reset_cores()
+    hp = beam_hp()
+    hp.beam_size = K
+    hp.decode_dtype = "float32"
+    model = hp.model_name
+    Pn = beam_params(hp, model)
+    assert np.allclose(param_probe(Pn), fx["param_probe"], rtol=1e-12, atol=0)
+    src = beam_sources()
+    get_core(hp, model, Pn)
+    ref_seq, ref_score = fx["seqs_k%d" % K], fx["scores_k%d" % K]
+    ref_tsc, ref_tix = fx["trace_scores_k%d" % K], fx["trace_idx_k%d" % K]
+    exact = allbeams = n = 0
+    rel = 0.0
+    misses = []
+    steps = 0
+    import time as _time
+    t0 = _time.time()
+    for i in range(0, src.shape[0], 32):
+        seqs, scores = tower_infer_graph({"source": src[i:i + 32]}, registry.get_model(model), hp)
+        seqs = np.asarray(seqs)
+        steps += seqs.shape[2]
+        hyp = decode_hypothesis(seqs, hp)
+        ref_hyp = decode_hypothesis(ref_seq[i:i + 32], hp)
+        L = min(seqs.shape[2], ref_seq.shape[2])
+        bad = []
+        for j, (a, b) in enumerate(zip(hyp, ref_hyp)):
+            n += 1
+            same = list(a) == list(b)
+            exact += int(same)
+            allbeams += int(np.array_equal(seqs[j, :, :L], ref_seq[i + j, :, :L]))
+            if same:
+                rel = max(rel, abs(float(scores[j, 0]) - float(ref_score[i + j, 0])) / max(abs(float(ref_score[i + j, 0])), 1e-6))
+            else:
+                bad.append(j)
+        if bad:
+            hp.search_trace = []
+            tower_infer_graph({"source": src[i:i + 32]}, registry.get_model(model), hp)
+            trace, hp.search_trace = hp.search_trace, None
+            for j in bad:
+                d = _first_divergence(trace, ref_tsc, ref_tix, j, i + j, K)
+                misses.append(dict(d or {"step": None}, sentence=i + j))
+    wall = _time.time() - t0
+    ends, reps = _hyp_stats(ref_seq, src)
+    rep = {"beam": K, "sentences": n, "token_exact": exact, "all_beams_token_exact": allbeams,
+           "best_score_rel_diff_max": rel, "misses": misses, "oracle_eos_terminated_frac": ends, "oracle_repeat_frac": reps,
+           "decode_wall_s_incl_startup": wall, "decode_steps_sum_over_batches": steps}
+    print(json.dumps(rep, sort_keys=True))
+    _report("beam_fp32_k%d" % K, rep)
+    assert exact == n, rep
+    assert rel < 1e-4, rep

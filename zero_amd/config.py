@@ -55,6 +55,9 @@ _DEFAULTS = [
     ("nthreads", 6), ("random_seed", 1234), ("train_continue", True),
     ("default_dtype", "float32"), ("dtype_epsilon", 1e-8), ("dtype_inf", 1e8),
     ("loss_scale", 1.0),
+    # build-specific (round 5): "bfloat16" = the product decode path; "float32" = fp32 masters / activations / accumulation
+    # through zk_f32_* (zero_amd/models/_decode_f32.py): rounds where the reference's default dtype rounds
+    ("decode_dtype", "bfloat16"),
     ("l0_norm_reg_scalar", 1.0), ("l0_norm_start_reg_ramp_up", 0),
     ("l0_norm_end_reg_ramp_up", 10000), ("l0_norm_warm_up", True),
 ]

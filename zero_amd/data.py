@@ -9,8 +9,12 @@ semantics: ``utils/util.py:17-65`` (``batch_indexer``, ``token_indexer``) and
 order, and the "leak" rule that carries tail batches smaller than
 ``size * data_leak_ratio`` over to the next buffer (data.py:98-117)).
 
-The reference module itself cannot be imported here (it pulls TensorFlow in through
-utils.util), so the tests pin the semantics with hand-derived known answers.
+The reference modules cannot be IMPORTED here (utils/util.py imports TensorFlow at module level), but the three
+definitions on this path are plain Python: tests/golden/make_data_golden.py lifts ``batch_indexer`` / ``token_indexer``
+/ ``Dataset`` out of the reference's syntax trees, runs them unchanged on seeded inputs and stores inputs + outputs
+(tests/golden/reference_data.json); tests/test_data.py replays them through this module -- the row is pinned by the
+reference's own code (round 5) -- beside hand-derived known answers and hypothesis properties against an independently
+written statement of the batching rule.
 """
 
 import numpy as np

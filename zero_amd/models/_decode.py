@@ -28,6 +28,7 @@ import torch
 
 from zero_amd.func import Mat
 from zero_amd.models._factory import get_core
+from zero_amd.models import _decode_f32 as _f32
 from zero_amd.utils import dtype as zdtype
 
 F32 = torch.float32
@@ -76,7 +77,9 @@ def _graph_pointers(state, book):
     for l in range(core.hp.num_decoder_layer):
         lay = state["decoder"]["state"]["layer_%d" % l]
         ptrs += [lay["mk"].ptr, lay["mv"].ptr]
-    for nm in ("dc.aan.0", "dc.aan.1", "dc.k.0", "dc.k.1", "dc.v.0", "dc.v.1"):
+    ptrs.append(core.store.master.data_ptr())
+    for nm in ("dc.aan.0", "dc.aan.1", "dc.k.0", "dc.k.1", "dc.v.0", "dc.v.1",
+               "dq.aan.0", "dq.aan.1", "dq.k.0", "dq.k.1", "dq.v.0", "dq.v.1", "dq.logits"):
         b = e.bufs.get(nm)
         ptrs.append(b.data_ptr() if b is not None else 0)
     ptrs += [m.ptr for _, m in sorted(state.get("wt", {}).items())]
@@ -100,7 +103,7 @@ def adopt_graphs(state, book, temperature, forbid_value, noise):
     # 16 rows per workgroup -- must not be adopted by a single-stream decode, nor the reverse)
     from zero_amd import hip as _hip
     key = (state["B"], state["K"], state["Ls"], state["Tmax"], book is not None, float(temperature),
-           float(forbid_value), bool(noise), int(_hip.lib().raw("zk_dec_group")(-1)))
+           float(forbid_value), bool(noise), int(_hip.lib().raw("zk_dec_group")(-1)), bool(state.get("f32")))
     state["_gkey"] = key
     if os.environ.get("ZERO_HIP_DECODE_GRAPH_CACHE", "1") == "0":
         return
@@ -217,6 +220,9 @@ class DecodeState(dict):
                     lay[nm] = e.buf("dc.%s.%d" % (nm, pp), (nl, BK, self["Tmax"], H))[l]
 
 
+DecodeStateF32 = _f32.make_state_class(DecodeState)      # decode_dtype = float32: 4-byte caches, `dq.*` buffers
+
+
 def _fuse_att_ok(core, hp, K):
     """The attention sub-layers of a cached decode step as one launch per (sentence, head) (zk_dec_cross / zk_dec_self)."""
     import os
@@ -282,6 +288,10 @@ def make_infer_fns(params, model_name):
         K = hp.beam_size if beam_size is None else beam_size
         import os
         pad = max(1, int(os.environ.get("ZERO_HIP_DECODE_PAD_LEN", "8")))
+        if _f32.wanted(hp):
+            # the fp32 mode (round 5): fp32 masters, activations and caches through zk_f32_* (models/_decode_f32.py)
+            from zero_amd.models._core import trim_columns
+            return finish_state(_f32.encoding_state(core, hp, source, K, max_steps, DecodeStateF32, pad, trim_columns))
         if pad > 1:
             # Shape bucketing for the step-graph cache: the source is padded (id 0 = pad: masked in the encoder's
             # self-attention and in every cross-attention, func.py:372-387) and the cache length rounded up to a multiple
@@ -346,6 +356,14 @@ def make_infer_fns(params, model_name):
                     e.buf("dc.%s.%d" % (nm, half), (nl, BK, max_steps, H))
         state.bind_caches()
         state["zero_flag"] = e.buf("dc.zflag", (1,), torch.int32)
+        return finish_state(state)
+
+    def finish_state(state):
+        """The part of a batch's state that does not depend on the step's dtype: the packed host <-> device buffers of
+        the search and the graph table."""
+        core = state["_core"]
+        e = core.eng
+        B, K, BK = state["B"], state["K"], state["BK"]
         # per-step scalars live in device memory ({time, float bits of the length penalty, EOS-ban id}):
         # a captured decode-step graph reads the current values at replay time
         # what the host hands to a (replayed) step -- last tokens, previous log-probs, beam reorder index and
@@ -474,6 +492,8 @@ def make_infer_fns(params, model_name):
         BK, K, B, Ls, Tmax = state["BK"], state["K"], state["B"], state["Ls"], state["Tmax"]
         if time_dev is None and time >= Tmax:
             raise RuntimeError("decode step %d exceeds the allocated cache length %d" % (time, Tmax))
+        if state.get("f32"):
+            return _f32.step_cache(target, state, time, time_dev, hp)
         import os as _os
         zf = state["zero_flag"]
         fuse_head = True
@@ -728,6 +748,10 @@ def make_infer_fns(params, model_name):
     def decoding_fn(target, state, time):
         if hp.search_mode == "cache":
             return _step_cache(target, state, time)
+        if _f32.wanted(hp):
+            from zero_amd.hip import ZeroHipError
+            raise ZeroHipError("decode_dtype=float32 decodes with search_mode=cache only (the dev mode re-runs the bf16 "
+                               "training-path decoder, transformer.py:277-281)")
         return _step_dev(target, state, time)
 
     decoding_fn.step_static = step_static
