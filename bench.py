@@ -349,6 +349,37 @@ class LaunchProfiler(object):
         return self._agg(lambda r: r[1] if r[0] == cls else None)
 
 
+def current_round():
+    """The build round this tree belongs to: one more than the round VERDICT.md reviews (1 without a verdict)."""
+    import re
+    here = os.path.dirname(os.path.abspath(__file__))
+    try:
+        m = re.search(r"round\s+(\d+)", open(os.path.join(here, "VERDICT.md")).readline())
+        return int(m.group(1)) + 1 if m else 1
+    except OSError:
+        return 1
+
+
+def counter_status(fname, commit):
+    """{'stale': bool, 'why': ...} of a committed counter summary: counters come from separate
+    rocprofv3 --pmc passes, so a line can only CITE them; it must say when what it cites was measured on other code.  Stale =
+    the file belongs to an earlier round (rNN_ prefix below current_round()), carries no commit, or was measured on a
+    dirty tree."""
+    import re
+    if fname is None:
+        return None
+    m = re.match(r"r(\d+)_", fname)
+    rnd = int(m.group(1)) if m else None
+    why = []
+    if rnd is None or rnd < current_round():
+        why.append("measured in round %s, this tree is round %d" % (rnd, current_round()))
+    if not commit:
+        why.append("no commit recorded")
+    elif str(commit).endswith("+dirty"):
+        why.append("measured on a dirty tree (%s)" % commit)
+    return {"stale": bool(why), "why": "; ".join(why) or None}
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary
     (profiles/*_pmc_traffic.json, written by scripts/pmc_traffic.sh on the GPU box in separate
@@ -581,9 +612,66 @@ def decode_measure(args, rank, world):
     out["single_batch_ms_per_step"] = (time.perf_counter() - t1) / max(single_steps, 1) * 1e3
     out["single_batch_sample"] = "%d of the %d batches, one after the other on one lane, %d decode steps" % (
         len(sample), len(batches), single_steps)
+    if model == "transformer_aan" and world == 1 and not getattr(args, "no_modellike", False):
+        try:
+            out["eos_terminated_weights"] = decode_modellike(args, batches, streams)
+        except Exception as exc:      # noqa: BLE001 -- a side measurement must not cost the line
+            out["eos_terminated_weights"] = {"error": repr(exc)}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_decode_baseline(hp, model, batches)
     return out
+
+
+def decode_modellike(args, batches, streams):
+    """"... plus a run with a weight set whose eos logit is biased so lengths ~ source lengths".  The same
+    3000-sentence job with the weight set of the BASELINE-size decode fixture (tests/fullsize.py beam_params: a random
+    Transformer that decodes like a model -- sparse-bigram softmax table, fitted EOS row; built here from
+    zero_amd.variables.initial_values, the same numpy stream as the fixture's, without touching oracle/), in the bf16
+    product mode with `streams` batches in flight and in the fp32 mode (decode_dtype = float32, zk_f32_*), where the
+    hypotheses are token-exact against the fp32 oracle (tests/test_gpu_fullsize.py)."""
+    from tests.fullsize import beam_hp, beam_params
+    from zero_amd.variables import initial_values
+    from zero_amd.models import model as registry
+    from zero_amd.models._factory import get_core
+    from zero_amd.search import beam_search
+    from zero_amd.evalu import decode_many
+    res = {"weights": "tests/fullsize.py beam_params (gain-0.1 scope initialiser, scaled target embedding / cross attention, "
+                      "successor-map softmax table, fitted EOS row tests/golden/aan_base_beam_eos_row.npy)"}
+    src_len = np.concatenate([(b != 0).sum(1) for b in batches])
+    for tag, dd, lanes in (("bf16", "bfloat16", streams), ("fp32_mode", "float32", 1)):
+        hp = beam_hp()
+        hp.decode_dtype = dd
+        hp.scope_name = "bench_modellike_" + tag
+        model = hp.model_name
+        Pn = beam_params(hp, model, init=lambda hp_, m_, seed_: initial_values(hp_, m_, seed_))
+        get_core(hp, model, Pn)
+        graph = registry.get_model(model)
+        key = "fns_" + tag
+
+        def work(src, hp=hp, key=key, graph=graph):
+            fns = _LANE_FNS.__dict__.get(key)
+            if fns is None:
+                fns = graph.infer_fn(hp)
+                setattr(_LANE_FNS, key, fns)
+            r = beam_search({"source": src}, fns[0], fns[1], hp)
+            best = np.asarray(r["seq"])[:, 0]
+            return r["steps"], [int((row == 2).any()) for row in best], \
+                [int(np.argmax(row == 2)) + 1 if (row == 2).any() else int((row != 0).sum()) for row in best]
+        job = batches if tag == "bf16" else batches[::4]          # the fp32 mode on a quarter of the job (bounded)
+        decode_many(job[-max(args.warmup, 1):], work, lanes, each_lane=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = decode_many(job, work, lanes)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        steps = sum(g[0] for g in got)
+        ends = sum(sum(g[1]) for g in got)
+        lens = np.concatenate([np.asarray(g[2]) for g in got])
+        n = int(sum(b.shape[0] for b in job))
+        res[tag] = {"sentences_per_s": n / dt, "sentences": n, "decode_steps": steps, "ms_per_step": dt / steps * 1e3,
+                    "batches_in_flight": lanes, "eos_terminated_frac": ends / float(n), "mean_hypothesis_len": float(lens.mean()),
+                    "mean_source_len": float(src_len.mean()), "decode_dtype": dd}
+    return res
 
 
 def decode_main(args, rank, world):
@@ -651,6 +739,11 @@ def main():
     ap.add_argument("--static-batch", action="store_true",
                     help="SIDE measurement: time the replay of ONE pre-uploaded batch (rounds 1-3's loop) instead of "
                          "Trainer.step on rotating batches; the default line carries both")
+    ap.add_argument("--no-modellike", action="store_true",
+                    help="decode leg: skip the side run with the EOS-terminating weight set (bf16 and fp32 mode)")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="warm-up + the timed loop and nothing else (no second loop, no instrumented pass, no decode / CPU "
+                         "legs): what a rocprofv3 --kernel-trace of the CAPTURED step should see (scripts/gpu_round5.sh profstep)")
     ap.add_argument("--decode-streams", type=int, default=0,
                     help="decode batches in flight at once (0 = ZERO_HIP_DECODE_STREAMS or its default)")
     args = ap.parse_args()
@@ -803,6 +896,15 @@ def main():
         for _ in range(2):
             rotating(0)
     dt, loss = chosen["_dt"], chosen["_loss"]
+    if args.timed_only:
+        if rank == 0:
+            line = bench_line(chosen, legs)
+            line["timed_only"] = True
+            line["launches_per_step"] = getattr(tr.core.eng, "last_graph_nodes", None) if (use_graph and world == 1) else None
+            print(json.dumps(line))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     loss_v = float(loss.reshape(-1)[0].cpu())
     gnorm, pnorm, skipped = tr.train_op.stats()
     step_launches = getattr(tr.core.eng, "last_graph_nodes", None) if (use_graph and world == 1) else None
@@ -928,7 +1030,9 @@ def main():
                             "flop_per_launch": agg[key][0] / agg[key][2]} if key in agg else None),
         "traffic": traffic, "traffic_unit": "bytes/launch of worst_instance (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC)",
         "traffic_source": traffic_src, "traffic_measured_at_commit": traffic_commit,
+        "traffic_status": counter_status(traffic_src, traffic_commit),
         "mfma_busy": mfma_busy, "mfma_busy_source": mfma_src, "mfma_busy_measured_at_commit": mfma_commit,
+        "mfma_busy_status": counter_status(mfma_src, mfma_commit),
         "step_frac": flops / (ms * 1e-3) / (MFMA_BF16_PEAK_TFLOPS * 1e12),
         "event_pair_overhead_us": prof.overhead_s() * 1e6,
         "all_gemm_achieved": tot_fl / tot_s / 1e12, "all_gemm_ms_per_step": tot_s / NPROF * 1e3,

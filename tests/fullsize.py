@@ -38,9 +38,14 @@ def fullsize_batch(seed=1234):
     return src, tgt
 
 
-def fullsize_params(hp, model, seed=1234):
-    from oracle import ref_torch as rt
-    return perturb(rt.init_params(hp, model, seed=seed), np.random.default_rng(seed + 1))
+def fullsize_params(hp, model, seed=1234, init=None):
+    """init: (hp, model, seed) -> {name: array}; default the oracle's init_params.  zero_amd.variables.initial_values
+    draws the same values from the same numpy stream (tests/test_oracle.py holds the two equal), which lets bench.py build
+    the decode fixture's weight set without touching oracle/."""
+    if init is None:
+        from oracle import ref_torch as rt
+        init = lambda hp_, model_, seed_: rt.init_params(hp_, model_, seed=seed_)
+    return perturb(init(hp, model, seed), np.random.default_rng(seed + 1))
 
 
 def param_probe(Pn):
@@ -89,11 +94,11 @@ BEAM_EOS_RIDGE = 300.0
 BEAM_EOS_ROW = "aan_base_beam_eos_row.npy"
 
 
-def beam_params(hp, model="transformer_aan", seed=1234, eos_row="file"):
+def beam_params(hp, model="transformer_aan", seed=1234, eos_row="file", init=None):
     """Parameters of the decode fixture (see above), regenerated on both sides from numpy streams + the stored EOS row.
     eos_row: "file" (tests/golden/aan_base_beam_eos_row.npy), an array, or None (row of zeros: make_beam_eos_row.py)."""
     import os
-    Pn = fullsize_params(hp, model, seed)
+    Pn = fullsize_params(hp, model, seed, init=init)
     rng = np.random.default_rng(seed + 3087)
     Et = Pn["tgt_embedding"]
     Es = np.zeros_like(Pn["softmax_embedding"])

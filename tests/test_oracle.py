@@ -193,3 +193,35 @@ def test_golden_fixtures_reproduce(model):
         enc, dec = rt.infer_fn(hp, P, model)
         b = rt.beam_search({"source": torch.tensor(fx["source"])}, enc, dec, hp)
         assert np.array_equal(b["seq"], fx["beam%d_seq" % K])
+
+
+# ---- round 5: the BASELINE-size decode fixture (tests/golden/aan_base_beam.npz) and its weight set ---------------------
+def test_initial_values_of_the_package_equal_the_oracles():
+    """zero_amd.variables.initial_values and oracle.ref_torch.init_params draw the same values from the same numpy
+    stream: bench.py can build the decode fixture's weight set (tests/fullsize.py beam_params(init=...)) without oracle/."""
+    from zero_amd.variables import initial_values
+    for model in MODELS:
+        hp = make_hp(model, shared_target_softmax_embedding=False, initializer_gain=0.1)
+        a = rt.init_params(hp, model, seed=77)
+        b = initial_values(hp, model, 77)
+        assert list(a.keys()) == list(b.keys()) and all(np.array_equal(a[k], b[k]) for k in a)
+
+
+def test_the_decode_fixture_is_a_decode_workload():
+    """the committed fixture itself -- >= 90 % of the oracle's best hypotheses end in an EOS, < 30 % of
+    the positions repeat the previous token, hypothesis lengths follow the source lengths, the steps are not all trivial
+    (1 % of the alive / dropped boundaries closer than 0.05 in score) and a batch decodes for >= 40 steps.  The stored
+    statistics are recomputed from the stored hypotheses."""
+    from tests.golden.make_fullsize_golden import STAT_KEYS, beam_stats
+    fx = np.load(os.path.join(GOLD, "aan_base_beam.npz"))
+    for K in (1, 4):
+        for prefix in ("", "bf16_"):
+            st = dict(zip(STAT_KEYS, fx[prefix + "stats_k%d" % K]))
+            assert st["eos_terminated_frac"] >= 0.9 and st["repeat_frac"] < 0.3, st
+            assert st["corr_len_src"] > 0.7 and abs(st["mean_len"] - st["mean_src_len"]) < 0.45 * st["mean_src_len"], st
+            assert st["p1_boundary_gap"] < 0.05 and st["decode_steps"] >= 40, st
+            again = beam_stats(fx[prefix + "seqs_k%d" % K][:, 0], fx["source"], fx[prefix + "trace_scores_k%d" % K], K)
+            assert all(abs(again[k] - st[k]) <= 1e-9 * max(1.0, abs(st[k])) for k in STAT_KEYS), (again, st)
+    # the two oracles (fp32 / bf16 storage model) are both in the file and do not agree everywhere: the yardstick of
+    # "token-exact" between two correct implementations that round at different points
+    assert fx["seqs_k1"].shape[0] == fx["bf16_seqs_k1"].shape[0] == 256

@@ -33,7 +33,7 @@ def check_model(core):
     if core.rpr or core.fuse:
         from zero_amd.hip import ZeroHipError
         raise ZeroHipError("decode_dtype=float32 is implemented for transformer and transformer_aan; %s decodes in bf16 only"
-                           % core.model_name)
+                           % ("transformer_rpr" if core.rpr else "transformer_fuse"))
 
 
 class _Ops(object):
