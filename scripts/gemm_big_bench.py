@@ -94,6 +94,57 @@ def grouped_one(name, M, N, K, ta, tb):
     print("%-12s %s" % (name, " | ".join(res)), flush=True)
 
 
+def sched_sweep():
+    """Round 5: the LDS-DMA issue schedule of the 256x256 tile's second half-workgroup (tuning key 14, gemm256_acc) on the
+    three launches that use the tile in the training step: all weight gradients of a step in one group (~495 GFLOP), the
+    logits forward (via the grouped launch: spread form) and dlogits x E."""
+    tune = e.lib.raw("zk_tune")
+    X = torch.randn(T, F, device="cuda").bfloat16()
+    dY = torch.randn(T, F, device="cuda").bfloat16()
+    DL = torch.randn(T, V, device="cuda").bfloat16()
+    probs, flops, outs = [], 0.0, []
+    shapes = []
+    for l in range(6):
+        shapes += [(H, 3 * H), (H, H), (H, F), (F, H)]                               # encoder layer
+        shapes += [(H, 3 * H), (H, H), (H, H), (H, H), (H, H), (H, H), (H, F), (F, H)]   # decoder layer
+    for (m, n) in shapes:
+        G = torch.empty(m, n, device="cuda", dtype=torch.float32)
+        outs.append(G)
+        probs.append((Mat(X, T, m, F), Mat(dY, T, n, F), Mat(G, m, n), m, n, T, None))
+        flops += 2.0 * m * n * T
+    GE = torch.empty(V, H, device="cuda", dtype=torch.float32)
+    probs.append((Mat(DL, T, V), Mat(X, T, H, F), Mat(GE, V, H), V, H, T, None))
+    flops += 2.0 * V * H * T
+    ref = X[:, :H].float().t() @ dY[:, :3 * H].float()
+    A = torch.randn(T, H, device="cuda").bfloat16()
+    E = torch.randn(V, H, device="cuda").bfloat16()
+    LG = torch.empty(T, V, device="cuda", dtype=torch.float32)
+    lref = A[:256].float() @ E.float().t()
+    base = {}
+    for sched in (0, 1, 2, 3, 4, 5, 6, 7, 0):
+        tune(14, sched)
+        for g_ in outs:
+            g_.zero_()
+        e.gemm_grouped(probs, 1, 0, tile=(256, 256, 0))
+        torch.cuda.synchronize()
+        err = float((outs[0] - ref).norm() / ref.norm())
+        us_w = timed(lambda: e.gemm_grouped(probs, 1, 0, tile=(256, 256, 0)), reps=4)
+        lp = [(Mat(A, T, H), Mat(E, V, H), Mat(LG, T, V), T, V, H, None)]
+        LG.zero_()
+        e.gemm_grouped(lp, 0, 1, tile=(256, 256, 0))
+        torch.cuda.synchronize()
+        lerr = float((LG[:256] - lref).norm() / lref.norm())
+        us_l = timed(lambda: e.gemm_grouped(lp, 0, 1, tile=(256, 256, 0)), reps=4)
+        us_l2 = timed(lambda: e.gemm_grouped(lp, 0, 1, tile=(256, 256)), reps=4)
+        print("sched %d: all weight gradients %7.1f us %5.0f TF (err %.1e) | logits fwd 256x256n %6.1f us %5.0f TF (err %.1e) | "
+              "logits fwd 256x256 spread %6.1f us" % (sched, us_w, flops / us_w / 1e6, err, us_l, 2.0 * T * V * H / us_l / 1e6,
+                                                      lerr, us_l2), flush=True)
+    tune(14, 0)
+
+
+if "--sched" in sys.argv:
+    sched_sweep()
+    sys.exit(0)
 if "--quick" not in sys.argv:
     single("logits fwd", T, V, H, 0, 1, 1)
     single("wgrad lgt", V, H, T, 1, 0, 1)

@@ -37,6 +37,7 @@ for st in $STAGES; do
     mfma)   bash scripts/pmc_mfma.sh ;;
     traffic) bash scripts/pmc_traffic.sh ;;
     trafficd) bash scripts/pmc_traffic_decode.sh ;;
+    gemmsched) timeout 600 python scripts/gemm_big_bench.py --sched > gpurun_out/gemm_sched.txt 2>&1; echo "rc=$?"; tail -12 gpurun_out/gemm_sched.txt ;;
     gemmbig) timeout 600 python scripts/gemm_big_bench.py > gpurun_out/gemm_big.txt 2>&1; echo "rc=$?"; tail -40 gpurun_out/gemm_big.txt ;;
     decode) timeout 600 python bench.py --mode decode > gpurun_out/bench_decode.json 2> gpurun_out/bench_decode.err; echo "rc=$?"; tail -c 900 gpurun_out/bench_decode.json ;;
   esac

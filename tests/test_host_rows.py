@@ -358,3 +358,33 @@ def test_vocab_and_vocabulary_preparation_match_the_reference(tmp_path):
         assert v.to_id(c["probe"]) == c["to_id"] and v.to_id(c["probe"], append_eos=False) == c["to_id_no_eos"]
         assert v.to_tokens(c["ids"]) == c["to_tokens"]
         assert (v.eos(), v.pad()) == (c["eos"], c["pad"]) == (2, 0)
+
+
+# ---- round 5: the hypothesis cut (evalu.py:14-46) and closing_dropout (util.py:106-114) against the reference's own
+# function bodies (tests/golden/make_evalu_golden.py lifts them out of the syntax trees; the modules import TensorFlow)
+def test_hypothesis_cut_and_closing_dropout_equal_the_reference_functions(tmp_path):
+    import json as _json
+    import os as _os
+    from zero_amd import evalu
+    from zero_amd.models._factory import closing_dropout
+    from zero_amd.search import decode_hypothesis as cut_best
+    from zero_amd.utils.hparams import HParams
+    from zero_amd.vocab import Vocab
+    fx = _json.load(open(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "reference_evalu.json")))
+    vp = tmp_path / "v.txt"
+    vp.write_text("\n".join(fx["vocab_lines"]) + "\n")
+    v = Vocab(str(vp))
+
+    class P(object):
+        tgt_vocab = v
+    assert len(fx["hypothesis"]) >= 12
+    for c in fx["hypothesis"]:
+        hyp, marks = evalu.decode_hypothesis(c["seqs"], c["scores"], P(), mask=c["mask"])
+        assert hyp == c["hypoes"] and marks == c["marks"], c
+        # the id-level cut the search tests use (beam 0, stop at the first eos or pad) is the same rule
+        for t, tower in enumerate(c["seqs"]):
+            ids = cut_best(np.asarray(tower), P())
+            assert [v.to_tokens(i) for i in ids] == [evalu.decode_target_token(s[0], v) for s in tower]
+    for c in fx["closing_dropout"]:
+        hp = HParams(**c["before"])
+        assert closing_dropout(hp).values() == c["after"], c

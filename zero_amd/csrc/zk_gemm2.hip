@@ -101,7 +101,7 @@ __global__ void __launch_bounds__((4 + PW) * 64) k_gemm_grouped(const GroupDesc*
 template <bool TA, bool TB, bool SPREAD, bool CS = false>
 __device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                             int lda, int ldb, int M, int N, int K, int m0, int n0, f32x16_t (&acc)[4][2],
-                                            bool cs_on = false, f32x16_t* acc_cs = nullptr) {
+                                            bool cs_on = false, f32x16_t* acc_cs = nullptr, int sched = 0) {
   constexpr int BM = 256, BN = 256, NS = 2, NW = 8, NWN = 4, WTM = 128, WTN = 64, TM = 4, TN = 2;
   constexpr int STAGE = (BM + BN) * 64;
   bf16_t* ring = reinterpret_cast<bf16_t*>(smem);
@@ -152,13 +152,24 @@ __device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* _
       }
     }
   };
+  // `sched` (round 5, tuning key 14; !SPREAD only): WHEN the second-dispatched half of the workgroup (waves 4-7, the
+  // partner of waves 0-3 on each SIMD) issues its eight LDS-DMA pieces of the next K tile.  With every wave issuing right
+  // behind the barrier, both waves of a SIMD sit in their DMA-issue stalls (~100-185 cycles a piece while the CU's
+  // texture-address path is busy) at the same time and the matrix pipe idles; shifted, one wave's issue stalls run under
+  // its partner's MFMAs (MI355X_MICROARCH.md "Two waves per SIMD": pair matrix with memory, not matrix with matrix).
+  //   bits 0-1: 0 = with the first half (rounds 2-4); 1 = four pieces after the first and four after the second 16-deep
+  //             slice's MFMAs; 2 = all eight after the second slice; 3 = two after every slice
+  //   bit 2:    the second half runs at s_setprio 1 (the arbitration loser otherwise)
+  const bool g1 = wave >= 4;
+  const int place = g1 ? (sched & 3) : 0;
+  if (g1 && (sched & 4)) __builtin_amdgcn_s_setprio(1);
   issue_part(0, 0, 8);
   __builtin_amdgcn_sched_barrier(0);
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt has landed (it was issued one compute phase ago)
     __builtin_amdgcn_s_barrier();                          // ... for every wave, and everybody is done with tile kt-1
     __builtin_amdgcn_sched_barrier(0);
-    if (!SPREAD) { issue_part(kt + 1, 0, 8); __builtin_amdgcn_sched_barrier(0); }
+    if (!SPREAD) { if (place == 0) issue_part(kt + 1, 0, 8); __builtin_amdgcn_sched_barrier(0); }
     const bf16_t* sA = ring + (kt % NS) * STAGE;
     const bf16_t* sB = sA + BM * 64;
     bf16x8_t af[2][TM], bfr[2][TN];
@@ -185,10 +196,18 @@ __device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* _
           acc_cs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bfr[kk & 1][j], acc_cs[j], 0, 0, 0);
       }
       if (SPREAD) issue_part(kt + 1, kk * 2, kk * 2 + 2);   // the other stage is free since this step's barrier
+      else if (place != 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (place == 1 && kk < 2) issue_part(kt + 1, kk * 4, kk * 4 + 4);
+        if (place == 2 && kk == 1) issue_part(kt + 1, 0, 8);
+        if (place == 3) issue_part(kt + 1, kk * 2, kk * 2 + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (all-zero) pieces
+  if (g1 && (sched & 4)) __builtin_amdgcn_s_setprio(0);
 }
 
 #ifdef ZK_EXPERIMENTS   // measured equal to the two-stage ring (profiles/r03_pmc_stall_split.txt): make EXPERIMENTS=1
@@ -318,6 +337,7 @@ struct UpdArgs {
   const float* hyper;                                  // [0] lr_t [1] beta1 [2] beta2 [3] eps [4] gradient scale
   float* sq;                                           // [tiles][8 waves][2]: sum g^2, sum theta^2 per wave (zeros for other tiles)
   int stagger;                                         // phases | us per phase << 8 (0: all workgroups start together)
+  int sched;                                           // gemm256_acc's LDS-DMA issue schedule (tuning key 14), every variant
 };
 
 template <bool TA, bool TB, bool SPREAD, bool CS = false, bool K32 = false, bool UPD = false>
@@ -391,7 +411,7 @@ __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __rest
     if (K32) gemm256_acc_k32<true>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, cs_on, acc_cs);
     else
 #endif
-    gemm256_acc<TA, TB, SPREAD, true>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, cs_on, acc_cs);
+    gemm256_acc<TA, TB, SPREAD, true>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, cs_on, acc_cs, ua.sched);
     if (cs_on && lane < 32) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -404,7 +424,7 @@ __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __rest
     gemm256_acc_k32<false>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, false, nullptr);
 #endif
   } else {
-    gemm256_acc<TA, TB, SPREAD>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc);
+    gemm256_acc<TA, TB, SPREAD>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, false, nullptr, ua.sched);
   }
   float* C = reinterpret_cast<float*>(d.C);
   if constexpr (UPD) {
@@ -761,21 +781,23 @@ int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int t
   dim3 grid((unsigned)total_tiles);
   if (tile == 7 || tile == 8) {     // fp32 outputs without epilogue options only (checked on the host copy by the caller)
     const dim3 blk(512);
+    UpdArgs ua0 = UpdArgs();
+    ua0.sched = g_tune[14];          // LDS-DMA issue schedule of the second half of the workgroup (gemm256_acc)
 #ifdef ZK_EXPERIMENTS
 #define ZK_G256_K32                                                                                                          \
-      else if (ta && !tb && k32 && cs) hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, true, true>), grid, blk, 0, stream, d, nprob, UpdArgs()); \
-      else if (ta && !tb && k32) hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, false, true>), grid, blk, 0, stream, d, nprob, UpdArgs());
+      else if (ta && !tb && k32 && cs) hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, true, true>), grid, blk, 0, stream, d, nprob, ua0); \
+      else if (ta && !tb && k32) hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, false, true>), grid, blk, 0, stream, d, nprob, ua0);
 #else
 #define ZK_G256_K32
 #endif
 #define ZK_G256(SP_)                                                                                         \
     do {                                                                                                     \
-      if (!ta && !tb) hipLaunchKernelGGL((k_gemm_grouped256<false, false, SP_>), grid, blk, 0, stream, d, nprob, UpdArgs());   \
-      else if (!ta && tb) hipLaunchKernelGGL((k_gemm_grouped256<false, true, SP_>), grid, blk, 0, stream, d, nprob, UpdArgs()); \
+      if (!ta && !tb) hipLaunchKernelGGL((k_gemm_grouped256<false, false, SP_>), grid, blk, 0, stream, d, nprob, ua0);   \
+      else if (!ta && tb) hipLaunchKernelGGL((k_gemm_grouped256<false, true, SP_>), grid, blk, 0, stream, d, nprob, ua0); \
       ZK_G256_K32                                                                                          \
-      else if (ta && !tb && cs) hipLaunchKernelGGL((k_gemm_grouped256<true, false, SP_, true>), grid, blk, 0, stream, d, nprob, UpdArgs()); \
-      else if (ta && !tb) hipLaunchKernelGGL((k_gemm_grouped256<true, false, SP_>), grid, blk, 0, stream, d, nprob, UpdArgs()); \
-      else hipLaunchKernelGGL((k_gemm_grouped256<true, true, SP_>), grid, blk, 0, stream, d, nprob, UpdArgs());               \
+      else if (ta && !tb && cs) hipLaunchKernelGGL((k_gemm_grouped256<true, false, SP_, true>), grid, blk, 0, stream, d, nprob, ua0); \
+      else if (ta && !tb) hipLaunchKernelGGL((k_gemm_grouped256<true, false, SP_>), grid, blk, 0, stream, d, nprob, ua0); \
+      else hipLaunchKernelGGL((k_gemm_grouped256<true, true, SP_>), grid, blk, 0, stream, d, nprob, ua0);               \
     } while (0)
     if (tile == 7) ZK_G256(true); else ZK_G256(false);
 #undef ZK_G256
@@ -814,6 +836,7 @@ int zk_gemm_grouped_update(const void* descs, int nprob, int total_tiles, float*
   UpdArgs ua;
   ua.master = master; ua.m = m; ua.v = v; ua.shadow = (bf16_t*)shadow; ua.grad_base = grad_base; ua.hyper = hyper; ua.sq = sq;
   ua.stagger = g_tune[12];         // tuning key 12 (default 4 phases, 28 us apart)
+  ua.sched = g_tune[14];
   hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, true, false, true>), dim3((unsigned)total_tiles), dim3(512), 0,
                      stream, (const GroupDesc*)descs, nprob, ua);
   ZK_LAUNCH_CHECK();
