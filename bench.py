@@ -702,6 +702,19 @@ def cpu_decode_baseline(hp, model, batches):
                       "torch-CPU fp32 restatement of search.py + transformer_aan.py" % r["steps"]}
 
 
+def choose_headline(legs):
+    """The leg whose time is the line's `value`: the fastest REFERENCE-EXACT leg (fp32 gradient buckets -- what
+    utils/parallel.py:184-196 averages) unless a bf16-bucket leg beats it by more than 3 %.  legs: dicts with `ms_per_step`
+    and `reference_exact` (skipped legs carry neither and are ignored); None if no fp32 leg finished."""
+    done = [l for l in legs if "ms_per_step" in l]
+    exact = [l for l in done if l.get("reference_exact")]
+    if not exact:
+        return None
+    best32 = min(exact, key=lambda l: l["ms_per_step"])
+    best16 = min((l for l in done if not l.get("reference_exact")), key=lambda l: l["ms_per_step"], default=None)
+    return best16 if (best16 is not None and best16["ms_per_step"] < 0.97 * best32["ms_per_step"]) else best32
+
+
 def spawn_ranks(n):
     """Re-launch this command line under `python -m torch.distributed.run --standalone --nproc-per-node n`."""
     import socket
@@ -807,6 +820,17 @@ def main():
 
     # ---- multi-GPU: one short timed leg per exchange mode, in this process group
     legs, chosen = [], None
+    ranks_seen_box = [None]
+
+    def gather_ranks_seen():
+        # which physical devices the ranks sit on (all-gather of the device UUIDs): SCALE shows N distinct GPUs
+        try:
+            me = str(torch.cuda.get_device_properties(local).uuid)
+        except Exception:      # noqa: BLE001
+            me = "%s:%d" % (os.uname().nodename, local)
+        seen = [None] * world
+        torch.distributed.all_gather_object(seen, me)
+        return {"distinct_devices": len(set(seen)), "device_uuids": seen}
     if world > 1:
         import threading
 
@@ -814,7 +838,10 @@ def main():
             # a leg that does not come back (a collective of the optional direct transport waiting for a rank that never
             # arrives) must not cost the run its line: print what was measured so far and leave
             if rank == 0:
-                print(json.dumps(bench_line(chosen, legs, aborted=name)), flush=True)
+                head = choose_headline(legs) or chosen       # the same rule as a complete run, over the legs that finished
+                line = bench_line(head, legs, aborted=name)
+                line.setdefault("rccl", {})["ranks_seen"] = ranks_seen_box[0]
+                print(json.dumps(line), flush=True)
             os._exit(0)
 
         def run_leg(dtype, direct, sparse, guard_s=None):
@@ -825,6 +852,8 @@ def main():
                 timer.daemon = True
                 timer.start()
             try:
+                if os.environ.get("ZERO_HIP_BENCH_FAKE_HANG") == name:     # test hook: a leg that never comes back
+                    time.sleep(3600)
                 ok = parallel.select_transport(direct)
                 if direct and not ok:
                     legs.append({"leg": name, "skipped": "the direct communicator did not come up on every rank"})
@@ -879,17 +908,16 @@ def main():
     else:
         # reference-exact first (fp32 buckets, torch.distributed = RCCL): the line exists before anything optional runs
         chosen = run_leg("fp32", False, False)
+        ranks_seen_box[0] = gather_ranks_seen()      # before anything optional runs: a leg that hangs later cannot lose it
         run_leg("fp32", False, True)
         run_leg("bf16", False, True)
         run_leg("bf16", False, False)
         if os.environ.get("ZERO_HIP_BENCH_DIRECT", "1") != "0":
-            run_leg("fp32", True, True, guard_s=120.0)
-            run_leg("bf16", True, True, guard_s=120.0)
-        done = [l for l in legs if "ms_per_step" in l]
-        best32 = min((l for l in done if l["reference_exact"]), key=lambda l: l["ms_per_step"])
-        best16 = min((l for l in done if not l["reference_exact"]), key=lambda l: l["ms_per_step"], default=None)
+            guard = float(os.environ.get("ZERO_HIP_BENCH_GUARD_S", "120"))
+            run_leg("fp32", True, True, guard_s=guard)
+            run_leg("bf16", True, True, guard_s=guard)
         # headline = the fastest reference-exact (fp32) leg unless bf16 buckets win by more than 3 %
-        chosen = best16 if (best16 is not None and best16["ms_per_step"] < 0.97 * best32["ms_per_step"]) else best32
+        chosen = choose_headline(legs)
         # leave the reducer in the chosen mode for what follows
         parallel.select_transport(chosen["transport"] == "zk_comm")
         tr.reducer.configure(bucket_dtype=chosen["bucket_dtype"], sparse=bool(chosen["sparse_rows_exchange"]))
@@ -945,16 +973,7 @@ def main():
     agg = prof.summary()
     cls_agg = prof.classes()
     barrier()
-    ranks_seen = None
-    if world > 1:
-        # which physical devices the ranks sit on (all-gather of the device UUIDs): SCALE shows N distinct GPUs
-        try:
-            me = str(torch.cuda.get_device_properties(local).uuid)
-        except Exception:      # noqa: BLE001
-            me = "%s:%d" % (os.uname().nodename, local)
-        seen = [None] * world
-        torch.distributed.all_gather_object(seen, me)
-        ranks_seen = {"distinct_devices": len(set(seen)), "device_uuids": seen}
+    ranks_seen = ranks_seen_box[0]
     if rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()

@@ -269,3 +269,18 @@ def test_pinned_ring_cpu_path_and_bench_rotation():
     assert np.array_equal(b[0][0][:, :-1], rng.integers(3, 32000, size=(64, 64), dtype=np.int64)[:, :-1])
     assert not np.array_equal(bench.synthetic_batch(1, None, 0)[0], b[0][0])
     assert all((x[0][:, -1] == 2).all() and (x[1][:, -1] == 2).all() for x in b)
+
+
+def test_headline_rule_of_the_multi_gpu_legs():
+    """bench.choose_headline: the fastest reference-exact (fp32-bucket) leg unless a bf16-bucket leg
+    wins by MORE than 3 %; skipped legs and a run whose optional legs never finished (watchdog) do not change the rule."""
+    import bench
+    L = lambda name, ms, exact: {"leg": name, "ms_per_step": ms, "reference_exact": exact}
+    legs = [L("fp32/torch/dense", 5.00, True), L("fp32/torch/rows", 4.90, True), L("bf16/torch/rows", 4.80, False),
+            {"leg": "fp32/zk_comm/rows", "skipped": "the direct communicator did not come up on every rank"}]
+    assert bench.choose_headline(legs)["leg"] == "fp32/torch/rows"            # bf16 wins by 2 %: not enough
+    legs[2]["ms_per_step"] = 4.70
+    assert bench.choose_headline(legs)["leg"] == "bf16/torch/rows"            # 4.1 %: bf16 is the headline
+    assert bench.choose_headline(legs[:1])["leg"] == "fp32/torch/dense"       # only the first leg finished
+    assert bench.choose_headline([legs[3]]) is None and bench.choose_headline([]) is None
+    assert bench.choose_headline([legs[2]]) is None                           # no reference-exact leg: no headline
