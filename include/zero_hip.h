@@ -624,6 +624,9 @@ int zk_beam_dev_run(void* graph_even, void* graph_odd, int parity, const int* ct
  *                     in elements; head h at columns h d ..): q * scale, + (1 - kmask) * (-mask_inf) (func.py:372-387;
  *                     kmask fp32 [B / kv_group, ldmask] may be NULL), softmax, x V.  nkeys_dev (may be NULL): only the
  *                     first *nkeys_dev + 1 keys exist (the self-attention cache of decode position *nkeys_dev).
+ *                     rpr_k / rpr_v (may be NULL; modules/rpr.py:10-75): relative-position tables [2 max_rel + 1, d] --
+ *                     logits += q . r_k[clip(i - j) + max_rel], o += sum_j p_j r_v[...], i = q_pos0 (or *q_pos_dev) + row.
+ *   zk_f32_add_rows   out[r] = a[r] + b[r]: the merged attention's o + aan_o (func.py:258-275, transformer_fuse).
  *   zk_f32_aan_step   transformer_aan.py:110-112: cat[r] = [x[r] | (x[r] + cache[r]) / (t + 1)], cache[r] += x[r].
  *   zk_f32_gate       transformer_aan.py:186-189: g = sigmoid(z[:, :H]) cat[:, :H] + sigmoid(z[:, H:]) cat[:, H:].
  * (cache appends and beam reorders are byte moves: zk_cache_rows / zk_gather_rows_ex with 4-byte elements.) */
@@ -635,10 +638,13 @@ int zk_f32_add_ln(const float* x, const float* y, const float* gamma, const floa
                   zk_stream_t stream);
 int zk_f32_attn(const float* q, const float* k, const float* v, float* out, int B, int nh, int Lq, int Lk, int d, int ldq,
                 int ldk, int ldv, int ldo, long bsq, long bsk, long bsv, long bso, const float* kmask, int ldmask, int kv_group,
-                float scale, float mask_inf, const int* nkeys_dev, zk_stream_t stream);
+                float scale, float mask_inf, const int* nkeys_dev, const float* rpr_k, const float* rpr_v, int max_rel,
+                int q_pos0, const int* q_pos_dev, zk_stream_t stream);
 int zk_f32_aan_step(const float* x, float* cache, float* cat, int rows, int H, int time, const int* time_dev,
                     zk_stream_t stream);
 int zk_f32_gate(const float* z, const float* cat, float* g, int rows, int H, zk_stream_t stream);
+int zk_f32_add_rows(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int rows, int cols,
+                    zk_stream_t stream);
 
 /* hipGraph plumbing: capture a sequence of the calls above once, replay per step */
 int zk_graph_begin(zk_stream_t stream);

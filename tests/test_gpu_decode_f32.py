@@ -108,7 +108,7 @@ def test_attention_f32(B, Lq, Lk, group, masked, cached):
     out = torch.empty(B * Lq, H, device="cuda")
     e.lib.call("zk_f32_attn", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, nh, Lq, Lk, d, H, H, H, H,
                Lq * H, Lk * H, Lk * H, Lq * H, mask.data_ptr() if masked else None, Lk, group, d ** -0.5, 1e8,
-               nk.data_ptr() if cached else None, e.stream)
+               nk.data_ptr() if cached else None, None, None, 0, 0, None, e.stream)
     torch.cuda.synchronize()
     n = Lk // 3 + 1 if cached else Lk
     qd = (q.view(B, Lq, nh, d).permute(0, 2, 1, 3) * (d ** -0.5)).double()
@@ -141,7 +141,8 @@ def test_aan_step_and_gate_f32():
     assert torch.allclose(g, ref, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("model,kw", [("transformer_aan", {}), ("transformer", {}), ("transformer_aan", {"use_ffn": True})])
+@pytest.mark.parametrize("model,kw", [("transformer_aan", {}), ("transformer", {}), ("transformer_aan", {"use_ffn": True}),
+                                      ("transformer_rpr", {}), ("transformer_fuse", {})])
 @pytest.mark.parametrize("K", [1, 4])
 def test_fp32_decode_is_token_exact_without_sharpening(model, kw, K):
     """The whole search in the fp32 mode against the fp32 oracle on an UNSHARPENED random toy model: every hypothesis of
@@ -172,14 +173,42 @@ def test_fp32_decode_is_token_exact_without_sharpening(model, kw, K):
 
 
 def test_fp32_decode_refuses_what_it_does_not_cover():
+    """search_mode = "dev" re-runs the bf16 training-path decoder (transformer.py:277-281): the fp32 mode says so."""
     from zero_amd.hip import ZeroHipError
     from zero_amd.main import tower_infer_graph
     reset_cores()
     rng = np.random.default_rng(2)
-    hp = make_hp("transformer_rpr", decode_dtype="float32")
-    Pn = perturb(rt.init_params(hp, "transformer_rpr", seed=2), rng)
+    hp = make_hp("transformer", decode_dtype="float32")
+    Pn = perturb(rt.init_params(hp, "transformer", seed=2), rng)
     src, _ = make_batch(rng, 3, 6, 5, hp.src_vocab.size(), hp.tgt_vocab.size())
-    hp.search_mode = "cache"
-    get_core(hp, "transformer_rpr", Pn)
+    hp.search_mode = "dev"
+    get_core(hp, "transformer", Pn)
     with pytest.raises(ZeroHipError):
-        tower_infer_graph({"source": src}, registry.get_model("transformer_rpr"), hp)
+        tower_infer_graph({"source": src}, registry.get_model("transformer"), hp)
+
+
+def test_attention_f32_relative_positions():
+    """modules/rpr.py:10-75 inside zk_f32_attn: logits += q . r_k[clip(i - j) + m], o += sum_j p_j r_v[...], for a full
+    (encoder) block and for one cached decode row at position *q_pos_dev."""
+    e = eng()
+    nh, d, m = 2, 64, 4
+    H = nh * d
+    for (B, Lq, Lk, pos) in ((3, 11, 11, None), (4, 1, 13, 7)):
+        q, k, v = _rand(B * Lq, H, seed=1), _rand(B * Lk, H, seed=2), _rand(B * Lk, H, seed=3)
+        rk, rv = _rand(2 * m + 1, d, seed=4), _rand(2 * m + 1, d, seed=5)
+        out = torch.empty(B * Lq, H, device="cuda")
+        pd = torch.tensor([pos or 0], dtype=torch.int32, device="cuda")
+        e.lib.call("zk_f32_attn", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, nh, Lq, Lk, d, H, H, H, H,
+                   Lq * H, Lk * H, Lk * H, Lq * H, None, 0, 1, d ** -0.5, 1e8, pd.data_ptr() if pos is not None else None,
+                   rk.data_ptr(), rv.data_ptr(), m, 0, pd.data_ptr() if pos is not None else None, e.stream)
+        torch.cuda.synchronize()
+        n = pos + 1 if pos is not None else Lk
+        qd = (q.view(B, Lq, nh, d).permute(0, 2, 1, 3) * (d ** -0.5)).double()
+        kd = k.view(B, Lk, nh, d).permute(0, 2, 1, 3).double()[:, :, :n]
+        vd = v.view(B, Lk, nh, d).permute(0, 2, 1, 3).double()[:, :, :n]
+        i = (torch.arange(Lq) + (pos or 0))[:, None]
+        idx = (torch.clamp(i - torch.arange(n)[None, :], -m, m) + m).cuda()
+        lg = qd @ kd.transpose(-1, -2) + torch.einsum("bhqd,qkd->bhqk", qd, rk.double()[idx])
+        pr = torch.softmax(lg, -1)
+        ref = (pr @ vd + torch.einsum("bhqk,qkd->bhqd", pr, rv.double()[idx])).permute(0, 2, 1, 3).reshape(B * Lq, H)
+        assert (out.double() - ref).abs().max().item() < 5e-6

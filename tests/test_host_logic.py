@@ -284,3 +284,17 @@ def test_headline_rule_of_the_multi_gpu_legs():
     assert bench.choose_headline(legs[:1])["leg"] == "fp32/torch/dense"       # only the first leg finished
     assert bench.choose_headline([legs[3]]) is None and bench.choose_headline([]) is None
     assert bench.choose_headline([legs[2]]) is None                           # no reference-exact leg: no headline
+
+
+def test_counter_files_of_an_earlier_round_or_a_dirty_tree_are_flagged_stale(monkeypatch):
+    """bench.counter_status: PMC summaries can only be cited by a line; a citation of another round's
+    file, of a file without a commit or of one measured on a dirty tree says so."""
+    import bench
+    monkeypatch.setattr(bench, "current_round", lambda: 5)
+    assert bench.counter_status("r05_pmc_traffic.json", "abc123def456") == {"stale": False, "why": None}
+    assert bench.counter_status("r04_pmc_traffic.json", "abc123def456")["stale"] is True
+    assert bench.counter_status("r05_pmc_mfma.json", "abc123def456+dirty")["stale"] is True
+    assert bench.counter_status("r05_pmc_mfma.json", None)["stale"] is True
+    assert bench.counter_status("pmc.json", "abc")["stale"] is True and bench.counter_status(None, None) is None
+    monkeypatch.undo()
+    assert bench.current_round() >= 1

@@ -241,7 +241,9 @@ __global__ void __launch_bounds__(256) k_f32_attn(const float* __restrict__ q, c
                                                   const float* __restrict__ v, float* __restrict__ out, int B, int nh, int Lq,
                                                   int Lk, int d, int ldq, int ldk, int ldv, int ldo, long bsq, long bsk,
                                                   long bsv, long bso, const float* __restrict__ kmask, int ldmask,
-                                                  int kv_group, float scale, float mask_inf, const int* __restrict__ nkeys_dev) {
+                                                  int kv_group, float scale, float mask_inf, const int* __restrict__ nkeys_dev,
+                                                  const float* __restrict__ rpr_k, const float* __restrict__ rpr_v, int max_rel,
+                                                  int q_pos0, const int* __restrict__ q_pos_dev) {
   extern __shared__ float sm[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long idx = (long)blockIdx.x * 4 + wave;
@@ -249,6 +251,7 @@ __global__ void __launch_bounds__(256) k_f32_attn(const float* __restrict__ q, c
   const int i = (int)(idx % Lq), h = (int)((idx / Lq) % nh), b = active ? (int)(idx / ((long)Lq * nh)) : 0;
   const int bk = b / kv_group;
   const int nk = nkeys_dev != nullptr ? min(*nkeys_dev + 1, Lk) : Lk;
+  const int qpos = (q_pos_dev != nullptr ? *q_pos_dev : q_pos0) + i;      // absolute position of the query (relative positions)
   float* sp = sm + (size_t)wave * (Lk + d);      // [Lk] scores -> probabilities, then [d] the scaled query
   float* sq = sp + Lk;
   if (active) {
@@ -267,6 +270,15 @@ __global__ void __launch_bounds__(256) k_f32_attn(const float* __restrict__ q, c
         for (int c = 0; c < d; c += 4) {
           const float4 kv = *reinterpret_cast<const float4*>(kp + c);
           s = fmaf(sq[c], kv.x, s); s = fmaf(sq[c + 1], kv.y, s); s = fmaf(sq[c + 2], kv.z, s); s = fmaf(sq[c + 3], kv.w, s);
+        }
+        if (rpr_k != nullptr) {       // modules/rpr.py:10-41: logits = q k^T + q r^T, r = table[clip(i - j, -m, m) + m]
+          const float* rp = rpr_k + (size_t)(min(max(qpos - j, -max_rel), max_rel) + max_rel) * d;
+          float s2 = 0.f;
+          for (int c = 0; c < d; c += 4) {
+            const float4 rv4 = *reinterpret_cast<const float4*>(rp + c);
+            s2 = fmaf(sq[c], rv4.x, s2); s2 = fmaf(sq[c + 1], rv4.y, s2); s2 = fmaf(sq[c + 2], rv4.z, s2); s2 = fmaf(sq[c + 3], rv4.w, s2);
+          }
+          s = s + s2;
         }
         if (kmask != nullptr) s = s + (1.0f - kmask[(size_t)bk * ldmask + j]) * (-mask_inf);
         sp[j] = s;
@@ -300,22 +312,32 @@ __global__ void __launch_bounds__(256) k_f32_attn(const float* __restrict__ q, c
     const float* vp = v + (size_t)bk * bsv + h * d + c;
     float acc = 0.f;
     for (int j = 0; j < nk; ++j) acc = fmaf(sp[j], vp[(size_t)j * ldv], acc);
+    if (rpr_v != nullptr) {         // o = P V + sum_j P_j r_v[clip(i - j) + m]
+      float acc2 = 0.f;
+      for (int j = 0; j < nk; ++j)
+        acc2 = fmaf(sp[j], rpr_v[(size_t)(min(max(qpos - j, -max_rel), max_rel) + max_rel) * d + c], acc2);
+      acc = acc + acc2;
+    }
     op[c] = acc;
   }
 }
 
 extern "C" int zk_f32_attn(const float* q, const float* k, const float* v, float* out, int B, int nh, int Lq, int Lk, int d,
                            int ldq, int ldk, int ldv, int ldo, long bsq, long bsk, long bsv, long bso, const float* kmask,
-                           int ldmask, int kv_group, float scale, float mask_inf, const int* nkeys_dev, hipStream_t stream) {
+                           int ldmask, int kv_group, float scale, float mask_inf, const int* nkeys_dev, const float* rpr_k,
+                           const float* rpr_v, int max_rel, int q_pos0, const int* q_pos_dev, hipStream_t stream) {
   ZK_CHECK_ARG(q != nullptr && k != nullptr && v != nullptr && out != nullptr && nh >= 1 && Lq >= 1 && Lk >= 1 && d >= 4 &&
                d % 4 == 0 && kv_group >= 1, "zk_f32_attn: bad shape (nh=%d Lq=%d Lk=%d d=%d)", nh, Lq, Lk, d);
   ZK_CHECK_ARG(ldk % 4 == 0 && bsk % 4 == 0 && (((uintptr_t)k) & 15) == 0, "zk_f32_attn: keys must be 16-byte aligned rows");
+  ZK_CHECK_ARG((rpr_k == nullptr) == (rpr_v == nullptr) && (rpr_k == nullptr || (max_rel >= 0 && ((((uintptr_t)rpr_k) & 15) == 0))),
+               "zk_f32_attn: relative positions need both tables (16-byte aligned) and max_rel >= 0");
   const size_t lds = (size_t)4 * (Lk + d) * sizeof(float);
   ZK_CHECK_ARG(lds <= 64 * 1024, "zk_f32_attn: %d keys need %zu bytes of LDS (at most 64 KiB)", Lk, lds);
   if (B <= 0) return 0;
   const long waves = (long)B * nh * Lq;
   hipLaunchKernelGGL(k_f32_attn, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, stream, q, k, v, out, B, nh, Lq, Lk, d, ldq,
-                     ldk, ldv, ldo, bsq, bsk, bsv, bso, kmask, ldmask, kv_group, scale, mask_inf, nkeys_dev);
+                     ldk, ldv, ldo, bsq, bsk, bsv, bso, kmask, ldmask, kv_group, scale, mask_inf, nkeys_dev, rpr_k, rpr_v, max_rel,
+                     q_pos0, q_pos_dev);
   ZK_LAUNCH_CHECK();
   return 0;
 }
@@ -366,6 +388,27 @@ extern "C" int zk_f32_gate(const float* z, const float* cat, float* g, int rows,
   if (rows <= 0) return 0;
   const size_t n = (size_t)rows * H;
   hipLaunchKernelGGL(k_f32_gate, dim3((unsigned)min((size_t)2048, (n + 255) / 256)), dim3(256), 0, stream, z, cat, g, rows, H);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[r][0 .. cols) = a[r] + b[r] (row strides in elements): the merged attention's  o + aan_o  (func.py:258-275)
+__global__ void __launch_bounds__(256) k_f32_add_rows(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                      float* __restrict__ out, int ldo, int rows, int cols) {
+  const size_t n = (size_t)rows * cols;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / cols, c = i % cols;
+    out[r * ldo + c] = a[r * lda + c] + b[r * ldb + c];
+  }
+}
+
+extern "C" int zk_f32_add_rows(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int rows, int cols,
+                               hipStream_t stream) {
+  ZK_CHECK_ARG(a != nullptr && b != nullptr && out != nullptr && cols >= 1, "zk_f32_add_rows: bad arguments");
+  if (rows <= 0) return 0;
+  const size_t n = (size_t)rows * cols;
+  hipLaunchKernelGGL(k_f32_add_rows, dim3((unsigned)min((size_t)2048, (n + 255) / 256)), dim3(256), 0, stream, a, lda, b, ldb, out,
+                     ldo, rows, cols);
   ZK_LAUNCH_CHECK();
   return 0;
 }

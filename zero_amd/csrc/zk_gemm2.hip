@@ -165,11 +165,24 @@ __device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* _
   if (g1 && (sched & 4)) __builtin_amdgcn_s_setprio(1);
   issue_part(0, 0, 8);
   __builtin_amdgcn_sched_barrier(0);
+  // make TRACE=1 (scripts/trace_gemm256.py): waves 0 and 4 of workgroup 100 stamp the 100 MHz clock at the phase
+  // boundaries of their first 64 K steps: [0] loop top, [1] LDS-DMA of this tile landed, [2] barrier passed, [3] next
+  // tile's LDS-DMA issued (schedule 0), [4..7] the 16-deep slices' MFMAs issued
+#ifdef ZK_GEMM_TRACE
+  const bool tr256 = blockIdx.x == 100 && (tid == 0 || tid == 256);
+#define ZK_T256(slot) do { if (tr256 && kt < 64) zk_trace_buf[kt * 16 + (tid ? 8 : 0) + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ZK_T256(slot) do { } while (0)
+#endif
   for (int kt = 0; kt < nk; ++kt) {
+    ZK_T256(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt has landed (it was issued one compute phase ago)
+    ZK_T256(1);
     __builtin_amdgcn_s_barrier();                          // ... for every wave, and everybody is done with tile kt-1
     __builtin_amdgcn_sched_barrier(0);
+    ZK_T256(2);
     if (!SPREAD) { if (place == 0) issue_part(kt + 1, 0, 8); __builtin_amdgcn_sched_barrier(0); }
+    ZK_T256(3);
     const bf16_t* sA = ring + (kt % NS) * STAGE;
     const bf16_t* sB = sA + BM * 64;
     bf16x8_t af[2][TM], bfr[2][TN];
@@ -195,6 +208,10 @@ __device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* _
         for (int j = 0; j < TN; ++j)
           acc_cs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bfr[kk & 1][j], acc_cs[j], 0, 0, 0);
       }
+#ifdef ZK_GEMM_TRACE
+      __builtin_amdgcn_sched_barrier(0);
+      ZK_T256(4 + kk);
+#endif
       if (SPREAD) issue_part(kt + 1, kk * 2, kk * 2 + 2);   // the other stage is free since this step's barrier
       else if (place != 0) {
         __builtin_amdgcn_sched_barrier(0);

@@ -8,8 +8,9 @@ cannot deliver that (round 4: the fp32 and the bf16-storage ORACLES disagree wit
 a path that rounds where the reference rounds can.  It is the same search (zero_amd/search.py: device-resident
 bookkeeping, step graphs, fused top-2K on fp32 logits) over a different step: one launch per op of
 models/transformer.py:15-84 (encoder), 120-196 (decoder step) and transformer_aan.py:92-117, 165-192 on the kernels of
-zero_amd/csrc/zk_f32.hip.  Models: ``transformer`` and ``transformer_aan`` (incl. ``use_ffn``); relative positions and
-the merged attention raise -- their fp32 kernels are not written.
+zero_amd/csrc/zk_f32.hip.  All four registered models: ``transformer``, ``transformer_aan`` (incl. ``use_ffn``),
+``transformer_rpr`` (relative positions inside zk_f32_attn: modules/rpr.py:10-75) and ``transformer_fuse`` (merged attention,
+func.py:258-275).
 
 The state nest, caches and reorder follow models/_decode.py (beam-invariant tensors stored once per sentence, per-beam
 caches double-buffered and reordered by one row gather); buffers are named ``dq.*`` so that a bf16 and an fp32 decode of
@@ -30,10 +31,9 @@ def wanted(hp):
 
 
 def check_model(core):
-    if core.rpr or core.fuse:
+    if core.d % 4 != 0:
         from zero_amd.hip import ZeroHipError
-        raise ZeroHipError("decode_dtype=float32 is implemented for transformer and transformer_aan; %s decodes in bf16 only"
-                           % ("transformer_rpr" if core.rpr else "transformer_fuse"))
+        raise ZeroHipError("decode_dtype=float32 needs a head size that is a multiple of 4 (got %d)" % core.d)
 
 
 class _Ops(object):
@@ -68,11 +68,18 @@ class _Ops(object):
                       st.w(scope + "/layer_norm/offset").data_ptr(), out.ptr, x.rows, self.H, zdtype.epsilon(), self.e.stream)
         return out
 
-    def attn(self, q, k, v, out, B, Lq, Lk, bsq, bsk, bsv, kmask=None, ldmask=0, kv_group=1, nkeys_dev=None):
+    def attn(self, q, k, v, out, B, Lq, Lk, bsq, bsk, bsv, kmask=None, ldmask=0, kv_group=1, nkeys_dev=None, rpr=None,
+             q_pos0=0, q_pos_dev=None):
+        """rpr: attention scope prefix (".../dot_attention/") whose rpr_keys / rpr_values tables take part, or None."""
+        rk = rv = None
+        if rpr is not None:
+            rk = self.core.store.w(rpr + "rpr_keys/embeddings").data_ptr()
+            rv = self.core.store.w(rpr + "rpr_values/embeddings").data_ptr()
         self.lib.call("zk_f32_attn", q.ptr, k.ptr, v.ptr, out.ptr, B, self.nh, Lq, Lk, self.d, q.ld, k.ld, v.ld, out.ld,
                       int(bsq), int(bsk), int(bsv), int(Lq * out.ld), kmask.data_ptr() if kmask is not None else None,
                       int(ldmask), int(kv_group), float(self.d) ** -0.5, zdtype.inf(),
-                      nkeys_dev.data_ptr() if nkeys_dev is not None else None, self.e.stream)
+                      nkeys_dev.data_ptr() if nkeys_dev is not None else None, rk, rv, int(self.core.hp.max_relative_position),
+                      int(q_pos0), q_pos_dev.data_ptr() if q_pos_dev is not None else None, self.e.stream)
         return out
 
     def ffn(self, x, scope, tag):
@@ -102,7 +109,7 @@ def encode(core, hp, batch):
         o.linear(x, p + "qkv_map", qkv)
         att = o.mat("enc.att", T, H)
         o.attn(qkv.cols_slice(0, H), qkv.cols_slice(H, 2 * H), qkv.cols_slice(2 * H, 3 * H), att, B, Ls, Ls,
-               Ls * 3 * H, Ls * 3 * H, Ls * 3 * H, kmask=smask, ldmask=Ls)
+               Ls * 3 * H, Ls * 3 * H, Ls * 3 * H, kmask=smask, ldmask=Ls, rpr=p if core.rpr else None)
         y = o.mat("y", T, H)
         o.linear(att, p + "o_map", y)
         x = o.add_ln(x, y, pre + "/self_attention", o.mat("e%d.sa.o" % l, T, H))
@@ -182,18 +189,18 @@ def encoding_state(core, hp, source, K, max_steps, state_cls, pad, trim_columns)
                   "mask": mask_keep, "time_filled": 0, "decoder": {"state": {}}, "f32": True, "wt": {}})
     nl = hp.num_decoder_layer
     for l in range(nl):
-        p = "decoder/layer_%d/cross_attention/dot_attention/" % l
+        p = "decoder/layer_%d/%s/dot_attention/" % (l, core.cross)
         kv = o.mat("%d.kv" % l, B * Ls, 2 * H)
         o.linear(enc_keep, p + "k_map", kv.cols_slice(0, H))
         o.linear(enc_keep, p + "v_map", kv.cols_slice(H, 2 * H))
         lay = {"mk": kv.cols_slice(0, H), "mv": kv.cols_slice(H, 2 * H)}
-        if core.aan:
+        if core.aan or core.fuse:
             lay["aan"] = None
         else:
             lay["k"] = lay["v"] = None
         state["decoder"]["state"]["layer_%d" % l] = lay
     state["_pp"] = 0
-    if core.aan:
+    if core.aan or core.fuse:
         e.zero(e.buf("dq.aan.0", (nl, BK, H), F32))
         e.buf("dq.aan.1", (nl, BK, H), F32)
     else:
@@ -240,7 +247,7 @@ def step_cache(target, state, time, time_dev, hp):
             g = o.mat("y", BK, H)
             e.lib.call("zk_f32_gate", z.ptr, cat.ptr, g.ptr, BK, H, e.stream)
             x = o.add_ln(x, g, a, o.mat("d%d.aa.o" % l, BK, H))
-        else:
+        elif not core.fuse:
             p = pre + "/self_attention/dot_attention/"
             qkv = o.mat("qkv", BK, 3 * H)
             o.linear(x, p + "qkv_map", qkv)
@@ -256,19 +263,28 @@ def step_cache(target, state, time, time_dev, hp):
             # one query per beam row over the positions 0 .. time of ITS cache (no padding mask on the target side,
             # transformer.py:136; causality is the cache's length)
             o.attn(qkv.cols_slice(0, H), kc, vc, att, BK, 1, Tmax if time_dev is not None else time + 1, 3 * H, Tmax * H,
-                   Tmax * H, nkeys_dev=time_dev)
+                   Tmax * H, nkeys_dev=time_dev, rpr=p if core.rpr else None, q_pos0=t_host, q_pos_dev=time_dev)
             y = o.mat("y", BK, H)
             o.linear(att, p + "o_map", y)
             x = o.add_ln(x, y, pre + "/self_attention", o.mat("d%d.sa.o" % l, BK, H))
         # encoder-decoder attention over the sentence's keys / values (stored once per sentence: kv_group = K)
-        p = pre + "/cross_attention/dot_attention/"
+        p = pre + "/" + core.cross + "/dot_attention/"
         qm = o.mat("q", BK, H)
         o.linear(x, p + "q_map", qm)
         att = o.mat("att", BK, H)
-        o.attn(qm, lay["mk"], lay["mv"], att, BK, 1, Ls, H, Ls * 2 * H, Ls * 2 * H, kmask=state["mask"], ldmask=Ls, kv_group=K)
+        # (relative positions, transformer_rpr.py:167-169: the query sits at position `time` against the SOURCE positions)
+        o.attn(qm, lay["mk"], lay["mv"], att, BK, 1, Ls, H, Ls * 2 * H, Ls * 2 * H, kmask=state["mask"], ldmask=Ls, kv_group=K,
+               rpr=p if core.rpr else None, q_pos0=t_host, q_pos_dev=time_dev)
+        if core.fuse:
+            # func.py:258-275: v_q = v_map(query); aan_o = (v_q + cache) / (time + 1); cache += v_q; o += aan_o
+            vq = o.mat("vq", BK, H)
+            o.linear(x, p + "v_map", vq)
+            cat = o.mat("cat", BK, 2 * H)
+            e.lib.call("zk_f32_aan_step", vq.ptr, lay["aan"].data_ptr(), cat.ptr, BK, H, t_host, tdev, e.stream)
+            e.lib.call("zk_f32_add_rows", att.ptr, att.ld, cat.ptr + H * 4, 2 * H, att.ptr, att.ld, BK, H, e.stream)
         y = o.mat("y", BK, H)
         o.linear(att, p + "o_map", y)
-        x = o.add_ln(x, y, pre + "/cross_attention", o.mat("d%d.ca.o" % l, BK, H))
+        x = o.add_ln(x, y, pre + "/" + core.cross, o.mat("d%d.ca.o" % l, BK, H))
         x = o.ffn(x, pre + "/feed_forward", "d%d.ff" % l)
     logits = Mat(e.buf("dq.logits", (BK, core.Vpad), F32), BK, core.Vpad)
     o.gemm(x, o.w(core.soft_emb), logits, BK, core.V, H, tb=1)
