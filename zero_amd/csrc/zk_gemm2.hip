@@ -98,7 +98,10 @@ __global__ void __launch_bounds__((4 + PW) * 64) k_gemm_grouped(const GroupDesc*
 // CS (tb = 0 only): acc_cs[j] additionally accumulates ones[32 x 16] x B-fragment, i.e. every row of it holds the column
 // sums over k of this wave's 32 columns of B -- the bias gradient sum_k dY[k][n] (func.py:16, 58-60) of a weight-gradient
 // problem, from the fragments the wave has in registers anyway (2 extra MFMAs per 8; waves with cs_on only).
-template <bool TA, bool TB, bool SPREAD, bool CS = false>
+// HP (round 5 experiment, tuning key 14 bit 5): only the FIRST half of the workgroup (waves 0-3) issues LDS-DMA -- all 16
+// pieces of a wave pair -- and the second half starts multiplying right behind the barrier: the two waves of a SIMD are then
+// never in their issue stalls at the same time.
+template <bool TA, bool TB, bool SPREAD, bool CS = false, bool HP = false>
 __device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                             int lda, int ldb, int M, int N, int K, int m0, int n0, f32x16_t (&acc)[4][2],
                                             bool cs_on = false, f32x16_t* acc_cs = nullptr, int sched = 0) {
@@ -125,29 +128,37 @@ __device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* _
     const v8s_ o = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};     // bf16 1.0
     ones = __builtin_bit_cast(bf16x8_t, o);
   }
-  DmaPlan<BM, NW> planA;
-  DmaPlan<BN, NW> planB;
-  dma_plan<BM, TA, NW>(planA, A, lda, m0, M, 0, wave, lane);
-  dma_plan<BN, !TB, NW>(planB, B, ldb, n0, N, 0, wave, lane);
+  constexpr int NDW = HP ? 4 : NW;                 // waves that issue LDS-DMA
+  constexpr int NI = DmaPlan<BM, NDW>::NINSTR;    // pieces per issuing wave and operand (4, HP: 8)
+  const bool issuer = !HP || wave < 4;
+  DmaPlan<BM, NDW> planA;
+  DmaPlan<BN, NDW> planB;
+  if (issuer) {
+    dma_plan<BM, TA, NDW>(planA, A, lda, m0, M, 0, wave, lane);
+    dma_plan<BN, !TB, NDW>(planB, B, ldb, n0, N, 0, wave, lane);
+  }
   const size_t stepA = TA ? (size_t)64 * lda : (size_t)64;
   const size_t stepB = !TB ? (size_t)64 * ldb : (size_t)64;
   const uint32_t ring_addr = lds_addr(ring);
-  // LDS-DMA of K tile t, pieces [j0, j1) of this wave's 4 + 4
+  // LDS-DMA of K tile t, pieces [j0, j1) of this wave's NI + NI (HP: full calls -- j0 = 0, j1 = 8 -- issue all 16)
   auto issue_part = [&](int tt, int j0, int j1) {
+    if (!issuer) return;
+    if (HP) { j0 *= 2; j1 *= 2; }
     const uint32_t st = ring_addr + (uint32_t)((tt % NS) * STAGE * 2);
     const bool tail = tt * 64 + 64 > K;
 #pragma unroll
-    for (int j = j0; j < j1; ++j) {
-      if (j < 4) {
+    for (int j = 0; j < 2 * NI; ++j) {
+      if (j < j0 || j >= j1) continue;
+      if (j < NI) {
         const bf16_t* g = planA.cur[j];
         if (tail) g = (tt * 64 + planA.kofs[j] < K) ? g : reinterpret_cast<const bf16_t*>(zk_zero_page);
-        glds16(g, st + (uint32_t)(wave * DmaPlan<BM, NW>::PER_WAVE + j * 64) * 16u);
+        glds16(g, st + (uint32_t)(wave * DmaPlan<BM, NDW>::PER_WAVE + j * 64) * 16u);
         planA.cur[j] += stepA;
       } else {
-        const int jb = j - 4;
+        const int jb = j - NI;
         const bf16_t* g = planB.cur[jb];
         if (tail) g = (tt * 64 + planB.kofs[jb] < K) ? g : reinterpret_cast<const bf16_t*>(zk_zero_page);
-        glds16(g, st + BM * 128 + (uint32_t)(wave * DmaPlan<BN, NW>::PER_WAVE + jb * 64) * 16u);
+        glds16(g, st + BM * 128 + (uint32_t)(wave * DmaPlan<BN, NDW>::PER_WAVE + jb * 64) * 16u);
         planB.cur[jb] += stepB;
       }
     }
@@ -161,7 +172,19 @@ __device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* _
   //             slice's MFMAs; 2 = all eight after the second slice; 3 = two after every slice
   //   bit 2:    the second half runs at s_setprio 1 (the arbitration loser otherwise)
   const bool g1 = wave >= 4;
-  const int place = g1 ? (sched & 3) : 0;
+  if (HP) sched &= 4;                               // (the placements below are about the second half's OWN pieces)
+  int place = g1 ? (sched & 3) : 0;
+  //   bits 3-4: the eight pieces of a wave go out in ONE slot of the step (slot 0 = behind the barrier, slot s = behind
+  //             the MFMAs of slice s - 1), the slots dealt by SIMD so that few waves queue on the CU's one texture-address
+  //             path at a time (64 pieces a step at ~16 cycles each: a wave that issues ALONE is through in ~130 cycles,
+  //             eight at once block each other for ~1000): 1 = slot w % 4 for both waves of a SIMD, 2 = w % 4 for the
+  //             first half and (w + 2) % 4 for the second (a SIMD always has one wave multiplying), 3 = w % 4 / (w + 1) % 4
+  const int stag = (sched >> 3) & 3;
+  int slot = -1;
+  if (stag == 1) slot = wave & 3;
+  else if (stag == 2) slot = g1 ? ((wave + 2) & 3) : (wave & 3);
+  else if (stag == 3) slot = g1 ? ((wave + 1) & 3) : (wave & 3);
+  if (slot >= 0) place = slot == 0 ? 0 : 4;      // 4: none of the fixed placements below
   if (g1 && (sched & 4)) __builtin_amdgcn_s_setprio(1);
   issue_part(0, 0, 8);
   __builtin_amdgcn_sched_barrier(0);
@@ -218,6 +241,7 @@ __device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* _
         if (place == 1 && kk < 2) issue_part(kt + 1, kk * 4, kk * 4 + 4);
         if (place == 2 && kk == 1) issue_part(kt + 1, 0, 8);
         if (place == 3) issue_part(kt + 1, kk * 2, kk * 2 + 2);
+        if (place == 4 && kk == slot - 1) issue_part(kt + 1, 0, 8);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -357,7 +381,7 @@ struct UpdArgs {
   int sched;                                           // gemm256_acc's LDS-DMA issue schedule (tuning key 14), every variant
 };
 
-template <bool TA, bool TB, bool SPREAD, bool CS = false, bool K32 = false, bool UPD = false>
+template <bool TA, bool TB, bool SPREAD, bool CS = false, bool K32 = false, bool UPD = false, bool HP = false>
 __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __restrict__ descs, int nprob, UpdArgs ua) {
   constexpr int BM = 256, BN = 256, NS = 2, NWN = 4, WTM = 128, WTN = 64, TM = 4, TN = 2;
   constexpr int STAGE = (BM + BN) * 64;
@@ -428,7 +452,7 @@ __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __rest
     if (K32) gemm256_acc_k32<true>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, cs_on, acc_cs);
     else
 #endif
-    gemm256_acc<TA, TB, SPREAD, true>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, cs_on, acc_cs, ua.sched);
+    gemm256_acc<TA, TB, SPREAD, true, HP>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, cs_on, acc_cs, ua.sched);
     if (cs_on && lane < 32) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -441,7 +465,7 @@ __global__ void __launch_bounds__(512) k_gemm_grouped256(const GroupDesc* __rest
     gemm256_acc_k32<false>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, false, nullptr);
 #endif
   } else {
-    gemm256_acc<TA, TB, SPREAD>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, false, nullptr, ua.sched);
+    gemm256_acc<TA, TB, SPREAD, false, HP>(smem, d.A, d.B, d.lda, d.ldb, M, N, d.K, m0, n0, acc, false, nullptr, ua.sched);
   }
   float* C = reinterpret_cast<float*>(d.C);
   if constexpr (UPD) {
@@ -816,6 +840,13 @@ int zk_gemm_grouped(const void* descs, int nprob, int total_tiles, int ta, int t
       else if (ta && !tb) hipLaunchKernelGGL((k_gemm_grouped256<true, false, SP_>), grid, blk, 0, stream, d, nprob, ua0); \
       else hipLaunchKernelGGL((k_gemm_grouped256<true, true, SP_>), grid, blk, 0, stream, d, nprob, ua0);               \
     } while (0)
+#ifdef ZK_EXPERIMENTS   // half-producer form (HP): measured, no robust gain (profiles/r05_gemm256_half_producer_sweep.txt)
+    if (tile == 8 && (g_tune[14] & 32) && ((ta && !tb) || (!ta && tb))) {
+      if (ta && cs) hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, true, false, false, true>), grid, blk, 0, stream, d, nprob, ua0);
+      else if (ta) hipLaunchKernelGGL((k_gemm_grouped256<true, false, false, false, false, false, true>), grid, blk, 0, stream, d, nprob, ua0);
+      else hipLaunchKernelGGL((k_gemm_grouped256<false, true, false, false, false, false, true>), grid, blk, 0, stream, d, nprob, ua0);
+    } else
+#endif
     if (tile == 7) ZK_G256(true); else ZK_G256(false);
 #undef ZK_G256
     ZK_LAUNCH_CHECK();
