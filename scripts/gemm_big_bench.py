@@ -121,7 +121,7 @@ def sched_sweep():
     LG = torch.empty(T, V, device="cuda", dtype=torch.float32)
     lref = A[:256].float() @ E.float().t()
     lp = [(Mat(A, T, H), Mat(E, V, H), Mat(LG, T, V), T, V, H, None)]
-    scheds = (0, 32, 36, 0, 32, 36)
+    scheds = (0, 129, 130, 133, 134, 8, 16, 24)
     res = {sc: [[], [], []] for sc in set(scheds)}
     for rep in range(5):                 # round-robin, five rounds: the clocks drift by ~15 % over the first seconds of a run
         for sched in scheds:

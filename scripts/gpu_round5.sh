@@ -25,7 +25,7 @@ for st in $STAGES; do
     smoke)  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "rc=$?"; tail -3 gpurun_out/smoke.log ;;
     bench)  timeout 900 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "rc=$?"; tail -c 1500 gpurun_out/bench.json; tail -3 gpurun_out/bench.err ;;
     benchq) timeout 600 python bench.py --no-cpu-baseline --no-decode > gpurun_out/benchq.json 2> gpurun_out/benchq.err; echo "rc=$?"; grep -o '"ms_per_step": [0-9.]*\|"static_batch_ms_per_step": [0-9.]*\|"feed_overhead_frac": [-0-9.e]*' gpurun_out/benchq.json; tail -3 gpurun_out/benchq.err ;;
-    ab)     for kv in ${AB:-}; do echo "--- $kv"; env $kv timeout 600 python bench.py --no-cpu-baseline --no-decode --steps 30 --timed-only > gpurun_out/ab_$kv.json 2> gpurun_out/ab_$kv.err; grep -o '"ms_per_step": [0-9.]*' gpurun_out/ab_$kv.json; tail -2 gpurun_out/ab_$kv.err; done ;;
+    ab)     for kv in ${AB:-}; do fn=$(echo "$kv" | tr '/=:' '___'); echo "--- $kv"; env $kv timeout 600 python bench.py --no-cpu-baseline --no-decode --steps 40 --timed-only ${AB_ARGS:-} > gpurun_out/ab_$fn.json 2> gpurun_out/ab_$fn.err; grep -o '"ms_per_step": [0-9.]*' gpurun_out/ab_$fn.json; tail -1 gpurun_out/ab_$fn.err | cut -c1-200; done ;;
     profstep) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/profs -o r1 -- python $OLDPWD/bench.py --steps 40 --warmup 2 --timed-only > $OLDPWD/gpurun_out/profstep.log 2>&1); echo "rc=$?"
             python scripts/prof_summary.py $(find gpurun_out/profs -name "*.db" | head -1) 42 > gpurun_out/rocprof_captured_step.txt 2>&1
             rm -rf gpurun_out/profs; head -${PROF_HEAD:-50} gpurun_out/rocprof_captured_step.txt; tail -2 gpurun_out/profstep.log ;;

@@ -21,7 +21,7 @@ for (ta, tb, name) in ((1, 0, "weight-gradient form (X^T dY)"), (0, 1, "logits f
     B = torch.randn((N, K) if tb else (K, N), device="cuda").bfloat16()
     C = torch.empty(M, N, device="cuda", dtype=torch.float32)
     probs = [(Mat(A, *A.shape), Mat(B, *B.shape), Mat(C, M, N), M, N, K, None)]
-    for sched in (0, 32):
+    for sched in (0, 130):
         tune(14, sched)
         for _ in range(3):
             e.gemm_grouped(probs, ta, tb, tile=(256, 256, 0))

@@ -1450,7 +1450,7 @@ size_t zk_add_ln_bwd_workspace(int rows, int H) {
   return (size_t)g * 3 * H * sizeof(float);
 }
 
-int g_tune[16] = {1, 0, 0, 0, 0, 0, 0x44, 0, 0, 2, 512, 0, 4 | (28 << 8), 0, 0, 0};   // [12]: phases | us << 8 of the updating weight-gradient launch   // [0] wide LayerNorm backward kernel; [1] GEMM: legacy split-K rule (A/B)
+int g_tune[16] = {1, 0, 0, 0, 0, 0, 0x44, 0, 0, 2, 512, 0, 4 | (28 << 8), 0, 129, 0};   // [14] = 129: 256x256 tile, the first half of the workgroup issues its LDS-DMA behind its first two slices (round 5)   // [12]: phases | us << 8 of the updating weight-gradient launch   // [0] wide LayerNorm backward kernel; [1] GEMM: legacy split-K rule (A/B)
 static int ln_bwd_blocks(int rows) {
   int g = (rows + 15) / 16;
   if (g > 256) g = 256;

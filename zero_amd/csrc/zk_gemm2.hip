@@ -130,36 +130,44 @@ __device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* _
   }
   constexpr int NDW = HP ? 4 : NW;                 // waves that issue LDS-DMA
   constexpr int NI = DmaPlan<BM, NDW>::NINSTR;    // pieces per issuing wave and operand (4, HP: 8)
-  const bool issuer = !HP || wave < 4;
+  // (sched bit 6, HP only: the SECOND-dispatched half issues and the first, older, half multiplies first)
+  const bool issuer = !HP || ((sched & 64) ? wave >= 4 : wave < 4);
+  const int dw = HP ? (wave & 3) : wave;             // index among the issuing waves
   DmaPlan<BM, NDW> planA;
   DmaPlan<BN, NDW> planB;
   if (issuer) {
-    dma_plan<BM, TA, NDW>(planA, A, lda, m0, M, 0, wave, lane);
-    dma_plan<BN, !TB, NDW>(planB, B, ldb, n0, N, 0, wave, lane);
+    dma_plan<BM, TA, NDW>(planA, lda, m0, M, dw, lane);
+    dma_plan<BN, !TB, NDW>(planB, ldb, n0, N, dw, lane);
   }
   const size_t stepA = TA ? (size_t)64 * lda : (size_t)64;
   const size_t stepB = !TB ? (size_t)64 * ldb : (size_t)64;
   const uint32_t ring_addr = lds_addr(ring);
-  // LDS-DMA of K tile t, pieces [j0, j1) of this wave's NI + NI (HP: full calls -- j0 = 0, j1 = 8 -- issue all 16)
+  // LDS-DMA of K tile t, pieces [j0, j1) of this wave's NI + NI (HP: full calls -- j0 = 0, j1 = 8 -- issue all 16).  The
+  // pieces are 32-bit offsets against the tile's wave-uniform base (glds16s): no vector instruction per piece.
   auto issue_part = [&](int tt, int j0, int j1) {
     if (!issuer) return;
     if (HP) { j0 *= 2; j1 *= 2; }
+    if (tt * 64 >= K) return;                       // (past the end: nothing to bring in; the waits are vmcnt(0))
     const uint32_t st = ring_addr + (uint32_t)((tt % NS) * STAGE * 2);
-    const bool tail = tt * 64 + 64 > K;
+    const bf16_t* bA = A + (size_t)tt * stepA;
+    const bf16_t* bB = B + (size_t)tt * stepB;
+    const bool tail = tt * 64 + 64 > K;              // the one tile that crosses K: pointer form with the per-lane select
 #pragma unroll
     for (int j = 0; j < 2 * NI; ++j) {
       if (j < j0 || j >= j1) continue;
-      if (j < NI) {
-        const bf16_t* g = planA.cur[j];
-        if (tail) g = (tt * 64 + planA.kofs[j] < K) ? g : reinterpret_cast<const bf16_t*>(zk_zero_page);
-        glds16(g, st + (uint32_t)(wave * DmaPlan<BM, NDW>::PER_WAVE + j * 64) * 16u);
-        planA.cur[j] += stepA;
+      const bool isA = j < NI;
+      const int jj = isA ? j : j - NI;
+      const uint32_t dst = isA ? st + (uint32_t)(dw * DmaPlan<BM, NDW>::PER_WAVE + jj * 64) * 16u
+                               : st + BM * 128 + (uint32_t)(dw * DmaPlan<BN, NDW>::PER_WAVE + jj * 64) * 16u;
+      const uint32_t off = isA ? planA.off[jj] : planB.off[jj];
+      const bf16_t* base = isA ? bA : bB;
+      if (!tail) {
+        glds16s(off, base, dst);
       } else {
-        const int jb = j - NI;
-        const bf16_t* g = planB.cur[jb];
-        if (tail) g = (tt * 64 + planB.kofs[jb] < K) ? g : reinterpret_cast<const bf16_t*>(zk_zero_page);
-        glds16(g, st + BM * 128 + (uint32_t)(wave * DmaPlan<BN, NDW>::PER_WAVE + jb * 64) * 16u);
-        planB.cur[jb] += stepB;
+        const int kofs = isA ? planA.kofs[jj] : planB.kofs[jj];
+        const bf16_t* g = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(base) + off);
+        g = (tt * 64 + kofs < K) ? g : reinterpret_cast<const bf16_t*>(zk_zero_page);
+        glds16(g, dst);
       }
     }
   };
@@ -172,8 +180,12 @@ __device__ __forceinline__ void gemm256_acc(unsigned char* smem, const bf16_t* _
   //             slice's MFMAs; 2 = all eight after the second slice; 3 = two after every slice
   //   bit 2:    the second half runs at s_setprio 1 (the arbitration loser otherwise)
   const bool g1 = wave >= 4;
+  const int sched_hp = sched;
   if (HP) sched &= 4;                               // (the placements below are about the second half's OWN pieces)
-  int place = g1 ? (sched & 3) : 0;
+  //   bit 7: the placements of bits 0-1 apply to the FIRST half instead (the second half issues behind the barrier and
+  //          the first, older, half multiplies first)
+  const bool late = (sched & 128) ? !g1 : g1;
+  int place = late ? (sched & 3) : 0;
   //   bits 3-4: the eight pieces of a wave go out in ONE slot of the step (slot 0 = behind the barrier, slot s = behind
   //             the MFMAs of slice s - 1), the slots dealt by SIMD so that few waves queue on the CU's one texture-address
   //             path at a time (64 pieces a step at ~16 cycles each: a wave that issues ALONE is through in ~130 cycles,

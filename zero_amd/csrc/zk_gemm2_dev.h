@@ -38,6 +38,22 @@ __device__ __forceinline__ void glds16(const bf16_t* gsrc, uint32_t lds_byte_add
                  : "v"(gsrc), "s"(lds_byte_addr)
                  : "memory");
 }
+// The same with the address as a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane byte offset (saddr form): a K loop
+// whose pieces advance by a uniform stride keeps ONE offset register per piece and advances the base with scalar adds --
+// no vector instruction per piece (the pointer form costs a 64-bit add and, with the K-tail select, ~7 VALU per piece).
+template <bool FRESH = false>
+__device__ __forceinline__ void glds16s(uint32_t voff, const void* sbase, uint32_t lds_byte_addr) {
+  if (FRESH)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
+                 : "memory");
+  else
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
+                 : "memory");
+}
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) unsigned char*)p);
 }
@@ -52,17 +68,21 @@ __device__ __forceinline__ int swz_trans(int k) { return R >= 128 ? ((k & 3) << 
 // the K-tail predicate.  Tile rows / column chunks outside the matrix are CLAMPED to a valid
 // row / chunk 0: what they bring in only feeds output rows / columns the epilogue never stores.
 // Only a K tile that crosses kend needs zero fill (both operands), done by the TAIL variant.
+// (round 5: the plan holds 32-bit BYTE OFFSETS against a wave-uniform tile base instead of running 64-bit pointers: the
+// K loop advances the base with scalar adds and a piece costs no vector instruction -- glds16s.  An operand must span less
+// than 4 GB from its first element to the last byte a tile touches: checked by the launchers' callers' shapes, every
+// matrix of the path is far below.)
 template <int R, int NW = 4>
 struct DmaPlan {
   static constexpr int PER_WAVE = R * 8 / NW;     // 16-byte chunks per wave
   static constexpr int NINSTR = PER_WAVE / 64;
-  const bf16_t* cur[NINSTR];
+  uint32_t off[NINSTR];                           // byte offset of the lane's 16 bytes against the K tile's base
   int kofs[NINSTR];
 };
 
+// K tile t of an operand starts at  src + kbeg + 64 t  (k contiguous)  or  src + (kbeg + 64 t) ld  (TRANS: k-major rows)
 template <int R, bool TRANS, int NW>
-__device__ __forceinline__ void dma_plan(DmaPlan<R, NW>& pl, const bf16_t* __restrict__ src, int ld, int row0,
-                                         int rows_total, int kbeg, int wave, int lane) {
+__device__ __forceinline__ void dma_plan(DmaPlan<R, NW>& pl, int ld, int row0, int rows_total, int wave, int lane) {
 #pragma unroll
   for (int j = 0; j < DmaPlan<R, NW>::NINSTR; ++j) {
     const int P = wave * DmaPlan<R, NW>::PER_WAVE + j * 64 + lane;
@@ -71,7 +91,7 @@ __device__ __forceinline__ void dma_plan(DmaPlan<R, NW>& pl, const bf16_t* __res
       const int c = pos ^ swz_direct(row);
       const int grow = min(row0 + row, rows_total - 1);
       pl.kofs[j] = c * 8;
-      pl.cur[j] = src + (size_t)grow * ld + kbeg + c * 8;
+      pl.off[j] = (uint32_t)(((size_t)grow * ld + c * 8) * 2);
     } else {
       constexpr int CPR = R / 8;             // chunks per k row
       const int k = P / CPR, pos = P % CPR;
@@ -79,21 +99,26 @@ __device__ __forceinline__ void dma_plan(DmaPlan<R, NW>& pl, const bf16_t* __res
       int grow = row0 + c * 8;
       grow = grow < rows_total ? grow : 0;
       pl.kofs[j] = k;
-      pl.cur[j] = src + (size_t)(kbeg + k) * ld + grow;
+      pl.off[j] = (uint32_t)(((size_t)k * ld + grow) * 2);
     }
   }
 }
 
-// issue the LDS-DMA of the next K tile `t` (k range [kbeg + 64 t, ...)) of one operand into `stage`
-// and advance the plan.  TAIL: the tile crosses (or lies past) kend.
+// issue the LDS-DMA of K tile `t` of one operand (its base: `tile_base`, wave-uniform) into `stage`.
+// TAIL: the tile crosses (or lies past) kend -- pointer form with a per-lane select against the zero page.
 template <int R, bool TRANS, bool TAIL, int NW, bool FRESH = false>
-__device__ __forceinline__ void dma_tile(DmaPlan<R, NW>& pl, size_t step, int t, int klen, uint32_t stage_addr, int wave) {
+__device__ __forceinline__ void dma_tile(const DmaPlan<R, NW>& pl, const bf16_t* tile_base, int t, int klen, uint32_t stage_addr,
+                                         int wave) {
 #pragma unroll
   for (int j = 0; j < DmaPlan<R, NW>::NINSTR; ++j) {
-    const bf16_t* g = pl.cur[j];
-    if (TAIL) g = (t * 64 + pl.kofs[j] < klen) ? g : reinterpret_cast<const bf16_t*>(zk_zero_page);
-    glds16<FRESH>(g, stage_addr + (uint32_t)(wave * DmaPlan<R, NW>::PER_WAVE + j * 64) * 16u);
-    pl.cur[j] += step;
+    const uint32_t dst = stage_addr + (uint32_t)(wave * DmaPlan<R, NW>::PER_WAVE + j * 64) * 16u;
+    if (TAIL) {
+      const bf16_t* g = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(tile_base) + pl.off[j]);
+      g = (t * 64 + pl.kofs[j] < klen) ? g : reinterpret_cast<const bf16_t*>(zk_zero_page);
+      glds16<FRESH>(g, dst);
+    } else {
+      glds16s<FRESH>(pl.off[j], tile_base, dst);
+    }
   }
 }
 
@@ -199,21 +224,24 @@ __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16
 
   DmaPlan<BM, NDW> planA;
   DmaPlan<BN, NDW> planB;
-  if (!KSEG && (PW == 0 || producer)) {
-    dma_plan<BM, TA, NDW>(planA, A, lda, m0, M, kbeg, dwave, lane);
-    dma_plan<BN, !TB, NDW>(planB, B, ldb, n0, N, kbeg, dwave, lane);
+  if (PW == 0 || producer) {                       // (the offsets do not depend on the K segment: one plan per tile)
+    dma_plan<BM, TA, NDW>(planA, lda, m0, M, dwave, lane);
+    dma_plan<BN, !TB, NDW>(planB, ldb, n0, N, dwave, lane);
   }
   [[maybe_unused]] int seg_left = 0, seg_id = 0;   // KSEG: K tiles left in the current segment, next segment
   const int klen = kend - kbeg;
   const size_t stepA = TA ? (size_t)64 * lda : (size_t)64;
   const size_t stepB = !TB ? (size_t)64 * ldb : (size_t)64;
+  // wave-uniform bases of the NEXT K tile to issue (tiles are issued in order), advanced by scalar adds
+  const bf16_t* baseA = KSEG ? nullptr : A + (TA ? (size_t)kbeg * lda : (size_t)kbeg);
+  const bf16_t* baseB = KSEG ? nullptr : B + (!TB ? (size_t)kbeg * ldb : (size_t)kbeg);
   const uint32_t ring_addr = lds_addr(ring);
   auto issue = [&](int t) {
-    if (KSEG) {                                   // tiles are issued in order: re-plan at every segment start
+    if (KSEG) {                                   // tiles are issued in order: new bases at every segment start
       if (seg_left == 0) {
         if (seg_id < ks->nseg) {
-          dma_plan<BM, TA, NDW>(planA, ks->A[seg_id], lda, m0, M, 0, dwave, lane);
-          dma_plan<BN, !TB, NDW>(planB, ks->B[seg_id], ldb, n0, N, 0, dwave, lane);
+          baseA = ks->A[seg_id];
+          baseB = ks->B[seg_id];
           ++seg_id;
           seg_left = ks->tps;
         } else {
@@ -224,12 +252,14 @@ __device__ __forceinline__ void gemm_tile_to_lds(unsigned char* smem, const bf16
     }
     const uint32_t st = ring_addr + (uint32_t)((t % NS) * STAGE * 2);
     if (t * 64 + 64 <= klen) {
-      dma_tile<BM, TA, false, NDW, FRESH>(planA, stepA, t, klen, st, dwave);
-      dma_tile<BN, !TB, false, NDW>(planB, stepB, t, klen, st + BM * 128, dwave);
+      dma_tile<BM, TA, false, NDW, FRESH>(planA, baseA, t, klen, st, dwave);
+      dma_tile<BN, !TB, false, NDW>(planB, baseB, t, klen, st + BM * 128, dwave);
     } else {
-      dma_tile<BM, TA, true, NDW, FRESH>(planA, stepA, t, klen, st, dwave);
-      dma_tile<BN, !TB, true, NDW>(planB, stepB, t, klen, st + BM * 128, dwave);
+      dma_tile<BM, TA, true, NDW, FRESH>(planA, baseA, t, klen, st, dwave);
+      dma_tile<BN, !TB, true, NDW>(planB, baseB, t, klen, st + BM * 128, dwave);
     }
+    baseA += stepA;
+    baseB += stepB;
   };
   // MFMAs of K tile kt out of its ring stage
   auto compute = [&](int kt) {

@@ -892,7 +892,9 @@ class TransformerCore(object):
                 # 223 us against 274-291 us for the 128x128 kernels on the 4096 x 32000 x 512 problem).  bf16 logits
                 # were measured and are slower (profiles/r03_negative_results.txt: a bf16 32x32 MFMA tile leaves
                 # as 64-byte half lines, +118 us on a GEMM that is not output-bound, for -16 us of cross entropy)
-                e.gemm_grouped([(feat, E, logits, Tt, self.V, self.H, None)], 0, 1, tile=(256, 256))
+                # (round 5: the form that issues its LDS-DMA in one place per half-workgroup -- tuning key 14 -- instead of
+                # spread between the MFMA groups: 163-167 us against 171-175 in scripts/gemm_big_bench.py --sched)
+                e.gemm_grouped([(feat, E, logits, Tt, self.V, self.H, None)], 0, 1, tile=(256, 256, 0))
             else:
                 e.gemm(feat, E, logits, Tt, self.V, self.H, 0, 1)
             dlogits = e.mat("dlogits", Tt, self.Vpad) if need_grad else None
