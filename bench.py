@@ -846,6 +846,8 @@ def main():
 
         def run_leg(dtype, direct, sparse, guard_s=None):
             name = "%s/%s/%s" % (dtype, "zk_comm" if direct else "torch", "rows" if sparse else "dense")
+            if os.environ.get("ZERO_HIP_BENCH_FAKE_HANG") == name and not guard_s:      # test hook: guard the leg that will hang
+                guard_s = float(os.environ.get("ZERO_HIP_BENCH_GUARD_S", "120"))
             timer = None
             if guard_s:
                 timer = threading.Timer(guard_s, bail, args=(name,))

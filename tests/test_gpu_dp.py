@@ -245,20 +245,20 @@ def test_bench_line_survives_a_leg_that_never_returns():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=root, ZERO_DIST_BACKEND="gloo", ZERO_SINGLE_DEVICE="1",
-               ZERO_HIP_BENCH_FAKE_HANG="fp32/zk_comm/rows", ZERO_HIP_BENCH_GUARD_S="4")
+               ZERO_HIP_BENCH_FAKE_HANG="fp32/torch/rows", ZERO_HIP_BENCH_GUARD_S="4")
+    # (the SECOND leg hangs: one leg of gloo all-reduces over the 308-MB gradient on the host is all the test pays for)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
            "--warmup", "2"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
     out = json.loads(lines[0])
     rc = out["rccl"]
-    assert rc["aborted_leg"] == "fp32/zk_comm/rows"
+    assert rc["aborted_leg"] == "fp32/torch/rows"
     names = [l["leg"] for l in rc["legs"]]
-    assert names == ["fp32/torch/dense", "fp32/torch/rows", "bf16/torch/rows", "bf16/torch/dense"], names
+    assert names == ["fp32/torch/dense"], names
     assert rc["ranks_seen"]["distinct_devices"] == 1 and len(rc["ranks_seen"]["device_uuids"]) == 2
-    head = [l for l in rc["legs"] if l["leg"] == rc["headline_leg"]][0]
-    best32 = min(l["ms_per_step"] for l in rc["legs"][:2])
-    assert head["reference_exact"] or head["ms_per_step"] < 0.97 * best32
+    head = rc["legs"][0]
+    assert rc["headline_leg"] == "fp32/torch/dense" and head["reference_exact"]
     assert abs(head["ms_per_step"] - out["ms_per_step"]) < 1e-9 and out["n_gpus"] == 2 and out["value"] > 0

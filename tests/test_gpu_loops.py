@@ -149,6 +149,14 @@ def test_cli_train_test_score(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "bleu" in r.stdout and len((out / "t.txt").read_text().splitlines()) == 8
+    # the same test set in the fp32 decode mode (round 5: decode_dtype=float32 through the CLI, four batches on lanes)
+    r = subprocess.run(base + ["--mode", "test", "--parameters",
+                               "output_dir=%s,test_output=%s,decode_dtype=float32" % (out, out / "t32.txt")],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    t16, t32 = (out / "t.txt").read_text().splitlines(), (out / "t32.txt").read_text().splitlines()
+    assert "bleu" in r.stdout and len(t32) == 8
+    assert sum(a == b for a, b in zip(t16, t32)) >= 4          # (a barely trained 32-wide model: most lines agree)
     r = subprocess.run(base + ["--mode", "score", "--parameters", "output_dir=%s,test_output=%s" % (out, out / "s.txt")],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
