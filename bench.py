@@ -799,14 +799,18 @@ def main():
     def timed(step_fn, steps, warm):
         """warm untimed steps, then EXACTLY `steps` steps between barrier + synchronize; max over ranks (seconds)."""
         loss = None
-        for i in range(warm):
-            step_fn(i)
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            loss = step_fn(warm + i)
-        barrier()
-        dt = time.perf_counter() - t0
+        import contextlib
+        # as zero_amd.main.train issues its steps: from the engine's work stream (ZERO_HIP_BENCH_DEFAULT_STREAM=1: from the
+        # default stream, with a stream hand-off per step -- the A/B of profiles/r05_rocprof_captured_step_gaps*.txt)
+        with (contextlib.nullcontext() if os.environ.get("ZERO_HIP_BENCH_DEFAULT_STREAM") == "1" else tr.on_work_stream()):
+            for i in range(warm):
+                step_fn(i)
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                loss = step_fn(warm + i)
+            barrier()
+            dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         if world > 1:
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)

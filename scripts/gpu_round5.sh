@@ -28,7 +28,8 @@ for st in $STAGES; do
     ab)     for kv in ${AB:-}; do fn=$(echo "$kv" | tr '/=:' '___'); echo "--- $kv"; env $kv timeout 600 python bench.py --no-cpu-baseline --no-decode --steps 40 --timed-only ${AB_ARGS:-} > gpurun_out/ab_$fn.json 2> gpurun_out/ab_$fn.err; grep -o '"ms_per_step": [0-9.]*' gpurun_out/ab_$fn.json; tail -1 gpurun_out/ab_$fn.err | cut -c1-200; done ;;
     profstep) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/profs -o r1 -- python $OLDPWD/bench.py --steps 40 --warmup 2 --timed-only > $OLDPWD/gpurun_out/profstep.log 2>&1); echo "rc=$?"
             python scripts/prof_summary.py $(find gpurun_out/profs -name "*.db" | head -1) 42 > gpurun_out/rocprof_captured_step.txt 2>&1
-            rm -rf gpurun_out/profs; head -${PROF_HEAD:-50} gpurun_out/rocprof_captured_step.txt; tail -2 gpurun_out/profstep.log ;;
+            python scripts/prof_gaps.py $(find gpurun_out/profs -name "*.db" | head -1) > gpurun_out/rocprof_captured_step_gaps.txt 2>&1
+            rm -rf gpurun_out/profs; head -${PROF_HEAD:-50} gpurun_out/rocprof_captured_step.txt; tail -2 gpurun_out/profstep.log; head -${GAP_HEAD:-30} gpurun_out/rocprof_captured_step_gaps.txt ;;
     prof)   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o r1 -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-decode > $OLDPWD/gpurun_out/prof.log 2>&1); echo "rc=$?"
             python scripts/prof_summary.py $(find gpurun_out/prof -name "*.db" | head -1) > gpurun_out/rocprof_kernel_stats.txt 2>&1
             rm -rf gpurun_out/prof; head -${PROF_HEAD:-45} gpurun_out/rocprof_kernel_stats.txt ;;

@@ -198,6 +198,11 @@ class Trainer(object):
         self.global_step += 1          # (the update launch advanced the dropout seed)
         return loss
 
+    def on_work_stream(self):
+        """``with trainer.on_work_stream(): ...`` -- the calling loop issues its steps from the engine's work stream (step
+        graphs cannot be captured or replayed on the legacy default stream), so that step() needs no stream hand-off."""
+        return torch.cuda.stream(self.core.eng.work_stream)
+
     # -- one entry point for the training loop: captured steps whenever the shapes allow ---------
     def step(self, features, use_graph=True):
         """One micro step on ``features`` (update on the last one of a cycle), replaying a captured
@@ -227,7 +232,12 @@ class Trainer(object):
                 scale = self.train_op.set_hyper(self.lr.get_lr(), parallel.world_size(), dst=hstage)
                 ev_up = torch.cuda.Event()
                 ev_up.record(up)
-            ws.wait_stream(cur)
+            # (a caller that already runs on the engine's work stream -- zero_amd.main.train and bench.py do, via
+            # Trainer.on_work_stream() -- pays no cross-stream hand-off per step: two event packets fewer between two
+            # step graphs, profiles/r05_rocprof_captured_step_gaps*.txt)
+            same = cur == ws
+            if not same:
+                ws.wait_stream(cur)
             ws.wait_event(ev_up)
             with torch.cuda.stream(ws):
                 self.batch = self.core.commit(staged, extra=self.train_op.hyper_pairs(hstage))
@@ -236,7 +246,8 @@ class Trainer(object):
                 evs[slot].record(ws)
                 self._declare_sparse(self.batch)
                 loss = self._step_static(True, scale=scale)
-            cur.wait_stream(ws)
+            if not same:
+                cur.wait_stream(ws)
             return loss
         if hp.update_cycle == 1:
             eng = self.core.eng
@@ -507,6 +518,8 @@ class Trainer(object):
         eng = self.core.eng
         cur = torch.cuda.current_stream(eng.device)
         ws = eng.work_stream
+        if cur == ws:                    # (Trainer.on_work_stream: no hand-off)
+            return self._step_static(use_graph)
         ws.wait_stream(cur)
         with torch.cuda.stream(ws):
             loss = self._step_static(use_graph)
@@ -657,6 +670,24 @@ def train(params):
     start_time, cum_tokens = time.time(), 0
     bad_seen = trainer.train_op.bad_updates()
     pending = []
+    # the loop issues everything from the engine's work stream (Trainer.on_work_stream): the steps need no stream
+    # hand-off, and the loop's own reads (loss, norms, checkpoints, dev-set decoding) are ordered behind them on that stream
+    on_ws = trainer.on_work_stream() if trainer.core.eng.device.type == "cuda" else None
+    if on_ws is not None:
+        on_ws.__enter__()
+    try:
+        best = _train_epochs(params, trainer, rec, saver, checkpoint, train_dataset, dev_dataset, log, rank, world, pending,
+                             start_time, cum_tokens, bad_seen, queuer)
+    finally:
+        if on_ws is not None:
+            on_ws.__exit__(None, None, None)
+            torch.cuda.current_stream(trainer.core.eng.device).wait_stream(trainer.core.eng.work_stream)
+    return best
+
+
+def _train_epochs(params, trainer, rec, saver, checkpoint, train_dataset, dev_dataset, log, rank, world, pending, start_time,
+                  cum_tokens, bad_seen, queuer):
+    """The epoch loop of train() (main.py:255-466), issued from the engine's work stream."""
     for epoch in range(rec.epoch, params.epoches + 1):
         rec.epoch = epoch
         log.info("Training the model for epoch %d", epoch)
