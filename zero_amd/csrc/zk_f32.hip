@@ -85,14 +85,20 @@ __global__ void __launch_bounds__(256) k_f32_gemm(const float* __restrict__ A, c
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   if (live && kbeg < kend) {
-    F32Chunk cur, nxt;
-    f32_load_chunk<TB>(cur, A, B, lda, ldb, arow, bcol, kbeg, kend, lane);
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-      const bool more = k0 + 16 < kend;
-      if (more) f32_load_chunk<TB>(nxt, A, B, lda, ldb, arow, bcol, k0 + 16, kend, lane);
+    // PF chunks of 16 k in flight per wave (a chunk's loads take ~1-2 us from L2 / HBM, its eight MFMAs 0.2 us: with one
+    // chunk of prefetch a decode-step product was a chain of exposed round trips).  Chunks past kend load zeros and add
+    // exact zeros; the k order of every output's fmaf chain is unchanged.
+    constexpr int PF = 4;
+    F32Chunk ch[PF];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[j], cur.b[j], acc, 0, 0, 0);
-      if (more) cur = nxt;
+    for (int p = 0; p < PF; ++p) f32_load_chunk<TB>(ch[p], A, B, lda, ldb, arow, bcol, kbeg + 16 * p, kend, lane);
+    for (int k0 = kbeg; k0 < kend; k0 += 16 * PF) {
+#pragma unroll
+      for (int p = 0; p < PF; ++p) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ch[p].a[j], ch[p].b[j], acc, 0, 0, 0);
+        f32_load_chunk<TB>(ch[p], A, B, lda, ldb, arow, bcol, k0 + 16 * (p + PF), kend, lane);
+      }
     }
   }
   if (KSPLIT > 1) {
