@@ -5,10 +5,10 @@
 # ASan runtime into python and runs the `not gpu` tests that load the library.  Log: profiles/rNN_asan_host.log.
 set -u
 cd "$(dirname "$0")/.."
-OUT=${1:-profiles/r04_asan_host.log}
+OUT=${1:-profiles/r05_asan_host.log}
 B=/tmp/zk_asan; rm -rf $B; mkdir -p $B
 HIPCC=/opt/rocm/bin/hipcc
-for f in zk_elem zk_gemm zk_gemm2 zk_attn zk_decode zk_probe zk_comm zk_decfuse zk_rows zk_prep; do
+for f in zk_elem zk_gemm zk_gemm2 zk_attn zk_decode zk_probe zk_comm zk_decfuse zk_rows zk_prep zk_f32; do
   $HIPCC --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-value -Xarch_host -fsanitize=address \
      -Xarch_host -fno-omit-frame-pointer -c zero_amd/csrc/$f.hip -o $B/$f.o || exit 1 &
 done
@@ -29,6 +29,9 @@ RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
     ZERO_HIP_LIB=$B/libzero_hip.so LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:protect_shadow_gap=0 \
       timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q -p no:cacheprovider \
         -k "batches_in_flight or step_graphs_are_reused or rotating_batches or device_resident_search" 2>&1 | tail -8
+    # round 5: the fp32 decode mode (zk_f32_* argument handling, 4-byte cache rows) and the give-up / skip-word paths of the exchange
+    ZERO_HIP_LIB=$B/libzero_hip.so LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:protect_shadow_gap=0 \
+      timeout 900 python -m pytest tests/test_gpu_decode_f32.py tests/test_gpu_sync_ln.py -m gpu -q -p no:cacheprovider 2>&1 | tail -4
     echo "# exit code: ${PIPESTATUS[0]}"
   fi
 } > $OUT 2>&1

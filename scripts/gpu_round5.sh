@@ -40,6 +40,8 @@ for st in $STAGES; do
     trafficd) bash scripts/pmc_traffic_decode.sh ;;
     gemmsched) timeout 600 python scripts/gemm_big_bench.py --sched > gpurun_out/gemm_sched.txt 2>&1; echo "rc=$?"; tail -12 gpurun_out/gemm_sched.txt ;;
     gemmbig) timeout 600 python scripts/gemm_big_bench.py > gpurun_out/gemm_big.txt 2>&1; echo "rc=$?"; tail -40 gpurun_out/gemm_big.txt ;;
+    twin)   bash scripts/launch_blocking_twin.sh ;;
+    soak)   timeout 600 python scripts/soak_decode.py 200 4 > gpurun_out/soak_decode.json 2> gpurun_out/soak_decode.err; echo "rc=$?"; cat gpurun_out/soak_decode.json; tail -3 gpurun_out/soak_decode.err ;;
     decode) timeout 600 python bench.py --mode decode > gpurun_out/bench_decode.json 2> gpurun_out/bench_decode.err; echo "rc=$?"; tail -c 900 gpurun_out/bench_decode.json ;;
   esac
 done

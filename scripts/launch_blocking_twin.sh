@@ -13,6 +13,6 @@ L=gpurun_out/launch_blocking_twin.log
     echo "# DIFFERENT:"; cat gpurun_out/twin.diff
   fi
   echo "# GPU tests under HIP_LAUNCH_BLOCKING=1:"
-  HIP_LAUNCH_BLOCKING=1 timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_loops.py tests/test_gpu_dp.py -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -3
+  HIP_LAUNCH_BLOCKING=1 timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_loops.py tests/test_gpu_dp.py tests/test_gpu_sync_ln.py tests/test_gpu_decode_f32.py -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -3
 } > $L 2>&1
 tail -8 $L

@@ -29,8 +29,9 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 LANES = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 load_all()
 out = {"batches": N, "lanes": LANES, "models": {}}
-for model in ("transformer_aan", "transformer"):
-    hp = make_hp(model, beam_size=4, decode_length=8)
+# round 5: third leg = the fp32 decode mode (decode_dtype=float32) on the same lanes
+for model, ddtype in (("transformer_aan", "bfloat16"), ("transformer", "bfloat16"), ("transformer_aan", "float32")):
+    hp = make_hp(model, beam_size=4, decode_length=8, decode_dtype=ddtype)
     hp = copy.copy(hp)
     hp.search_mode = "cache"
     rng = np.random.default_rng(17)
@@ -60,9 +61,9 @@ for model in ("transformer_aan", "transformer"):
     bad = [i for i, ((a, b, c), (x, y, z)) in enumerate(zip(seq, par))
            if not (np.array_equal(a, x) and np.array_equal(b, y) and c == z)]
     shapes = len(set((s_.shape[0], -(-s_.shape[1] // 8)) for s_ in batches))
-    out["models"][model] = {"mismatching_batches": bad, "distinct_shape_buckets": shapes,
+    out["models"][model + ("" if ddtype == "bfloat16" else "/" + ddtype)] = {"mismatching_batches": bad, "distinct_shape_buckets": shapes,
                             "decode_steps": int(sum(c for _, _, c in seq)),
                             "sequential_s": round(t1 - t0, 2), "lanes_s": round(t2 - t1, 2)}
-    assert not bad, (model, bad[:10])
+    assert not bad, (model, ddtype, bad[:10])
 torch.cuda.synchronize()
 print(json.dumps(out))
