@@ -360,6 +360,28 @@ def current_round():
         return 1
 
 
+def tree_stamp():
+    """{"round", "commit"} of the code this line was measured on.  The GPU box receives no .git: scripts/gpu.sh writes the
+    commit (+dirty) of the snapshot into .head_commit before it travels; in a checkout git answers.  commit null = unknown."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    commit = None
+    if os.path.isdir(os.path.join(here, ".git")):
+        try:
+            commit = subprocess.run(["git", "-C", here, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
+                                    timeout=10).stdout.strip() or None
+            if commit and subprocess.run(["git", "-C", here, "diff", "--quiet"], timeout=10).returncode:
+                commit += "+dirty"
+        except (OSError, subprocess.SubprocessError):
+            commit = None
+    else:
+        try:
+            commit = open(os.path.join(here, ".head_commit")).read().strip() or None
+        except OSError:
+            pass
+    return {"round": current_round(), "commit": commit}
+
+
 def counter_status(fname, commit):
     """{'stale': bool, 'why': ...} of a committed counter summary: counters come from separate
     rocprofv3 --pmc passes, so a line can only CITE them; it must say when what it cites was measured on other code.  Stale =
@@ -988,6 +1010,7 @@ def main():
     flops = train_flops_per_step(hp, b=nb)
     out = bench_line(chosen, legs)
     out.update({"loss": loss_v, "gnorm": gnorm, "update_skipped": skipped, "launches_per_step": step_launches})
+    out["tree"] = tree_stamp()
     # the in-launch LayerNorm exchange bounds every wait and records a give-up on the device: a line measured with one is void
     out["sync_ln_errors"] = int(tr.core.eng.sync_ln_errors())
     if out["sync_ln_errors"]:
