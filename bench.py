@@ -660,7 +660,7 @@ def decode_modellike(args, batches, streams):
     res = {"weights": "tests/fullsize.py beam_params (gain-0.1 scope initialiser, scaled target embedding / cross attention, "
                       "successor-map softmax table, fitted EOS row tests/golden/aan_base_beam_eos_row.npy)"}
     src_len = np.concatenate([(b != 0).sum(1) for b in batches])
-    for tag, dd, lanes in (("bf16", "bfloat16", streams), ("fp32_mode", "float32", 1)):
+    for tag, dd, lanes in (("bf16", "bfloat16", streams), ("fp32_mode", "float32", streams)):
         hp = beam_hp()
         hp.decode_dtype = dd
         hp.scope_name = "bench_modellike_" + tag
