@@ -659,6 +659,9 @@ int zk_graph_last_nodes(void);
 int zk_probe_mfma32(const void* A, const void* Bt, float* D, zk_stream_t stream);
 int zk_probe_mfma16(const void* A, const void* Bt, float* D, zk_stream_t stream);
 int zk_probe_tr16(void* out, zk_stream_t stream);
+/* measurement aid: reads each of `bytes` (16-byte aligned, multiple of 16 KB) once with access pattern 0..4 (zk_probe.hip)
+ * -- a known byte count per access shape for calibrating the FETCH_SIZE counter (scripts/fetch_calibrate.sh) */
+int zk_probe_read(const void* src, size_t bytes, int pattern, float* sink, zk_stream_t stream);
 
 #ifdef __cplusplus
 }

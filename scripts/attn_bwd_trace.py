@@ -15,6 +15,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zero_amd.func import Engine, Mat  # noqa: E402
 
 e = Engine("cuda:0")
+for kv in os.environ.get("ZERO_HIP_TUNE", "").split(","):     # A/B keys as in bench.py, e.g. 15:4 = head-major grid
+    if ":" in kv:
+        e.lib.raw("zk_tune")(int(kv.split(":")[0]), int(kv.split(":")[1], 0))
 B, nh, L, d = 64, 8, 64, 64
 H = nh * d
 T = B * L
@@ -24,7 +27,7 @@ MARKS = {0: "start", 1: "prologue loads issued (oproj: chunk loop starts)", 2: "
          8: "dQ / dK / dV products", 11: "bucket sums", 12: "table products", 9: "outputs staged, barrier", 10: "stores issued"}
 ORDER = [0, 1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 9, 10]
 
-for variant in ("plain", "oproj", "rpr", "rpr-resident"):
+for variant in (sys.argv[1:] or ("plain", "oproj", "rpr", "rpr-resident")):
     rpr = variant.startswith("rpr")
     e.rpr_bwd_resident = variant == "rpr-resident"
     sets = []

@@ -7,7 +7,7 @@ import csv, glob, json, sys, collections
 
 
 def load(d, counter):
-    acc = collections.defaultdict(lambda: [0.0, 0])
+    acc = collections.defaultdict(lambda: [0.0, 0, collections.Counter()])
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
@@ -16,17 +16,24 @@ def load(d, counter):
             a = acc[name]
             a[0] += float(r["Counter_Value"])
             a[1] += 1
+            a[2][float(r["Counter_Value"])] += 1          # per-dispatch values (summed over the XCDs by rocprofv3)
     return acc
 
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 out = {}
 for name in sorted(set(fetch) | set(write)):
-    fk, fn = fetch.get(name, [0.0, 0])
-    wk, wn = write.get(name, [0.0, 0])
+    fk, fn, fh = fetch.get(name, [0.0, 0, {}])
+    wk, wn, _ = write.get(name, [0.0, 0, {}])
     out[name] = {"launches": max(fn, wn),
                  "fetch_bytes_per_launch": 2.0 * 1024.0 * fk / max(fn, 1),
                  "write_bytes_per_launch": 1024.0 * wk / max(wn, 1)}
+    if "--clusters" in sys.argv and fn > 1:
+        # a kernel name covers several problem shapes (the 64x64 chain: K = 512 / 1536 / 2048): launches binned by MB fetched
+        bins = collections.Counter()
+        for v, c in fh.items():
+            bins[int(round(2.0 * 1024.0 * v / 2e6)) * 2] += c
+        out[name]["fetch_mb_bins"] = {str(k): bins[k] for k in sorted(bins)}
 import datetime
 if "--decode" in sys.argv:
     # the decode leg: everything the job launched, per decode step (k_beam_prepare runs once per step)

@@ -8,6 +8,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $c -d $OLDPWD/gpurun_out/pmct_$c -o p --output-format csv -- \
      python $OLDPWD/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-decode --no-graph > $OLDPWD/gpurun_out/pmct_$c.log 2>&1); echo "$c rc=$?"
 done
-python scripts/pmc_traffic.py gpurun_out/pmct_FETCH_SIZE gpurun_out/pmct_WRITE_SIZE > gpurun_out/pmc_traffic.json
+python scripts/pmc_traffic.py gpurun_out/pmct_FETCH_SIZE gpurun_out/pmct_WRITE_SIZE --clusters > gpurun_out/pmc_traffic.json
 rm -rf gpurun_out/pmct_FETCH_SIZE gpurun_out/pmct_WRITE_SIZE      # raw counter CSVs: tens of MB, gpurun merges back at most 64 MiB
 head -c 600 gpurun_out/pmc_traffic.json; echo

@@ -548,8 +548,18 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_fused64(AttnArgs a, const b
                                                              bf16_t* __restrict__ dv, int lddv, float* __restrict__ rpr_part,
                                                              AttnOProj op) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[RPR ? ATTN_BWD64_RPR_LDS_BYTES : ATTN_BWD64_LDS_BYTES];
-  attn_bwd_fused64_tile<RPR, OPROJ>(smem, a, o, ldo, dout, lddo, lse, dq, lddq, dk, lddk, dv, lddv, blockIdx.y, blockIdx.z,
-                                    rpr_part, op);
+  int h = blockIdx.y, b = blockIdx.z;
+  if (gridDim.y == 1) {
+    // 1-D grid (bwd64_grid): workgroups go round-robin over the 8 XCDs, so id = xcd + 8 * slot puts the nh heads of a
+    // sentence on ONE XCD -- they read the same 64 rows of dY (OPROJ) and the same rows of the qkv buffer, which then come
+    // from HBM once instead of once per head (head-major ids sent every head of a sentence to a different XCD: 47 MB
+    // fetched per launch against 17 MB algorithmic, profiles/r05_pmc_traffic.json)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    h = slot % a.nh;
+    b = (slot / a.nh) * 8 + xcd;
+    if (b >= a.B) return;
+  }
+  attn_bwd_fused64_tile<RPR, OPROJ>(smem, a, o, ldo, dout, lddo, lse, dq, lddq, dk, lddk, dv, lddv, h, b, rpr_part, op);
 }
 
 #ifdef ZK_EXPERIMENTS   // measured, no gain over the two launches (profiles/r04_negative_results.txt item 8)
@@ -668,6 +678,9 @@ static bool attn_mfma_ok(const AttnArgs& a, int extra_ld_or) {
 }
 
 extern "C" int zk_zero(void* p, size_t bytes, hipStream_t stream);   // zk_elem.hip
+// grid of k_attn_bwd_fused64: one id per (sentence, head), sentences dealt to the XCDs (see the kernel); tuning key 15 bit 2
+// restores the head-major 3-D grid for A/B runs
+static dim3 bwd64_grid(int nh, int B) { return (g_tune[15] & 4) ? dim3(1, nh, B) : dim3(nh * ((B + 7) / 8) * 8); }
 #ifdef ZK_ATTN_TRACE
 __device__ unsigned long long zk_attn_trace_buf[16];
 extern "C" int zk_attn_trace_read(unsigned long long* out16) {
@@ -939,13 +952,13 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
     // table-gradient partials behind Dbuf in the workspace, summed over the B*nh (sentence, head) tiles afterwards
     float* part = (float*)workspace + (size_t)B * nh * Lq;
     if (oproj_dy != nullptr)
-      hipLaunchKernelGGL((k_attn_bwd_fused64<true, true>), dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
+      hipLaunchKernelGGL((k_attn_bwd_fused64<true, true>), bwd64_grid(nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
                          (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, part, op);
     else if (!resident_tiles)
       hipLaunchKernelGGL(k_attn_bwd_rpr64, dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)dout, lddo, lse,
                          (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, part);
     else
-      hipLaunchKernelGGL((k_attn_bwd_fused64<true, false>), dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
+      hipLaunchKernelGGL((k_attn_bwd_fused64<true, false>), bwd64_grid(nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
                          (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, part, op);
     ZK_LAUNCH_CHECK();
     if (defer_tables) return 1;
@@ -963,11 +976,11 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
   }
   if ((impl == 0 || impl == 2) && ok && Lq <= TQ && Lk <= TQ) {      // impl 3 forces the two-kernel form
     if (oproj_dy != nullptr)
-      hipLaunchKernelGGL((k_attn_bwd_fused64<false, true>), dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
+      hipLaunchKernelGGL((k_attn_bwd_fused64<false, true>), bwd64_grid(nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
                          (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv,
                          (float*)nullptr, op);
     else
-      hipLaunchKernelGGL((k_attn_bwd_fused64<false, false>), dim3(1, nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
+      hipLaunchKernelGGL((k_attn_bwd_fused64<false, false>), bwd64_grid(nh, B), dim3(256), 0, stream, a, (const bf16_t*)out, ldo,
                          (const bf16_t*)dout, lddo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv,
                          (float*)nullptr, op);
     ZK_LAUNCH_CHECK();
