@@ -15,6 +15,8 @@ Data loading, evaluation cadence, checkpoints and logging of main.py are host co
 outside the hot path.
 """
 
+import os
+
 import torch
 
 from zero_amd import lrs
@@ -203,6 +205,10 @@ class Trainer(object):
         graphs cannot be captured or replayed on the legacy default stream), so that step() needs no stream hand-off."""
         return torch.cuda.stream(self.core.eng.work_stream)
 
+    # staging sets of the rotating-batch loop and how often "sets up to here are free again" is recorded (see step())
+    STAGE_SLOTS = int(os.environ.get("ZERO_HIP_STAGE_SLOTS", "16"))
+    STAGE_EVENT_EVERY = max(1, STAGE_SLOTS // 2)
+
     # -- one entry point for the training loop: captured steps whenever the shapes allow ---------
     def step(self, features, use_graph=True):
         """One micro step on ``features`` (update on the last one of a cycle), replaying a captured
@@ -212,17 +218,32 @@ class Trainer(object):
             return self.micro_step(features)
         if hp.update_cycle == 1 and self.pad_len == 1:
             # The batch is uploaded (asynchronous copies through pinned slots) and prepared (zk_batch_prep: masks, loss
-            # weights, token rows grouped by embedding id) on a SIDE stream into one of two staging sets -- in the steady
-            # state, where the host runs ahead of the device, that happens while the PREVIOUS step is still running --
-            # and the captured step then starts with one small copy launch (commit) instead of waiting for a ~60-us
+            # weights, token rows grouped by embedding id) on a SIDE stream into one of STAGE_SLOTS staging sets -- in the
+            # steady state, where the host runs ahead of the device, that happens while the PREVIOUS step is still running
+            # -- and the captured step then starts with one small copy launch (commit) instead of waiting for a ~60-us
             # single-workgroup sort.  The step itself is unchanged; one graph per batch shape as before.
+            #
+            # A staging set may be overwritten once the commit that read it is done.  Rounds 4-5 had two sets and recorded
+            # an event behind EVERY commit; an event record on the work stream costs ~65 us of the step (same-box A/B,
+            # whether in front of the step's graph or behind it, torch's events or hipEventDisableSystemFence ones; the
+            # WAIT for the upload's event costs nothing) -- so there are eight sets now and the event is recorded every
+            # fourth step: set s of step n was last read by the commit of step n - 8, and the upload stream has waited for
+            # an event of a step >= n - 8 (the oldest one there is, n - 8 .. n - 5) before it writes the set again.
             eng = self.core.eng
             cur = torch.cuda.current_stream(eng.device)
             ws, up = eng.work_stream, eng.upload_stream
-            slot = self._stage_slot = 1 - getattr(self, "_stage_slot", 1)
-            evs = self.__dict__.setdefault("_commit_events", [None, None])
-            if evs[slot] is not None:
-                up.wait_event(evs[slot])            # the commit that last read this staging set is done
+            S, R = self.STAGE_SLOTS, self.STAGE_EVENT_EVERY
+            n = self._stage_n = getattr(self, "_stage_n", -1) + 1
+            slot = n % S
+            evs = self.__dict__.setdefault("_commit_events", {})        # step index (a multiple of R) -> event
+            need = n - S                                                   # the commit that last read this set
+            if need >= 0:
+                j = -(-need // R) * R                                      # oldest recorded step >= need
+                if getattr(self, "_stage_waited", -1) < j:
+                    up.wait_event(evs[j])
+                    self._stage_waited = j
+                    for k in [k for k in evs if k < j]:
+                        del evs[k]
             self.lr.step(self.global_step)
             self.train_op.count = 0
             with torch.cuda.stream(up):
@@ -241,9 +262,9 @@ class Trainer(object):
             ws.wait_event(ev_up)
             with torch.cuda.stream(ws):
                 self.batch = self.core.commit(staged, extra=self.train_op.hyper_pairs(hstage))
-                if evs[slot] is None:
-                    evs[slot] = torch.cuda.Event()
-                evs[slot].record(ws)
+                if n % R == 0:
+                    evs[n] = torch.cuda.Event()
+                    evs[n].record(ws)
                 self._declare_sparse(self.batch)
                 loss = self._step_static(True, scale=scale)
             if not same:
