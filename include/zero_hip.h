@@ -650,6 +650,10 @@ int zk_f32_add_rows(const float* a, int lda, const float* b, int ldb, float* out
 int zk_graph_begin(zk_stream_t stream);
 int zk_graph_end(zk_stream_t stream, void** exec_out);
 int zk_graph_launch(void* exec, zk_stream_t stream);
+/* rewrite the arguments of the ONE zk_copy_many launch a captured graph holds (arguments as for zk_copy_many, n >= 1): the
+ * training step's graph starts with the copy of the prepared batch out of one of several staging sets -- the feed_dict of
+ * main.py:286-294 -- and the set changes from step to step (zero_amd/main.py Trainer.step) */
+int zk_graph_set_copy_many(void* exec, void* const* dsts, const void* const* srcs, const size_t* nbytes, int n);
 int zk_graph_destroy(void* exec);
 /* number of nodes (= kernel launches) of the graph the last zk_graph_end instantiated: lets bench.py report the
  * launches per captured step without a profiler */

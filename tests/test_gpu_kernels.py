@@ -1122,3 +1122,40 @@ def test_dropout_decisions_are_fair_and_independent():
     torch.cuda.synchronize()
     want = (x.float() + y.float() * mk.view(T, H)).to(torch.bfloat16)
     assert torch.equal(ssum, want)
+
+
+def test_the_copy_node_of_a_captured_graph_takes_new_arguments():
+    """zk_graph_set_copy_many: the one zk_copy_many launch inside an instantiated graph is re-pointed before a replay (the
+    training step's graph starts with the copy out of a staging set that changes from step to step); a destination in PINNED
+    HOST memory works too (the commit's sequence word); graphs without, or with two, such launches are refused."""
+    import ctypes
+    from zero_amd.hip import ZeroHipError
+    e = eng()
+    a = [torch.arange(1000, dtype=torch.int32, device="cuda") + 1000 * k for k in range(3)]
+    b = [torch.full((7,), float(k), device="cuda") for k in range(3)]
+    da, db = torch.zeros(1000, dtype=torch.int32, device="cuda"), torch.zeros(7, device="cuda")
+    pin = torch.full((1,), -1, dtype=torch.int32).pin_memory()
+    seq = [torch.tensor([40 + k], dtype=torch.int32, device="cuda") for k in range(3)]
+    y = torch.zeros(1000, device="cuda")
+    with torch.cuda.stream(e.work_stream):
+        def body():
+            e.copy_many([(da, a[0]), (db, b[0]), (pin, seq[0])])
+            y.copy_(da.float() * 2)                     # a consumer behind the copy, inside the same graph
+        body()
+        torch.cuda.synchronize()
+        g = e.graph_capture(body)
+        for k in (1, 2, 0, 2):
+            assert e.graph_set_copy_many(g, [(da, a[k]), (db, b[k]), (pin, seq[k])])
+            e.graph_launch(g)
+            torch.cuda.synchronize()
+            assert torch.equal(da, a[k]) and torch.equal(db, b[k]) and torch.equal(y, a[k].float() * 2)
+            assert int(pin[0]) == 40 + k
+        assert not e.graph_set_copy_many(g, [])         # nothing to copy: not one launch
+        g0 = e.graph_capture(lambda: y.mul_(1.0))
+        with pytest.raises(ZeroHipError):
+            e.graph_set_copy_many(g0, [(da, a[0])])
+        g2 = e.graph_capture(lambda: (e.copy_many([(da, a[0])]), e.copy_many([(db, b[0])])))
+        with pytest.raises(ZeroHipError):
+            e.graph_set_copy_many(g2, [(da, a[1])])
+        for h in (g, g0, g2):
+            e.lib.call("zk_graph_destroy", h)

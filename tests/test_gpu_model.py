@@ -741,16 +741,20 @@ def test_many_shapes_many_replays_match_eager():
     assert not any(b for _, _, b in traces[True])
 
 
-def test_steps_on_rotating_batches_without_host_syncs_match_eager():
+@pytest.mark.parametrize("slots,steps", [(16, 12), (16, 44), (2, 20), (3, 20)])
+def test_steps_on_rotating_batches_without_host_syncs_match_eager(slots, steps, monkeypatch):
     """Trainer.step as the training loop calls it: a NEW batch every step, the host never waiting for the device (the
     next batch is uploaded and prepared -- zk_batch_prep -- on a side stream into a staging set while the previous step
-    runs, then committed by one copy launch).  12 steps over 5 different batches of one shape, no synchronisation in
-    between, against eager micro steps with a synchronisation after every step: same losses, same weights."""
+    runs, then committed by the first node of the step's graph, whose arguments are rewritten per step).  Steps over 5
+    different batches of two shapes, no synchronisation in between, against eager micro steps with a synchronisation after
+    every step: same losses, same weights.  44 steps go round the 16 staging sets almost three times; 2 and 3 sets make
+    the host wait for the pinned commit word on nearly every step."""
     from zero_amd.main import Trainer
+    monkeypatch.setattr(Trainer, "STAGE_SLOTS", slots)
     hp, Pn, _, _ = _setup("transformer", H=128, F=256, lrate=0.5, warmup_steps=10)
     feats = []
     for i in range(5):
-        src, tgt = make_batch(np.random.default_rng(100 + i), 6, 12, 14, hp.src_vocab.size(), hp.tgt_vocab.size())
+        src, tgt = make_batch(np.random.default_rng(100 + i), 6, 12 if i != 3 else 9, 14, hp.src_vocab.size(), hp.tgt_vocab.size())
         src[:, -1], tgt[:, -1] = 2, 2
         feats.append({"source": src, "target": tgt})
     runs = {}
@@ -758,7 +762,7 @@ def test_steps_on_rotating_batches_without_host_syncs_match_eager():
         reset_cores()
         tr = Trainer(hp, initializer=Pn)
         held = []
-        for i in range(12):
+        for i in range(steps):
             if mode == "eager":
                 loss = tr.micro_step(feats[i % 5])
                 torch.cuda.synchronize()

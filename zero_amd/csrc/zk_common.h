@@ -280,3 +280,6 @@ static inline uint32_t zk_drop_threshold(float p) {
   if (t > 4294967295.0) t = 4294967295.0;
   return (uint32_t)t;
 }
+
+// the hipGraph an executable of zk_graph_end was instantiated from (kept alive until zk_graph_destroy); zk_elem.hip
+hipGraph_t zk_graph_template_of(void* exec);

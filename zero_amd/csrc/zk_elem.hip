@@ -6,9 +6,23 @@
 #include "zk_common.h"
 #include "zk_ln_dev.h"
 #include "zk_prog.h"
+#ifdef ZK_STEP_STAMPS   // make STEPSTAMPS=1 (scripts/step_stamps.py): 100 MHz-clock stamps at the head and the tail of a training step
+__device__ unsigned long long zk_step_stamp_buf[2 * 4096];
+__device__ unsigned int zk_step_stamp_n[2];
+extern "C" int zk_step_stamps_read(unsigned long long* out, unsigned int* n2) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(zk_step_stamp_buf), sizeof(unsigned long long) * 2 * 4096) != hipSuccess) return 1;
+  return (int)hipMemcpyFromSymbol(n2, HIP_SYMBOL(zk_step_stamp_n), sizeof(unsigned int) * 2);
+}
+extern "C" int zk_step_stamps_reset(void) {
+  unsigned int z[2] = {0, 0};
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(zk_step_stamp_n), z, sizeof(z));
+}
+#endif
 #include <cstring>
+#include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
+#include <unordered_map>
 
 thread_local char zk_err_buf[512] = {0};
 int zk_set_error(int code, const char* fmt, ...) {
@@ -35,6 +49,12 @@ __global__ void __launch_bounds__(256) k_embed_fwd(
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
+#ifdef ZK_STEP_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned int i_ = atomicAdd(&zk_step_stamp_n[0], 1u);
+    if (i_ < 4096) zk_step_stamp_buf[i_] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   const uint64_t seed = (thr != 0) ? *seedp : 0;
   const bool zero_all = (zero_flag != nullptr) && (*zero_flag != 0);
   if (pos0_dev != nullptr) pos0 = *pos0_dev;   // decode step read at run time (captured graphs)
@@ -1307,6 +1327,12 @@ __global__ void __launch_bounds__(256) k_norm_final2(const float* __restrict__ p
     hyper[7] = bad ? 1.f : 0.f;
     if (bad) hyper[10] += 1.f;
     if (pnorm_out != nullptr) pnorm_out[0] = sqrtf(b);
+#ifdef ZK_STEP_STAMPS
+    {
+      const unsigned int i_ = atomicAdd(&zk_step_stamp_n[1], 1u);
+      if (i_ < 4096) zk_step_stamp_buf[4096 + i_] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
   }
 }
 // hyper[6] was written by zk_l2norm on a path whose update does not look at it (per-bucket updates of the
@@ -2012,6 +2038,15 @@ int zk_zero(void* p, size_t bytes, hipStream_t stream) {
 }
 
 // ---- thin hipGraph wrappers (launch-bound step loop is captured once and replayed)
+}  // extern "C"
+static std::mutex g_graph_mu;
+static std::unordered_map<void*, hipGraph_t> g_graph_of;      // executable -> the graph it was instantiated from
+hipGraph_t zk_graph_template_of(void* exec) {                   // (zk_common.h; used by zk_prep.hip)
+  std::lock_guard<std::mutex> lk(g_graph_mu);
+  auto it = g_graph_of.find(exec);
+  return it == g_graph_of.end() ? nullptr : it->second;
+}
+extern "C" {
 int zk_graph_begin(hipStream_t stream) {
   hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) return zk_set_error((int)e, "hipStreamBeginCapture: %s", hipGetErrorString(e));
@@ -2032,8 +2067,15 @@ int zk_graph_end(hipStream_t stream, void** exec_out) {
   g_last_graph_nodes = (int)n_nodes;
   hipGraphExec_t exec = nullptr;
   e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
-  if (e != hipSuccess) return zk_set_error((int)e, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  if (e != hipSuccess) {
+    hipGraphDestroy(graph);
+    return zk_set_error((int)e, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  }
+  {   // the captured graph stays alive beside its executable: its node handles name the nodes whose parameters
+      // zk_graph_set_copy_many rewrites before a replay (released by zk_graph_destroy)
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    g_graph_of[(void*)exec] = graph;
+  }
   *exec_out = (void*)exec;
   return 0;
 }
@@ -2044,7 +2086,15 @@ int zk_graph_launch(void* exec, hipStream_t stream) {
   return 0;
 }
 int zk_graph_destroy(void* exec) {
-  if (exec) hipGraphExecDestroy((hipGraphExec_t)exec);
+  if (exec == nullptr) return 0;
+  hipGraph_t graph = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    auto it = g_graph_of.find(exec);
+    if (it != g_graph_of.end()) { graph = it->second; g_graph_of.erase(it); }
+  }
+  hipGraphExecDestroy((hipGraphExec_t)exec);
+  if (graph) hipGraphDestroy(graph);
   return 0;
 }
 

@@ -19,6 +19,8 @@
 // barrier: 42.6 us per batch, 0.9 % of the step; profiles/r04_rocprof_kernel_stats_v0.txt.)  Up to 4096 rows per side:
 // 256 threads; up to 16384: 1024 threads; beyond: the plain LDS-free network on a caller-provided global scratch.
 #include "zk_common.h"
+#include <cstring>
+#include <vector>
 
 
 struct PrepSide {
@@ -395,26 +397,75 @@ int zk_batch_prep(const int* src_ids, const int* tgt_ids, int B, int Ls, int Lt,
 }
 
 // dsts / srcs / nbytes: HOST arrays of n (<= 16) device pointers and byte counts (multiples of 4, 4-byte aligned)
-int zk_copy_many(void* const* dsts, const void* const* srcs, const size_t* nbytes, int n, hipStream_t stream) {
-  ZK_CHECK_ARG(n >= 0 && n <= ZK_COPY_MAX, "zk_copy_many: n=%d out of range (<= %d)", n, ZK_COPY_MAX);
-  if (n == 0) return 0;
-  CopyMany c;
+static int fill_copy_many(CopyMany* c, unsigned* gx_out, void* const* dsts, const void* const* srcs, const size_t* nbytes, int n) {
   size_t big = 0;
   for (int i = 0; i < ZK_COPY_MAX; ++i) {
     const bool on = i < n;
     ZK_CHECK_ARG(!on || (nbytes[i] % 4 == 0 && nbytes[i] < (1ull << 33) && (nbytes[i] == 0 || (dsts[i] != nullptr && srcs[i] != nullptr)) &&
                          ((((uintptr_t)dsts[i]) | ((uintptr_t)srcs[i])) & 3) == 0),
                  "zk_copy_many: copy %d must be 4-byte aligned, a multiple of 4 bytes and non-null", i);
-    c.dst[i] = on ? (uint32_t*)dsts[i] : nullptr;
-    c.src[i] = on ? (const uint32_t*)srcs[i] : nullptr;
-    c.words[i] = on ? (unsigned)(nbytes[i] / 4) : 0;
+    c->dst[i] = on ? (uint32_t*)dsts[i] : nullptr;
+    c->src[i] = on ? (const uint32_t*)srcs[i] : nullptr;
+    c->words[i] = on ? (unsigned)(nbytes[i] / 4) : 0;
     if (on && nbytes[i] > big) big = nbytes[i];
   }
   unsigned gx = (unsigned)((big / 16 + 255) / 256);
   if (gx < 1) gx = 1;
   if (gx > 64) gx = 64;
+  *gx_out = gx;
+  return 0;
+}
+
+int zk_copy_many(void* const* dsts, const void* const* srcs, const size_t* nbytes, int n, hipStream_t stream) {
+  ZK_CHECK_ARG(n >= 0 && n <= ZK_COPY_MAX, "zk_copy_many: n=%d out of range (<= %d)", n, ZK_COPY_MAX);
+  if (n == 0) return 0;
+  CopyMany c;
+  unsigned gx = 1;
+  if (int rc = fill_copy_many(&c, &gx, dsts, srcs, nbytes, n)) return rc;
   hipLaunchKernelGGL(k_copy_many, dim3(gx, n), dim3(256), 0, stream, c);
   ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+// The captured training step starts with its zk_copy_many launch (the prepared batch moves from a staging set into the
+// buffers the step reads).  Which staging set that is changes from step to step: instead of a launch of its own in front of
+// every replay (a second submission per step: ~20 us of idle time at the step boundary), the parameters of that
+// ONE node are rewritten in the instantiated graph.  exec: a handle of zk_graph_end whose capture holds exactly one
+// zk_copy_many launch; the arguments as for zk_copy_many (n >= 1).
+int zk_graph_set_copy_many(void* exec, void* const* dsts, const void* const* srcs, const size_t* nbytes, int n) {
+  ZK_CHECK_ARG(exec != nullptr && n >= 1 && n <= ZK_COPY_MAX, "zk_graph_set_copy_many: null graph or n=%d out of range", n);
+  hipGraph_t graph = zk_graph_template_of(exec);
+  ZK_CHECK_ARG(graph != nullptr, "zk_graph_set_copy_many: not a handle of zk_graph_end");
+  size_t nn = 0;
+  hipError_t e = hipGraphGetNodes(graph, nullptr, &nn);
+  if (e != hipSuccess) return zk_set_error((int)e, "hipGraphGetNodes: %s", hipGetErrorString(e));
+  std::vector<hipGraphNode_t> nodes(nn);
+  e = hipGraphGetNodes(graph, nodes.data(), &nn);
+  if (e != hipSuccess) return zk_set_error((int)e, "hipGraphGetNodes: %s", hipGetErrorString(e));
+  hipGraphNode_t node = nullptr;
+  int found = 0;
+  for (size_t i = 0; i < nn; ++i) {
+    hipGraphNodeType t;
+    if (hipGraphNodeGetType(nodes[i], &t) != hipSuccess || t != hipGraphNodeTypeKernel) continue;
+    hipKernelNodeParams p;
+    if (hipGraphKernelNodeGetParams(nodes[i], &p) != hipSuccess) continue;
+    if (p.func == (void*)k_copy_many) { node = nodes[i]; ++found; }
+  }
+  ZK_CHECK_ARG(found == 1, "zk_graph_set_copy_many: the graph holds %d zk_copy_many launches (need exactly one)", found);
+  CopyMany c;
+  unsigned gx = 1;
+  if (int rc = fill_copy_many(&c, &gx, dsts, srcs, nbytes, n)) return rc;
+  void* args[1] = {&c};
+  hipKernelNodeParams np;
+  memset(&np, 0, sizeof(np));
+  np.func = (void*)k_copy_many;
+  np.gridDim = dim3(gx, n);
+  np.blockDim = dim3(256);
+  np.sharedMemBytes = 0;
+  np.kernelParams = args;
+  np.extra = nullptr;
+  e = hipGraphExecKernelNodeSetParams((hipGraphExec_t)exec, node, &np);
+  if (e != hipSuccess) return zk_set_error((int)e, "hipGraphExecKernelNodeSetParams: %s", hipGetErrorString(e));
   return 0;
 }
 

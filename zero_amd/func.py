@@ -169,17 +169,28 @@ class Engine(object):
             self._pins = PinnedRing(self.device)
         self._pins.put(dst, arr)
 
+    @staticmethod
+    def _copy_many_args(chunk):
+        n = len(chunk)
+        assert all(d.numel() * d.element_size() == s_.numel() * s_.element_size() for d, s_ in chunk)
+        return ((ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in chunk]),
+                (ctypes.c_void_p * n)(*[s_.data_ptr() for _, s_ in chunk]),
+                (ctypes.c_size_t * n)(*[d.numel() * d.element_size() for d, _ in chunk]), n)
+
     def copy_many(self, pairs):
-        """[(dst tensor, src tensor)] (same byte counts, multiples of 4): one launch (zk_copy_many)."""
+        """[(dst tensor, src tensor)] (same byte counts, multiples of 4): one launch (zk_copy_many) per 16 pairs."""
         pairs = [(d, s_) for d, s_ in pairs if d.numel()]
         for i in range(0, len(pairs), 16):
-            chunk = pairs[i:i + 16]
-            n = len(chunk)
-            dsts = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in chunk])
-            srcs = (ctypes.c_void_p * n)(*[s_.data_ptr() for _, s_ in chunk])
-            sizes = (ctypes.c_size_t * n)(*[d.numel() * d.element_size() for d, _ in chunk])
-            assert all(d.numel() * d.element_size() == s_.numel() * s_.element_size() for d, s_ in chunk)
-            self.lib.call("zk_copy_many", dsts, srcs, sizes, n, self.stream)
+            self.lib.call("zk_copy_many", *(self._copy_many_args(pairs[i:i + 16]) + (self.stream,)))
+
+    def graph_set_copy_many(self, exec_, pairs):
+        """Rewrite the one zk_copy_many launch inside the captured graph ``exec_`` to these (dst, src) pairs (at most 16 with
+        elements; the same filter as copy_many).  False when the pairs do not fit one launch."""
+        pairs = [(d, s_) for d, s_ in pairs if d.numel()]
+        if not 1 <= len(pairs) <= 16:
+            return False
+        self.lib.call("zk_graph_set_copy_many", exec_, *self._copy_many_args(pairs))
+        return True
 
     @property
     def upload_stream(self):

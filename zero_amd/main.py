@@ -16,6 +16,7 @@ outside the hot path.
 """
 
 import os
+import time
 
 import torch
 
@@ -24,6 +25,7 @@ from zero_amd.models import model as model_registry
 from zero_amd.models import load_all
 from zero_amd.utils import parallel
 from zero_amd.utils.cycle import TrainOp
+from zero_amd.hip import ZeroHipError
 
 
 def tower_train_graph(train_features, graph, params, reducer=None):
@@ -205,9 +207,8 @@ class Trainer(object):
         graphs cannot be captured or replayed on the legacy default stream), so that step() needs no stream hand-off."""
         return torch.cuda.stream(self.core.eng.work_stream)
 
-    # staging sets of the rotating-batch loop and how often "sets up to here are free again" is recorded (see step())
-    STAGE_SLOTS = int(os.environ.get("ZERO_HIP_STAGE_SLOTS", "16"))
-    STAGE_EVENT_EVERY = max(1, STAGE_SLOTS // 2)
+    # staging sets of the rotating-batch loop (see step())
+    STAGE_SLOTS = max(2, int(os.environ.get("ZERO_HIP_STAGE_SLOTS", "16")))
 
     # -- one entry point for the training loop: captured steps whenever the shapes allow ---------
     def step(self, features, use_graph=True):
@@ -223,35 +224,43 @@ class Trainer(object):
             # -- and the captured step then starts with one small copy launch (commit) instead of waiting for a ~60-us
             # single-workgroup sort.  The step itself is unchanged; one graph per batch shape as before.
             #
-            # A staging set may be overwritten once the commit that read it is done.  Rounds 4-5 had two sets and recorded
-            # an event behind EVERY commit; an event record on the work stream costs ~65 us of the step (same-box A/B,
-            # whether in front of the step's graph or behind it, torch's events or hipEventDisableSystemFence ones; the
-            # WAIT for the upload's event costs nothing) -- so there are eight sets now and the event is recorded every
-            # fourth step: set s of step n was last read by the commit of step n - 8, and the upload stream has waited for
-            # an event of a step >= n - 8 (the oldest one there is, n - 8 .. n - 5) before it writes the set again.
+            # A staging set may be overwritten once the commit that read it is done.  Rounds 4-5 had two sets and an
+            # event recorded on the work stream behind every commit, for the upload stream to wait on: that event costs
+            # 40-65 us PER STEP of kernel time inside the step (in-kernel stamps, scripts/step_stamps.py: with it the
+            # step's interior is that much longer than a static replay's, without it the two are equal) -- wherever it
+            # is recorded, with or without its system fence, and still 40 us at one record per eight steps.  So no event
+            # is recorded on the work stream at all: the commit launch itself copies the step's sequence number (it
+            # travels with the host scalars) into a PINNED HOST word, and the HOST does not enqueue the upload into set
+            # n % S before that word says commit n - S + 1 has been reached (kernels of a stream run in order: commit
+            # n - S is complete then).  In the steady state the host is a few steps ahead of the device and never waits.
             eng = self.core.eng
             cur = torch.cuda.current_stream(eng.device)
             ws, up = eng.work_stream, eng.upload_stream
-            S, R = self.STAGE_SLOTS, self.STAGE_EVENT_EVERY
+            S = self.STAGE_SLOTS
             n = self._stage_n = getattr(self, "_stage_n", -1) + 1
             slot = n % S
-            evs = self.__dict__.setdefault("_commit_events", {})        # step index (a multiple of R) -> event
-            need = n - S                                                   # the commit that last read this set
-            if need >= 0:
-                j = -(-need // R) * R                                      # oldest recorded step >= need
-                if getattr(self, "_stage_waited", -1) < j:
-                    up.wait_event(evs[j])
-                    self._stage_waited = j
-                    for k in [k for k in evs if k < j]:
-                        del evs[k]
+            done = self.__dict__.get("_commit_reached")
+            if done is None:
+                done = self._commit_reached = torch.full((1,), -1, dtype=torch.int32).pin_memory()
+            if n >= S:
+                spins = 0
+                while int(done[0]) < n - S + 1:          # plain host read of the pinned word (no HIP call)
+                    spins += 1
+                    time.sleep(0 if spins < 50 else 2e-4)
+                    if spins > 300000:                   # ~a minute: the device is not making progress
+                        raise ZeroHipError("Trainer.step: commit %d was never reached (pinned word %d)" % (n - S + 1, int(done[0])))
             self.lr.step(self.global_step)
             self.train_op.count = 0
             with torch.cuda.stream(up):
                 staged = self.core.upload(features["source"], features["target"], suffix=".stg%d" % slot)
-                # the step's host scalars (lr_t, ...) travel the same way: no copy of their own between two step graphs
+                # the step's host scalars (lr_t, ...) and its sequence number travel the same way: no copy of their own
+                # between two step graphs
                 hstage = eng.buf("hyper.stg%d" % slot, (12,), torch.float32)
-                scale = self.train_op.set_hyper(self.lr.get_lr(), parallel.world_size(), dst=hstage)
-                ev_up = torch.cuda.Event()
+                scale = self.train_op.set_hyper(self.lr.get_lr(), parallel.world_size(), dst=hstage, seq=n)
+                ups = self.__dict__.setdefault("_upload_events", {})
+                ev_up = ups.get(slot)
+                if ev_up is None:
+                    ev_up = ups[slot] = torch.cuda.Event()
                 ev_up.record(up)
             # (a caller that already runs on the engine's work stream -- zero_amd.main.train and bench.py do, via
             # Trainer.on_work_stream() -- pays no cross-stream hand-off per step: two event packets fewer between two
@@ -261,12 +270,7 @@ class Trainer(object):
                 ws.wait_stream(cur)
             ws.wait_event(ev_up)
             with torch.cuda.stream(ws):
-                self.batch = self.core.commit(staged, extra=self.train_op.hyper_pairs(hstage))
-                if n % R == 0:
-                    evs[n] = torch.cuda.Event()
-                    evs[n].record(ws)
-                self._declare_sparse(self.batch)
-                loss = self._step_static(True, scale=scale)
+                loss = self._step_staged(staged, hstage, scale)
             if not same:
                 cur.wait_stream(ws)
             return loss
@@ -288,6 +292,44 @@ class Trainer(object):
             loss = self._step_accumulate(features)
         cur.wait_stream(ws)
         return loss
+
+    def _step_staged(self, staged, hstage, scale):
+        """The step on a batch that sits prepared in a staging set (Trainer.step, on the work stream).
+
+        Single rank, whole-step graph: the commit launch (staging set -> the buffers the step reads, zk_copy_many) is the
+        FIRST NODE of the step's graph -- one submission per step, as for a static replay -- and its arguments are
+        rewritten in the instantiated graph before every launch (zk_graph_set_copy_many; the graphs with that node are
+        keyed ("stg", B, Ls, Lt), apart from the ones step_static() captures for the same shape).  Everything else (first
+        sight of a shape, several ranks, the side-stream variants): the commit launch in front, then _step_static().
+        Either way the commit also copies the step's sequence number into the pinned word step() polls."""
+        eng = self.core.eng
+        extra = self.train_op.hyper_pairs(hstage) + [(self._commit_reached.view(torch.float32), hstage[11:12])]
+        fast = parallel.world_size() == 1 and not self.force_segmented and not self.core.use_side and \
+            os.environ.get("ZERO_HIP_COMMIT_IN_GRAPH", "1") != "0"
+        key = ("stg", staged["B"], staged["Ls"], staged.get("Lt", 0))
+        self._check_graph_cache()
+        g = self._graphs.pop(key, None) if fast else None
+        if g is None:
+            if fast:
+                self._graphs[key] = "warm"                 # eager now (sizes every scratch buffer), captured next time
+            self.batch = self.core.commit(staged, extra=extra)
+            self._declare_sparse(self.batch)
+            return self._step_static(not fast, scale=scale)     # fast: eager this once; else the usual routes
+        if g == "warm":
+            def body():
+                self.batch = self.core.commit(staged, extra=extra)
+                self._train_and_update(scale)
+            g = eng.graph_capture(body)
+        else:
+            self.batch, pairs = self.core.commit(staged, extra=extra, launch=False)
+            if not eng.graph_set_copy_many(g, pairs):
+                raise ZeroHipError("Trainer.step: the commit of a batch no longer fits one zk_copy_many launch")
+        self._graphs[key] = g                              # most recently used last
+        self._declare_sparse(self.batch)
+        eng.graph_launch(g)
+        self.store.step += 1
+        self.global_step += 1
+        return eng.buf("loss", (1,), torch.float32)
 
     def _graph_run(self, key, body):
         eng = self.core.eng

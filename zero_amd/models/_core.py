@@ -759,10 +759,11 @@ class TransformerCore(object):
             e.batch_prep(out)
         return out
 
-    def commit(self, staged, extra=()):
+    def commit(self, staged, extra=(), launch=True):
         """Move a batch that upload(..., suffix=...) prepared in staging buffers into the static buffers the captured
         step reads: one launch (zk_copy_many) on the current stream.  extra: more (dst, src) pairs for the same launch
-        (the step's host scalars).  Returns the batch dict over the static buffers."""
+        (the step's host scalars).  Returns the batch dict over the static buffers.  launch=False: no launch, the (dst,
+        src) pairs are returned beside the dict (Trainer.step rewrites the copy node of the step's graph with them)."""
         e = self.eng
         B, Ls, Lt = staged["B"], staged["Ls"], staged.get("Lt", 0)
         out = {"B": B, "Ls": Ls, "suffix": ""}
@@ -787,7 +788,10 @@ class TransformerCore(object):
             take("tmask", "tmask", (B, Lt), F32)
             take("tw", "tw", (B, Lt), F32)
             out["tw_scale"] = staged["tw_scale"]
-        e.copy_many(pairs + list(extra))
+        pairs = pairs + list(extra)
+        if not launch:
+            return out, pairs
+        e.copy_many(pairs)
         return out
 
     def _sort_buffers(self, name, T):

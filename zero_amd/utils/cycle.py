@@ -75,7 +75,7 @@ class TrainOp(object):
         self.eng.lib.call("zk_axpby_f32", st.grad.data_ptr(), st.accum.data_ptr(), 1.0, 1.0, st.numel,
                           self.eng.stream)
 
-    def set_hyper(self, lr, world=1, dst=None):
+    def set_hyper(self, lr, world=1, dst=None, seq=None):
         """Host-side scalars of this update (lr is fed per step: main.py:157,292).  dst: a staging copy of ``hyper``
         to fill instead (Trainer.step uploads the next step's scalars on its side stream; hyper_pairs() lists what the
         commit launch then copies)."""
@@ -87,6 +87,18 @@ class TrainOp(object):
         clip = float(clip) if isinstance(clip, float) else 0.0
         scale = 1.0 / (float(world) * float(hp.loss_scale) * float(self.count + 1))
         import numpy as _np
+        if seq is not None:
+            # a staging copy (dst): one upload of all twelve words -- [6], [7], [9], [10] are the device's own in the live
+            # array and never leave a staging copy; [11] carries the caller's sequence number (int32 bits), which the
+            # commit launch copies to a pinned host word (Trainer.step)
+            v = _np.zeros(12, dtype=_np.float32)
+            v[:6] = [lr_t, hp.beta1, hp.beta2, hp.epsilon, scale, clip]
+            if self.ema is not None:
+                t_ = self.store.step + 1
+                v[8] = min(float(hp.ema_decay), (1.0 + t_) / (10.0 + t_))
+            v[11:12] = _np.array([seq], dtype=_np.int32).view(_np.float32)
+            self._pins.put(hyper[:12], v)
+            return scale
         self._pins.put(hyper[:6], _np.array([lr_t, hp.beta1, hp.beta2, hp.epsilon, scale, clip], dtype=_np.float32))
         if self.ema is not None:
             # num_updates = global_step after this update (ema.apply runs under train_op's control
