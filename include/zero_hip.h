@@ -645,6 +645,22 @@ int zk_f32_aan_step(const float* x, float* cache, float* cat, int rows, int H, i
 int zk_f32_gate(const float* z, const float* cat, float* g, int rows, int H, zk_stream_t stream);
 int zk_f32_add_rows(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int rows, int cols,
                     zk_stream_t stream);
+/* round 6: row-local neighbours of the fp32 decode step's launches folded together (a step is a chain of ~5 us launches).
+ *   zk_f32_ln_fused    zk_f32_add_ln with, optionally, the average-attention gate as the producer of y (z / cat_in given,
+ *                      x = ybuf = NULL: y = sigmoid(z_i) x_c + sigmoid(z_f) y_c and the residual is x_c = cat_in[:, :H];
+ *                      transformer_aan.py:186-192) and / or the NEXT layer's average attention from the normalised row
+ *                      (cache / cat_out given: cache += out, cat_out = [out | cache / (t + 1)]; transformer_aan.py:110-112).
+ *                      H % 4 == 0, H <= 2048, every pointer 16-byte aligned.
+ *   zk_f32_embed_step  zk_f32_embed for one decode position with the all-pad test of transformer.py:113-115 inside the
+ *                      launch (pad_id >= 0) and, optionally, the first layer's average attention (cache / cat_out).
+ *   zk_f32_gemm_legacy A/B switch: 1 = the round-5 GEMM kernels for every shape; returns the old value (< 0: query). */
+int zk_f32_ln_fused(const float* x, const float* ybuf, const float* z, const float* cat_in, const float* gamma,
+                    const float* beta, float* out, int rows, int H, float eps, float* cache, float* cat_out, int time,
+                    const int* time_dev, zk_stream_t stream);
+int zk_f32_embed_step(const int* ids, int rows, const float* table, const float* bias, const float* timing, int timing_rows,
+                      float* out, int H, float scale, int pos0, const int* pos_dev, int pad_id, float* cache, float* cat_out,
+                      zk_stream_t stream);
+int zk_f32_gemm_legacy(int on);
 
 /* hipGraph plumbing: capture a sequence of the calls above once, replay per step */
 int zk_graph_begin(zk_stream_t stream);
@@ -654,6 +670,9 @@ int zk_graph_launch(void* exec, zk_stream_t stream);
  * training step's graph starts with the copy of the prepared batch out of one of several staging sets -- the feed_dict of
  * main.py:286-294 -- and the set changes from step to step (zero_amd/main.py Trainer.step) */
 int zk_graph_set_copy_many(void* exec, void* const* dsts, const void* const* srcs, const size_t* nbytes, int n);
+/* the most (dst, src) pairs one zk_copy_many launch takes (16): a commit with more pairs makes several launches and cannot
+ * be the rewritable first node of a step graph */
+int zk_copy_many_max(void);
 int zk_graph_destroy(void* exec);
 /* number of nodes (= kernel launches) of the graph the last zk_graph_end instantiated: lets bench.py report the
  * launches per captured step without a profiler */

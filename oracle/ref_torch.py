@@ -178,6 +178,9 @@ def to_torch(params_np, dtype=torch.float32, requires_grad=False):
 # --------------------------------------------------------------------------
 # func.py restated
 # --------------------------------------------------------------------------
+TRACE_RUNNER_UPS = 8      # candidates kept beyond the 2K of search.py:172-176 in hp.search_trace (checker aid)
+
+
 class Cfg(object):
     """dtype.py:12-15 constants + run-time switches of the restatement."""
     eps = 1e-8
@@ -778,9 +781,11 @@ def beam_search(features, encoding_fn, decoding_fn, hp):
         flat_scores = _merge(curr_scores, 1)
         topk_scores, topk_idx = _top_k(flat_scores, 2 * beam_size)
         if trace is not None:
-            # checker aid (tests/test_gpu_fullsize.py): the 2K candidates search.py:172-176 keeps PLUS the runner-up, so
-            # that a path that leaves this one at some step can be judged by the score gap it had to bridge there
-            ts, ti = _top_k(flat_scores, min(2 * beam_size + 1, flat_scores.shape[1]))
+            # checker aid (tests/test_gpu_fullsize.py): the 2K candidates search.py:172-176 keeps PLUS the runner-ups
+            # (round 6: eight of them, one before -- a candidate the other path ranks inside its 2K was sometimes below
+            # the single runner-up and had no gap on record), so that a path that leaves this one at some step can be
+            # judged by the score gap it had to bridge there
+            ts, ti = _top_k(flat_scores, min(2 * beam_size + TRACE_RUNNER_UPS, flat_scores.shape[1]))
             trace.append((ts.numpy().copy(), ti.numpy().copy()))
         beam_idx = topk_idx // V
         sym_idx = topk_idx % V

@@ -16,12 +16,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--sentences", type=int, default=256)
 ap.add_argument("--model", default="transformer_aan")
 ap.add_argument("--beam", type=int, default=4)
+ap.add_argument("--dtype", default="bfloat16", help="decode_dtype: bfloat16 (product mode) or float32 (token-exact mode, zk_f32_*)")
 args = ap.parse_args()
 load_all()
 V = 32000
 hp = transformer_base_params(model_name=args.model, scope_name=args.model, beam_size=args.beam, decode_alpha=0.6,
                              decode_length=50, eval_batch_size=32)
 hp.src_vocab = SyntheticVocab(V); hp.tgt_vocab = SyntheticVocab(V)
+hp.decode_dtype = args.dtype
 rng = np.random.default_rng(1234)
 lens = np.clip(np.rint(rng.normal(28, 14, args.sentences)), 4, 100).astype(int)
 order = np.argsort(lens, kind="stable")                     # length-sorted batches (data.py:69-73)
@@ -42,6 +44,6 @@ for b0 in range(0, args.sentences, hp.eval_batch_size):
     if b0 > 0:                                              # first batch = warm-up (buffer sizing)
         t_all += dt; tot_steps += out["steps"]; tot_sent += len(idx)
         tot_tok += int((out["seq"][:, 0] != 0).sum())
-print(json.dumps({"model": args.model, "beam": args.beam, "sentences": tot_sent, "decode_steps": tot_steps,
+print(json.dumps({"model": args.model, "decode_dtype": args.dtype, "beam": args.beam, "sentences": tot_sent, "decode_steps": tot_steps,
                   "seconds": t_all, "steps_per_s": tot_steps / t_all, "sentences_per_s": tot_sent / t_all,
                   "ms_per_step": 1e3 * t_all / tot_steps, "rows_per_step": hp.eval_batch_size * args.beam}))

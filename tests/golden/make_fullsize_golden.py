@@ -134,7 +134,7 @@ def beam_fixture():
             # tests/test_gpu_fullsize.py uses them to measure the score gap at the step where the HIP search first
             # leaves the oracle's path.
             T = max(len(t) for t in traces)
-            W = 2 * K + 1
+            W = 2 * K + rt.TRACE_RUNNER_UPS
             tsc = np.full((T, src.shape[0], W), np.nan, dtype=np.float32)
             tix = np.full((T, src.shape[0], W), -1, dtype=np.int32)
             for bi, tr in enumerate(traces):

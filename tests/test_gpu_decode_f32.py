@@ -141,6 +141,109 @@ def test_aan_step_and_gate_f32():
     assert torch.allclose(g, ref, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("M,N,K,tb", [(128, 512, 512, 0), (128, 512, 2048, 0), (128, 1024, 1024, 0), (128, 2048, 512, 0),
+                                      (1280, 1536, 512, 0), (128, 32000, 512, 1), (97, 31, 260, 1), (640, 512, 2048, 0)])
+def test_gemm_f32_k_sliced_against_the_round5_kernel(M, N, K, tb):
+    """Round 6: the K-sliced kernel (every operand chunk requested up front, 4 / 8 / 16 waves per tile) and the column-major
+    tile order of the logits product against the round-5 kernels (zk_f32_gemm_legacy): the same products summed in a
+    different association -- equal to a few units of fp32 round-off of the sum of magnitudes, both equally far from fp64."""
+    e = eng()
+    A = _rand(M, K, seed=1)
+    B = _rand(N, K, seed=2) if tb else _rand(K, N, seed=2)
+    bias = _rand(N, seed=3)
+    out = []
+    for legacy in (1, 2, 0):         # round-5 kernels; round 6 without the 16 x 16 tiles; the default
+        C = torch.full((M, N), 7.0, device="cuda")
+        e.lib.raw("zk_f32_gemm_legacy")(legacy)
+        try:
+            e.lib.call("zk_f32_gemm", A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, K, K if tb else N, N, tb,
+                       bias.data_ptr(), 1, e.stream)
+            torch.cuda.synchronize()
+        finally:
+            e.lib.raw("zk_f32_gemm_legacy")(0)
+        out.append(C)
+    ref = (A.double() @ (B.double().t() if tb else B.double()) + bias.double()).clamp_min(0)
+    mag = A.double().abs() @ (B.double().abs().t() if tb else B.double().abs()) + bias.double().abs()
+    errs = [((o_.double() - ref).abs() / mag).max().item() for o_ in out]
+    assert max(errs) < 1e-6, errs
+    for o_ in out[1:]:
+        assert ((out[0] - o_).double().abs() / mag).max().item() < 1e-6
+
+
+def test_ln_fused_f32_equals_the_launches_it_replaces():
+    """zk_f32_ln_fused / zk_f32_embed_step (round 6) against zk_f32_gate + zk_f32_add_ln + zk_f32_aan_step /
+    zk_all_equal + zk_f32_embed: the same values up to the association of the two row sums (mean / variance)."""
+    e = eng()
+    rows, H = 131, 512
+    x, y = _rand(rows, H, seed=1, scale=3.0) + 5.0, _rand(rows, H, seed=2)
+    gam, bet = 1.0 + 0.2 * _rand(H, seed=3), 0.1 * _rand(H, seed=4)
+    t = torch.tensor([6], dtype=torch.int32, device="cuda")
+    # plain + next layer's average attention
+    want = torch.empty(rows, H, device="cuda")
+    e.lib.call("zk_f32_add_ln", x.data_ptr(), y.data_ptr(), gam.data_ptr(), bet.data_ptr(), want.data_ptr(), rows, H, 1e-8, e.stream)
+    cache0 = _rand(rows, H, seed=5)
+    cache_w, cat_w = cache0.clone(), torch.empty(rows, 2 * H, device="cuda")
+    e.lib.call("zk_f32_aan_step", want.data_ptr(), cache_w.data_ptr(), cat_w.data_ptr(), rows, H, 0, t.data_ptr(), e.stream)
+    got, cache_g, cat_g = torch.empty_like(want), cache0.clone(), torch.empty_like(cat_w)
+    e.lib.call("zk_f32_ln_fused", x.data_ptr(), y.data_ptr(), None, None, gam.data_ptr(), bet.data_ptr(), got.data_ptr(), rows, H,
+               1e-8, cache_g.data_ptr(), cat_g.data_ptr(), 0, t.data_ptr(), e.stream)
+    torch.cuda.synchronize()
+    assert (got - want).abs().max().item() < 2e-6
+    assert torch.equal(cat_g[:, :H], got) and torch.equal(cache_g, got + cache0)
+    assert torch.equal(cat_g[:, H:], torch.from_numpy(((got + cache0).cpu().numpy() / np.float32(7.0)).astype(np.float32)).cuda())
+    # the gate as the producer of y; the residual is cat[:, :H]
+    z, cat = _rand(rows, 2 * H, seed=6, scale=2.0), _rand(rows, 2 * H, seed=7)
+    g = torch.empty(rows, H, device="cuda")
+    e.lib.call("zk_f32_gate", z.data_ptr(), cat.data_ptr(), g.data_ptr(), rows, H, e.stream)
+    xc = cat[:, :H].contiguous()
+    e.lib.call("zk_f32_add_ln", xc.data_ptr(), g.data_ptr(), gam.data_ptr(), bet.data_ptr(), want.data_ptr(), rows, H, 1e-8, e.stream)
+    e.lib.call("zk_f32_ln_fused", None, None, z.data_ptr(), cat.data_ptr(), gam.data_ptr(), bet.data_ptr(), got.data_ptr(), rows, H,
+               1e-8, None, None, 0, None, e.stream)
+    torch.cuda.synchronize()
+    assert (got - want).abs().max().item() < 3e-6
+    # decoder input of one position: all-pad test inside the launch, first layer's average attention
+    V = 50
+    tab, bias = _rand(V, H, seed=8), _rand(H, seed=9)
+    tim = e.timing(12, H)
+    for ids in (torch.randint(1, V, (rows,), dtype=torch.int32, device="cuda"), torch.zeros(rows, dtype=torch.int32, device="cuda")):
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        e.lib.call("zk_all_equal", ids.data_ptr(), rows, 0, flag.data_ptr(), e.stream)
+        e.lib.call("zk_f32_embed", ids.data_ptr(), rows, 1, tab.data_ptr(), bias.data_ptr(), tim.data_ptr(), int(tim.shape[0]),
+                   want.data_ptr(), H, float(H) ** 0.5, 0, t.data_ptr(), flag.data_ptr(), e.stream)
+        cache_w = cache0.clone()
+        e.lib.call("zk_f32_aan_step", want.data_ptr(), cache_w.data_ptr(), cat_w.data_ptr(), rows, H, 0, t.data_ptr(), e.stream)
+        cache_g = cache0.clone()
+        e.lib.call("zk_f32_embed_step", ids.data_ptr(), rows, tab.data_ptr(), bias.data_ptr(), tim.data_ptr(), int(tim.shape[0]),
+                   got.data_ptr(), H, float(H) ** 0.5, 0, t.data_ptr(), 0, cache_g.data_ptr(), cat_g.data_ptr(), e.stream)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want) and torch.equal(cache_g, cache_w) and torch.equal(cat_g, cat_w)
+    assert torch.equal(got, tim[6:7].repeat(rows, 1))          # all ids = pad: timing signal only
+
+
+@pytest.mark.parametrize("model", ["transformer_aan", "transformer"])
+def test_fp32_step_with_folded_launches_equals_one_launch_per_op(model, monkeypatch):
+    """ZERO_HIP_F32_FUSE=0 (one launch per op, round 5) and the default step (round 6) decode the same hypotheses with the
+    same scores to fp32 round-off."""
+    from zero_amd.main import tower_infer_graph
+    rng = np.random.default_rng(31)
+    hp = make_hp(model, decode_dtype="float32")
+    Pn = perturb(rt.init_params(hp, model, seed=32), rng)
+    src, _ = make_batch(rng, 6, 11, 5, hp.src_vocab.size(), hp.tgt_vocab.size())
+    hp = copy.copy(hp)
+    hp.beam_size = 4
+    hp.search_mode = "cache"
+    res = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("ZERO_HIP_F32_FUSE", fuse)
+        reset_cores()
+        get_core(hp, model, Pn)
+        seqs, scores = tower_infer_graph({"source": src}, registry.get_model(model), hp)
+        res.append((np.asarray(seqs).copy(), np.asarray(scores).copy()))
+    assert np.array_equal(res[0][0], res[1][0])
+    fin = res[0][1] > -1e30
+    assert np.allclose(res[0][1][fin], res[1][1][fin], rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("model,kw", [("transformer_aan", {}), ("transformer", {}), ("transformer_aan", {"use_ffn": True}),
                                       ("transformer_rpr", {}), ("transformer_fuse", {})])
 @pytest.mark.parametrize("K", [1, 4])

@@ -15,15 +15,18 @@ Tolerances:
                   global norm within 1e-2, EVERY variable's gradient norm within 1.5e-2 (measured <= 1.1 %, also
                   for the variables whose gradient is 1e-4 of the largest), slices within SLICE_TOL relative L2;
                   against the pure fp32 oracle the global norm must stay within 3e-2;
-  beam search     (round 5) the weight set that decodes like a model (tests/fullsize.py beam_params): every oracle
-                  hypothesis ends in an EOS at a length around its source's, 5-10 % of the positions repeat, the two
-                  ORACLES (fp32 / bf16 storage model) agree with each other on 206 (beam 1) / 190 (beam 4) of 256.
+  beam search     the weight set that decodes like a model (tests/fullsize.py beam_params): every oracle hypothesis ends
+                  in an EOS at a length around its source's, 5-10 % of the positions repeat, the two ORACLES (fp32 / bf16
+                  storage model) agree with each other on 206 (beam 1) / 190 (beam 4) of 256.
                   fp32 decode mode (decode_dtype = float32): 256 / 256 token-exact, every beam, scores within 1e-4
-                  relative (measured 1.5e-6 / 3.2e-6).  bf16 product mode: held to the oracle pair -- not many more
-                  misses than the bf16-storage oracle has, and every first divergence a near-tie of the fp32 oracle
-                  (reproduced by the bf16-storage oracle, inside the oracle pair's own disagreement at that step, or a gap
-                  below BF16_TIE); per-divergence records go to gpurun_out/fullsize_beam_*.json (copied to
-                  profiles/r05_parity_fullsize_beam_*.json).
+                  relative (measured 1.5e-6 / 3.2e-6).  bf16 product mode (round 6, after the residual sums of a decode
+                  step stopped being rounded to bf16 in front of the LayerNorm: 209 / 203 of 256 token-exact against
+                  the fp32 oracle, 205 / 198 against the bf16-storage oracle): NOT MORE misses than the bf16-storage
+                  oracle has (+ 4), EVERY first divergence located and a near-tie of the fp32 oracle -- reproduced by the
+                  bf16-storage oracle at that step, inside the oracle pair's own score distance at the last step the two
+                  oracles share, or an fp32-oracle gap below BF16_TIE; no unexplained divergence is tolerated
+                  (ACCEPTED_FAR lists exceptions by sentence id: none).  Per-divergence records go to
+                  gpurun_out/fullsize_beam_*.json (copied to profiles/r06_parity_fullsize_beam_*.json).
 """
 import copy
 import json
@@ -153,11 +156,26 @@ def _first_divergence(hip_trace, ref_scores, ref_idx, s_local, s_global, K):
                 continue
             where = np.nonzero(r_idx == h_idx[j])[0]
             gap = float(r_sc[j] - r_sc[int(where[0])]) if len(where) else None
+            # a candidate below the oracle's last kept runner-up: the gap is AT LEAST the distance to that runner-up
+            kept = r_sc[np.isfinite(r_sc) & (r_sc > -1e30)]
+            lower = float(r_sc[j] - kept.min()) if not len(where) and kept.size else None
             return {"step": t, "rank": j, "oracle_flat_index": int(r_idx[j]), "hip_flat_index": int(h_idx[j]),
-                    "oracle_score": float(r_sc[j]), "oracle_gap": gap, "oracle_pos_of_hip_candidate": int(where[0]) if len(where) else None,
+                    "oracle_score": float(r_sc[j]), "oracle_gap": gap, "oracle_gap_lower_bound": lower,
+                    "oracle_pos_of_hip_candidate": int(where[0]) if len(where) else None,
                     "hip_gap_seen": float(hip_trace[t][0][s_local][j] - hip_trace[t][0][s_local][min(j + 1, 2 * K - 1)]),
                     "tolerance": NEAR_TIE_REL * max(abs(float(r_sc[j])), 1.0)}
     return None
+
+
+def _pair_score_distance(f_sc, f_ix, b_sc, b_ix, t):
+    """largest distance between the two oracles' scores of the candidates BOTH list at step t (comparable while the two
+    hold the same alive set, i.e. up to and including the first step at which their kept candidates differ)"""
+    moved = 0.0
+    for a, ia in enumerate(f_ix[t]):
+        w = np.nonzero(b_ix[t] == ia)[0]
+        if ia >= 0 and len(w) and f_sc[t, a] > -1e30 and b_sc[t, int(w[0])] > -1e30:
+            moved = max(moved, abs(float(f_sc[t, a]) - float(b_sc[t, int(w[0])])))
+    return moved
 
 
 def _bf16_oracle_view(fx, K, d, s_global):
@@ -166,10 +184,15 @@ def _bf16_oracle_view(fx, K, d, s_global):
       bf16_oracle_same_choice          the bf16-storage oracle -- still on the common path up to that step -- has the
                                        HIP path's candidate at that rank: the miss is REPRODUCED by the checker itself;
       inside_oracle_pair_disagreement  the fp32 oracle's gap between the two candidates is no larger than the largest
-                                       distance between the two oracles' scores of the SAME candidates at that step
-                                       (x 2: either candidate may move): the two restatements of one algorithm move
-                                       these scores by more than what separates them."""
-    if d.get("step") is None or d.get("oracle_gap") is None:
+                                       distance between the two oracles' scores of the SAME candidates (x 2: either
+                                       candidate may move), measured at the divergence step when the bf16-storage oracle is
+                                       still on the common path there, otherwise (round 6: this case used to be accepted
+                                       unconditionally) at the LAST step the two oracles share on this sentence -- the step
+                                       at which they part, whose tables are still over the same alive set."""
+    gap = d.get("oracle_gap")
+    if gap is None:
+        gap = d.get("oracle_gap_lower_bound")
+    if d.get("step") is None or gap is None:
         return {}
     t, j = d["step"], d["rank"]
     f_sc, f_ix = fx["trace_scores_k%d" % K][:, s_global], fx["trace_idx_k%d" % K][:, s_global]
@@ -184,31 +207,31 @@ def _bf16_oracle_view(fx, K, d, s_global):
     out["bf16_oracle_on_common_path"] = bool(common)
     if not common:
         # the two oracles part on this very sentence BEFORE the HIP search does (which followed the fp32 oracle longer
-        # than the bf16-storage oracle did): their own disagreement on the sentence is the larger one
+        # than the bf16-storage oracle did).  Their tables at the divergence step are over different alive sets; the
+        # yardstick is their score distance at the parting step, the last one they share
         out["oracle_pair_parted_at_step"] = int(first_off)
-        out["inside_oracle_pair_disagreement"] = True
+        moved = _pair_score_distance(f_sc, f_ix, b_sc, b_ix, first_off)
+        out["oracle_pair_score_distance_at_parting_step"] = moved
+        out["inside_oracle_pair_disagreement"] = bool(d.get("oracle_gap") is not None and gap <= 2.0 * moved)
         return out
     out["bf16_oracle_flat_index"] = int(b_ix[t, j])
-    out["bf16_oracle_same_choice"] = bool(common and int(b_ix[t, j]) == d["hip_flat_index"])
-    # distance between the two oracles' scores of the candidates both list at step t
-    moved = 0.0
-    for a, ia in enumerate(f_ix[t]):
-        w = np.nonzero(b_ix[t] == ia)[0]
-        if ia >= 0 and len(w) and f_sc[t, a] > -1e30 and b_sc[t, int(w[0])] > -1e30:
-            moved = max(moved, abs(float(f_sc[t, a]) - float(b_sc[t, int(w[0])])))
+    out["bf16_oracle_same_choice"] = bool(int(b_ix[t, j]) == d["hip_flat_index"])
+    moved = _pair_score_distance(f_sc, f_ix, b_sc, b_ix, t)
     out["oracle_pair_score_distance_at_step"] = moved
-    out["inside_oracle_pair_disagreement"] = bool(common and d["oracle_gap"] <= 2.0 * moved)
+    out["inside_oracle_pair_disagreement"] = bool(d.get("oracle_gap") is not None and gap <= 2.0 * moved)
     return out
 
 
 @pytest.mark.parametrize("K", [1, 4])
 def test_aan_beam_search_base_size(K):
-    """BASELINE configs[3] subset: transformer_aan, d=512, V=32000, 256 length-sorted sentences, eval batch 32.
-    north_star: token-id exact greedy decode.  Every hypothesis that is NOT token-exact must be explained: the test
-    finds the first step at which the HIP search's candidate table leaves the oracle's (fixture `trace_*`: the
-    oracle's 2K kept candidates + the runner-up of every step) and requires the oracle's own score gap between the two
-    candidates involved to be a near-tie (< 2e-3 |score|: two bf16 implementations cannot be expected to order them
-    alike).  A divergence with a larger gap fails the test -- that would be a bug in zk_dec_* / zk_beam_*."""
+    """BASELINE configs[3] subset: transformer_aan, d=512, V=32000, 256 length-sorted sentences, eval batch 32, the bf16
+    PRODUCT decode mode (the fp32 mode, which meets "token-id exact" outright, is the next test).
+    Criterion (round 6): (a) not more hypotheses off the fp32 oracle than the bf16-storage oracle has off it (+ 4);
+    (b) every hypothesis that is NOT token-exact is located -- the first step at which the HIP search's candidate table
+    leaves the oracle's (fixture `trace_*`: the oracle's 2K kept candidates + eight runner-ups of every step) -- and is a
+    near-tie of the fp32 oracle there: the bf16-storage oracle makes the same choice, or the fp32 oracle's gap between the
+    two candidates is inside the oracle pair's own score distance, or it is below BF16_TIE (absolute, score units).  A
+    divergence that is none of these fails the test -- that would be a bug in zk_dec_* / zk_beam_*."""
     from zero_amd.main import tower_infer_graph
     from zero_amd.search import decode_hypothesis
     fx = np.load(os.path.join(GOLD, "aan_base_beam.npz"))
@@ -289,44 +312,49 @@ def test_aan_beam_search_base_size(K):
     print(json.dumps({k: rep[k] for k in ("oracle_fp32_vs_bf16storage_token_exact", "reproduced_by_bf16_oracle",
                                           "bracketed_by_oracle_pair")}))
     _report("beam_k%d" % K, rep)
-    # Round 5: on the fixture that decodes like a model the two ORACLES (fp32 / bf16 storage model) agree with each other on
-    # 206 (beam 1) and 190 (beam 4) of 256 hypotheses, their first differing tokens spread over positions 0 .. 43: "token-id
+    # On the fixture that decodes like a model the two ORACLES (fp32 / bf16 storage model) agree with each other on 206
+    # (beam 1) and 190 (beam 4) of 256 hypotheses, their first differing tokens spread over positions 0 .. 43: "token-id
     # exact" between an fp32 and a bf16-storage implementation is an 80 % / 74 % property on a decode workload whose steps
-    # matter (it was 97 % on the degenerate round-4 fixture, where only step 0 did).  The bf16 product path is therefore
-    # held to the checker's own yardstick; exactness is the fp32 mode's job (test_aan_beam_search_base_size_fp32_is_token_exact).
+    # matter.  The bf16 product path is held to the checker's own yardstick; exactness is the fp32 mode's job
+    # (test_aan_beam_search_base_size_fp32_is_token_exact).
     n_pair = rep["oracle_fp32_vs_bf16storage_token_exact"]
-    rep["criterion"] = {"misses_hip_vs_fp32": n - exact, "misses_oracle_pair": n - n_pair}
+    rep["criterion"] = {"misses_hip_vs_fp32": n - exact, "misses_oracle_pair": n - n_pair, "bf16_tie": BF16_TIE}
     _report("beam_k%d" % K, rep)
-    # (a) the HIP path must not part from the fp32 oracle much more often than the bf16-storage oracle does.  Measured
-    #     (round 5, MI355X): beam 1: 76 misses against the oracle pair's 50; beam 4: 74 against 66 -- the product path rounds
-    #     at a few more points than the storage model places (fp32 partial sums of the fused decode launches are rounded
-    #     once more when they are added), and the three pairs (HIP, fp32 oracle, bf16-storage oracle) agree with each other
-    #     on 70-80 % alike.
-    assert n - exact <= 1.6 * (n - n_pair) + 4, rep
+    # (a) the HIP path must not part from the fp32 oracle more often than the bf16-storage oracle does (+ 4: which of two
+    #     near-tied candidates a rounding picks is a coin flip).  Measured (round 6, MI355X): beam 1: 47 misses against the
+    #     oracle pair's 50; beam 4: 53 against 66 (round 5, with the residual sums rounded to bf16: 76 / 74).
+    assert n - exact <= (n - n_pair) + 4, rep
+    # ... and agrees with the bf16-storage oracle at least as often as the fp32 oracle does, less the same allowance
+    # (measured 205 / 198 of 256)
+    assert rep["token_exact_vs_bf16storage_oracle"] >= n_pair - 12, rep
     assert dscore_same < 0.3, rep
-    # (b) every divergence is located (a step, a rank, the oracle's gap between the two candidates).  The fixture keeps the
-    #     oracle's 2K candidates + ONE runner-up per step: a HIP candidate that the oracle ranks below that has no gap on
-    #     record -- tolerated only at the last kept rank and at most twice per run (measured: one, beam 1)
-    outside = [d for d in divergences if d.get("step") is not None and d.get("oracle_gap") is None]
-    rep["criterion"]["candidate_outside_the_oracles_table"] = outside
-    assert len(outside) <= 2 and all(d["rank"] == 2 * K - 1 for d in outside), outside
-    divergences = [d for d in divergences if d not in outside]
+    # (b) every divergence is located (a step, a rank) ...
     for d in divergences:
-        assert d["step"] is not None and d["oracle_gap"] is not None, ("unexplained divergence", d)
+        assert d["step"] is not None, ("unlocated divergence", d)
     # ... and is a near-tie for a bf16 implementation: reproduced by the bf16-storage oracle, inside the oracle pair's own
-    # disagreement at that step, or closer than BF16_TIE (absolute, in score units: the logits of this weight set carry
-    # ~1e-2 .. 1e-1 of bf16 noise -- softmax rows of norm 3, the EOS row of norm 6 -- against scores of -3 .. -30)
-    far = [d for d in divergences if not (d.get("bf16_oracle_same_choice") or d.get("inside_oracle_pair_disagreement")
-                                          or d["oracle_gap"] < BF16_TIE)]
+    # score distance, or closer than BF16_TIE (absolute, in score units: the logits of this weight set carry ~1e-2 of
+    # bf16 noise -- softmax rows of norm 3, the EOS row of norm 6 -- against scores of -3 .. -30).  A HIP candidate below
+    # the oracle's eight runner-ups has only a LOWER bound of its gap on record: it counts as far unless the bf16-storage
+    # oracle reproduces it.
+    def explained(d):
+        if d.get("bf16_oracle_same_choice"):
+            return True
+        if d.get("oracle_gap") is None:
+            return False
+        return bool(d.get("inside_oracle_pair_disagreement")) or d["oracle_gap"] < BF16_TIE
+    far = [d for d in divergences if not explained(d)]
     rep["criterion"]["far_divergences"] = far
+    rep["criterion"]["largest_oracle_gap"] = max([d["oracle_gap"] for d in divergences if d.get("oracle_gap") is not None] or [0.0])
     _report("beam_k%d" % K, rep)
-    assert len(far) <= max(2, len(divergences) // 10), far
-    # the divergences are no longer all at step 0
+    assert [d["sentence"] for d in far if d["sentence"] not in ACCEPTED_FAR[K]] == [], far
+    # the divergences are not all at step 0
     if len(divergences) >= 8:
         assert sum(1 for d in divergences if d["step"] > 0) >= len(divergences) // 3, [d["step"] for d in divergences]
 
 
-BF16_TIE = 0.15          # (measured: the largest fp32-oracle gap at a first divergence is 0.059 at beam 1, 0.106 at beam 4)
+BF16_TIE = 0.08          # (measured, round 6: the largest fp32-oracle gap at a first divergence is 0.046 at beam 1, 0.055 at beam 4;
+                         #  round 5, with the extra rounding of the residual sums: 0.059 / 0.106 under a bound of 0.15)
+ACCEPTED_FAR = {1: (), 4: ()}      # sentence ids of divergences accepted although unexplained: none
 
 
 def _hyp_stats(seqs, src):

@@ -15,13 +15,13 @@ from tests.util_gpu import eng, rand_bf, mat, rel_err  # noqa: E402
 F32 = torch.float32
 
 
-def _two_launches(e, A, W, b, R, gam, bet, drop, sid):
+def _two_launches(e, A, W, b, R, gam, bet, drop, sid, save=True):
     M, N = A.shape[0], W.shape[1]
     y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     out, s = torch.empty_like(y), torch.empty_like(y)
     mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
     e.gemm(mat(A), mat(W), mat(y), M, N, A.shape[1], 0, 0, bias=b)
-    e.add_ln_fwd(mat(R), mat(y), gam, bet, mat(out), mat(s), mean, rstd, drop, sid)
+    e.add_ln_fwd(mat(R), mat(y), gam, bet, mat(out), mat(s) if save else None, mean, rstd, drop, sid)
     return out, s, mean, rstd
 
 
@@ -67,11 +67,20 @@ def test_one_launch_against_gemm_then_layernorm(M, N, K, drop):
     assert torch.equal(got[1], ref[1])
     assert _ulp_close(got[0], ref[0]) and rel_err(got[0], ref[0]) < 2e-3
     assert torch.allclose(got[2], ref[2], rtol=1e-5, atol=1e-6) and torch.allclose(got[3], ref[3], rtol=1e-5, atol=0)
-    # without the outputs the backward reads
+    # without the outputs the backward reads (inference): nothing is saved, so the residual sum is NOT rounded to bf16 before
+    # the statistics (round 6: the checker's bf16 storage model has no rounding between residual_fn and layer_norm) -- in
+    # the one launch as in zk_add_ln_fwd without sum_out; against the saving form the rows move by the sum's rounding
     e.ln_epoch_bump()
     lean = _one_launch(e, A, W, b, R, gam, bet, drop, 11, save=False)
+    ref_lean = _two_launches(e, A, W, b, R, gam, bet, drop, 11, save=False)
     torch.cuda.synchronize()
-    assert torch.equal(lean[0], got[0])
+    assert _ulp_close(lean[0], ref_lean[0]) and rel_err(lean[0], ref_lean[0]) < 2e-3
+    assert rel_err(lean[0], got[0]) < 6e-3 and not torch.equal(ref_lean[0], ref[0])
+    # the fp32 sum is the better LayerNorm input: closer to the fp32 statement of the same rows
+    y32 = (A.float() @ W.float() + b).to(torch.bfloat16).float()
+    if drop == 0.0:
+        want = torch.nn.functional.layer_norm(R.float() + y32, (N,), gam, bet, 1e-8)
+        assert rel_err(lean[0], want) <= rel_err(got[0], want) * 1.02 + 1e-6
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 512, 2048), (4096, 512, 512), (4096, 512, 1536), (66, 512, 512), (700, 512, 1536),
@@ -253,7 +262,7 @@ def test_repeated_launches_reuse_the_slots():
     want = []
     for A, R in ins:
         e.ln_epoch_bump()
-        want.append(_one_launch(e, A, W, None, R, gam, bet, 0.0, 0)[0].clone())
+        want.append(_one_launch(e, A, W, None, R, gam, bet, 0.0, 0, save=False)[0].clone())     # (as the loop below: nothing saved)
     torch.cuda.synchronize()
     assert not torch.equal(want[0], want[1])
     out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
@@ -480,6 +489,10 @@ def test_the_exchange_survives_a_busy_second_stream():
     torch.cuda.synchronize()
     out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     ds = torch.empty_like(ds0)
+    # (the loop's forward saves nothing: the inference form of the launch, whose residual sum is not rounded to bf16)
+    e.ln_epoch_bump()
+    good_out = _one_launch(e, A, W, None, R, gam, bet, 0.0, 0, save=False)[0].clone()
+    torch.cuda.synchronize()
     bad = 0
     for rep in range(4):
         with torch.cuda.stream(side):
@@ -494,6 +507,6 @@ def test_the_exchange_survives_a_busy_second_stream():
             e.gemm_ln_bwd(mat(dY), mat(W2), M, N, K, None, mat(good[1]), good[2], good[3], gam, mat(ds), None, part)
             if it % 10 == 9:
                 torch.cuda.current_stream().synchronize()
-                bad += int(not torch.equal(out, good[0])) + int(not torch.equal(ds, ds0))
+                bad += int(not torch.equal(out, good_out)) + int(not torch.equal(ds, ds0))
         torch.cuda.synchronize()
     assert e.sync_ln_errors() == 0 and bad == 0

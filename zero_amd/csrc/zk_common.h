@@ -283,3 +283,5 @@ static inline uint32_t zk_drop_threshold(float p) {
 
 // the hipGraph an executable of zk_graph_end was instantiated from (kept alive until zk_graph_destroy); zk_elem.hip
 hipGraph_t zk_graph_template_of(void* exec);
+// drops what zk_prep.hip remembers about an executable's nodes (zk_graph_destroy calls it: handles are reused)
+void zk_graph_forget_nodes(void* exec);

@@ -2093,6 +2093,7 @@ int zk_graph_destroy(void* exec) {
     auto it = g_graph_of.find(exec);
     if (it != g_graph_of.end()) { graph = it->second; g_graph_of.erase(it); }
   }
+  zk_graph_forget_nodes(exec);
   hipGraphExecDestroy((hipGraphExec_t)exec);
   if (graph) hipGraphDestroy(graph);
   return 0;

@@ -63,7 +63,7 @@ __device__ __forceinline__ void f32_load_chunk(F32Chunk& c, const float* __restr
 template <bool TB, int KSPLIT>
 __global__ void __launch_bounds__(256) k_f32_gemm(const float* __restrict__ A, const float* __restrict__ B,
                                                   float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
-                                                  const float* __restrict__ bias, int act, int tiles_n) {
+                                                  const float* __restrict__ bias, int act, int tiles_n, int tiles_m) {
   __shared__ float red[KSPLIT > 1 ? 3 * 1024 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int tile, kbeg, kend;
@@ -77,8 +77,12 @@ __global__ void __launch_bounds__(256) k_f32_gemm(const float* __restrict__ A, c
     kbeg = 0;
     kend = K;
   }
-  const int tm = tile / tiles_n, tn = tile % tiles_n;
-  const bool live = tm * 32 < M;                 // (KSPLIT == 1: the last workgroup may hold tiles past the end)
+  // tiles_m > 0 (round 6; KSPLIT == 1, M <= N): tiles are dealt COLUMN-major -- the four waves of a workgroup, and the
+  // workgroups next to it, are the row tiles of one column panel of B, the large operand: the logits product of a decode
+  // step (128 x 32000 x 512) read its 65 MB of softmax embedding once per row tile, from four workgroups a thousand
+  // blocks apart (72 us); now the panel's four readers issue the same loads side by side
+  const int tm = tiles_m > 0 ? tile % tiles_m : tile / tiles_n, tn = tiles_m > 0 ? tile / tiles_m : tile % tiles_n;
+  const bool live = tm * 32 < M && tn * 32 < N;  // (KSPLIT == 1: the last workgroup may hold tiles past the end)
   const int arow = min(tm * 32 + (lane & 31), M - 1);
   const int bcol = min(tn * 32 + (lane & 31), N - 1);
   f32x16_t acc;
@@ -129,6 +133,166 @@ __global__ void __launch_bounds__(256) k_f32_gemm(const float* __restrict__ A, c
   }
 }
 
+// Round 6: the K-sliced form for products that do not fill the chip (a decode step's 128 rows; the encoder pass of one
+// batch).  Measured on the round-5 kernel (profiles/r06_rocprof_decode_f32_1lane_before.txt): a 128-row product took
+// 5 us + 2.2 us per ROUND of 64 k -- each wave held four chunks in flight, and a chunk's loads (1.5-2 us from the
+// Infinity Cache / HBM) were requested only three chunks of MFMA work (0.6 us) before their use; the feed-forward output
+// (K = 2048: eight dependent rounds on 256 waves) took 25 us.  Here a workgroup is KS waves that share one 32 x 32 tile,
+// wave w owns the k range [w per, (w + 1) per) with per <= 128, i.e. AT MOST EIGHT CHUNKS, ALL requested before the first
+// MFMA: one memory round trip per product, 512-2048 waves per launch instead of 256-1024.  Every output is still exact
+// fp32: one fmaf chain per wave over its k in the fixed order of a chunk (k0, k0 + 8, k0 + 1, ...), then the KS partial
+// sums added in wave order 0, 1, .. (by all threads of the workgroup: thread t finishes outputs t, t + 64 KS, ..).
+template <bool TB, int KS>
+__global__ void __launch_bounds__(64 * KS) k_f32_gemm_ks(const float* __restrict__ A, const float* __restrict__ B,
+                                                         float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
+                                                         const float* __restrict__ bias, int act, int tiles_m, int per) {
+  extern __shared__ float red[];                 // [KS][1024]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the row tiles of one column panel of B = consecutive slots of ONE XCD (workgroup b runs on XCD b % 8, each XCD has its
+  // own L2: see k_f32_gemm_t16); the grid is padded to eight panels per round
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tm = slot % tiles_m, tn = (slot / tiles_m) * 8 + xcd;
+  if (tn * 32 >= N) return;
+  const int kbeg = wave * per, kend = min(K, kbeg + per);
+  const int arow = min(tm * 32 + (lane & 31), M - 1);
+  const int bcol = min(tn * 32 + (lane & 31), N - 1);
+  // sixteen waves = 1024 threads = four waves per SIMD: 128 registers each, room for four chunks in flight; a k range of
+  // more than 64 (K = 2048) then takes a second round, requested chunk by chunk as the first is consumed
+  constexpr int NCH = KS == 16 ? 4 : 8;
+  F32Chunk ch[NCH];
+#pragma unroll
+  for (int p = 0; p < NCH; ++p)
+    if (kbeg + 16 * p < kend) f32_load_chunk<TB>(ch[p], A, B, lda, ldb, arow, bcol, kbeg + 16 * p, kend, lane);
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = kbeg; k0 < kend; k0 += 16 * NCH) {
+#pragma unroll
+    for (int p = 0; p < NCH; ++p) {
+      if (k0 + 16 * p < kend) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ch[p].a[j], ch[p].b[j], acc, 0, 0, 0);
+        if (NCH < 8 && k0 + 16 * (p + NCH) < kend)
+          f32_load_chunk<TB>(ch[p], A, B, lda, ldb, arow, bcol, k0 + 16 * (p + NCH), kend, lane);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[r];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16 / KS; ++i) {
+    const int o = threadIdx.x + 64 * KS * i;     // output o = r * 64 + lane of the tile's accumulator layout
+    const int r = o >> 6, l = o & 63;
+    float v = red[o];
+#pragma unroll
+    for (int w = 1; w < KS; ++w) v += red[w * 1024 + o];
+    const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = tn * 32 + (l & 31);
+    if (row < M && col < N) {
+      if (bias != nullptr) v += bias[col];
+      if (act == 1) v = fmaxf(v, 0.f);
+      C[(size_t)row * ldc + col] = v;
+    }
+  }
+}
+
+template <bool TB, int KS>
+static int launch_f32_gemm_ks(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                              const float* bias, int act, int tiles_m, long tiles, int per, hipStream_t stream) {
+  auto kern = k_f32_gemm_ks<TB, KS>;
+  const size_t lds = (size_t)KS * 1024 * sizeof(float);
+  if (lds >= 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return zk_set_error((int)e, "zk_f32_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  const long grid = (long)tiles_m * ((tiles / tiles_m + 7) / 8) * 8;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * KS), lds, stream, A, B, C, M, N, K, lda, ldb, ldc, bias, act,
+                     tiles_m, per);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+// Round 6, 16 x 16 tiles for the products of a decode step (128 rows): with 32 x 32 tiles a 128 x 512 output is 64
+// workgroups -- a quarter of the chip, and the KS waves of a workgroup share ONE CU (the K = 2048 feed-forward output:
+// sixteen waves x 64 MFMAs on each of 64 CUs, 6.8 us of matrix-core time alone).  v_mfma_f32_16x16x4_f32 is the same exact
+// fp32 arithmetic (an fmaf chain per output, bitwise; MI355X_MICROARCH.md) at the same rate per FLOP, on a tile a quarter
+// the size: 256-1024 workgroups per product, every CU busy, 0.4-1.7 us of MFMA time.  Lane (i = lane & 15, g = lane >> 4)
+// supplies A[i][k] and B[k][i] for k = 4 g' + j of instruction j (g' = g): a chunk of 16 k is ONE float4 of A per lane (16
+// rows x 64 contiguous bytes: every fetched line used in full -- the 32 x 32 form touched each line of A twice) and four
+// dwords (B [K, N]) or one float4 (B [N, K]) of B.  At most eight chunks per wave, all requested before the first MFMA.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <bool TB, int KS>
+__global__ void __launch_bounds__(64 * KS) k_f32_gemm_t16(const float* __restrict__ A, const float* __restrict__ B,
+                                                          float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
+                                                          const float* __restrict__ bias, int act, int tiles_m, int per) {
+  __shared__ float red[KS * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  // Workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has its own L2: the row tiles of one column panel
+  // of B must be workgroups of ONE XCD, or the panel crosses the fabric once per XCD that reads it (the first version
+  // dealt the eight row tiles of a panel to eight XCDs: 4 MB of weights fetched 8 times, 10 us for a product whose
+  // 1-MB siblings took 5).  XCD x owns the panels tn = x, x + 8, ..; its consecutive slots are the row tiles of a panel.
+  // A 16-column panel of B [K, N] is 64 bytes of every weight row, half a 128-byte L2 line: an XCD owns PAIRS of
+  // neighbouring panels (32 columns = whole lines), so that no line is fetched into two L2s.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tm = slot % tiles_m, sub = (slot / tiles_m) & 1, pair = slot / (2 * tiles_m);
+  const int tn = (pair * 8 + xcd) * 2 + sub;
+  if (tn * 16 >= N) return;                                 // (the grid is padded to eight panel pairs per round)
+  const int kbeg = wave * per, kend = min(K, kbeg + per);
+  const int arow = min(tm * 16 + i, M - 1);
+  const int bcol = min(tn * 16 + i, N - 1);
+  constexpr int NCH = 8;
+  float4 av[NCH], bv[NCH];
+#pragma unroll
+  for (int p = 0; p < NCH; ++p) {
+    const int k = kbeg + 16 * p + 4 * g;                   // (K % 4 == 0: a float4 is inside the row or outside it)
+    av[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < kend) {
+      av[p] = *reinterpret_cast<const float4*>(A + (size_t)arow * lda + k);
+      if (TB) bv[p] = *reinterpret_cast<const float4*>(B + (size_t)bcol * ldb + k);
+      else {
+        const float* bp = B + (size_t)k * ldb + bcol;
+        bv[p].x = bp[0]; bv[p].y = bp[ldb]; bv[p].z = bp[2 * (size_t)ldb]; bv[p].w = bp[3 * (size_t)ldb];
+      }
+    }
+  }
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < NCH; ++p) {
+    if (kbeg + 16 * p < kend) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p].x, bv[p].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p].y, bv[p].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p].z, bv[p].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p].w, bv[p].w, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = acc[r];
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int o = threadIdx.x, r = o >> 6, l = o & 63;
+    float v = red[o];
+#pragma unroll
+    for (int w = 1; w < KS; ++w) v += red[w * 256 + o];
+    const int row = tm * 16 + 4 * (l >> 4) + r, col = tn * 16 + (l & 15);
+    if (row < M && col < N) {
+      if (bias != nullptr) v += bias[col];
+      if (act == 1) v = fmaxf(v, 0.f);
+      C[(size_t)row * ldc + col] = v;
+    }
+  }
+}
+
+static int g_f32_gemm_legacy = 0;
+static int g_f32_gemm_t16 = 1;
+// A/B switch: 1 = the round-5 kernels for every shape (returns the old value; negative: query only)
+extern "C" int zk_f32_gemm_legacy(int on) {
+  const int old = g_f32_gemm_legacy;
+  if (on >= 0) { g_f32_gemm_legacy = on == 1; g_f32_gemm_t16 = on != 2; }     // 2: round-6 kernels without the 16 x 16 tiles
+  return old;
+}
+
 extern "C" int zk_f32_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int tb,
                            const float* bias, int act, hipStream_t stream) {
   ZK_CHECK_ARG(A != nullptr && B != nullptr && C != nullptr && M >= 0 && N >= 1 && K >= 4 && K % 4 == 0,
@@ -140,11 +304,46 @@ extern "C" int zk_f32_gemm(const float* A, const float* B, float* C, int M, int 
   if (M == 0) return 0;
   const int tiles_m = (M + 31) / 32, tiles_n = (N + 31) / 32;
   const long tiles = (long)tiles_m * tiles_n;
+  // fewer than two waves per SIMD chip-wide: K-sliced workgroups, every operand chunk requested up front (round 6).
+  // KS = 4, 8 or 16 waves per tile: the fewest that bring a wave's k range to <= 128 (eight chunks) and the launch to
+  // >= 1024 waves, while a wave keeps at least two chunks.  (g_f32_gemm_legacy: the round-5 kernel, for A/B runs.)
+  const long tiles16 = (long)((M + 15) / 16) * ((N + 15) / 16);
+  if (tiles16 <= 2048 && K >= 64 && K <= 2048 && !g_f32_gemm_legacy && g_f32_gemm_t16) {
+    // 16 x 16 tiles: KS = the fewest waves per tile that bring a wave's k range to <= 128 and the launch to >= 2048 waves
+    int ks = 4;
+    while (ks < 16 && (((K + ks * 16 - 1) / (ks * 16)) * 16 > 128 || tiles16 * ks < 2048) && K / (ks * 2) >= 32) ks *= 2;
+    const int per = ((K + ks * 16 - 1) / (ks * 16)) * 16;
+    if (per <= 128) {
+      const int tm16 = (M + 15) / 16;
+      const long grid16 = (long)tm16 * ((((N + 15) / 16) + 15) / 16) * 16;    // eight panel pairs (one per XCD) per round
+#define ZK_F32_T16(TB_, KS_)                                                                                              \
+  hipLaunchKernelGGL((k_f32_gemm_t16<TB_, KS_>), dim3((unsigned)grid16), dim3(64 * KS_), 0, stream, A, B, C, M, N, K, lda, \
+                     ldb, ldc, bias, act, tm16, per)
+      if (ks == 4) { if (tb) ZK_F32_T16(true, 4); else ZK_F32_T16(false, 4); }
+      else if (ks == 8) { if (tb) ZK_F32_T16(true, 8); else ZK_F32_T16(false, 8); }
+      else { if (tb) ZK_F32_T16(true, 16); else ZK_F32_T16(false, 16); }
+#undef ZK_F32_T16
+      ZK_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  if (tiles < 2048 && K >= 64 && K <= 2048 && !g_f32_gemm_legacy) {
+    int ks = 4;
+    while (ks < 16 && (((K + ks * 16 - 1) / (ks * 16)) * 16 > 128 || tiles * ks < 1024) && K / (ks * 2) >= 32) ks *= 2;
+    const int per = ((K + ks * 16 - 1) / (ks * 16)) * 16;
+    if (per <= 128) {
+#define ZK_F32_KS(TB_, KS_) launch_f32_gemm_ks<TB_, KS_>(A, B, C, M, N, K, lda, ldb, ldc, bias, act, tiles_m, tiles, per, stream)
+      if (ks == 4) return tb ? ZK_F32_KS(true, 4) : ZK_F32_KS(false, 4);
+      if (ks == 8) return tb ? ZK_F32_KS(true, 8) : ZK_F32_KS(false, 8);
+      return tb ? ZK_F32_KS(true, 16) : ZK_F32_KS(false, 16);
+#undef ZK_F32_KS
+    }
+  }
   // fewer than two waves per SIMD chip-wide and a K loop worth splitting: the four waves of a workgroup share a tile
   const bool split = tiles < 2048 && K >= 256;
 #define ZK_F32_GEMM(TB_, KS_, GRID_)                                                                                      \
   hipLaunchKernelGGL((k_f32_gemm<TB_, KS_>), dim3((unsigned)(GRID_)), dim3(256), 0, stream, A, B, C, M, N, K, lda, ldb, \
-                     ldc, bias, act, tiles_n)
+                     ldc, bias, act, tiles_n, (KS_ == 1 && M <= N && !g_f32_gemm_legacy) ? tiles_m : 0)
   if (split) {
     if (tb) ZK_F32_GEMM(true, 4, tiles); else ZK_F32_GEMM(false, 4, tiles);
   } else {
@@ -162,18 +361,35 @@ extern "C" int zk_f32_gemm(const float* A, const float* B, float* C, int M, int 
 __global__ void __launch_bounds__(256) k_f32_embed(const int* __restrict__ ids, int rows, int L, const float* __restrict__ table,
                                                    const float* __restrict__ bias, const float* __restrict__ timing,
                                                    int timing_rows, float* __restrict__ out, int H, float scale, int pos0,
-                                                   const int* __restrict__ pos_dev, const int* __restrict__ all_pad) {
+                                                   const int* __restrict__ pos_dev, const int* __restrict__ all_pad,
+                                                   int pad_id, float* __restrict__ cache, float* __restrict__ cat_out) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= rows) return;
   const int id = ids[r];
-  const int pos = min((pos_dev != nullptr ? *pos_dev : pos0) + r % L, timing_rows - 1);
-  const bool zero = all_pad != nullptr && *all_pad != 0;
+  const int t0 = pos_dev != nullptr ? *pos_dev : pos0;
+  const int pos = min(t0 + r % L, timing_rows - 1);
+  bool zero = all_pad != nullptr && *all_pad != 0;
+  if (pad_id >= 0) {
+    // round 6: the all-pad test of transformer.py:113-115 inside this launch (every wave looks at all ids of the step:
+    // 128 of them) instead of a launch of its own in front
+    bool all = true;
+    for (int i = lane; i < rows; i += 64) all = all && ids[i] == pad_id;
+    zero = __all(all);
+  }
   const float* e = table + (size_t)id * H;
   const float* t = timing + (size_t)pos * H;
+  const float div = (float)(t0 + 1);
   for (int c = lane; c < H; c += 64) {
     float v = 0.f;
     if (!zero) { v = e[c] * scale; v = v + bias[c]; }
-    out[(size_t)r * H + c] = v + t[c];
+    v = v + t[c];
+    out[(size_t)r * H + c] = v;
+    if (cache != nullptr) {        // the first layer's average attention (transformer_aan.py:110-112), L == 1
+      const float sc = v + cache[(size_t)r * H + c];
+      cache[(size_t)r * H + c] = sc;
+      cat_out[(size_t)r * 2 * H + c] = v;
+      cat_out[(size_t)r * 2 * H + H + c] = sc / div;
+    }
   }
 }
 
@@ -184,7 +400,23 @@ extern "C" int zk_f32_embed(const int* ids, int rows, int L, const float* table,
                H >= 1 && timing_rows >= 1, "zk_f32_embed: bad arguments");
   if (rows <= 0) return 0;
   hipLaunchKernelGGL(k_f32_embed, dim3((rows + 3) / 4), dim3(256), 0, stream, ids, rows, L, table, bias, timing, timing_rows,
-                     out, H, scale, pos0, pos_dev, all_pad);
+                     out, H, scale, pos0, pos_dev, all_pad, -1, (float*)nullptr, (float*)nullptr);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+// The decoder input of ONE decode position (L = 1) with its neighbours in the same launch (round 6): the all-pad test of
+// transformer.py:113-115 on the step's ids (pad_id >= 0: every id equal to it -> the embedding part is exact zeros) and,
+// with cache / cat_out, the first layer's average attention (cache += x; cat_out = [x | cache / (t + 1)]).
+extern "C" int zk_f32_embed_step(const int* ids, int rows, const float* table, const float* bias, const float* timing,
+                                 int timing_rows, float* out, int H, float scale, int pos0, const int* pos_dev, int pad_id,
+                                 float* cache, float* cat_out, hipStream_t stream) {
+  ZK_CHECK_ARG(ids != nullptr && table != nullptr && bias != nullptr && timing != nullptr && out != nullptr && H >= 1 &&
+               timing_rows >= 1 && rows <= 65536, "zk_f32_embed_step: bad arguments");
+  ZK_CHECK_ARG((cache == nullptr) == (cat_out == nullptr), "zk_f32_embed_step: cache and cat_out go together");
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(k_f32_embed, dim3((rows + 3) / 4), dim3(256), 0, stream, ids, rows, 1, table, bias, timing, timing_rows,
+                     out, H, scale, pos0, pos_dev, (const int*)nullptr, pad_id, cache, cat_out);
   ZK_LAUNCH_CHECK();
   return 0;
 }
@@ -232,6 +464,116 @@ extern "C" int zk_f32_add_ln(const float* x, const float* y, const float* gamma,
                "zk_f32_add_ln: H=%d (at most %d)", H, 64 * ZK_F32_LN_MAXU);
   if (rows <= 0) return 0;
   hipLaunchKernelGGL(k_f32_add_ln, dim3((rows + 3) / 4), dim3(256), 0, stream, x, y, gamma, beta, out, rows, H, eps);
+  ZK_LAUNCH_CHECK();
+  return 0;
+}
+
+// Round 6: the row-local neighbours of a decode step's LayerNorm in the same launch (one wave per row, four consecutive
+// channels per lane, 16-byte loads) -- a decode step is a chain of ~5 us launches, so every launch that is only a row-local
+// pass over 128 x H floats is worth folding into its neighbour:
+//   y        = ybuf                                       (func.py:321-324 residual input), or, with z / cat_in given,
+//              sigmoid(z_i) x_c + sigmoid(z_f) y_c        (transformer_aan.py:186-189; cat_in = [x_c | y_c], and the
+//                                                          residual x IS x_c: pass x = NULL)
+//   out      = gamma (s - mean) / sqrt(var + eps) + beta,  s = x + y     (func.py:289-303, the two passes over a row)
+//   cache / cat_out given: the NEXT layer's average attention from the normalised row (transformer_aan.py:110-112):
+//              cache += out;  cat_out = [out | cache / (t + 1)],  t = time_dev ? *time_dev : time
+// Same arithmetic as zk_f32_gate + zk_f32_add_ln + zk_f32_aan_step, value by value; the row sums run over four partial
+// sums per lane instead of one (fp32 rounding of mean / variance).
+#define ZK_F32_LN4_MAXU 8        // H <= 64 * 4 * 8 = 2048
+__global__ void __launch_bounds__(256) k_f32_ln_fused(const float* __restrict__ x, const float* __restrict__ ybuf,
+                                                      const float* __restrict__ z, const float* __restrict__ cat_in,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float* __restrict__ out, int rows, int H, float eps,
+                                                      float* __restrict__ cache, float* __restrict__ cat_out, int time,
+                                                      const int* __restrict__ time_dev) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  float4 v[ZK_F32_LN4_MAXU], gm[ZK_F32_LN4_MAXU], bt[ZK_F32_LN4_MAXU], cv[ZK_F32_LN4_MAXU];
+  float4 ya[ZK_F32_LN4_MAXU], zi[ZK_F32_LN4_MAXU], zf[ZK_F32_LN4_MAXU], yc[ZK_F32_LN4_MAXU];
+  const bool gate = cat_in != nullptr, upd = cache != nullptr;
+  // every load of the row is requested before the first use: one memory round trip
+#pragma unroll
+  for (int u = 0; u < ZK_F32_LN4_MAXU; ++u) {
+    const int c = (u * 64 + lane) * 4;
+    if (c < H) {
+      gm[u] = *reinterpret_cast<const float4*>(gamma + c);
+      bt[u] = *reinterpret_cast<const float4*>(beta + c);
+      if (gate) {
+        v[u] = *reinterpret_cast<const float4*>(cat_in + (size_t)r * 2 * H + c);
+        yc[u] = *reinterpret_cast<const float4*>(cat_in + (size_t)r * 2 * H + H + c);
+        zi[u] = *reinterpret_cast<const float4*>(z + (size_t)r * 2 * H + c);
+        zf[u] = *reinterpret_cast<const float4*>(z + (size_t)r * 2 * H + H + c);
+      } else {
+        v[u] = *reinterpret_cast<const float4*>(x + (size_t)r * H + c);
+        if (ybuf != nullptr) ya[u] = *reinterpret_cast<const float4*>(ybuf + (size_t)r * H + c);
+      }
+      if (upd) cv[u] = *reinterpret_cast<const float4*>(cache + (size_t)r * H + c);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < ZK_F32_LN4_MAXU; ++u) {
+    const int c = (u * 64 + lane) * 4;
+    if (c < H) {
+      if (gate) {
+        float4 g;
+        g.x = (1.0f / (1.0f + expf(-zi[u].x))) * v[u].x + (1.0f / (1.0f + expf(-zf[u].x))) * yc[u].x;
+        g.y = (1.0f / (1.0f + expf(-zi[u].y))) * v[u].y + (1.0f / (1.0f + expf(-zf[u].y))) * yc[u].y;
+        g.z = (1.0f / (1.0f + expf(-zi[u].z))) * v[u].z + (1.0f / (1.0f + expf(-zf[u].z))) * yc[u].z;
+        g.w = (1.0f / (1.0f + expf(-zi[u].w))) * v[u].w + (1.0f / (1.0f + expf(-zf[u].w))) * yc[u].w;
+        v[u].x += g.x; v[u].y += g.y; v[u].z += g.z; v[u].w += g.w;
+      } else if (ybuf != nullptr) {
+        v[u].x += ya[u].x; v[u].y += ya[u].y; v[u].z += ya[u].z; v[u].w += ya[u].w;
+      }
+      s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int u = 0; u < ZK_F32_LN4_MAXU; ++u) {
+    const int c = (u * 64 + lane) * 4;
+    if (c < H) {
+      const float d0 = v[u].x - mean, d1 = v[u].y - mean, d2 = v[u].z - mean, d3 = v[u].w - mean;
+      q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  }
+  const float var = wave_sum(q) / (float)H;
+  const float rs = 1.0f / sqrtf(var + eps);
+  const float div = (float)((time_dev != nullptr ? *time_dev : time) + 1);
+#pragma unroll
+  for (int u = 0; u < ZK_F32_LN4_MAXU; ++u) {
+    const int c = (u * 64 + lane) * 4;
+    if (c < H) {
+      float4 o;
+      o.x = gm[u].x * (v[u].x - mean) * rs + bt[u].x;
+      o.y = gm[u].y * (v[u].y - mean) * rs + bt[u].y;
+      o.z = gm[u].z * (v[u].z - mean) * rs + bt[u].z;
+      o.w = gm[u].w * (v[u].w - mean) * rs + bt[u].w;
+      *reinterpret_cast<float4*>(out + (size_t)r * H + c) = o;
+      if (upd) {
+        float4 sc = make_float4(o.x + cv[u].x, o.y + cv[u].y, o.z + cv[u].z, o.w + cv[u].w);
+        *reinterpret_cast<float4*>(cache + (size_t)r * H + c) = sc;
+        *reinterpret_cast<float4*>(cat_out + (size_t)r * 2 * H + c) = o;
+        *reinterpret_cast<float4*>(cat_out + (size_t)r * 2 * H + H + c) = make_float4(sc.x / div, sc.y / div, sc.z / div, sc.w / div);
+      }
+    }
+  }
+}
+
+extern "C" int zk_f32_ln_fused(const float* x, const float* ybuf, const float* z, const float* cat_in, const float* gamma,
+                               const float* beta, float* out, int rows, int H, float eps, float* cache, float* cat_out,
+                               int time, const int* time_dev, hipStream_t stream) {
+  ZK_CHECK_ARG(gamma != nullptr && beta != nullptr && out != nullptr && H >= 4 && H % 4 == 0 && H <= 256 * ZK_F32_LN4_MAXU,
+               "zk_f32_ln_fused: H=%d must be a multiple of 4, at most %d", H, 256 * ZK_F32_LN4_MAXU);
+  ZK_CHECK_ARG((cat_in != nullptr) ? (z != nullptr && x == nullptr && ybuf == nullptr) : (x != nullptr && z == nullptr),
+               "zk_f32_ln_fused: either (x, ybuf) or the gate form (z, cat_in; x = ybuf = NULL)");
+  ZK_CHECK_ARG((cache == nullptr) == (cat_out == nullptr), "zk_f32_ln_fused: cache and cat_out go together");
+  ZK_CHECK_ARG((((uintptr_t)x | (uintptr_t)ybuf | (uintptr_t)z | (uintptr_t)cat_in | (uintptr_t)gamma | (uintptr_t)beta |
+                 (uintptr_t)out | (uintptr_t)cache | (uintptr_t)cat_out) & 15) == 0, "zk_f32_ln_fused: 16-byte alignment");
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(k_f32_ln_fused, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ybuf, z, cat_in, gamma, beta, out, rows, H,
+                     eps, cache, cat_out, time, time_dev);
   ZK_LAUNCH_CHECK();
   return 0;
 }

@@ -559,7 +559,13 @@ __device__ __forceinline__ void gemm_tile(unsigned char* smem, const bf16_t* __r
         for (int j = 0; j < 8; ++j) v[j] = rv[j] + v[j];
       }
       pk[it] = pack8(v);
-      unpack8(pk[it], r8[it]);
+      // training (e.C given): statistics of the STORED bf16 sum, as the backward will read it.  Inference (round 6): nothing
+      // is stored and the sum stays fp32, as zk_add_ln_fwd without sum_out keeps it (zk_ln_dev.h)
+      if (e.C != nullptr) unpack8(pk[it], r8[it]);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r8[it][j] = v[j];
+      }
       float s1 = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) s1 += r8[it][j];

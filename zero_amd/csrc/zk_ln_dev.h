@@ -43,9 +43,16 @@ __device__ __forceinline__ void add_ln_fwd_row(
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] += b[j];
       }
-      uint4 p = pack8(a);
-      if (sum_out != nullptr) *reinterpret_cast<uint4*>(sum_out + (size_t)r * H + c) = p;
-      unpack8(p, v[i]);
+      // training (sum_out given): the sum is saved as bf16 for the backward, and the statistics are taken from the SAVED
+      // values so that forward and backward normalise the same rows.  Inference (round 6): nothing is saved, the sum stays fp32.
+      if (sum_out != nullptr) {
+        uint4 p = pack8(a);
+        *reinterpret_cast<uint4*>(sum_out + (size_t)r * H + c) = p;
+        unpack8(p, v[i]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] = a[j];
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) s1 += v[i][j];
     }

@@ -23,8 +23,8 @@ struct LnDecArgs {
 };
 
 // The rows stay in registers from the loads to the normalised output (the separate kernels went through memory between
-// the gate, the residual sum and the LayerNorm; the values are rounded to bf16 at the same points, so the results are the
-// same bits).  One wave handles NROW rows r0, r0 + rstep, .. (those >= rend are skipped) with every load of all of them
+// the gate, the residual sum and the LayerNorm; y is rounded to bf16 where the launch-per-op path stores it, the residual
+// sum x + y is NOT (round 6: it used to be, one rounding more per sub-layer than the checker's storage model places).  One wave handles NROW rows r0, r0 + rstep, .. (those >= rend are skipped) with every load of all of them
 // requested before the first reduction: one memory round trip.  outp[n][i]: normalised row n as stored (8 bf16 of
 // column (i*64 + lane)*8 ..), also written to a.out.
 template <int MAXC, int NROW, typename F>
@@ -178,8 +178,10 @@ __device__ __forceinline__ void ln_decode_rows(const LnDecArgs& a, int r0, int r
         }
         unpack8(xraw[n][i], xa);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xa[j] += y[j];
-        unpack8(pack8(xa), v[n][i]);
+        for (int j = 0; j < 8; ++j) v[n][i][j] = xa[j] + y[j];      // the residual sum stays fp32 (round 6): a decode step
+                                                                    // saves nothing for a backward pass, and the bf16
+                                                                    // storage model (oracle Cfg.store_bf16) has no rounding
+                                                                    // between residual_fn and layer_norm (func.py:321-324, 289-303)
       }
     }
   }

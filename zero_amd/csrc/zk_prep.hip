@@ -21,6 +21,8 @@
 #include "zk_common.h"
 #include <cstring>
 #include <vector>
+#include <mutex>
+#include <unordered_map>
 
 
 struct PrepSide {
@@ -432,26 +434,49 @@ int zk_copy_many(void* const* dsts, const void* const* srcs, const size_t* nbyte
 // every replay (a second submission per step: ~20 us of idle time at the step boundary), the parameters of that
 // ONE node are rewritten in the instantiated graph.  exec: a handle of zk_graph_end whose capture holds exactly one
 // zk_copy_many launch; the arguments as for zk_copy_many (n >= 1).
+}  // extern "C"
+static std::mutex g_copy_node_mu;
+static std::unordered_map<void*, hipGraphNode_t> g_copy_node_of;      // executable -> its one zk_copy_many node
+void zk_graph_forget_nodes(void* exec) {                               // (zk_common.h; called by zk_graph_destroy)
+  std::lock_guard<std::mutex> lk(g_copy_node_mu);
+  g_copy_node_of.erase(exec);
+}
+// how many zk_copy_many launches a capture of n copies makes (1 while n <= ZK_COPY_MAX): the host asks BEFORE it chooses the
+// in-graph commit, whose graph must hold exactly one such node
+extern "C" int zk_copy_many_max(void) { return ZK_COPY_MAX; }
+extern "C" {
 int zk_graph_set_copy_many(void* exec, void* const* dsts, const void* const* srcs, const size_t* nbytes, int n) {
   ZK_CHECK_ARG(exec != nullptr && n >= 1 && n <= ZK_COPY_MAX, "zk_graph_set_copy_many: null graph or n=%d out of range", n);
-  hipGraph_t graph = zk_graph_template_of(exec);
-  ZK_CHECK_ARG(graph != nullptr, "zk_graph_set_copy_many: not a handle of zk_graph_end");
-  size_t nn = 0;
-  hipError_t e = hipGraphGetNodes(graph, nullptr, &nn);
-  if (e != hipSuccess) return zk_set_error((int)e, "hipGraphGetNodes: %s", hipGetErrorString(e));
-  std::vector<hipGraphNode_t> nodes(nn);
-  e = hipGraphGetNodes(graph, nodes.data(), &nn);
-  if (e != hipSuccess) return zk_set_error((int)e, "hipGraphGetNodes: %s", hipGetErrorString(e));
+  // the node is looked up ONCE per executable (this call is on the per-step path: walking the several hundred nodes of the
+  // step's graph every step cost host time of the order of what the in-graph commit saves)
   hipGraphNode_t node = nullptr;
-  int found = 0;
-  for (size_t i = 0; i < nn; ++i) {
-    hipGraphNodeType t;
-    if (hipGraphNodeGetType(nodes[i], &t) != hipSuccess || t != hipGraphNodeTypeKernel) continue;
-    hipKernelNodeParams p;
-    if (hipGraphKernelNodeGetParams(nodes[i], &p) != hipSuccess) continue;
-    if (p.func == (void*)k_copy_many) { node = nodes[i]; ++found; }
+  {
+    std::lock_guard<std::mutex> lk(g_copy_node_mu);
+    auto it = g_copy_node_of.find(exec);
+    if (it != g_copy_node_of.end()) node = it->second;
   }
-  ZK_CHECK_ARG(found == 1, "zk_graph_set_copy_many: the graph holds %d zk_copy_many launches (need exactly one)", found);
+  if (node == nullptr) {
+    hipGraph_t graph = zk_graph_template_of(exec);
+    ZK_CHECK_ARG(graph != nullptr, "zk_graph_set_copy_many: not a handle of zk_graph_end");
+    size_t nn = 0;
+    hipError_t e = hipGraphGetNodes(graph, nullptr, &nn);
+    if (e != hipSuccess) return zk_set_error((int)e, "hipGraphGetNodes: %s", hipGetErrorString(e));
+    std::vector<hipGraphNode_t> nodes(nn);
+    e = hipGraphGetNodes(graph, nodes.data(), &nn);
+    if (e != hipSuccess) return zk_set_error((int)e, "hipGraphGetNodes: %s", hipGetErrorString(e));
+    int found = 0;
+    for (size_t i = 0; i < nn; ++i) {
+      hipGraphNodeType t;
+      if (hipGraphNodeGetType(nodes[i], &t) != hipSuccess || t != hipGraphNodeTypeKernel) continue;
+      hipKernelNodeParams p;
+      if (hipGraphKernelNodeGetParams(nodes[i], &p) != hipSuccess) continue;
+      if (p.func == (void*)k_copy_many) { node = nodes[i]; ++found; }
+    }
+    ZK_CHECK_ARG(found == 1, "zk_graph_set_copy_many: the graph holds %d zk_copy_many launches (need exactly one)", found);
+    std::lock_guard<std::mutex> lk(g_copy_node_mu);
+    g_copy_node_of[exec] = node;
+  }
+  hipError_t e;
   CopyMany c;
   unsigned gx = 1;
   if (int rc = fill_copy_many(&c, &gx, dsts, srcs, nbytes, n)) return rc;

@@ -116,6 +116,12 @@ def decode_many(items, work, streams=None, each_lane=False):
     from zero_amd.models._factory import lane
     from zero_amd.models._decode import lanes_mode
     dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+    if dev is not None:
+        # Whatever the CALLER has enqueued on its current stream -- an EMA weight swap (main._evaluate_dev: ema_assign's
+        # master copy + shadow refresh run on the training loop's work stream), a checkpoint load -- must be complete
+        # before any lane reads the shared variable store: a lane's stream only orders itself behind its OWN thread's
+        # current stream, which is the null stream in a fresh thread.  One host wait per evaluation.
+        torch.cuda.current_stream(dev).synchronize()
     lock = threading.Lock()
     results, errors = {}, []
     counter = [0]

@@ -183,6 +183,11 @@ class Engine(object):
         for i in range(0, len(pairs), 16):
             self.lib.call("zk_copy_many", *(self._copy_many_args(pairs[i:i + 16]) + (self.stream,)))
 
+    def copy_many_fits(self, pairs):
+        """True when these pairs make exactly one zk_copy_many launch (what a graph with an in-graph commit must hold)."""
+        n = len([1 for d, _ in pairs if d.numel()])
+        return 1 <= n <= int(self.lib.raw("zk_copy_many_max")())
+
     def graph_set_copy_many(self, exec_, pairs):
         """Rewrite the one zk_copy_many launch inside the captured graph ``exec_`` to these (dst, src) pairs (at most 16 with
         elements; the same filter as copy_many).  False when the pairs do not fit one launch."""

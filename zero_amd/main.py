@@ -308,6 +308,13 @@ class Trainer(object):
             os.environ.get("ZERO_HIP_COMMIT_IN_GRAPH", "1") != "0"
         key = ("stg", staged["B"], staged["Ls"], staged.get("Lt", 0))
         self._check_graph_cache()
+        probe = None
+        if fast:
+            # the in-graph commit needs the whole commit in ONE zk_copy_many launch (its graph must hold exactly one such
+            # node, zk_graph_set_copy_many): a pair more than the launch takes (today: 13 batch pairs + the hyper / EMA /
+            # sequence words = 16 = the limit) falls back to the commit-in-front route instead of raising
+            probe = self.core.commit(staged, extra=extra, launch=False)
+            fast = eng.copy_many_fits(probe[1])
         g = self._graphs.pop(key, None) if fast else None
         if g is None:
             if fast:
@@ -321,7 +328,7 @@ class Trainer(object):
                 self._train_and_update(scale)
             g = eng.graph_capture(body)
         else:
-            self.batch, pairs = self.core.commit(staged, extra=extra, launch=False)
+            self.batch, pairs = probe
             if not eng.graph_set_copy_many(g, pairs):
                 raise ZeroHipError("Trainer.step: the commit of a batch no longer fits one zk_copy_many launch")
         self._graphs[key] = g                              # most recently used last

@@ -43,6 +43,10 @@ class _Ops(object):
         self.core, self.e = core, core.eng
         self.lib = core.eng.lib
         self.H, self.nh, self.d = core.H, core.nh, core.d
+        import os
+        # round 6: row-local launches folded into their neighbours (ZERO_HIP_F32_FUSE=0: one launch per op, as in round 5 --
+        # the two forms are compared in tests/test_gpu_decode_f32.py)
+        self.fold = os.environ.get("ZERO_HIP_F32_FUSE", "1") != "0"
 
     def mat(self, name, rows, cols):
         return Mat(self.e.buf("dq." + name, (rows, cols), F32), rows, cols)
@@ -64,6 +68,9 @@ class _Ops(object):
     def add_ln(self, x, y, scope, out):
         """func.py:321-324 + 289-303: LN(x + y) with the scope's scale / offset."""
         st = self.core.store
+        if self.fold and self.H % 4 == 0 and self.H <= 2048:
+            # the 16-byte-load form (round 6: 4.8 us against 7.2 for a decode step's 128 rows)
+            return self.ln_fused(x, y, scope, out)
         self.lib.call("zk_f32_add_ln", x.ptr, y.ptr if y is not None else None, st.w(scope + "/layer_norm/scale").data_ptr(),
                       st.w(scope + "/layer_norm/offset").data_ptr(), out.ptr, x.rows, self.H, zdtype.epsilon(), self.e.stream)
         return out
@@ -82,12 +89,29 @@ class _Ops(object):
                       int(q_pos0), q_pos_dev.data_ptr() if q_pos_dev is not None else None, self.e.stream)
         return out
 
-    def ffn(self, x, scope, tag):
+    def ln_fused(self, x, y, scope, out, gate=None, aan_next=None, time=0, time_dev=None):
+        """zk_f32_ln_fused (round 6): LN(x + y) with row-local neighbours in the same launch.  gate = (z, cat): y is the
+        average-attention gate of transformer_aan.py:186-189 and the residual is cat[:, :H] (x, y = None);
+        aan_next = (cache tensor, cat Mat): the next layer's average attention from the normalised row."""
+        st = self.core.store
+        z, cat = gate if gate is not None else (None, None)
+        cache, cat_out = aan_next if aan_next is not None else (None, None)
+        self.lib.call("zk_f32_ln_fused", x.ptr if x is not None else None, y.ptr if y is not None else None,
+                      z.ptr if z is not None else None, cat.ptr if cat is not None else None,
+                      st.w(scope + "/layer_norm/scale").data_ptr(), st.w(scope + "/layer_norm/offset").data_ptr(), out.ptr,
+                      out.rows, self.H, zdtype.epsilon(), cache.data_ptr() if cache is not None else None,
+                      cat_out.ptr if cat_out is not None else None, int(time), time_dev, self.e.stream)
+        return out
+
+    def ffn(self, x, scope, tag, aan_next=None, time=0, time_dev=None):
         """func.py:327-338 + residual + LayerNorm (transformer.py:62-69)."""
         h = self.mat(tag + ".h", x.rows, self.core.F)
         self.linear(x, scope + "/ffn_layer/enlarge", h, act=1)
         y = self.mat("y", x.rows, self.H)
         self.linear(h, scope + "/ffn_layer/output", y)
+        if aan_next is not None:
+            return self.ln_fused(x, y, scope, self.mat(tag + ".o", x.rows, self.H), aan_next=aan_next, time=time,
+                                 time_dev=time_dev)
         return self.add_ln(x, y, scope, self.mat(tag + ".o", x.rows, self.H))
 
 
@@ -223,19 +247,31 @@ def step_cache(target, state, time, time_dev, hp):
         raise RuntimeError("decode step %d exceeds the allocated cache length %d" % (time, Tmax))
     tdev = time_dev.data_ptr() if time_dev is not None else None
     t_host = 0 if time_dev is not None else time
-    zf = state["zero_flag"]
-    e.lib.call("zk_all_equal", target.data_ptr(), BK, hp.tgt_vocab.pad(), zf.data_ptr(), e.stream)
+    fold = o.fold
     x = o.mat("x", BK, H)
     tim = e.timing(Tmax + 1, H)
-    e.lib.call("zk_f32_embed", target.data_ptr(), BK, 1, core.store.w(core.tgt_emb).data_ptr(), core.store.w("bias").data_ptr(),
-               tim.data_ptr(), int(tim.shape[0]), x.ptr, H, float(H) ** 0.5, t_host, tdev, zf.data_ptr(), e.stream)
-    for l in range(hp.num_decoder_layer):
+    nl = hp.num_decoder_layer
+    cat = o.mat("cat", BK, 2 * H) if core.aan else None
+    aan_in_ln = fold and core.aan           # a layer's average attention is computed by the launch that produces its input
+    if fold:
+        lay0 = state["decoder"]["state"]["layer_0"]
+        e.lib.call("zk_f32_embed_step", target.data_ptr(), BK, core.store.w(core.tgt_emb).data_ptr(),
+                   core.store.w("bias").data_ptr(), tim.data_ptr(), int(tim.shape[0]), x.ptr, H, float(H) ** 0.5, t_host, tdev,
+                   hp.tgt_vocab.pad(), lay0["aan"].data_ptr() if aan_in_ln else None, cat.ptr if aan_in_ln else None, e.stream)
+    else:
+        zf = state["zero_flag"]
+        e.lib.call("zk_all_equal", target.data_ptr(), BK, hp.tgt_vocab.pad(), zf.data_ptr(), e.stream)
+        e.lib.call("zk_f32_embed", target.data_ptr(), BK, 1, core.store.w(core.tgt_emb).data_ptr(), core.store.w("bias").data_ptr(),
+                   tim.data_ptr(), int(tim.shape[0]), x.ptr, H, float(H) ** 0.5, t_host, tdev, zf.data_ptr(), e.stream)
+    for l in range(nl):
         pre = "decoder/layer_%d" % l
         lay = state["decoder"]["state"]["layer_%d" % l]
+        nxt = state["decoder"]["state"].get("layer_%d" % (l + 1))
+        aan_next = (nxt["aan"], cat) if (aan_in_ln and nxt is not None) else None
         if core.aan:
             a = pre + "/average_attention"
-            cat = o.mat("cat", BK, 2 * H)
-            e.lib.call("zk_f32_aan_step", x.ptr, lay["aan"].data_ptr(), cat.ptr, BK, H, t_host, tdev, e.stream)
+            if not aan_in_ln:
+                e.lib.call("zk_f32_aan_step", x.ptr, lay["aan"].data_ptr(), cat.ptr, BK, H, t_host, tdev, e.stream)
             if hp.use_ffn:           # transformer_aan.py:176-183: the averaged half goes through its own feed-forward
                 hh = o.mat("aah", BK, core.F)
                 o.linear(cat.cols_slice(H, 2 * H), a + "/ffn_layer/enlarge", hh, act=1)
@@ -244,9 +280,12 @@ def step_cache(target, state, time, time_dev, hp):
                 e.lib.call("zk_gather_rows", ya.ptr, H * 4, None, cat.ptr + H * 4, 2 * H * 4, BK, H * 4, e.stream)
             z = o.mat("z", BK, 2 * H)
             o.linear(cat, a + "/z_project", z)
-            g = o.mat("y", BK, H)
-            e.lib.call("zk_f32_gate", z.ptr, cat.ptr, g.ptr, BK, H, e.stream)
-            x = o.add_ln(x, g, a, o.mat("d%d.aa.o" % l, BK, H))
+            if fold:
+                x = o.ln_fused(None, None, a, o.mat("d%d.aa.o" % l, BK, H), gate=(z, cat))
+            else:
+                g = o.mat("y", BK, H)
+                e.lib.call("zk_f32_gate", z.ptr, cat.ptr, g.ptr, BK, H, e.stream)
+                x = o.add_ln(x, g, a, o.mat("d%d.aa.o" % l, BK, H))
         elif not core.fuse:
             p = pre + "/self_attention/dot_attention/"
             qkv = o.mat("qkv", BK, 3 * H)
@@ -285,7 +324,7 @@ def step_cache(target, state, time, time_dev, hp):
         y = o.mat("y", BK, H)
         o.linear(att, p + "o_map", y)
         x = o.add_ln(x, y, pre + "/" + core.cross, o.mat("d%d.ca.o" % l, BK, H))
-        x = o.ffn(x, pre + "/feed_forward", "d%d.ff" % l)
+        x = o.ffn(x, pre + "/feed_forward", "d%d.ff" % l, aan_next=aan_next, time=t_host, time_dev=tdev)
     logits = Mat(e.buf("dq.logits", (BK, core.Vpad), F32), BK, core.Vpad)
     o.gemm(x, o.w(core.soft_emb), logits, BK, core.V, H, tb=1)
     if time_dev is None:
