@@ -29,7 +29,7 @@ def _rand(*shape, seed=0, scale=1.0):
 
 @pytest.mark.parametrize("M,N,K,tb", [(128, 512, 512, 0), (128, 512, 2048, 0), (128, 1024, 1024, 0), (3232, 512, 512, 0),
                                       (3232, 1536, 512, 0), (128, 32000, 512, 1), (5, 104, 128, 1), (33, 70, 36, 0),
-                                      (1, 512, 512, 0), (700, 2048, 512, 0), (97, 31, 260, 1)])
+                                      (1, 512, 512, 0), (700, 2048, 512, 0), (97, 31, 260, 1), (200, 4100, 96, 1)])
 @pytest.mark.parametrize("act", [0, 1])
 def test_gemm_f32(M, N, K, tb, act):
     """zk_f32_gemm against an fp64 product: relative error of a K-long fp32 fmaf chain (<= K * 2^-24 of sum |a b|)."""
@@ -168,6 +168,9 @@ def test_gemm_f32_k_sliced_against_the_round5_kernel(M, N, K, tb):
     assert max(errs) < 1e-6, errs
     for o_ in out[1:]:
         assert ((out[0] - o_).double().abs() / mag).max().item() < 1e-6
+    if tb and N >= 2048:
+        # the LDS-staged logits kernel keeps the round-5 kernel's fmaf chain per output: the same bits
+        assert torch.equal(out[0], out[2])
 
 
 def test_ln_fused_f32_equals_the_launches_it_replaces():

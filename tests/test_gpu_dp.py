@@ -108,11 +108,42 @@ def test_two_rank_step_on_one_gpu(tmp_path):
     src[src == 0] = 5; tgt[tgt == 0] = 5
     tr = Trainer(hp)
     tr.prepare_static({"source": src, "target": tgt})
+    P0 = {k: v.copy() for k, v in tr.store.export("master").items()}       # the weights every run above started from
     l0 = float(tr.step_static(use_graph=False).cpu()[0])
     torch.cuda.synchronize()
     # step 1 of the two-rank job started from the same weights: its per-rank losses average to l0
     both = 0.5 * (g[0]["loss"][0] + g[1]["loss"][0])
     assert abs(both - l0) / abs(l0) < 2e-3, (both, l0)
+    # ... and its EXCHANGED gradient (the sum over the ranks; 1 / N is folded into the update) is twice the gradient of
+    # the concatenated batch (utils/parallel.py:184-196 averages the towers; both halves hold four sentences), variable
+    # by variable: same kernels on both sides, so what differs is the summation order over 4 + 4 against 8 sentences
+    g1 = tr.store.grad.cpu().numpy()
+    ex = 0.5 * g[0]["grad1"]
+    assert ex.shape == g1.shape
+    num, den = float(np.linalg.norm(ex - g1)), float(np.linalg.norm(g1))
+    assert num / den < 1e-2, (num, den)
+    exd, g1d = tr.store.export(torch.from_numpy(ex.copy())), tr.store.export(torch.from_numpy(g1.copy()))
+    worst = 0.0
+    for name in exd:
+        nb = float(np.linalg.norm(g1d[name]))
+        if nb > 1e-3 * den:
+            worst = max(worst, float(np.linalg.norm(exd[name] - g1d[name])) / nb)
+    assert worst < 3e-2, worst
+    # ... and the oracle's tower mean (oracle/ref_torch.py: the fp32 restatement of average_gradients over two towers of
+    # four sentences) agrees with the exchanged gradient as well as it agrees with any single-rank bf16 gradient
+    from oracle import ref_torch as rt
+    Pt = rt.to_torch(P0, torch.float32, requires_grad=True)
+    tot = 0.0
+    for half in (slice(0, 4), slice(4, 8)):
+        r = rt.train_fn({"source": torch.tensor(src[half]), "target": torch.tensor(tgt[half])}, hp, Pt, "transformer",
+                        training=False)
+        (0.5 * r["loss"]).backward()
+        tot += 0.5 * float(r["loss"].detach())
+    assert abs(tot - both) / abs(tot) < 2e-3
+    og = {k: v.grad.numpy() for k, v in Pt.items() if v.grad is not None}
+    num = sum(float(((exd[k].astype(np.float64) - og[k]) ** 2).sum()) for k in og)
+    den2 = sum(float((og[k].astype(np.float64) ** 2).sum()) for k in og)
+    assert (num / den2) ** 0.5 < 6e-2, (num / den2) ** 0.5
 
 
 def test_exchange_modes_bf16_buckets_and_sparse_rows(tmp_path):

@@ -284,6 +284,85 @@ __global__ void __launch_bounds__(64 * KS) k_f32_gemm_t16(const float* __restric
   }
 }
 
+// Round 6, the logits product of a decode step (transformer.py:182-196: 128 rows x 32000 words x 512, B = the softmax
+// embedding [V, H], K-contiguous): 4.2 GFLOP of exact-fp32 MFMA = 26.7 us at the chip's 157 TF; the one-wave-per-tile kernel
+// took 70 us -- every wave pulled its own 32 x 16 fragments of A and B through the CU's L1 (a 64-byte piece of each of
+// 32 + 32 rows per chunk: as many L1 line accesses as MFMA cycles) and every workgroup re-read all of A that way.
+// Here a workgroup of eight waves owns 128 rows x 64 columns (wave = row tile w & 3, column tile w >> 2) and stages A
+// [128 x 32 k] and B [64 x 32 k] through LDS with full-line loads (eight lanes per 128-byte row piece), double-buffered,
+// one barrier per 32 k; the fragments come from LDS (row stride 36 floats: the 16 rows a ds_read_b128 phase touches fall
+// on distinct banks).  Per output the SAME fmaf chain as k_f32_gemm (k0, k0 + 8, k0 + 1, ... over chunks of 16, no K
+// split): the logits are bit-identical to the round-5 kernel's.
+template <int DUMMY>
+__global__ void __launch_bounds__(512) k_f32_gemm_tb_lds(const float* __restrict__ A, const float* __restrict__ B,
+                                                         float* __restrict__ C, int M, int N, int K, int lda, int ldb,
+                                                         int ldc, const float* __restrict__ bias, int act) {
+  constexpr int S = 36;                               // LDS row stride (floats): 32 k + 4 pad
+  __shared__ __align__(16) float sA[2][128 * S];
+  __shared__ __align__(16) float sB[2][64 * S];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rt = wave & 3, ct = wave >> 2;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 64;
+  // staging roles: thread -> (row, float4 column) of the A / B slab
+  const int ar0 = tid >> 3, ac = (tid & 7) * 4;       // A rows ar0 and ar0 + 64
+  const int br = tid >> 3;                            // B row (of 64)
+  const float* ap0 = A + (size_t)min(m0 + ar0, M - 1) * lda + ac;
+  const float* ap1 = A + (size_t)min(m0 + ar0 + 64, M - 1) * lda + ac;
+  const float* bp = B + (size_t)min(n0 + br, N - 1) * ldb + ac;
+  float4 ra0, ra1, rb;
+  auto gload = [&](int k0) {
+    ra0 = *reinterpret_cast<const float4*>(ap0 + k0);
+    ra1 = *reinterpret_cast<const float4*>(ap1 + k0);
+    rb = *reinterpret_cast<const float4*>(bp + k0);
+  };
+  auto lstore = [&](int st) {
+    *reinterpret_cast<float4*>(&sA[st][ar0 * S + ac]) = ra0;
+    *reinterpret_cast<float4*>(&sA[st][(ar0 + 64) * S + ac]) = ra1;
+    *reinterpret_cast<float4*>(&sB[st][br * S + ac]) = rb;
+  };
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int i = lane & 31, h = lane >> 5;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int nk = K / 32;
+  for (int kb = 0; kb < nk; ++kb) {
+    const int st = kb & 1;
+    if (kb + 1 < nk) gload((kb + 1) * 32);
+    const float* fa = &sA[st][(rt * 32 + i) * S + 8 * h];
+    const float* fb = &sB[st][(ct * 32 + i) * S + 8 * h];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {                     // the two 16-k chunks of the slab, in k order
+      const float4 a0 = *reinterpret_cast<const float4*>(fa + 16 * c), a1 = *reinterpret_cast<const float4*>(fa + 16 * c + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(fb + 16 * c), b1 = *reinterpret_cast<const float4*>(fb + 16 * c + 4);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc, 0, 0, 0);
+    }
+    if (kb + 1 < nk) lstore(st ^ 1);
+    __syncthreads();
+  }
+  const int col = n0 + ct * 32 + (lane & 31);
+  if (col >= N) return;
+  const float bv = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < M) {
+      float v = acc[r] + bv;
+      if (act == 1) v = fmaxf(v, 0.f);
+      C[(size_t)row * ldc + col] = v;
+    }
+  }
+}
+
 static int g_f32_gemm_legacy = 0;
 static int g_f32_gemm_t16 = 1;
 // A/B switch: 1 = the round-5 kernels for every shape (returns the old value; negative: query only)
@@ -307,6 +386,12 @@ extern "C" int zk_f32_gemm(const float* A, const float* B, float* C, int M, int 
   // fewer than two waves per SIMD chip-wide: K-sliced workgroups, every operand chunk requested up front (round 6).
   // KS = 4, 8 or 16 waves per tile: the fewest that bring a wave's k range to <= 128 (eight chunks) and the launch to
   // >= 1024 waves, while a wave keeps at least two chunks.  (g_f32_gemm_legacy: the round-5 kernel, for A/B runs.)
+  if (tb && N >= 2048 && K % 32 == 0 && ldb % 4 == 0 && !g_f32_gemm_legacy && g_f32_gemm_t16) {
+    hipLaunchKernelGGL(k_f32_gemm_tb_lds<0>, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 127) / 128)), dim3(512), 0, stream,
+                       A, B, C, M, N, K, lda, ldb, ldc, bias, act);
+    ZK_LAUNCH_CHECK();
+    return 0;
+  }
   const long tiles16 = (long)((M + 15) / 16) * ((N + 15) / 16);
   if (tiles16 <= 2048 && K >= 64 && K <= 2048 && !g_f32_gemm_legacy && g_f32_gemm_t16) {
     // 16 x 16 tiles: KS = the fewest waves per tile that bring a wave's k range to <= 128 and the launch to >= 2048 waves
