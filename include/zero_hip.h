@@ -223,6 +223,22 @@ int zk_sum_slices(float* out, const float* in, int nslices, size_t n, size_t str
 int zk_embed_fwd(const int* ids, const void* table, const float* bias, const float* timing, void* out, int B,
                  int L, int H, float scale, int shift, int pos0, const int* zero_flag, float drop_p,
                  const uint64_t* seed, uint32_t sid, const int* pos0_dev, zk_stream_t stream);
+/* round 6: the encoder's and the decoder's input embeddings of a training step in ONE launch (side a: ids [B, La] as they
+ * are; side b: ids [B, Lb] shifted right by one position, transformer.py:104-108); per side the arithmetic of zk_embed_fwd */
+int zk_embed_fwd_pair(const int* ids_a, const void* table_a, void* out_a, int La, uint32_t sid_a, const int* ids_b,
+                      const void* table_b, void* out_b, int Lb, uint32_t sid_b, const float* bias, const float* timing, int B,
+                      int H, float scale, float drop_p, const uint64_t* seed, zk_stream_t stream);
+/* round 6: more small launches of the training step merged pairwise.  zk_embed_bwd_sorted_pair: the gradient scatters of
+ * two DIFFERENT embedding tables (arguments per side as zk_embed_bwd_sorted) in one launch.  zk_colsum_pair: out = colsum(a)
+ * + colsum(b) (the shared input bias of transformer.py:16-33 / 88-119; rows r % skip == 0 of a side left out when skip > 0)
+ * in two launches instead of four; workspace >= zk_colsum_workspace(rows_a, N) + zk_colsum_workspace(rows_b, N). */
+int zk_embed_bwd_sorted_pair(const int* rows_a, const int* seg_a, const int* uid_a, const int* n_a, int max_a, const void* dout_a,
+                             float* dtable_a, int acc_a, uint32_t sid_a, const int* rows_b, const int* seg_b, const int* uid_b,
+                             const int* n_b, int max_b, const void* dout_b, float* dtable_b, int acc_b, uint32_t sid_b, int H,
+                             float scale, float drop_p, const uint64_t* seed, zk_stream_t stream);
+int zk_colsum_pair(const void* a, int rows_a, int lda, int skip_a, uint32_t sid_a, const void* b, int rows_b, int ldb,
+                   int skip_b, uint32_t sid_b, int N, float* out, float drop_p, const uint64_t* seed, void* workspace,
+                   size_t ws_bytes, zk_stream_t stream);
 /* dtable (fp32 [V,H]) and dbias (fp32 [H]) are ACCUMULATED into with atomics. */
 int zk_embed_bwd(const int* ids, const void* dout, float* dtable, float* dbias, int B, int L, int H,
                  float scale, int shift, float drop_p, const uint64_t* seed, uint32_t sid, zk_stream_t stream);
@@ -445,6 +461,13 @@ int zk_comm_allreduce_multi(void* comm, void* const* bufs, const size_t* counts,
                             zk_stream_t stream);
 /* recv[r*count .. (r+1)*count) <- send of rank r (row-sparse source-embedding gradient, parallel.py:142-181) */
 int zk_comm_allgather(void* comm, const void* send, void* recv, size_t count, int dtype, zk_stream_t stream);
+/* round 6: ordering a second stream behind the compute stream WITHOUT an event on the compute stream (an event recorded
+ * there slows every dispatch of that stream: 40-65 us per training step, DESIGN.md 6e).  flag: an 8-byte aligned device
+ * word that only ever grows.  zk_flag_add (on the producer's stream): flag += 1 with agent-scope release; zk_flag_wait (on
+ * the consumer's stream): a one-thread kernel that ends once flag >= target (gives up after ~2 s and sets *err, may be
+ * NULL).  zero_amd/utils/parallel.py RcclComm uses the pair per gradient bucket under ZERO_HIP_COMM_HANDOFF=flag. */
+int zk_flag_add(void* flag, zk_stream_t stream);
+int zk_flag_wait(const void* flag, unsigned long long target, int* err, zk_stream_t stream);
 
 #ifdef ZK_EXPERIMENTS   /* measured 1.25x slower than launch-per-op (profiles/r02_layer_program_experiment.txt) */
 /* ---- Layer program (zk_layer.hip): a run of dependent, sentence-local ops -- the linear / attention / residual +

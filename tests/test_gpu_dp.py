@@ -266,6 +266,37 @@ def test_rccl_communicator_through_the_c_abi_single_rank():
     comm.close()          # idempotent
 
 
+def test_flag_handoff_orders_the_communication_stream_like_the_event(monkeypatch):
+    """ZERO_HIP_COMM_HANDOFF=flag: the per-bucket ordering of RCCL's stream behind the backward through
+    a monotonic device word + a poll kernel instead of an event recorded on the compute stream.  The collective must see
+    what the compute stream wrote before the hand-off -- also when the compute stream is still busy for milliseconds
+    after the host has enqueued everything -- and give the same bits as the event form."""
+    from zero_amd.utils import parallel
+    from tests.util_gpu import eng
+    e = eng()
+    res = {}
+    for mode in ("event", "flag"):
+        monkeypatch.setenv("ZERO_HIP_COMM_HANDOFF", mode)
+        comm = parallel.RcclComm("cuda:0")
+        x = torch.zeros(1 << 22, device="cuda:0")
+        outs = []
+        for it in range(6):
+            e.lib.call("zk_spin", 3000, torch.cuda.current_stream().cuda_stream)      # 3 ms of compute-stream work in front
+            x.add_(float(it + 1))                                                     # the "gradient" the bucket carries
+            ev = comm.all_reduce(x)                                                   # one rank: identity, AFTER the add
+            y = torch.empty_like(x)
+            with torch.cuda.stream(comm.stream):
+                y.copy_(x)                                                            # ordered behind the collective
+            outs.append(y)
+            torch.cuda.current_stream().wait_event(ev)
+        torch.cuda.synchronize()
+        assert comm.handoff_errors() == 0
+        res[mode] = [float(o[0]) for o in outs] + [float(o[-1]) for o in outs]
+        comm.close()
+    want = [1.0, 3.0, 6.0, 10.0, 15.0, 21.0]
+    assert res["event"] == want + want and res["flag"] == want + want
+
+
 def test_bench_line_survives_a_leg_that_never_returns():
     """a leg of the optional direct transport that hangs (a collective waiting for a rank that never
     arrives; here: the ZERO_HIP_BENCH_FAKE_HANG test hook) must not cost the run its line.  The watchdog prints it with the

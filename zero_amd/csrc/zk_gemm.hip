@@ -248,7 +248,7 @@ static bool mfma_ok(const void* A, const void* B, int M, int N, int K, int lda, 
 // goal is >= ~3 co-resident workgroups per CU (thread-level parallelism hides the L2 latency)
 // before tile area (arithmetic intensity) is considered.  Large outputs use 128x128; mid-size
 // ones 64x128 / 128x64; small ones 64x64 plus split-K when the epilogue allows it.
-extern int g_tune[16];
+extern int g_tune[24];
 static void pick_config(int M, int N, int K, int allow_split, int* bm, int* bn, int* splits, int* wide = nullptr) {
   if (wide) *wide = 0;
   // Measured on MI355X (scripts/gemm_bench.py at base and big widths, profiles/r01_gemm_microbench*.txt):

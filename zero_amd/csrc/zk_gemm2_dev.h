@@ -154,7 +154,7 @@ __device__ __forceinline__ bf16x8_t load_frag(const bf16_t* stage, int r0, int k
   }
 }
 
-extern int g_tune[16];   // A/B switches (zk_tune, zk_elem.hip)
+extern int g_tune[24];   // A/B switches (zk_tune, zk_elem.hip)
 
 struct EpiVec {
   int vec_ok;   // 16-byte vector epilogue allowed (alignment checked on the host)

@@ -855,6 +855,13 @@ class Engine(object):
                       out.ptr, B, L, H, float(H) ** 0.5, 1 if shift else 0, pos0, hip.ptr(zero_flag),
                       float(drop_p), self.seed.data_ptr(), sid, hip.ptr(pos0_dev), self.stream)
 
+    def embed_fwd_pair(self, ids_a, table_a, out_a, La, sid_a, ids_b, table_b, out_b, Lb, sid_b, bias, B, H, drop_p=0.0):
+        """Encoder input (ids_a) and shifted decoder input (ids_b) of a training step in one launch (zk_embed_fwd_pair)."""
+        tim = self.timing(max(La, Lb), H)
+        self.lib.call("zk_embed_fwd_pair", ids_a.data_ptr(), table_a.data_ptr(), out_a.ptr, La, sid_a, ids_b.data_ptr(),
+                      table_b.data_ptr(), out_b.ptr, Lb, sid_b, bias.data_ptr(), tim.data_ptr(), B, H, float(H) ** 0.5,
+                      float(drop_p), self.seed.data_ptr(), self.stream)
+
     def beam_topk(self, logits, prev_lp, out_s, out_i, B, K, V, k2, temperature, penalty, forbid_id, forbid_value,
                   scal_dev=None):
         ws_bytes = self.lib.query("zk_beam_topk_workspace", B, K, k2)
@@ -873,6 +880,22 @@ class Engine(object):
                       sort["uid"].data_ptr(), sort["n"].data_ptr(), sort["max_uniq"], dout.ptr,
                       dtable.data_ptr(), H, float(H) ** 0.5, 1 if accumulate else 0, float(drop_p),
                       self.seed.data_ptr(), sid, self.stream)
+
+    def embed_bwd_sorted_pair(self, sort_a, dout_a, dtable_a, acc_a, sid_a, sort_b, dout_b, dtable_b, acc_b, sid_b, H, drop_p=0.0):
+        """Both embedding tables' gradient scatters in one launch (different tables; zk_embed_bwd_sorted_pair)."""
+        self.lib.call("zk_embed_bwd_sorted_pair", sort_a["rows"].data_ptr(), sort_a["seg"].data_ptr(), sort_a["uid"].data_ptr(),
+                      sort_a["n"].data_ptr(), sort_a["max_uniq"], dout_a.ptr, dtable_a.data_ptr(), 1 if acc_a else 0, sid_a,
+                      sort_b["rows"].data_ptr(), sort_b["seg"].data_ptr(), sort_b["uid"].data_ptr(), sort_b["n"].data_ptr(),
+                      sort_b["max_uniq"], dout_b.ptr, dtable_b.data_ptr(), 1 if acc_b else 0, sid_b, H, float(H) ** 0.5,
+                      float(drop_p), self.seed.data_ptr(), self.stream)
+
+    def colsum_pair(self, A, skip_a, sid_a, B, skip_b, sid_b, out, drop_p=0.0):
+        """out = colsum(A) + colsum(B) (rows r % skip == 0 left out when skip > 0): zk_colsum_pair."""
+        assert A.cols == B.cols
+        ws_bytes = self.lib.query("zk_colsum_workspace", A.rows, A.cols) + self.lib.query("zk_colsum_workspace", B.rows, B.cols)
+        ws = self.workspace(ws_bytes)
+        self.lib.call("zk_colsum_pair", A.ptr, A.rows, A.ld, skip_a, sid_a, B.ptr, B.rows, B.ld, skip_b, sid_b, A.cols,
+                      out.data_ptr(), float(drop_p), self.seed.data_ptr(), ws.data_ptr(), ws.numel(), self.stream)
 
     # ---- residual + layer norm (func.py:289-303, 321-324) -------------------------
     def add_ln_fwd(self, x, y, gamma, beta, out, sum_out=None, mean=None, rstd=None, drop_p=0.0, sid=0):

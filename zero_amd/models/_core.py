@@ -142,6 +142,11 @@ class TransformerCore(object):
         # is an experiment: only in a `make EXPERIMENTS=1` library, only with ZERO_HIP_LAZY_LN=1.
         self.lazy_ln_mode = os.environ.get("ZERO_HIP_LAZY_LN", "0").lower() if self.eng.lib.experiments else "0"
         self.sync_ln_mode = os.environ.get("ZERO_HIP_SYNC_LN", "1") != "0"
+        # round 6: small launches of the step merged pairwise (both input embeddings; their two gradient scatters; the two
+        # bias column sums; per-sentence loss + mean): ZERO_HIP_MERGE_SMALL=0 restores the round-5 launches (A/B, tests)
+        self.merge_small = os.environ.get("ZERO_HIP_MERGE_SMALL", "1") != "0"
+        if self.eng.device.type == "cuda":
+            self.eng.lib.raw("zk_tune")(16, 0 if self.merge_small else 1)      # (bit 0: per-sentence loss + mean as two launches)
         # (A/B: "noattn" keeps the attention forward a launch of its own, "fwd" also the LayerNorm backward)
         self.sync_ln_bwd = os.environ.get("ZERO_HIP_SYNC_LN", "1") != "fwd"
         self.sync_attn = os.environ.get("ZERO_HIP_SYNC_LN", "1") not in ("noattn", "fwd", "0")
@@ -825,8 +830,9 @@ class TransformerCore(object):
             smask = e.buf("smask", (B, Ls), F32)
             e.make_mask(batch["src"], smask, Ts)
         x = e.mat("enc.x0", Ts, H)
-        e.embed_fwd(batch["src"], self.store.s(self.src_emb), self.b("bias"), x, B, Ls, H,
-                    drop_p=hp.dropout if train else 0.0, sid=9001)
+        if not self.__dict__.get("_embeds_done"):      # (forward(): both embeddings went out as one launch)
+            e.embed_fwd(batch["src"], self.store.s(self.src_emb), self.b("bias"), x, B, Ls, H,
+                        drop_p=hp.dropout if train else 0.0, sid=9001)
         def layers(x=x):
             for l in range(hp.num_encoder_layer):
                 pre = "encoder/layer_%d" % l
@@ -853,8 +859,9 @@ class TransformerCore(object):
             w = e.buf("tw", (B, Lt), F32)
             e.target_stats(batch["tgt"], tmask, w, B, Lt, want)
         x = e.mat("dec.x0", Tt, H)
-        e.embed_fwd(batch["tgt"], self.store.s(self.tgt_emb), self.b("bias"), x, B, Lt, H, shift=True,
-                    drop_p=hp.dropout if train else 0.0, sid=9002)
+        if not self.__dict__.get("_embeds_done"):
+            e.embed_fwd(batch["tgt"], self.store.s(self.tgt_emb), self.b("bias"), x, B, Lt, H, shift=True,
+                        drop_p=hp.dropout if train else 0.0, sid=9002)
         NE = hp.num_encoder_layer
         group_kv = self.group_wgrad and e.gemm_impl == 0
         if group_kv:
@@ -919,8 +926,21 @@ class TransformerCore(object):
             self.eng.ln_epoch_bump()
         if self._lazy:
             self._fold_weights()
-        enc, smask = self.encode(batch, train, save)
-        feat, tmask, w = self.decode_train(batch, enc, smask, train, save)
+        # round 6: both input embeddings depend on the ids alone -- one launch in front of the step instead of two
+        # (ZERO_HIP_MERGE_SMALL=0: the round-5 launches)
+        self._embeds_done = False
+        if self.merge_small and "tgt" in batch and not self.eng.lib.recording:
+            e_, H_ = self.eng, self.H
+            e_.embed_fwd_pair(batch["src"], self.store.s(self.src_emb), e_.mat("enc.x0", batch["B"] * batch["Ls"], H_),
+                              batch["Ls"], 9001, batch["tgt"], self.store.s(self.tgt_emb),
+                              e_.mat("dec.x0", batch["B"] * batch["Lt"], H_), batch["Lt"], 9002, self.b("bias"), batch["B"], H_,
+                              drop_p=self.hp.dropout if train else 0.0)
+            self._embeds_done = True
+        try:
+            enc, smask = self.encode(batch, train, save)
+            feat, tmask, w = self.decode_train(batch, enc, smask, train, save)
+        finally:
+            self._embeds_done = False
         loss, per_sample, logits, dlogits = self.loss_head(batch, feat, w, ls, save)
         self._lazy = False        # (encode() / decode_train() are also called directly by the decode path)
         self._sync_ln = False
@@ -1092,13 +1112,16 @@ class TransformerCore(object):
                     self._side(lambda key=key: on_ready(key))
                 ready_d, ready_e = [], []
         dxs = Q[cur]
+        # round 6 (one rank, different tables): the two gradient scatters as one launch, the two bias column sums as one pair
+        pair = self.group_all and self.merge_small and self.src_emb != self.tgt_emb
         if self.group_all:
             if ready_d:                            # a model without encoder layers
                 self._flush_wgrads()
                 for key in ready_d:
                     self._side(lambda key=key: on_ready(key))
-            self._side(tgt_embed_grads)       # after the (single) grouped launch that overwrote the shared softmax table
-            tables_ready()
+            if not pair:
+                self._side(tgt_embed_grads)   # after the (single) grouped launch that overwrote the shared softmax table
+                tables_ready()
 
         def src_embed_grads():
             e.embed_bwd_sorted(batch["src_sort"], dxs, st.g(self.src_emb), H,
@@ -1106,5 +1129,15 @@ class TransformerCore(object):
             e.colsum(dxs, st.g("bias"), skip_L=0, accumulate=True, drop_p=hp.dropout, sid=9001)
             on_ready("bias")
             on_ready(self.src_emb)
-        self._side(src_embed_grads)
+
+        def both_embed_grads():
+            e.embed_bwd_sorted_pair(batch["tgt_sort"], dxt, st.g(self.tgt_emb), self.tgt_emb == self.soft_emb, 9002,
+                                    batch["src_sort"], dxs, st.g(self.src_emb), False, 9001, H, drop_p=hp.dropout)
+            e.colsum_pair(dxt, Lt, 9002, dxs, 0, 9001, st.g("bias"), drop_p=hp.dropout)
+        if pair:
+            self._side(both_embed_grads)
+            tables_ready()
+            self._side(lambda: (on_ready("bias"), on_ready(self.src_emb)))
+        else:
+            self._side(src_embed_grads)
         self._join_side()

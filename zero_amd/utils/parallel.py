@@ -101,9 +101,30 @@ class RcclComm(object):
         self.calls = 0
 
     def _after_compute(self):
+        """Order this communicator's stream behind the compute stream's position.  Default: an event.
+        ZERO_HIP_COMM_HANDOFF=flag (round 6): a monotonic device word instead -- the compute stream adds one (a one-thread
+        launch), a one-thread poll kernel on the communication stream waits for the count; no event is recorded on the
+        compute stream (the single-rank loop measured 40-65 us per step for one such event).  Same
+        ordering, same collectives: results are bit-identical (tests/test_gpu_dp.py)."""
+        cur = torch.cuda.current_stream(self.device)
+        if os.environ.get("ZERO_HIP_COMM_HANDOFF", "event").lower() == "flag":
+            if getattr(self, "_flag", None) is None:
+                self._flag = torch.zeros(2, dtype=torch.int64, device=self.device)       # [count, error word]
+                self._handoffs = 0
+                torch.cuda.current_stream(self.device).synchronize()
+            self._handoffs += 1
+            self.lib.call("zk_flag_add", self._flag.data_ptr(), cur.cuda_stream)
+            self.lib.call("zk_flag_wait", self._flag.data_ptr(), self._handoffs, self._flag.data_ptr() + 8,
+                          self.stream.cuda_stream)
+            return
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
+        ev.record(cur)
         self.stream.wait_event(ev)
+
+    def handoff_errors(self):
+        """Number of flag hand-offs that gave up waiting (0 unless the device is wedged); forces a sync."""
+        f = getattr(self, "_flag", None)
+        return 0 if f is None else int(f[1:2].cpu()[0] & 0xffffffff)
 
     def all_reduce(self, t):
         """In-place sum over the ranks of a contiguous fp32 / bf16 tensor; returns the completion event."""
