@@ -224,10 +224,11 @@ int zk_embed_fwd(const int* ids, const void* table, const float* bias, const flo
                  int L, int H, float scale, int shift, int pos0, const int* zero_flag, float drop_p,
                  const uint64_t* seed, uint32_t sid, const int* pos0_dev, zk_stream_t stream);
 /* round 6: the encoder's and the decoder's input embeddings of a training step in ONE launch (side a: ids [B, La] as they
- * are; side b: ids [B, Lb] shifted right by one position, transformer.py:104-108); per side the arithmetic of zk_embed_fwd */
+ * are; side b: ids [B, Lb] shifted right by one position, transformer.py:104-108); per side the arithmetic of zk_embed_fwd.
+ * ln_epoch (may be NULL): the epoch word of the in-launch LayerNorm exchanges, advanced as zk_ln_epoch_bump advances it */
 int zk_embed_fwd_pair(const int* ids_a, const void* table_a, void* out_a, int La, uint32_t sid_a, const int* ids_b,
                       const void* table_b, void* out_b, int Lb, uint32_t sid_b, const float* bias, const float* timing, int B,
-                      int H, float scale, float drop_p, const uint64_t* seed, zk_stream_t stream);
+                      int H, float scale, float drop_p, const uint64_t* seed, uint32_t* ln_epoch, zk_stream_t stream);
 /* round 6: more small launches of the training step merged pairwise.  zk_embed_bwd_sorted_pair: the gradient scatters of
  * two DIFFERENT embedding tables (arguments per side as zk_embed_bwd_sorted) in one launch.  zk_colsum_pair: out = colsum(a)
  * + colsum(b) (the shared input bias of transformer.py:16-33 / 88-119; rows r % skip == 0 of a side left out when skip > 0)

@@ -102,7 +102,11 @@ __global__ void __launch_bounds__(256) k_embed_fwd(
 // Round 6: the encoder's and the decoder's input embeddings of a training step in ONE launch (both depend on the ids
 // alone; they were two ~8 us launches, the second one in the middle of the step): the first waves take side a's rows, the
 // rest side b's.  Row by row the arithmetic of k_embed_fwd.
-__global__ void __launch_bounds__(256) k_embed_fwd_pair(EmbedFwdSide a, EmbedFwdSide b, const uint64_t* __restrict__ seedp) {
+__global__ void __launch_bounds__(256) k_embed_fwd_pair(EmbedFwdSide a, EmbedFwdSide b, const uint64_t* __restrict__ seedp,
+                                                        uint32_t* __restrict__ epoch) {
+  // (the step's first launch also advances the epoch word of the in-launch LayerNorm exchanges -- zk_ln_epoch_bump's
+  // one-thread launch of its own; nothing of this launch reads the word, every later launch runs behind it)
+  if (epoch != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { const uint32_t v = *epoch + 1; *epoch = (v & 0xffffffu) ? v : 1; }
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -1554,7 +1558,7 @@ int zk_embed_fwd(const int* ids, const void* table, const float* bias, const flo
 // transformer.py:104-108) in one launch; arguments per side as zk_embed_fwd
 int zk_embed_fwd_pair(const int* ids_a, const void* table_a, void* out_a, int La, uint32_t sid_a, const int* ids_b,
                       const void* table_b, void* out_b, int Lb, uint32_t sid_b, const float* bias, const float* timing, int B,
-                      int H, float scale, float drop_p, const uint64_t* seed, hipStream_t stream) {
+                      int H, float scale, float drop_p, const uint64_t* seed, uint32_t* ln_epoch, hipStream_t stream) {
   ZK_CHECK_ARG(H % 8 == 0, "zk_embed_fwd_pair: H=%d must be a multiple of 8", H);
   ZK_CHECK_ARG(drop_p == 0.f || seed != nullptr, "zk_embed_fwd_pair: dropout needs a seed pointer");
   const int ra = B * La, rb = B * Lb;
@@ -1563,7 +1567,7 @@ int zk_embed_fwd_pair(const int* ids_a, const void* table_a, void* out_a, int La
   const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const EmbedFwdSide a{ids_a, (const bf16_t*)table_a, bias, timing, (bf16_t*)out_a, ra, La > 0 ? La : 1, H, scale, 0, 0, thr, ik, sid_a};
   const EmbedFwdSide b{ids_b, (const bf16_t*)table_b, bias, timing, (bf16_t*)out_b, rb, Lb > 0 ? Lb : 1, H, scale, 1, 0, thr, ik, sid_b};
-  hipLaunchKernelGGL(k_embed_fwd_pair, dim3(row_grid(ra + rb)), dim3(256), 0, stream, a, b, seed);
+  hipLaunchKernelGGL(k_embed_fwd_pair, dim3(row_grid(ra + rb)), dim3(256), 0, stream, a, b, seed, ln_epoch);
   ZK_LAUNCH_CHECK();
   return 0;
 }

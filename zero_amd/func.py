@@ -855,12 +855,17 @@ class Engine(object):
                       out.ptr, B, L, H, float(H) ** 0.5, 1 if shift else 0, pos0, hip.ptr(zero_flag),
                       float(drop_p), self.seed.data_ptr(), sid, hip.ptr(pos0_dev), self.stream)
 
-    def embed_fwd_pair(self, ids_a, table_a, out_a, La, sid_a, ids_b, table_b, out_b, Lb, sid_b, bias, B, H, drop_p=0.0):
-        """Encoder input (ids_a) and shifted decoder input (ids_b) of a training step in one launch (zk_embed_fwd_pair)."""
+    def embed_fwd_pair(self, ids_a, table_a, out_a, La, sid_a, ids_b, table_b, out_b, Lb, sid_b, bias, B, H, drop_p=0.0,
+                       bump_epoch=False):
+        """Encoder input (ids_a) and shifted decoder input (ids_b) of a training step in one launch (zk_embed_fwd_pair).
+        bump_epoch: the launch also does what ln_epoch_bump() does (the forward pass starts with both)."""
         tim = self.timing(max(La, Lb), H)
+        meta = self.sync_ln_state(1, 64)[1] if bump_epoch else None
         self.lib.call("zk_embed_fwd_pair", ids_a.data_ptr(), table_a.data_ptr(), out_a.ptr, La, sid_a, ids_b.data_ptr(),
                       table_b.data_ptr(), out_b.ptr, Lb, sid_b, bias.data_ptr(), tim.data_ptr(), B, H, float(H) ** 0.5,
-                      float(drop_p), self.seed.data_ptr(), self.stream)
+                      float(drop_p), self.seed.data_ptr(), meta.data_ptr() if meta is not None else None, self.stream)
+        if bump_epoch:
+            self._sync_site = 0
 
     def beam_topk(self, logits, prev_lp, out_s, out_i, B, K, V, k2, temperature, penalty, forbid_id, forbid_value,
                   scal_dev=None):

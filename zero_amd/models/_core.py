@@ -922,19 +922,20 @@ class TransformerCore(object):
         # residual + LayerNorm inside the sub-layer output GEMMs (ZERO_HIP_SYNC_LN=0: a launch of their own)
         self._sync_ln = self.sync_ln_mode and not self._lazy and self.eng.gemm_impl == 0 and self.H % 64 == 0 and \
             self.H <= 1024 and self.F % 64 == 0 and self.eng.sync_ln_usable()
-        if self._sync_ln:
-            self.eng.ln_epoch_bump()
+        pair_embeds = self.merge_small and "tgt" in batch and not self.eng.lib.recording
+        if self._sync_ln and not pair_embeds:
+            self.eng.ln_epoch_bump()          # (else the paired embedding launch below advances the epoch)
         if self._lazy:
             self._fold_weights()
         # round 6: both input embeddings depend on the ids alone -- one launch in front of the step instead of two
         # (ZERO_HIP_MERGE_SMALL=0: the round-5 launches)
         self._embeds_done = False
-        if self.merge_small and "tgt" in batch and not self.eng.lib.recording:
+        if pair_embeds:
             e_, H_ = self.eng, self.H
             e_.embed_fwd_pair(batch["src"], self.store.s(self.src_emb), e_.mat("enc.x0", batch["B"] * batch["Ls"], H_),
                               batch["Ls"], 9001, batch["tgt"], self.store.s(self.tgt_emb),
                               e_.mat("dec.x0", batch["B"] * batch["Lt"], H_), batch["Lt"], 9002, self.b("bias"), batch["B"], H_,
-                              drop_p=self.hp.dropout if train else 0.0)
+                              drop_p=self.hp.dropout if train else 0.0, bump_epoch=self._sync_ln)
             self._embeds_done = True
         try:
             enc, smask = self.encode(batch, train, save)
