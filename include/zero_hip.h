@@ -83,6 +83,21 @@ int zk_attn_out_ln(const void* q, const void* k, const void* v, void* att, float
                    const float* beta, float eps, void* s_out, void* y, float* mean, float* rstd, void* slots,
                    size_t slots_bytes, void* flags, size_t flags_bytes, const uint32_t* epoch, uint32_t site, int* err,
                    zk_stream_t stream);
+/* The same launch with the projection in FRONT of the attention inside it as well (func.py:206-216): workgroup (sentence,
+ * head) first computes its own head's 64 columns of q (k, v) = x Wp + bp over its sentence's rows -- it is their only
+ * consumer in the forward pass, so no exchange between workgroups is needed -- writes them (the backward reads them) and
+ * goes on as zk_attn_out_ln.  pro = 3: Wp [Kp, 3 nh 64] = the merged qkv_map of a self-attention (k = q + nh*64 and
+ * v = q + 2 nh*64 columns of one [B*Lq, ldq] matrix, Lk = Lq, kv_group = 1); pro = 1: Wp [Kp, nh 64] = the q_map of a
+ * cross-attention (k, v given as before).  x [B*Lq, ldx] bf16, Kp a multiple of 64.  Replaces zk_gemm + zk_attn_out_ln with
+ * bit-identical results (same tile function and K order).  Returns 2 (nothing launched) when the shape is not covered. */
+int zk_proj_attn_out_ln(const void* x, int ldx, const void* Wp, int ldwp, const float* bp, int Kp, int pro,
+                   const void* q, const void* k, const void* v, void* att, float* lse, int B, int nh, int Lq, int Lk, int d,
+                   int ldq, int ldk, int ldv, int ldatt, const float* kmask, int causal, float scale, float mask_inf,
+                   float attn_drop_p, const uint64_t* seed, uint32_t attn_sid, int kv_group, const void* Wo, int ldw,
+                   const float* bias, const void* residual, int ldr, float drop_p, uint32_t sid, const float* gamma,
+                   const float* beta, float eps, void* s_out, void* y, float* mean, float* rstd, void* slots,
+                   size_t slots_bytes, void* flags, size_t flags_bytes, const uint32_t* epoch, uint32_t site, int* err,
+                   zk_stream_t stream);
 #ifdef ZK_EXPERIMENTS   /* measured, no gain over the two launches (profiles/r04_negative_results.txt item 8) */
 /* Attention backward (single-tile path of zk_attn_bwd with the o_map dgrad folded in: d = 64, Lq, Lk <= 64, no relative
  * positions) + the dgrad dx = dA W^T + residual that consumes its dq / dk / dv (dA [B*Lq, K]: the matrix they are columns of)

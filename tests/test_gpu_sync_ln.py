@@ -171,6 +171,57 @@ def test_attention_inside_the_output_projection_launch(B, Lq, Lk, causal, masked
     assert torch.equal(s1, s0) and torch.equal(y1, y0) and torch.equal(mean1, mean0) and torch.equal(rstd1, rstd0)
 
 
+@pytest.mark.parametrize("B,Lq,Lk,pro,causal,masked,drop", [(64, 64, 64, 3, True, False, 0.1), (64, 64, 64, 3, False, True, 0.1),
+                                                            (64, 64, 64, 1, False, True, 0.1), (16, 37, 37, 3, True, False, 0.1),
+                                                            (8, 13, 150, 1, False, True, 0.1), (5, 64, 64, 3, False, True, 0.0),
+                                                            (24, 50, 256, 1, False, True, 0.0), (3, 1, 1, 3, True, False, 0.0)])
+def test_projection_inside_the_attention_launch(B, Lq, Lk, pro, causal, masked, drop):
+    """zk_proj_attn_out_ln (round 6) against zk_gemm (the merged qkv_map / the q_map, func.py:206-216) followed by
+    zk_attn_out_ln: the projected q (k, v) tiles, the attention output, its log-sum-exp, the sum, the normalised rows and the
+    statistics are bit for bit the two launches' (same 64x64 tile function and K order whatever tile the projection launch
+    picks; each workgroup reads back only what it wrote).  Self-shaped (pro = 3: q, k, v column slices of one matrix) and
+    cross-shaped (pro = 1: keys / values given) problems, ragged sentences, a one-row sentence, grids that straddle XCDs."""
+    e = eng()
+    e.set_seed(23)
+    nh, d = 8, 64
+    H = nh * d
+    Tq, Tk = B * Lq, B * Lk
+    x = rand_bf(Tq, H, seed=11)
+    Wp, Wo, R = rand_bf(H, pro * H, seed=12, scale=0.05), rand_bf(H, H, seed=4, scale=0.05), rand_bf(Tq, H, seed=5)
+    g = torch.Generator().manual_seed(6)
+    b = (torch.randn(H, generator=g) * 0.1).cuda()
+    bp = (torch.randn(pro * H, generator=g) * 0.1).cuda()
+    gam, bet = (1.0 + 0.2 * torch.randn(H, generator=g)).cuda(), (0.1 * torch.randn(H, generator=g)).cuda()
+    kvt = rand_bf(Tk, 2 * H, seed=2)
+    kmask = None
+    if masked:
+        kmask = torch.ones(B, Lk, device="cuda")
+        for i in range(B):
+            kmask[i, Lk - (i % max(1, Lk // 2)):] = 0.0
+
+    def run(fused):
+        proj = torch.full((Tq, pro * H), 3.0, dtype=torch.bfloat16, device="cuda")
+        att, y, s = (torch.full((Tq, H), 3.0, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+        lse, mean, rstd = torch.zeros(B * nh * Lq, device="cuda"), torch.zeros(Tq, device="cuda"), torch.zeros(Tq, device="cuda")
+        q = mat(proj, Tq, H, pro * H, 0)
+        if pro == 3:
+            k, v = mat(proj, Tq, H, 3 * H, H), mat(proj, Tq, H, 3 * H, 2 * H)
+        else:
+            k, v = mat(kvt, Tk, H, 2 * H, 0), mat(kvt, Tk, H, 2 * H, H)
+        if not fused:
+            e.gemm(mat(x), mat(Wp), mat(proj), Tq, pro * H, H, 0, 0, bias=bp)
+        e.ln_epoch_bump()
+        ok = e.attn_out_ln(q, k, v, mat(att), lse, B, nh, Lq, Lk, d, kmask, causal, drop, 7, mat(Wo), b, mat(R), gam, bet,
+                           mat(y), mat(s), mean, rstd, drop, 8, proj=(mat(x), mat(Wp), bp, pro) if fused else None)
+        torch.cuda.synchronize()
+        assert ok and e.sync_ln_errors() == 0
+        return proj, att, lse, y, s, mean, rstd
+
+    ref, got = run(False), run(True)
+    for name, r, t in zip(("projection", "att", "lse", "y", "s", "mean", "rstd"), ref, got):
+        assert torch.equal(r, t), name
+
+
 @pytest.mark.parametrize("B,Lq,Lk,K3,causal,drop", [(64, 64, 64, True, True, 0.1), (64, 64, 64, False, False, 0.0),
                                                     (16, 37, 37, True, True, 0.1), (8, 13, 50, False, False, 0.1),
                                                     (5, 64, 64, True, False, 0.0)])
@@ -316,6 +367,40 @@ def test_training_steps_with_the_layernorm_inside_the_launch(model, monkeypatch)
         on = out[(mode, True)]
         assert np.allclose(on[0], off[0], rtol=2e-3, atol=0), (mode, on[0], off[0])
         assert np.linalg.norm(on[1] - off[1]) <= 2e-3 * np.linalg.norm(off[1])
+
+
+def test_training_steps_with_the_projection_inside_the_attention_launch(monkeypatch):
+    """Trainer with ZERO_HIP_PROJ_ATTN = 1 (round 6 default: qkv_map / q_map as the prologue of the attention launch) against 0
+    (a launch of its own): losses and every master weight equal bit for bit after five steps, eager and captured -- the
+    projection runs the same tile function over the same K order -- with 18 fewer launches per step at six layers a side."""
+    from tests.common import make_hp, make_batch, perturb
+    from oracle import ref_torch as rt
+    from zero_amd.main import Trainer
+    from zero_amd.models._factory import reset_cores
+    from zero_amd.variables import reset_stores
+    hp = make_hp("transformer", H=128, F=256, lrate=0.02, warmup_steps=10, dropout=0.1, residual_dropout=0.1)
+    rng = np.random.default_rng(3)
+    src, tgt = make_batch(rng, 6, 11, 13, hp.src_vocab.size(), hp.tgt_vocab.size())
+    Pn = perturb(rt.init_params(hp, "transformer", seed=8), rng)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ZERO_HIP_PROJ_ATTN", mode)
+        for use_graph in (False, True):
+            reset_cores(); reset_stores()
+            tr = Trainer(hp, initializer=Pn)
+            assert tr.core.proj_attn == (mode == "1")
+            tr.prepare_static({"source": src, "target": tgt})
+            tr.core.eng.set_seed(11)
+            n0 = tr.core.eng.lib.ncalls
+            losses = [float(tr.step_static(use_graph).cpu()[0]) for _ in range(5)]
+            torch.cuda.synchronize()
+            assert tr.core.eng.sync_ln_errors() == 0
+            out[(mode, use_graph)] = (losses, tr.store.master.cpu().numpy().copy(), tr.core.eng.lib.ncalls - n0)
+    ref = out[("0", False)]
+    for key in (("1", False), ("1", True), ("0", True)):
+        assert out[key][0] == ref[0] and np.array_equal(out[key][1], ref[1]), key
+    nl = hp.num_encoder_layer + 2 * hp.num_decoder_layer
+    assert out[("0", False)][2] - out[("1", False)][2] == 5 * nl      # one launch per attention sub-layer and step
 
 
 def test_the_exchange_passes_its_self_test_on_this_device():

@@ -254,18 +254,156 @@ __global__ void __launch_bounds__(256) k_attn_fwd_mfma(AttnArgs a, bf16_t* __res
 // point of coherence -- stores acknowledged (vmcnt) before the flag, the LDS-DMA of the K loop misses the L1 (nothing of
 // `att` was read by this CU before) -- otherwise agent-scope release / acquire around the flag.
 #define ZK_ATTN_FWD_BARRIERS(NKT) (4 * (NKT))     // workgroup barriers inside attn_fwd_tile<NKT> (no relative positions)
-template <int NKT>
+// PRO > 0 (zk_proj_attn_out_ln): the projection in front of the attention (func.py:206-216: the merged qkv_map of a
+// self-attention, PRO = 3, or the q_map of a cross-attention, PRO = 1) runs HERE as well: workgroup (b, h) needs nothing but
+// its own head's 64 columns of q (k, v) over its sentence's rows -- x[rows of b, :] W[:, p H + h*64 ..] + bias, PRO tiles of
+// the 64x64 GEMM with K = H -- so the projection launch, its drain and the attention's cold start disappear without any
+// exchange between workgroups.  The tiles are written to the q / k / v matrices as before (the backward reads them) and read
+// back by this workgroup's attention tile past the L1 (FRESH loads: the stores were acknowledged by the L2).  Same tile
+// function, same K order as the projection launch: bit-identical.
+struct AttnPro { const bf16_t* x; int ldx; const bf16_t* w; int ldw; const float* bias; int K; int N; };
+
+// The projection tiles of one (sentence, head) as ONE K loop (PRO = 3: q, k, v; PRO = 1: q): out[m0.., p nslab + n0 + 0..63] =
+// x[m0.., :] W[:, p nslab + n0 + 0..63] + bias for p < PRO.  Three calls of gemm_tile cost three ring fills, three epilogues
+// through the LDS and fetched the x rows three times (measured: as long as the projection launch they replaced).  Here the
+// ring runs through: K tile kt is a half stage {x tile, W_q tile} followed (PRO = 3) by a half stage {W_k tile, W_v tile};
+// the x fragments of a K tile stay in registers for the second half, so x goes through the address path once; four
+// producer waves issue every LDS-DMA, three half stages in flight; the accumulators leave straight from the registers
+// (64-byte row pieces) -- no LDS round trip, no barrier.  Per element the same MFMAs in the same K order as gemm_tile and
+// the same rounding (acc + bias -> bf16): bit-identical to the projection launch.  K % 64 == 0; rows >= M are not stored.
+template <int PRO>
+__device__ __forceinline__ void proj_heads_tile(unsigned char* smem, const bf16_t* __restrict__ X, int ldx,
+                                                const bf16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
+                                                bf16_t* __restrict__ out, int ldo, int K, int m0, int M, int n0, int nslab) {
+  constexpr int NS = 4, HALF = 128 * 64;            // bf16 elements per half stage (two 64 x 64 operand tiles)
+  constexpr int HPK = PRO == 3 ? 2 : 1;             // half stages per K tile
+  constexpr int PER = 4;                            // DMA instructions per producer wave per half stage
+  bf16_t* ring = reinterpret_cast<bf16_t*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;
+  const int dwave = wave - 4, wm = wave >> 1, wn = wave & 1;
+  const int nk = K >> 6, nh = nk * HPK;
+  const uint32_t ring_addr = lds_addr(ring);
+  f32x16_t acc[PRO];
+#pragma unroll
+  for (int p = 0; p < PRO; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  if (producer) {
+    DmaPlan<64, 4> planA, planB;
+    dma_plan<64, false, 4>(planA, ldx, m0, M, dwave, lane);
+    dma_plan<64, true, 4>(planB, ldw, 0, 64, dwave, lane);
+    const bf16_t* baseA = X;
+    const bf16_t* baseB = W + n0;
+    int hs = 0;                                     // next half stage to issue
+    auto issue = [&]() {
+      const uint32_t st = ring_addr + (uint32_t)((hs % NS) * HALF * 2);
+      if (PRO == 1 || (hs & 1) == 0) {
+        dma_tile<64, false, false, 4>(planA, baseA, 0, K, st, dwave);
+        dma_tile<64, true, false, 4>(planB, baseB, 0, K, st + 64 * 128, dwave);
+        baseA += 64;
+        if (PRO == 1) baseB += (size_t)64 * ldw;
+      } else {
+        dma_tile<64, true, false, 4>(planB, baseB + nslab, 0, K, st, dwave);
+        dma_tile<64, true, false, 4>(planB, baseB + 2 * nslab, 0, K, st + 64 * 128, dwave);
+        baseB += (size_t)64 * ldw;
+      }
+      ++hs;
+    };
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) if (i < nh) issue();
+    for (int s = 0; s < nh; ++s) {
+      // half stage s has landed once at most min(NS - 2, nh - 1 - s) later ones are still in flight
+      const int later = nh - 1 - s;
+      if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (hs < nh) issue();                         // refills the half stage everybody finished reading at this barrier
+    }
+  } else {
+    bf16x8_t af[4];
+    for (int s = 0; s < nh; ++s) {
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const bf16_t* h0 = ring + (s % NS) * HALF;
+      const bf16_t* h1 = h0 + 64 * 64;
+      if (PRO == 1 || (s & 1) == 0) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) af[kk] = load_frag<64, false>(h0, wm * 32, kk, lane);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk], load_frag<64, true>(h1, wn * 32, kk, lane), acc[0], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          acc[PRO > 1 ? 1 : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk], load_frag<64, true>(h0, wn * 32, kk, lane),
+                                                                         acc[PRO > 1 ? 1 : 0], 0, 0, 0);
+          acc[PRO > 2 ? 2 : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk], load_frag<64, true>(h1, wn * 32, kk, lane),
+                                                                         acc[PRO > 2 ? 2 : 0], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- epilogue through the LDS (the ring is dead): PRO fp32 tiles, then every thread stores 16-byte row pieces
+  // [straight from the registers -- 48 two-byte stores per lane -- the launch was 5 us LONGER than with three gemm_tile calls]
+  constexpr int CLD = 64 + 4;
+  float* sC = reinterpret_cast<float*>(smem);
+  __syncthreads();                                  // every compute wave is done reading the last half stages
+  if (!producer) {
+    // C layout of the 32x32 MFMA: column = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const int col = wn * 32 + (lane & 31);
+#pragma unroll
+    for (int p = 0; p < PRO; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sC[p * 64 * CLD + (wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CLD + col] = acc[p][r];
+  }
+  __syncthreads();
+  const int row = tid >> 3, cc = (tid & 7) * 8, gm = m0 + row;
+#pragma unroll
+  for (int p = 0; p < PRO; ++p) {
+    const int gn = p * nslab + n0 + cc;
+    float v[8], bv[8];
+    {
+      const float4 a = *reinterpret_cast<const float4*>(sC + p * 64 * CLD + row * CLD + cc);
+      const float4 b = *reinterpret_cast<const float4*>(sC + p * 64 * CLD + row * CLD + cc + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    if (bias != nullptr) {
+      const float4 a = *reinterpret_cast<const float4*>(bias + gn);
+      const float4 b = *reinterpret_cast<const float4*>(bias + gn + 4);
+      bv[0] = a.x; bv[1] = a.y; bv[2] = a.z; bv[3] = a.w; bv[4] = b.x; bv[5] = b.y; bv[6] = b.z; bv[7] = b.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bv[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] * 1.f + bv[j];
+    if (gm < M) *reinterpret_cast<uint4*>(out + (size_t)gm * ldo + gn) = pack8(v);
+  }
+}
+template <int NKT, int PRO = 0>
 __global__ void __launch_bounds__(512) k_attn_out_ln(AttnArgs a, bf16_t* __restrict__ att, int ldatt, float* __restrict__ lse,
                                                      const bf16_t* __restrict__ Wo, int ldw, int M, int N, TileSched ts,
-                                                     GemmEpi e, unsigned long long* __restrict__ flags) {
+                                                     GemmEpi e, unsigned long long* __restrict__ flags, AttnPro pro) {
   constexpr int GEMM_LDS = DldsCfg<64, 64, 4>::LDS_BYTES, ATT_LDS = AttnFwdLds<NKT, false>::BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[GEMM_LDS > ATT_LDS ? GEMM_LDS : ATT_LDS];
   int tm, tn, z;
   tile_of_block(ts, tm, tn, z);                   // tm: sentence, tn: head
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if constexpr (PRO > 0) {
+    const int M_pro = min(M, (tm + 1) * a.Lq);
+    proj_heads_tile<PRO>(smem, pro.x, pro.ldx, pro.w, pro.ldw, pro.bias, const_cast<bf16_t*>(a.q), a.ldq, pro.K, tm * a.Lq, M_pro,
+                         tn * 64, N);
+    __builtin_amdgcn_s_waitcnt(0);                // this thread's pieces of q / k / v have reached the L2
+    __syncthreads();                              // (and every wave is done with the ring: the attention tile reuses it)
+  }
   if (wave < 4) {
-    attn_fwd_tile<NKT, false, false>(smem, a, att, ldatt, lse, 0, tn, tm);
+    attn_fwd_tile<NKT, PRO != 0, false>(smem, a, att, ldatt, lse, 0, tn, tm);
   } else {
 #pragma unroll 1
     for (int i = 0; i < ZK_ATTN_FWD_BARRIERS(NKT); ++i) __syncthreads();
@@ -763,13 +901,13 @@ int zk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* l
 // not covered (the caller issues zk_attn_fwd and zk_gemm_add_ln).
 size_t zk_attn_out_ln_flags(int B, int nh) { return (size_t)B * nh * sizeof(unsigned long long); }
 
-int zk_attn_out_ln(const void* q, const void* k, const void* v, void* att, float* lse, int B, int nh, int Lq, int Lk, int d,
+static int attn_out_ln_impl(const void* q, const void* k, const void* v, void* att, float* lse, int B, int nh, int Lq, int Lk, int d,
                    int ldq, int ldk, int ldv, int ldatt, const float* kmask, int causal, float scale, float mask_inf,
                    float attn_drop_p, const uint64_t* seed, uint32_t attn_sid, int kv_group, const void* Wo, int ldw,
                    const float* bias, const void* residual, int ldr, float drop_p, uint32_t sid, const float* gamma,
                    const float* beta, float eps, void* s_out, void* y, float* mean, float* rstd, void* slots,
                    size_t slots_bytes, void* flags, size_t flags_bytes, const uint32_t* epoch, uint32_t site, int* err,
-                   hipStream_t stream) {
+                   hipStream_t stream, int npro, const AttnPro& pro) {
   const int N = nh * AD, M = B * Lq;
   if (d != AD || Lq < 1 || Lq > 64 || Lk < 1 || Lk > 256 || N > 1024 || kv_group < 1) return 2;
   ZK_CHECK_ARG(residual != nullptr && ldr % 8 == 0 && gamma != nullptr && beta != nullptr && y != nullptr && att != nullptr,
@@ -805,15 +943,59 @@ int zk_attn_out_ln(const void* q, const void* k, const void* v, void* att, float
   e.sy_local = (nwg % (8 * nh) == 0 && !(g_tune[15] & 1)) ? 1 : 0;
   const int nkt = (Lk + 63) / 64;
   const dim3 grid((unsigned)nwg), blk(512);
-#define ZK_AOL(NKT_) hipLaunchKernelGGL(k_attn_out_ln<NKT_>, grid, blk, 0, stream, a, (bf16_t*)att, ldatt, lse, \
-                                         (const bf16_t*)Wo, ldw, M, N, ts, e, (unsigned long long*)flags)
-  if (nkt == 1) ZK_AOL(1);
-  else if (nkt == 2) ZK_AOL(2);
-  else if (nkt == 3) ZK_AOL(3);
-  else ZK_AOL(4);
+#define ZK_AOL(NKT_, PRO_) hipLaunchKernelGGL((k_attn_out_ln<NKT_, PRO_>), grid, blk, 0, stream, a, (bf16_t*)att, ldatt, lse, \
+                                               (const bf16_t*)Wo, ldw, M, N, ts, e, (unsigned long long*)flags, pro)
+#define ZK_AOL_N(PRO_) do { if (nkt == 1) ZK_AOL(1, PRO_); else if (nkt == 2) ZK_AOL(2, PRO_); else if (nkt == 3) ZK_AOL(3, PRO_); \
+                            else ZK_AOL(4, PRO_); } while (0)
+  if (npro == 0) ZK_AOL_N(0);
+  else if (npro == 1) ZK_AOL_N(1);
+  else ZK_AOL_N(3);
+#undef ZK_AOL_N
 #undef ZK_AOL
   ZK_LAUNCH_CHECK();
   return 0;
+}
+
+int zk_attn_out_ln(const void* q, const void* k, const void* v, void* att, float* lse, int B, int nh, int Lq, int Lk, int d,
+                   int ldq, int ldk, int ldv, int ldatt, const float* kmask, int causal, float scale, float mask_inf,
+                   float attn_drop_p, const uint64_t* seed, uint32_t attn_sid, int kv_group, const void* Wo, int ldw,
+                   const float* bias, const void* residual, int ldr, float drop_p, uint32_t sid, const float* gamma,
+                   const float* beta, float eps, void* s_out, void* y, float* mean, float* rstd, void* slots,
+                   size_t slots_bytes, void* flags, size_t flags_bytes, const uint32_t* epoch, uint32_t site, int* err,
+                   hipStream_t stream) {
+  AttnPro pro = {nullptr, 0, nullptr, 0, nullptr, 0, 0};
+  return attn_out_ln_impl(q, k, v, att, lse, B, nh, Lq, Lk, d, ldq, ldk, ldv, ldatt, kmask, causal, scale, mask_inf, attn_drop_p,
+                          seed, attn_sid, kv_group, Wo, ldw, bias, residual, ldr, drop_p, sid, gamma, beta, eps, s_out, y, mean,
+                          rstd, slots, slots_bytes, flags, flags_bytes, epoch, site, err, stream, 0, pro);
+}
+
+// zk_attn_out_ln with the projection in front of the attention inside the launch as well (k_attn_out_ln<.., PRO>):
+// q (k, v) = x Wp + bp is computed by the workgroup that consumes it.  pro = 3: Wp [Kp, 3 nh 64] is the merged qkv_map of a
+// self-attention (q, k = q + nh*64, v = q + 2 nh*64 columns of ONE [B*Lq, ldq] matrix, Lk = Lq, kv_group = 1); pro = 1: Wp
+// [Kp, nh 64] is the q_map of a cross-attention (k, v as for zk_attn_out_ln).  x [B*Lq, ldx]; the projected tiles are still
+// written (the backward reads them).  Returns 2 (nothing launched) when the shape is not covered.
+int zk_proj_attn_out_ln(const void* x, int ldx, const void* Wp, int ldwp, const float* bp, int Kp, int pro,
+                   const void* q, const void* k, const void* v, void* att, float* lse, int B, int nh, int Lq, int Lk, int d,
+                   int ldq, int ldk, int ldv, int ldatt, const float* kmask, int causal, float scale, float mask_inf,
+                   float attn_drop_p, const uint64_t* seed, uint32_t attn_sid, int kv_group, const void* Wo, int ldw,
+                   const float* bias, const void* residual, int ldr, float drop_p, uint32_t sid, const float* gamma,
+                   const float* beta, float eps, void* s_out, void* y, float* mean, float* rstd, void* slots,
+                   size_t slots_bytes, void* flags, size_t flags_bytes, const uint32_t* epoch, uint32_t site, int* err,
+                   hipStream_t stream) {
+  ZK_CHECK_ARG(pro == 1 || pro == 3, "zk_proj_attn_out_ln: pro must be 1 (q_map) or 3 (merged qkv_map)");
+  ZK_CHECK_ARG(x != nullptr && Wp != nullptr && q != nullptr, "zk_proj_attn_out_ln: x, Wp and q are required");
+  const int N = nh * AD;
+  if (Kp < 64 || Kp % 64 != 0 || ldx % 8 != 0 || ldwp % 8 != 0 || ldq % 8 != 0) return 2;
+  if ((((uintptr_t)x | (uintptr_t)Wp | (uintptr_t)bp | (uintptr_t)q) & 15) != 0) return 2;
+  if (pro == 3) {
+    const bf16_t* qq = (const bf16_t*)q;
+    if ((const bf16_t*)k != qq + N || (const bf16_t*)v != qq + 2 * N || ldk != ldq || ldv != ldq || Lk != Lq || kv_group != 1)
+      return 2;
+  }
+  AttnPro ap = {(const bf16_t*)x, ldx, (const bf16_t*)Wp, ldwp, bp, Kp, pro * N};
+  return attn_out_ln_impl(q, k, v, att, lse, B, nh, Lq, Lk, d, ldq, ldk, ldv, ldatt, kmask, causal, scale, mask_inf, attn_drop_p,
+                          seed, attn_sid, kv_group, Wo, ldw, bias, residual, ldr, drop_p, sid, gamma, beta, eps, s_out, y, mean,
+                          rstd, slots, slots_bytes, flags, flags_bytes, epoch, site, err, stream, pro, ap);
 }
 
 #ifdef ZK_EXPERIMENTS   // measured, no gain over the two launches (profiles/r04_negative_results.txt item 8)

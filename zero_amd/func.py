@@ -275,9 +275,11 @@ class Engine(object):
                       slots.numel(), meta.data_ptr(), self._sync_site, meta.data_ptr() + 4, self.stream)
 
     def attn_out_ln(self, q, k, v, att, lse, B, nh, Lq, Lk, d, kmask, causal, attn_drop_p, attn_sid, Wo, bias, residual,
-                    gamma, beta, y, s_out=None, mean=None, rstd=None, drop_p=0.0, sid=0, kv_group=1):
+                    gamma, beta, y, s_out=None, mean=None, rstd=None, drop_p=0.0, sid=0, kv_group=1, proj=None):
         """Attention forward + o_map + residual + LayerNorm in one launch (zk_attn_out_ln).  False (nothing launched)
-        when the shape is not covered: the caller issues attn_fwd and gemm_add_ln."""
+        when the shape is not covered: the caller issues attn_fwd and gemm_add_ln.
+        proj = (x Mat, Wp Mat, bp, pro): the projection in front of the attention runs in the same launch
+        (zk_proj_attn_out_ln; pro = 3: merged qkv_map, q / k / v column slices of one matrix; pro = 1: q_map)."""
         if self.__dict__.get("_sync_site", 255) >= 255:
             self.ln_epoch_bump()
         M, N = B * Lq, nh * d
@@ -289,12 +291,17 @@ class Engine(object):
                 zdtype.epsilon(), s_out.ptr if s_out is not None else None, y.ptr, hip.ptr(mean), hip.ptr(rstd),
                 slots.data_ptr(), slots.numel(), fl.data_ptr(), fl.numel(), meta.data_ptr(), self._sync_site + 1,
                 meta.data_ptr() + 4, self.stream)
+        name = "zk_attn_out_ln"
+        if proj is not None:
+            px, pW, pb, pro = proj
+            args = (px.ptr, px.ld, pW.ptr, pW.ld, hip.ptr(pb), pW.rows, pro) + args
+            name = "zk_proj_attn_out_ln"
         self.lib.ncalls += 1
-        rc = self.lib.raw("zk_attn_out_ln")(*args)
+        rc = self.lib.raw(name)(*args)
         if rc == 2:
             return False
         if rc != 0:
-            self.lib.call("zk_attn_out_ln", *args)      # raises with the library's message
+            self.lib.call(name, *args)      # raises with the library's message
         self._sync_site += 1
         return True
 

@@ -150,6 +150,9 @@ class TransformerCore(object):
         # (A/B: "noattn" keeps the attention forward a launch of its own, "fwd" also the LayerNorm backward)
         self.sync_ln_bwd = os.environ.get("ZERO_HIP_SYNC_LN", "1") != "fwd"
         self.sync_attn = os.environ.get("ZERO_HIP_SYNC_LN", "1") not in ("noattn", "fwd", "0")
+        # round 6: the projection in front of the attention (merged qkv_map / q_map) as the prologue of that launch
+        # (zk_proj_attn_out_ln); ZERO_HIP_PROJ_ATTN=0 keeps it a launch of its own (A/B, bit-identity tests)
+        self.proj_attn = os.environ.get("ZERO_HIP_PROJ_ATTN", "1") != "0"
         # the attention BACKWARD inside the dgrad launch: measured, no gain (EXPERIMENTS=1 library, ZERO_HIP_SYNC_LN=attnbwd)
         self.sync_attn_bwd = os.environ.get("ZERO_HIP_SYNC_LN", "1") == "attnbwd" and self.eng.lib.experiments
         self._sync_ln = False
@@ -435,13 +438,18 @@ class TransformerCore(object):
         13.15 / 12.22; 4096 x 1024 (1024, sixteen peers): 10.63 / 10.51.  Rule: at most three workgroups per CU."""
         return ((rows + 63) // 64) * (self.H // 64) <= 3 * self.eng.cu_count
 
+    def _attn_out_ln_ok(self, B, Lq, Lk):
+        e = self.eng
+        return (self._sync_ln and self.sync_attn and not self.rpr and not e.lib.recording and self.d == 64 and
+                Lq <= 64 and Lk <= 256 and e.attn_impl in (0, 2) and B * self.nh <= 3 * e.cu_count)
+
     def _attn_out_ln(self, q, k, v, att, lse, B, Lq, Lk, kmask, causal, attn_drop, attn_sid, lin, x, scope, tag, save,
-                     drop_p, sid):
+                     drop_p, sid, proj=None):
         """attention + o_map + residual + LayerNorm in one launch when the in-launch LayerNorm is on and the shape is
-        covered (zk_attn_out_ln: no relative positions, Lq <= 64, Lk <= 256, 64-wide heads); None otherwise."""
+        covered (zk_attn_out_ln: no relative positions, Lq <= 64, Lk <= 256, 64-wide heads); None otherwise.
+        proj = (scope of the linear in front, 1 | 3): q (k, v) = x W + b is computed inside the launch as well."""
         e, H = self.eng, self.H
-        if not (self._sync_ln and self.sync_attn and not self.rpr and not e.lib.recording and self.d == 64 and
-                Lq <= 64 and Lk <= 256 and e.attn_impl in (0, 2) and B * self.nh <= 3 * e.cu_count):
+        if not self._attn_out_ln_ok(B, Lq, Lk):
             return None
         T = x.rows
         Wm = self.W(lin + "/W_0_0")
@@ -449,9 +457,12 @@ class TransformerCore(object):
         s = e.mat(tag + ".s", T, H) if save else None
         mean = e.buf(tag + ".mean", (T,), F32) if save else None
         rstd = e.buf(tag + ".rstd", (T,), F32) if save else None
+        pj = None
+        if proj is not None:
+            pj = (x, self.W(proj[0] + "/W_0_0"), self.b(proj[0] + "/b_0"), proj[1])
         ok = e.attn_out_ln(q, k, v, att, lse, B, self.nh, Lq, Lk, self.d, kmask, causal, attn_drop, attn_sid, Wm,
                            self.b(lin + "/b_0"), x, self.b(scope + "/layer_norm/scale"), self.b(scope + "/layer_norm/offset"),
-                           out, s, mean, rstd, drop_p, sid)
+                           out, s, mean, rstd, drop_p, sid, proj=pj)
         return out if ok else None
 
     def _ln_fwd(self, x, y, scope, tag, save, drop_p, sid):
@@ -474,16 +485,19 @@ class TransformerCore(object):
         T = x.rows
         p = scope + "/dot_attention/"
         qkv = e.mat(tag + ".qkv", T, 3 * H)
-        self._linear(x, p + "qkv_map", qkv)
         att = e.mat(tag + ".att", T, H)
         lse = e.buf(tag + ".lse", (B * self.nh * L,), F32) if save else None
         rk = self.store.s(p + "rpr_keys/embeddings") if self.rpr else None
         rv = self.store.s(p + "rpr_values/embeddings") if self.rpr else None
-        out = self._attn_out_ln(qkv.cols_slice(0, H), qkv.cols_slice(H, 2 * H), qkv.cols_slice(2 * H, 3 * H), att, lse, B, L, L,
-                                kmask, causal, hp.attention_dropout if train else 0.0, sid0, p + "o_map", x, scope, tag, save,
-                                hp.residual_dropout if train else 0.0, sid0 + 1)
-        if out is not None:
-            return out
+        fuse_proj = self.proj_attn and not isinstance(x, LazyLN) and self._attn_out_ln_ok(B, L, L)
+        for pj in ((p + "qkv_map", 3), None) if fuse_proj else (None,):
+            if pj is None:
+                self._linear(x, p + "qkv_map", qkv)
+            out = self._attn_out_ln(qkv.cols_slice(0, H), qkv.cols_slice(H, 2 * H), qkv.cols_slice(2 * H, 3 * H), att, lse, B,
+                                    L, L, kmask, causal, hp.attention_dropout if train else 0.0, sid0, p + "o_map", x, scope,
+                                    tag, save, hp.residual_dropout if train else 0.0, sid0 + 1, proj=pj)
+            if out is not None:
+                return out
         e.attn_fwd(qkv.cols_slice(0, H), qkv.cols_slice(H, 2 * H), qkv.cols_slice(2 * H, 3 * H), att, lse, B,
                    self.nh, L, L, self.d, kmask=kmask, causal=causal, rpr_k=rk, rpr_v=rv,
                    max_rel=hp.max_relative_position, drop_p=hp.attention_dropout if train else 0.0, sid=sid0)
@@ -508,7 +522,10 @@ class TransformerCore(object):
         hp = self.hp
         p = scope + "/dot_attention/"
         q = e.mat(tag + ".q", x.rows, H)
-        self._linear(x, p + "q_map", q)
+        fuse_proj = (self.proj_attn and fuse_tmask is None and not isinstance(x, LazyLN) and
+                     self._attn_out_ln_ok(B, Lq, Lk))
+        if not fuse_proj:
+            self._linear(x, p + "q_map", q)
         kv = e.mat(tag + ".kv", mem.rows, 2 * H)
         if not kv_ready:
             self._linear(mem, p + "k_map", kv.cols_slice(0, H))
@@ -518,11 +535,14 @@ class TransformerCore(object):
         rk = self.store.s(p + "rpr_keys/embeddings") if self.rpr else None
         rv = self.store.s(p + "rpr_values/embeddings") if self.rpr else None
         if fuse_tmask is None:
-            out = self._attn_out_ln(q, kv.cols_slice(0, H), kv.cols_slice(H, 2 * H), att, lse, B, Lq, Lk, kmask, False,
-                                    hp.attention_dropout if train else 0.0, sid0, p + "o_map", x, scope, tag, save,
-                                    hp.residual_dropout if train else 0.0, sid0 + 1)
-            if out is not None:
-                return out
+            for pj in ((p + "q_map", 1), None) if fuse_proj else (None,):
+                if pj is None and fuse_proj:
+                    self._linear(x, p + "q_map", q)           # the fused launch refused the shape
+                out = self._attn_out_ln(q, kv.cols_slice(0, H), kv.cols_slice(H, 2 * H), att, lse, B, Lq, Lk, kmask, False,
+                                        hp.attention_dropout if train else 0.0, sid0, p + "o_map", x, scope, tag, save,
+                                        hp.residual_dropout if train else 0.0, sid0 + 1, proj=pj)
+                if out is not None:
+                    return out
         e.attn_fwd(q, kv.cols_slice(0, H), kv.cols_slice(H, 2 * H), att, lse, B, self.nh, Lq, Lk, self.d,
                    kmask=kmask, causal=False, rpr_k=rk, rpr_v=rv, max_rel=hp.max_relative_position,
                    drop_p=hp.attention_dropout if train else 0.0, sid=sid0)
