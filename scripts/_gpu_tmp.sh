@@ -1,5 +1,8 @@
 export PYTHONPATH=$PWD TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_sync_ln.py -m gpu -q -p no:cacheprovider -x -k "projection_inside" > gpurun_out/t_proj.log 2>&1; echo "rc=$?"; tail -5 gpurun_out/t_proj.log
-for m in 1 0 1 0; do
-ZERO_HIP_PROJ_ATTN=$m timeout 600 python bench.py --no-cpu-baseline --no-decode --steps 40 > gpurun_out/benchq_proj$m.json 2> gpurun_out/benchq_proj$m.err; echo "PROJ_ATTN=$m rc=$?"; grep -o '"ms_per_step": [0-9.]*\|"static_batch_ms_per_step": [0-9.]*\|"launches_per_step": [0-9]*' gpurun_out/benchq_proj$m.json | head -3; tail -2 gpurun_out/benchq_proj$m.err
+for t in 0 1; do
+echo "##### trace tune 17:$t"
+ZERO_HIP_TUNE=17:$t ZERO_HIP_LIB=$PWD/zero_amd/csrc/libzero_hip_trace.so timeout 300 python scripts/attn_out_ln_trace.py 2>&1 | grep -v "half step [2-9]\|amdgpu.ids"
+done
+for t in 0 1 7 0 1 7; do
+ZERO_HIP_TUNE=17:$t timeout 600 python bench.py --no-cpu-baseline --no-decode --steps 40 > gpurun_out/benchq_t$t.json 2> gpurun_out/benchq_t$t.err; echo "TUNE17=$t rc=$?"; grep -o '"ms_per_step": [0-9.]*\|"static_batch_ms_per_step": [0-9.]*' gpurun_out/benchq_t$t.json | head -3 | tr '\n' ' '; echo
 done

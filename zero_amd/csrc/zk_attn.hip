@@ -261,6 +261,12 @@ __global__ void __launch_bounds__(256) k_attn_fwd_mfma(AttnArgs a, bf16_t* __res
 // exchange between workgroups.  The tiles are written to the q / k / v matrices as before (the backward reads them) and read
 // back by this workgroup's attention tile past the L1 (FRESH loads: the stores were acknowledged by the L2).  Same tile
 // function, same K order as the projection launch: bit-identical.
+#ifdef ZK_ATTN_TRACE
+__device__ unsigned long long zk_attn_wg_trace[4096];
+#define ZK_WG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) zk_attn_wg_trace[2 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ZK_WG_STAMP(k)
+#endif
 struct AttnPro { const bf16_t* x; int ldx; const bf16_t* w; int ldw; const float* bias; int K; int N; };
 
 // The projection tiles of one (sentence, head) as ONE K loop (PRO = 3: q, k, v; PRO = 1: q): out[m0.., p nslab + n0 + 0..63] =
@@ -328,6 +334,8 @@ __device__ __forceinline__ void proj_heads_tile(unsigned char* smem, const bf16_
     for (int s = 0; s < nh; ++s) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      if (s == 0) ZK_AT(1);
+      if (s >= 1 && s <= 9) ZK_AT(6 + s);
       const bf16_t* h0 = ring + (s % NS) * HALF;
       const bf16_t* h1 = h0 + 64 * 64;
       if (PRO == 1 || (s & 1) == 0) {
@@ -352,6 +360,7 @@ __device__ __forceinline__ void proj_heads_tile(unsigned char* smem, const bf16_
   // [straight from the registers -- 48 two-byte stores per lane -- the launch was 5 us LONGER than with three gemm_tile calls]
   constexpr int CLD = 64 + 4;
   float* sC = reinterpret_cast<float*>(smem);
+  ZK_AT(2);
   __syncthreads();                                  // every compute wave is done reading the last half stages
   if (!producer) {
     // C layout of the 32x32 MFMA: column = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -395,6 +404,8 @@ __global__ void __launch_bounds__(512) k_attn_out_ln(AttnArgs a, bf16_t* __restr
   tile_of_block(ts, tm, tn, z);                   // tm: sentence, tn: head
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  ZK_AT(0);
+  ZK_WG_STAMP(0);
   if constexpr (PRO > 0) {
     const int M_pro = min(M, (tm + 1) * a.Lq);
     proj_heads_tile<PRO>(smem, pro.x, pro.ldx, pro.w, pro.ldw, pro.bias, const_cast<bf16_t*>(a.q), a.ldq, pro.K, tm * a.Lq, M_pro,
@@ -402,12 +413,14 @@ __global__ void __launch_bounds__(512) k_attn_out_ln(AttnArgs a, bf16_t* __restr
     __builtin_amdgcn_s_waitcnt(0);                // this thread's pieces of q / k / v have reached the L2
     __syncthreads();                              // (and every wave is done with the ring: the attention tile reuses it)
   }
+  ZK_AT(3);
   if (wave < 4) {
     attn_fwd_tile<NKT, PRO != 0, false>(smem, a, att, ldatt, lse, 0, tn, tm);
   } else {
 #pragma unroll 1
     for (int i = 0; i < ZK_ATTN_FWD_BARRIERS(NKT); ++i) __syncthreads();
   }
+  ZK_AT(4);
   const bool local = e.sy_local != 0;
   const uint32_t tag = (*e.sy_epoch << 8) | e.sy_site;
   unsigned long long* fl = flags + (size_t)tm * a.nh;
@@ -436,6 +449,7 @@ __global__ void __launch_bounds__(512) k_attn_out_ln(AttnArgs a, bf16_t* __restr
     }
   }
   __syncthreads();
+  ZK_AT(5);
   if (!local) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   // The A operand is clamped to the SENTENCE's own rows (M_own): with Lq < 64 the 64-row tile would otherwise fetch rows
   // of sentence tm + 1 -- masked later by sy_rows, but the fetch could leave lines of `att` in this CU's L1 BEFORE that
@@ -444,6 +458,8 @@ __global__ void __launch_bounds__(512) k_attn_out_ln(AttnArgs a, bf16_t* __restr
   const int M_own = min(M, (tm + 1) * a.Lq);
   gemm_tile<64, 64, 4, false, false, 4, 4, false, false, 3>(smem, att, Wo, M_own, N, ldatt, ldw, 0, N, tm * a.Lq, tn * 64,
                                                             nullptr, e, 1);
+  ZK_AT(6);
+  ZK_WG_STAMP(1);
 }
 
 // ---- backward A: grid (ceil(Lq/64), nh, B) -> dQ, Dbuf
@@ -821,6 +837,9 @@ extern "C" int zk_zero(void* p, size_t bytes, hipStream_t stream);   // zk_elem.
 static dim3 bwd64_grid(int nh, int B) { return (g_tune[15] & 4) ? dim3(1, nh, B) : dim3(nh * ((B + 7) / 8) * 8); }
 #ifdef ZK_ATTN_TRACE
 __device__ unsigned long long zk_attn_trace_buf[16];
+extern "C" int zk_attn_wg_trace_read(unsigned long long* out, int n) {      // {start, end} of every workgroup of the last k_attn_out_ln launch
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(zk_attn_wg_trace), sizeof(unsigned long long) * (size_t)n);
+}
 extern "C" int zk_attn_trace_read(unsigned long long* out16) {
   return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zk_attn_trace_buf), sizeof(unsigned long long) * 16);
 }
