@@ -1,8 +1,8 @@
 export PYTHONPATH=$PWD TMPDIR=/tmp
-for t in 0 1; do
-echo "##### trace tune 17:$t"
-ZERO_HIP_TUNE=17:$t ZERO_HIP_LIB=$PWD/zero_amd/csrc/libzero_hip_trace.so timeout 300 python scripts/attn_out_ln_trace.py 2>&1 | grep -v "half step [2-9]\|amdgpu.ids"
+for rep in 1 2 3; do
+for v in v2 v5 def; do
+lib=$PWD/zero_amd/csrc/libzero_hip_$v.so; [ $v = def ] && lib=$PWD/zero_amd/csrc/libzero_hip.so
+echo -n "$v: "; ZERO_HIP_LIB=$lib timeout 600 python bench.py --no-cpu-baseline --no-decode --steps 600 --warmup 20 --timed-only --static-batch 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
 done
-for t in 0 1 7 0 1 7; do
-ZERO_HIP_TUNE=17:$t timeout 600 python bench.py --no-cpu-baseline --no-decode --steps 40 > gpurun_out/benchq_t$t.json 2> gpurun_out/benchq_t$t.err; echo "TUNE17=$t rc=$?"; grep -o '"ms_per_step": [0-9.]*\|"static_batch_ms_per_step": [0-9.]*' gpurun_out/benchq_t$t.json | head -3 | tr '\n' ' '; echo
+echo -n "unfused: "; ZERO_HIP_PROJ_ATTN=0 timeout 600 python bench.py --no-cpu-baseline --no-decode --steps 600 --warmup 20 --timed-only --static-batch 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
 done

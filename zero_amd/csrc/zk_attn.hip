@@ -280,7 +280,8 @@ struct AttnPro { const bf16_t* x; int ldx; const bf16_t* w; int ldw; const float
 template <int PRO>
 __device__ __forceinline__ void proj_heads_tile(unsigned char* smem, const bf16_t* __restrict__ X, int ldx,
                                                 const bf16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
-                                                bf16_t* __restrict__ out, int ldo, int K, int m0, int M, int n0, int nslab) {
+                                                int K, int m0, int M, int n0, int nslab,
+                                                bf16_t* tQ, bf16_t* tK, bf16_t* tVt, uint4 (&pk)[PRO]) {
   constexpr int NS = 4, HALF = 128 * 64;            // bf16 elements per half stage (two 64 x 64 operand tiles)
   constexpr int HPK = PRO == 3 ? 2 : 1;             // half stages per K tile
   constexpr int PER = 4;                            // DMA instructions per producer wave per half stage
@@ -296,6 +297,15 @@ __device__ __forceinline__ void proj_heads_tile(unsigned char* smem, const bf16_
   for (int p = 0; p < PRO; ++p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  // the epilogue's bias values (PRO x 64 floats) are brought into the LDS by the producer waves before the K loop (whose
+  // barriers order them): no global load stands between the last MFMA and the attention, and no registers are held
+  // across the K loop [24 + 8 prefetched registers per thread cost the kernel its second workgroup per CU: 49 us a launch]
+  __shared__ float s_pbias[PRO * 64];
+  const int row = tid >> 3, cc = (tid & 7) * 8;
+  if (producer && tid - 256 < PRO * 64) {
+    const int i = tid - 256;
+    s_pbias[i] = bias != nullptr ? bias[(i >> 6) * nslab + n0 + (i & 63)] : 0.f;
+  }
   if (producer) {
     DmaPlan<64, 4> planA, planB;
     dma_plan<64, false, 4>(planA, ldx, m0, M, dwave, lane);
@@ -358,6 +368,12 @@ __device__ __forceinline__ void proj_heads_tile(unsigned char* smem, const bf16_
   }
   // ---- epilogue through the LDS (the ring is dead): PRO fp32 tiles, then every thread stores 16-byte row pieces
   // [straight from the registers -- 48 two-byte stores per lane -- the launch was 5 us LONGER than with three gemm_tile calls]
+  // and leaves the SAME bf16 values where the attention tile of this workgroup expects its operands (tQ / tK: [row][ALD];
+  // tVt: [physical channel][key] as store_trans writes it; rows >= M zero as load_direct / load_trans return them): the
+  // attention starts from the LDS -- no store acknowledgement, no load round trip between the projection and the attention
+  // (2.3 us of the launch, profiles/r06_attn_out_ln_timeline_*).  The global copies (the backward reads them) are stored
+  // by the CALLER from pk[] (this thread's row m0 + tid / 8, columns p nslab + n0 + (tid % 8) 8 .. +7; rows >= M: none)
+  // behind the attention tile, next to the attention output's stores: a workgroup barrier in between would wait for them.
   constexpr int CLD = 64 + 4;
   float* sC = reinterpret_cast<float*>(smem);
   ZK_AT(2);
@@ -370,30 +386,43 @@ __device__ __forceinline__ void proj_heads_tile(unsigned char* smem, const bf16_
 #pragma unroll
       for (int r = 0; r < 16; ++r) sC[p * 64 * CLD + (wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CLD + col] = acc[p][r];
   }
-  __syncthreads();
-  const int row = tid >> 3, cc = (tid & 7) * 8, gm = m0 + row;
-#pragma unroll
-  for (int p = 0; p < PRO; ++p) {
-    const int gn = p * nslab + n0 + cc;
-    float v[8], bv[8];
-    {
-      const float4 a = *reinterpret_cast<const float4*>(sC + p * 64 * CLD + row * CLD + cc);
-      const float4 b = *reinterpret_cast<const float4*>(sC + p * 64 * CLD + row * CLD + cc + 4);
-      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    }
-    if (bias != nullptr) {
-      const float4 a = *reinterpret_cast<const float4*>(bias + gn);
-      const float4 b = *reinterpret_cast<const float4*>(bias + gn + 4);
-      bv[0] = a.x; bv[1] = a.y; bv[2] = a.z; bv[3] = a.w; bv[4] = b.x; bv[5] = b.y; bv[6] = b.z; bv[7] = b.w;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) bv[j] = 0.f;
-    }
+  // (LDS-only barriers from here on: __syncthreads() would also wait for global memory)
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  lds_barrier();
+  auto tile8 = [&](int p, int r, int c0, const float* bv) -> uint4 {          // bf16(acc + bias) of 8 consecutive columns
+    float v[8];
+    const float4 a = *reinterpret_cast<const float4*>(sC + p * 64 * CLD + r * CLD + c0);
+    const float4 b = *reinterpret_cast<const float4*>(sC + p * 64 * CLD + r * CLD + c0 + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = v[j] * 1.f + bv[j];
-    if (gm < M) *reinterpret_cast<uint4*>(out + (size_t)gm * ldo + gn) = pack8(v);
+    return pack8(v);
+  };
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+  for (int p = 0; p < PRO; ++p) pk[p] = tile8(p, row, cc, s_pbias + p * 64 + cc);
+  [[maybe_unused]] TransRegs vt;
+  if constexpr (PRO == 3) {
+    if (tid < 128) {
+      const int dc = tid & 7, rq = tid >> 3;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) vt.v[u] = (m0 + rq * 4 + u < M) ? tile8(2, rq * 4 + u, dc * 8, s_pbias + 2 * 64 + dc * 8) : zero4;
+    }
   }
+  lds_barrier();                                    // every read of the fp32 tiles is done: the operand tiles may land on them
+  const bool live = m0 + row < M;
+  *reinterpret_cast<uint4*>(tQ + row * ALD + cc) = live ? pk[0] : zero4;
+  if constexpr (PRO == 3) {
+    *reinterpret_cast<uint4*>(tK + row * ALD + cc) = live ? pk[1] : zero4;
+    if (tid < 128) store_trans(tVt, vt, tid);
+  }
+  lds_barrier();
 }
+
 template <int NKT, int PRO = 0>
 __global__ void __launch_bounds__(512) k_attn_out_ln(AttnArgs a, bf16_t* __restrict__ att, int ldatt, float* __restrict__ lse,
                                                      const bf16_t* __restrict__ Wo, int ldw, int M, int N, TileSched ts,
@@ -406,19 +435,28 @@ __global__ void __launch_bounds__(512) k_attn_out_ln(AttnArgs a, bf16_t* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   ZK_AT(0);
   ZK_WG_STAMP(0);
+  [[maybe_unused]] uint4 ppk[PRO > 0 ? PRO : 1];
   if constexpr (PRO > 0) {
     const int M_pro = min(M, (tm + 1) * a.Lq);
-    proj_heads_tile<PRO>(smem, pro.x, pro.ldx, pro.w, pro.ldw, pro.bias, const_cast<bf16_t*>(a.q), a.ldq, pro.K, tm * a.Lq, M_pro,
-                         tn * 64, N);
-    __builtin_amdgcn_s_waitcnt(0);                // this thread's pieces of q / k / v have reached the L2
-    __syncthreads();                              // (and every wave is done with the ring: the attention tile reuses it)
+    bf16_t* tQ = reinterpret_cast<bf16_t*>(smem);                                 // attn_fwd_tile's sQ, sK; V^T behind its tiles
+    proj_heads_tile<PRO>(smem, pro.x, pro.ldx, pro.w, pro.ldw, pro.bias, pro.K, tm * a.Lq, M_pro, tn * 64, N, tQ, tQ + TQ * ALD,
+                         reinterpret_cast<bf16_t*>(smem + AttnFwdLds<NKT, false>::BASE), ppk);
   }
   ZK_AT(3);
   if (wave < 4) {
-    attn_fwd_tile<NKT, PRO != 0, false>(smem, a, att, ldatt, lse, 0, tn, tm);
+    attn_fwd_tile<NKT, false, false, PRO>(smem, a, att, ldatt, lse, 0, tn, tm,
+                                                                      reinterpret_cast<const bf16_t*>(smem + AttnFwdLds<NKT, false>::BASE));
   } else {
 #pragma unroll 1
     for (int i = 0; i < ZK_ATTN_FWD_BARRIERS(NKT); ++i) __syncthreads();
+  }
+  if constexpr (PRO > 0) {                          // the projected tiles' global copies (see proj_heads_tile)
+    const int gm = tm * a.Lq + (tid >> 3);
+    if (gm < min(M, (tm + 1) * a.Lq)) {
+      bf16_t* dst = const_cast<bf16_t*>(a.q) + (size_t)gm * a.ldq + tn * 64 + (tid & 7) * 8;
+#pragma unroll
+      for (int p = 0; p < PRO; ++p) *reinterpret_cast<uint4*>(dst + p * N) = ppk[p];
+    }
   }
   ZK_AT(4);
   const bool local = e.sy_local != 0;
@@ -968,7 +1006,7 @@ static int attn_out_ln_impl(const void* q, const void* k, const void* v, void* a
                             else ZK_AOL(4, PRO_); } while (0)
   if (npro == 0) ZK_AOL_N(0);
   else if (npro == 1) ZK_AOL_N(1);
-  else ZK_AOL_N(3);
+  else ZK_AOL(1, 3);                               // (merged qkv_map: Lk = Lq <= 64, one key tile)
 #undef ZK_AOL_N
 #undef ZK_AOL
   ZK_LAUNCH_CHECK();

@@ -297,9 +297,14 @@ struct AttnFwdLds {
 // RPR (modules/rpr.py:10-75 folded into the tile): with only 2*max_rel+1 <= 64 distinct table rows, q.R_k[idx(i,j)] is
 // a gather from G = Q_h.Rk^T (64 x 64, one MFMA pass over the LDS-resident table) and sum_j P[i,j] R_v[idx(i,j)] is
 // PB.Rv with PB[i,r] = the sum of P over the keys of relative index r -- no products through HBM, no extra launches.
-template <int NKT, bool FRESH = false, bool RPR = false>
+// PRE (zk_proj_attn_out_ln: the projection ran in this workgroup): 1 = the Q tile, 3 = the Q and K tiles and V^T
+// (`vt_pre`, the layout store_trans leaves: [physical channel][key], rows >= Lk zero) are already in the LDS, written behind a
+// workgroup barrier by the caller -- nothing of them is loaded here.  PRE = 3 needs NKT = 1 (self-attention of one tile).
+template <int NKT, bool FRESH = false, bool RPR = false, int PRE = 0>
 __device__ __forceinline__ void attn_fwd_tile(unsigned char* smem, const AttnArgs& a, bf16_t* __restrict__ out, int ldo,
-                                              float* __restrict__ lse, int qt, int h, int b) {
+                                              float* __restrict__ lse, int qt, int h, int b,
+                                              const bf16_t* vt_pre = nullptr) {
+  static_assert(PRE == 0 || PRE == 1 || (PRE == 3 && NKT == 1), "PRE = 3 is the single-tile self-attention");
   bf16_t* sQ = reinterpret_cast<bf16_t*>(smem);
   bf16_t* sK = sQ + TQ * ALD;     // K tile, later V^T tile
   bf16_t* sP = sK + TQ * ALD;
@@ -321,9 +326,11 @@ __device__ __forceinline__ void attn_fwd_tile(unsigned char* smem, const AttnArg
   DirectRegs rQ, rK;
   [[maybe_unused]] DirectRegs rRk;
   TransRegs rVt;
-  load_direct<FRESH>(rQ, qb, a.ldq, i0, a.Lq, tid);
-  load_direct<FRESH>(rK, kb, a.ldk, 0, a.Lk, tid);
-  if (tid < 128) load_trans<FRESH>(rVt, vb, a.ldv, 0, a.Lk, tid);
+  if (PRE == 0) load_direct<FRESH>(rQ, qb, a.ldq, i0, a.Lq, tid);
+  if (PRE != 3) {
+    load_direct<FRESH>(rK, kb, a.ldk, 0, a.Lk, tid);
+    if (tid < 128) load_trans<FRESH>(rVt, vb, a.ldv, 0, a.Lk, tid);
+  }
   if (RPR) {
     // the two tables ride in the same round trip (staged one after the other behind the Q / K stores they cost the
     // forward two more L2 latencies: 17.6 us per launch against 10.4 without relative positions)
@@ -336,8 +343,8 @@ __device__ __forceinline__ void attn_fwd_tile(unsigned char* smem, const AttnArg
     const int j = t * 16 + (lane & 15);
     kbias[t] = (a.kmask != nullptr && a.kmask[(size_t)(b / a.kv_group) * a.ldmask + min(j, a.Lk - 1)] == 0.f) ? -a.mask_inf : 0.f;
   }
-  store_direct(sQ, rQ, tid);
-  store_direct(sK, rK, tid);
+  if (PRE == 0) store_direct(sQ, rQ, tid);
+  if (PRE != 3) store_direct(sK, rK, tid);
   if (RPR) {
     store_direct(sRk, rRk, tid);                          // [r][channel], rows >= nrel zero
     if (tid >= 128) store_trans(sRvT, rVt, tid - 128);    // [physical channel][r]
@@ -468,15 +475,16 @@ __device__ __forceinline__ void attn_fwd_tile(unsigned char* smem, const AttnArg
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
     __syncthreads();   // sK readers done / sP complete
-    if (kt == 0) { if (tid < 128) store_trans(sK, rVt, tid); }
+    if (kt == 0) { if (PRE != 3 && tid < 128) store_trans(sK, rVt, tid); }
     else stage_trans<FRESH>(sK, vb, a.ldv, kt * 64, a.Lk, tid);
     __syncthreads();
+    const bf16_t* sVt = PRE == 3 ? vt_pre : sK;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const uint4 pa = *reinterpret_cast<const uint4*>(sP + (w * 16 + (lane & 15)) * PLD + kt * 64 + kk * 32 +
                                                        (lane >> 4) * 8);
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) O[nb] = mfma16(pa, frag(sK, nb * 16, kk, lane), O[nb]);
+      for (int nb = 0; nb < 4; ++nb) O[nb] = mfma16(pa, frag(sVt, nb * 16, kk, lane), O[nb]);
     }
   }
   if (RPR) {
