@@ -105,8 +105,8 @@ HBM_PEAK_TBS = 8.0               # same guide: HBM3E peak
 CLASSES = (
     ("small_gemm_chain", "mfma", "linear forward + dgrad on the 4096-row activations (k_gemm_dlds tiles; 58 of them carry a "
                                  "residual + LayerNorm forward or backward in their epilogue, 18 of those also the "
-                                 "attention forward of their sub-layer), grouped K/V projections, K-segmented d(encoder "
-                                 "output)"),
+                                 "attention forward of their sub-layer AND the qkv_map / q_map projection in front of it "
+                                 "(round 6)), grouped K/V projections, K-segmented d(encoder output)"),
     ("big_gemms", "mfma", "all weight gradients (one grouped launch of 256x256 tiles), logits forward, dlogits x E"),
     ("attention", "hbm", "attention backward, one (sentence, head) tile per workgroup, incl. the folded o_map dgrad (the "
                          "forward runs inside the output-projection launches of small_gemm_chain)"),
@@ -242,12 +242,19 @@ class LaunchProfiler(object):
             fl = 4.0 * Bn * Lq * Lk * H + 2.0 * M * H * H
             by = (2 * Bn * Lq + 2 * Bn * Lk) * H * 2 + (M * H + H * H) * 2 + 3 * M * H * 2
             nkt = (Lk + 63) // 64
+            pro = kw["proj"][3] if kw.get("proj") is not None else 0
+            if pro:
+                # round 6: the merged qkv_map (pro = 3) / q_map (pro = 1) runs inside the launch as well (zk_proj_attn_out_ln):
+                # its product is booked here; x and the weight are read, the projected tiles written (the attention tile takes
+                # them from the LDS: their read disappears)
+                fl += 2.0 * M * H * pro * H
+                by += (M * H + H * pro * H) * 2 + M * pro * H * 2 - pro * M * H * 2
             s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s0.record()
             ok = keep["attn_out_ln"](q, k, v, att, lse, Bn, nh, Lq, Lk, d, *a, **kw)
             e0.record()
             if ok:
-                self.records.append(("small_gemm_chain", "k_attn_out_ln<%d>" % nkt, fl, float(by), s0, e0))
+                self.records.append(("small_gemm_chain", "k_attn_out_ln<%d, %d>" % (nkt, pro), fl, float(by), s0, e0))
             return ok
 
         def gemm_ln_bwd(dY, W, M, N, K, *a, **kw):
