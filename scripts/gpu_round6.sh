@@ -7,6 +7,8 @@
 #   profstep  rocprofv3 kernel table of the CAPTURED training step only (+ gaps)
 #   profd32 / profd16   rocprofv3 kernel table of a single-lane decode, fp32 mode / bf16 mode (scripts/decode_bench.py)
 #   dec32 / dec16       scripts/decode_bench.py without the profiler
+#   prof                rocprofv3 kernel table of the default training bench (incl. start-up and the eager profiling steps)
+#   mfma / traffic / trafficd   PMC passes (scripts/pmc_*.sh), each in runs of its own
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
@@ -29,6 +31,12 @@ for st in $STAGES; do
             python scripts/prof_summary.py $(find gpurun_out/profs -name "*.db" | head -1) 42 > gpurun_out/rocprof_captured_step.txt 2>&1
             python scripts/prof_gaps.py $(find gpurun_out/profs -name "*.db" | head -1) > gpurun_out/rocprof_captured_step_gaps.txt 2>&1
             rm -rf gpurun_out/profs; head -${PROF_HEAD:-50} gpurun_out/rocprof_captured_step.txt; tail -2 gpurun_out/profstep.log; head -${GAP_HEAD:-12} gpurun_out/rocprof_captured_step_gaps.txt ;;
+    prof)   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o r1 -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-decode > $OLDPWD/gpurun_out/prof.log 2>&1); echo "rc=$?"
+            python scripts/prof_summary.py $(find gpurun_out/prof -name "*.db" | head -1) > gpurun_out/rocprof_kernel_stats.txt 2>&1
+            rm -rf gpurun_out/prof; head -${PROF_HEAD:-45} gpurun_out/rocprof_kernel_stats.txt ;;
+    mfma)   bash scripts/pmc_mfma.sh ;;
+    traffic) bash scripts/pmc_traffic.sh ;;
+    trafficd) bash scripts/pmc_traffic_decode.sh ;;
     profd32) prof_decode float32 f32_1lane ;;
     profd16) prof_decode bfloat16 bf16_1lane ;;
     dec32)  ZERO_HIP_DECODE_STREAMS=1 timeout 600 python scripts/decode_bench.py --sentences 256 --dtype float32 2>&1 | tail -1 ;;
