@@ -1,8 +1,6 @@
 export PYTHONPATH=$PWD TMPDIR=/tmp
 for rep in 1 2 3; do
-for v in v2 v5 def; do
-lib=$PWD/zero_amd/csrc/libzero_hip_$v.so; [ $v = def ] && lib=$PWD/zero_amd/csrc/libzero_hip.so
-echo -n "$v: "; ZERO_HIP_LIB=$lib timeout 600 python bench.py --no-cpu-baseline --no-decode --steps 600 --warmup 20 --timed-only --static-batch 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
+for t in 0 1 3; do
+echo -n "tune18=$t: "; ZERO_HIP_TUNE=18:$t timeout 600 python bench.py --no-cpu-baseline --no-decode --steps 400 --warmup 20 --timed-only --static-batch 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
 done
-echo -n "unfused: "; ZERO_HIP_PROJ_ATTN=0 timeout 600 python bench.py --no-cpu-baseline --no-decode --steps 600 --warmup 20 --timed-only --static-batch 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
 done

@@ -1252,7 +1252,10 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
                                               bf16_t* __restrict__ shadow, size_t n,
                                               float* __restrict__ hyper, float* __restrict__ psq,
                                               float* __restrict__ gsq, uint64_t* __restrict__ seed,
-                                              const int* __restrict__ skip_word = nullptr) {
+                                              const int* __restrict__ skip_word = nullptr, int nt = 0) {
+  // nt (tuning key 18, A/B): bit 0 = the fp32 parameter / moment STORES are non-temporal (nobody reads them before the next
+  // step's update: they need not displace the bf16 shadow -- the next forward's weight operand -- from the L2 / Infinity
+  // Cache); bit 1 = their loads as well
   __shared__ float sm_[8];
   float pacc = 0.f;   // sum of squares of the parameters BEFORE this update (tf.global_norm(variables))
   float gacc = 0.f;   // sum of squares of the scaled gradient (GSQ)
@@ -1296,11 +1299,20 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
     for (int u = 0; u < UU; ++u) {
       const size_t i = i0 + u * stride;
       if (i < iend) {
-        pp[u] = reinterpret_cast<float4*>(p)[i];
         const zk_f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const zk_f32x4*>(g) + i);   // read once
         gg[u] = make_float4(t4.x, t4.y, t4.z, t4.w);
-        mm[u] = reinterpret_cast<float4*>(m)[i];
-        vv[u] = reinterpret_cast<float4*>(v)[i];
+        if (nt & 2) {
+          const zk_f32x4 a4 = __builtin_nontemporal_load(reinterpret_cast<const zk_f32x4*>(p) + i);
+          const zk_f32x4 b4 = __builtin_nontemporal_load(reinterpret_cast<const zk_f32x4*>(m) + i);
+          const zk_f32x4 c4 = __builtin_nontemporal_load(reinterpret_cast<const zk_f32x4*>(v) + i);
+          pp[u] = make_float4(a4.x, a4.y, a4.z, a4.w);
+          mm[u] = make_float4(b4.x, b4.y, b4.z, b4.w);
+          vv[u] = make_float4(c4.x, c4.y, c4.z, c4.w);
+        } else {
+          pp[u] = reinterpret_cast<float4*>(p)[i];
+          mm[u] = reinterpret_cast<float4*>(m)[i];
+          vv[u] = reinterpret_cast<float4*>(v)[i];
+        }
       }
     }
 #pragma unroll
@@ -1317,9 +1329,15 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
           Vv[j] = b2 * Vv[j] + (1.f - b2) * gj * gj;
           P[j] -= lr * M[j] / (sqrtf(Vv[j]) + eps);
         }
-        reinterpret_cast<float4*>(p)[i] = pp[u];
-        reinterpret_cast<float4*>(m)[i] = mm[u];
-        reinterpret_cast<float4*>(v)[i] = vv[u];
+        if (nt & 1) {
+          __builtin_nontemporal_store((zk_f32x4){pp[u].x, pp[u].y, pp[u].z, pp[u].w}, reinterpret_cast<zk_f32x4*>(p) + i);
+          __builtin_nontemporal_store((zk_f32x4){mm[u].x, mm[u].y, mm[u].z, mm[u].w}, reinterpret_cast<zk_f32x4*>(m) + i);
+          __builtin_nontemporal_store((zk_f32x4){vv[u].x, vv[u].y, vv[u].z, vv[u].w}, reinterpret_cast<zk_f32x4*>(v) + i);
+        } else {
+          reinterpret_cast<float4*>(p)[i] = pp[u];
+          reinterpret_cast<float4*>(m)[i] = mm[u];
+          reinterpret_cast<float4*>(v)[i] = vv[u];
+        }
         if (shadow != nullptr)
           reinterpret_cast<uint2*>(shadow)[i] = make_uint2(pack2bf(P[0], P[1]), pack2bf(P[2], P[3]));
       }
@@ -1619,7 +1637,7 @@ size_t zk_add_ln_bwd_workspace(int rows, int H) {
   return (size_t)g * 3 * H * sizeof(float);
 }
 
-int g_tune[24] = {1, 0, 0, 0, 0, 0, 0x44, 0, 0, 2, 512, 0, 4 | (28 << 8), 0, 129, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [16] (round 6): bit mask of merged small launches switched OFF (bit 0: per-sentence loss + mean as two launches)   // [14] = 129: 256x256 tile, the first half of the workgroup issues its LDS-DMA behind its first two slices (round 5)   // [12]: phases | us << 8 of the updating weight-gradient launch   // [0] wide LayerNorm backward kernel; [1] GEMM: legacy split-K rule (A/B)
+int g_tune[24] = {1, 0, 0, 0, 0, 0, 0x44, 0, 0, 2, 512, 0, 4 | (28 << 8), 0, 129, 0, 0, 0, 3, 0, 0, 0, 0, 0};   // [18] = 3 (round 6): Adam's fp32 parameter / moment loads and stores non-temporal (step 4.197 -> 4.184 ms, three interleaved runs)   // [16] (round 6): bit mask of merged small launches switched OFF (bit 0: per-sentence loss + mean as two launches)   // [14] = 129: 256x256 tile, the first half of the workgroup issues its LDS-DMA behind its first two slices (round 5)   // [12]: phases | us << 8 of the updating weight-gradient launch   // [0] wide LayerNorm backward kernel; [1] GEMM: legacy split-K rule (A/B)
 static int ln_bwd_blocks(int rows) {
   int g = (rows + 15) / 16;
   if (g > 256) g = 256;
@@ -2018,7 +2036,7 @@ int zk_adam_step(float* p, const float* g, float* m, float* v, void* shadow, siz
     // (default 2); tuning key 10: blocks (default 512; 0 = 2048).  scripts/adam_bench.py: 405 -> 391 us on one box
     // (fewer open DRAM pages); the box-to-box spread of this pass is larger than that (405 .. 477 us)
     const int gb = g_tune[10] > 0 && g_tune[10] <= 2048 ? (grid < g_tune[10] ? grid : g_tune[10]) : grid;
-#define ZK_ADAM_L(...) hipLaunchKernelGGL((k_adam<__VA_ARGS__>), dim3(gb), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n, hyper, psq, gsq, seed, skip_word)
+#define ZK_ADAM_L(...) hipLaunchKernelGGL((k_adam<__VA_ARGS__>), dim3(gb), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow, n, hyper, psq, gsq, seed, skip_word, g_tune[18])
     if (g_tune[9] == 1) ZK_ADAM_L(true, 1, true);
     else if (g_tune[9] == 2) ZK_ADAM_L(true, 2, true);
     else if (g_tune[9] == 4) ZK_ADAM_L(true, 4, true);
