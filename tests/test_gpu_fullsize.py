@@ -56,6 +56,9 @@ REPORT = os.path.join(os.path.dirname(GOLD), "..", "gpurun_out")
 # ffn enlarge, fourth encoder layer's o_map) sit 17 / 26 sub-layers deep in the backward chain: measured 3.5 % / 2.4 %
 # with the 6-layer encoder, 7.2 % / 3.3 % behind the 12-layer encoder (its output already differs by bf16 noise).
 # Slices 1 / 2 (last decoder layer, target embedding) are at the start of it: 0.5 % / 0.1 %.
+# round 6: two runs of the bf16-storage ORACLE that differ only in the order of their fp32 sums are 3.2 / 0.45 / 0.08 / 2.8 / 2.7 %
+# apart on these slices at the base size and 3.3 / 0.4 / 0.07 / 5.2 / 2.6 % with the 12-layer encoder
+# (scripts/bf16_grad_noise_floor.py, profiles/r06_bf16_grad_noise_floor.txt): the bound is ~1.5x the storage model's own spread.
 SLICE_TOL = (8e-2, 2e-2, 2e-2, 8e-2, 8e-2)      # round 4: 1e-1 -> 8e-2 (measured 3.0-6.6 %, attributed to the bf16 shadow
                                                   # weights in profiles/r03_grad_noise_attribution.json)
 
