@@ -1338,8 +1338,14 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
           reinterpret_cast<float4*>(m)[i] = mm[u];
           reinterpret_cast<float4*>(v)[i] = vv[u];
         }
-        if (shadow != nullptr)
-          reinterpret_cast<uint2*>(shadow)[i] = make_uint2(pack2bf(P[0], P[1]), pack2bf(P[2], P[3]));
+        if (shadow != nullptr) {
+          if (nt & 4) {
+            zk_u32x2 sh2; sh2.x = pack2bf(P[0], P[1]); sh2.y = pack2bf(P[2], P[3]);
+            __builtin_nontemporal_store(sh2, reinterpret_cast<zk_u32x2*>(shadow) + i);
+          } else {
+            reinterpret_cast<uint2*>(shadow)[i] = make_uint2(pack2bf(P[0], P[1]), pack2bf(P[2], P[3]));
+          }
+        }
       }
     }
   }
