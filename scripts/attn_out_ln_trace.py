@@ -21,9 +21,10 @@ T = B * L
 bf = lambda *s: (torch.randn(*s, device="cuda") * 0.3).to(torch.bfloat16)
 MARKS = {0: "start", 1: "first half stage landed (barrier 0 passed)", 2: "K loop done", 3: "projection stored, visible, barrier",
          4: "attention tile done", 5: "heads of the sentence arrived", 6: "o_map + LayerNorm tile done"}
-for i in range(7, 16):
-    MARKS[i] = "  half step %d starts" % (i - 6)
-ORDER = [0, 1] + list(range(7, 16)) + [2, 3, 4, 5, 6]
+MARKS.update({7: "  last half stage landed", 8: "  epilogue: all waves past the K loop (barrier)", 9: "  epilogue: accumulators written to the LDS",
+              10: "  epilogue: barrier", 11: "  epilogue: tiles read back, packed (+ V^T pieces)", 12: "  epilogue: barrier",
+              13: "  epilogue: operand tiles written"})
+ORDER = [0, 1, 7, 2, 8, 9, 10, 11, 12, 13, 3, 4, 5, 6]
 
 for pro in (3, 1, 0):
     sets = []

@@ -300,7 +300,7 @@ __device__ __forceinline__ void proj_heads_tile(unsigned char* smem, const bf16_
   // the epilogue's bias values (PRO x 64 floats) are brought into the LDS by the producer waves before the K loop (whose
   // barriers order them): no global load stands between the last MFMA and the attention, and no registers are held
   // across the K loop [24 + 8 prefetched registers per thread cost the kernel its second workgroup per CU: 49 us a launch]
-  __shared__ float s_pbias[PRO * 64];
+  __shared__ __attribute__((aligned(16))) float s_pbias[PRO * 64];
   const int row = tid >> 3, cc = (tid & 7) * 8;
   if (producer && tid - 256 < PRO * 64) {
     const int i = tid - 256;
@@ -345,7 +345,7 @@ __device__ __forceinline__ void proj_heads_tile(unsigned char* smem, const bf16_
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       if (s == 0) ZK_AT(1);
-      if (s >= 1 && s <= 9) ZK_AT(6 + s);
+      if (s == nh - 1) ZK_AT(7);
       const bf16_t* h0 = ring + (s % NS) * HALF;
       const bf16_t* h1 = h0 + 64 * 64;
       if (PRO == 1 || (s & 1) == 0) {
@@ -378,6 +378,7 @@ __device__ __forceinline__ void proj_heads_tile(unsigned char* smem, const bf16_
   float* sC = reinterpret_cast<float*>(smem);
   ZK_AT(2);
   __syncthreads();                                  // every compute wave is done reading the last half stages
+  ZK_AT(8);
   if (!producer) {
     // C layout of the 32x32 MFMA: column = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const int col = wn * 32 + (lane & 31);
@@ -392,34 +393,38 @@ __device__ __forceinline__ void proj_heads_tile(unsigned char* smem, const bf16_
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
+  ZK_AT(9);
   lds_barrier();
+  ZK_AT(10);
   auto tile8 = [&](int p, int r, int c0, const float* bv) -> uint4 {          // bf16(acc + bias) of 8 consecutive columns
     float v[8];
     const float4 a = *reinterpret_cast<const float4*>(sC + p * 64 * CLD + r * CLD + c0);
     const float4 b = *reinterpret_cast<const float4*>(sC + p * 64 * CLD + r * CLD + c0 + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = v[j] * 1.f + bv[j];
+    const float4 ba = *reinterpret_cast<const float4*>(bv), bb = *reinterpret_cast<const float4*>(bv + 4);
+    v[0] = a.x * 1.f + ba.x; v[1] = a.y * 1.f + ba.y; v[2] = a.z * 1.f + ba.z; v[3] = a.w * 1.f + ba.w;
+    v[4] = b.x * 1.f + bb.x; v[5] = b.y * 1.f + bb.y; v[6] = b.z * 1.f + bb.z; v[7] = b.w * 1.f + bb.w;
     return pack8(v);
   };
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
   for (int p = 0; p < PRO; ++p) pk[p] = tile8(p, row, cc, s_pbias + p * 64 + cc);
-  [[maybe_unused]] TransRegs vt;
-  if constexpr (PRO == 3) {
-    if (tid < 128) {
-      const int dc = tid & 7, rq = tid >> 3;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) vt.v[u] = (m0 + rq * 4 + u < M) ? tile8(2, rq * 4 + u, dc * 8, s_pbias + 2 * 64 + dc * 8) : zero4;
-    }
-  }
+  ZK_AT(11);
   lds_barrier();                                    // every read of the fp32 tiles is done: the operand tiles may land on them
+  ZK_AT(12);
   const bool live = m0 + row < M;
   *reinterpret_cast<uint4*>(tQ + row * ALD + cc) = live ? pk[0] : zero4;
   if constexpr (PRO == 3) {
     *reinterpret_cast<uint4*>(tK + row * ALD + cc) = live ? pk[1] : zero4;
-    if (tid < 128) store_trans(tVt, vt, tid);
+    // V^T as store_trans leaves it: element (key = row, channel c = cc + j) at [phys(c)][row], phys(c) = (c % 8) 8 + c / 8 =
+    // 8 j + cc / 8 -- eight two-byte writes per thread from the packed row piece it already holds [a second pass of 128
+    // threads over the fp32 tile (four more reads + conversions each) made the read-back phase 2.4 us]
+    const uint4 vv = live ? pk[2] : zero4;
+    const uint32_t w4[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      tVt[(8 * j + (cc >> 3)) * ALD + row] = (bf16_t)((j & 1) ? (w4[j >> 1] >> 16) : (w4[j >> 1] & 0xffffu));
   }
+  ZK_AT(13);
   lds_barrier();
 }
 
