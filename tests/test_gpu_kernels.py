@@ -14,6 +14,42 @@ from zero_amd import hip  # noqa: E402
 from zero_amd.func import Mat  # noqa: E402
 
 
+# ------------------------------------------------------------------ the bf16 rounding every kernel stores with
+def test_bf16_conversion_is_round_to_nearest_even_on_every_class_of_value():
+    """f2bf / pack2bf (zk_common.h) compile to v_cvt_pk_bf16_f32 since round 6 (the integer sequence of rounds 1-5 before).
+    zk_cast_f32_bf16 exposes exactly that conversion: against round-to-nearest-even computed on the bit patterns (numpy) -- and
+    against torch's own cast -- for random values, EXACT ties with even and odd kept mantissas, the neighbours of ties, values
+    that round up into the next binade / into infinity, fp32 denormals, signed zeros and infinities; NaN stays NaN."""
+    e = eng()
+    rng = np.random.default_rng(7)
+    hi = rng.integers(0, 1 << 16, size=200000, dtype=np.uint32)          # every exponent, both signs
+    hi = hi[(hi & 0x7f80) != 0x7f80]                                       # finite (and zero / denormal) upper halves
+    ties = (hi << 16) | 0x8000
+    cases = [rng.standard_normal(300000).astype(np.float32).view(np.uint32),
+             (rng.standard_normal(100000) * 1e-3).astype(np.float32).view(np.uint32),
+             ties, ties + 1, ties - 1, (hi << 16) | 0xffff, (hi << 16) | 0x7fff, hi << 16,
+             rng.integers(0, 1 << 23, size=50000, dtype=np.uint32),                     # denormals
+             rng.integers(0, 1 << 23, size=50000, dtype=np.uint32) | 0x80000000,
+             np.array([0x00000000, 0x80000000, 0x7f800000, 0xff800000, 0x7f7fffff, 0xff7fffff, 0x7f7f8000, 0x7f7f7fff,
+                       0x00008000, 0x00018000, 0x00007fff], dtype=np.uint32)]
+    u = np.concatenate([c.astype(np.uint32) for c in cases])
+    u = u[: (u.size // 8) * 8]
+    want = ((u.astype(np.uint64) + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)     # RNE on the bit pattern
+    x = torch.from_numpy(u.view(np.float32).copy()).cuda()
+    y = torch.empty(x.numel(), dtype=torch.bfloat16, device="cuda")
+    e.lib.call("zk_cast_f32_bf16", x.data_ptr(), y.data_ptr(), x.numel(), e.stream)
+    torch.cuda.synchronize()
+    got = y.view(torch.int16).cpu().numpy().view(np.uint16)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, [(hex(int(u[i])), hex(int(got[i])), hex(int(want[i]))) for i in bad[:8]]
+    assert torch.equal(y, x.to(torch.bfloat16))
+    nan = torch.tensor([float("nan"), -float("nan"), 1.0, 2.0, 3.0, 4.0, 5.0, 6.0], device="cuda")
+    yn = torch.empty(8, dtype=torch.bfloat16, device="cuda")
+    e.lib.call("zk_cast_f32_bf16", nan.data_ptr(), yn.data_ptr(), 8, e.stream)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(yn[:2].float()).all()) and torch.equal(yn[2:].float(), nan[2:])
+
+
 # ------------------------------------------------------------------ hardware layout probes
 def test_probe_mfma_layouts():
     e = eng()
